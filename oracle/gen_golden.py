@@ -1,0 +1,325 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE ITSELF (container only).
+
+TEST INFRASTRUCTURE.  Run with:
+
+    /opt/conda/bin/python3.9 -W ignore oracle/gen_golden.py
+
+It loads the reference's modules unmodified through `oracle/ref_shim.py` and
+stores inputs + the reference's outputs as small fixtures.  The fixtures are
+data (inputs and expected outputs); nothing of the reference's source travels.
+Large synthetic inputs are regenerated from a seed at test time and verified
+against the SHA-256 stored beside the expected outputs.
+"""
+
+import contextlib
+import hashlib
+import io
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+ref = ref_shim.load_reference()
+NCC = ref["ncc"].NormalizedCrossCorrelationMetric
+NDP = ref["ndp"].NormalizedDotProductMetric
+di = ref["di"]
+pat = ref["pattern"]
+Window = ref["window"].Window
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def run_di(exp, dic, metric="ncc", keep_n=20, n_per_iteration=None,
+           navigation_mask=None, signal_mask=None, dtype=np.float32):
+    """What EBSD.dictionary_indexing does (signals/ebsd.py:1921-1981) around
+    the reference's `_dictionary_indexing`, which is what runs here."""
+    nav_shape = exp.shape[:-2]
+    n_dict = dic.shape[0]
+    if n_per_iteration is None:
+        n_per_iteration = n_dict
+    cls = {"ncc": NCC, "ndp": NDP}[metric]
+    m = cls()
+    m.n_experimental_patterns = max(int(np.prod(nav_shape)), 1)
+    m.n_dictionary_patterns = max(n_dict, 1)
+    if navigation_mask is not None:
+        m.navigation_mask = navigation_mask
+    if signal_mask is not None:
+        m.signal_mask = signal_mask
+    m.dtype = dtype
+    m.raise_error_if_invalid()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+        xmap = di._dictionary_indexing(
+            experimental=exp, experimental_nav_shape=nav_shape, dictionary=dic,
+            step_sizes=(1,) * len(nav_shape), dictionary_xmap=ref_shim.FakeDictionaryXmap(),
+            metric=m, keep_n=keep_n, n_per_iteration=n_per_iteration,
+        )
+    prop = xmap.kw["prop"]
+    return (np.asarray(prop["scores"]), np.asarray(prop["simulation_indices"]),
+            buf.getvalue(), repr(m))
+
+
+# ------------------------------------------------------------------ dummy data
+# tests' `dummy_signal` / `dummy_background` (conftest.py:166-229): data only
+DUMMY = np.array(
+    [5, 6, 5, 7, 6, 5, 6, 1, 0, 9, 7, 8, 7, 0, 8, 8, 7, 6, 0, 3, 3, 5, 2,
+     9, 3, 3, 9, 8, 1, 7, 6, 4, 8, 8, 2, 2, 4, 0, 9, 0, 1, 0, 2, 2, 5, 8,
+     6, 0, 4, 7, 7, 7, 6, 0, 4, 1, 6, 3, 4, 0, 1, 1, 0, 5, 9, 8, 4, 6, 0,
+     2, 9, 2, 9, 4, 3, 6, 5, 6, 2, 5, 9], dtype=np.uint8).reshape((3, 3, 3, 3))
+DUMMY_BG = np.array([5, 4, 5, 4, 3, 4, 4, 4, 3], dtype=np.uint8).reshape((3, 3))
+
+
+def gen_dummy_di():
+    out = {"dummy": DUMMY, "dummy_bg": DUMMY_BG}
+    dic = DUMMY.reshape(-1, 3, 3)
+    sig_mask = np.array([[0, 0, 0], [0, 1, 0], [0, 0, 0]], dtype=bool)
+    nav_mask = np.array([[0, 0, 0], [0, 1, 0], [0, 0, 0]], dtype=bool)
+    cases = {
+        "ndp_all": dict(metric="ndp"),
+        "ncc_all": dict(metric="ncc"),
+        "ncc_sigmask_f64_it2": dict(metric="ncc", dtype=np.float64, n_per_iteration=2,
+                                    signal_mask=sig_mask),
+        "ndp_sigmask": dict(metric="ndp", signal_mask=sig_mask),
+        "ndp_it2": dict(metric="ndp", n_per_iteration=2),
+        "ncc_navmask_k1": dict(metric="ncc", keep_n=1, navigation_mask=nav_mask),
+        "ndp_navmask_inv": dict(metric="ndp", navigation_mask=~nav_mask),
+        "ncc_it4_k3": dict(metric="ncc", keep_n=3, n_per_iteration=4),
+    }
+    for name, kw in cases.items():
+        s, i, msg, rep = run_di(DUMMY, dic, **kw)
+        out[f"{name}__scores"] = s
+        out[f"{name}__indices"] = i
+        out[f"{name}__msg"] = np.array(msg)
+        out[f"{name}__repr"] = np.array(rep)
+    out["sig_mask"] = sig_mask
+    out["nav_mask"] = nav_mask
+    np.savez_compressed(os.path.join(OUT, "di_dummy.npz"), **out)
+    print("di_dummy", len(out))
+
+
+# ------------------------------------------------------------------ synthetic DI
+def synth(seed, m, n, sy=60, sx=60):
+    rng = np.random.default_rng(seed)
+    exp = rng.integers(0, 256, (m, sy, sx)).astype(np.uint8)
+    dic = rng.random((n, sy, sx)).astype(np.float32)
+    return exp, dic
+
+
+def gen_synth_di():
+    out = {}
+    seed, m, n = 2024, 48, 3000
+    exp, dic = synth(seed, m, n)
+    out["seed"], out["m"], out["n"] = seed, m, n
+    out["exp_sha"], out["dic_sha"] = np.array(sha(exp)), np.array(sha(dic))
+    circ = ~Window("circular", (60, 60)).astype(bool)
+    out["circular_mask"] = np.asarray(circ)
+    nav = np.zeros((6, 8), dtype=bool)
+    nav[1, 2] = nav[4, 7] = nav[0, 0] = True
+    out["nav_mask"] = nav
+    cases = {
+        "ncc_k20": dict(metric="ncc", keep_n=20),
+        "ncc_k1": dict(metric="ncc", keep_n=1),
+        "ncc_k5_it700": dict(metric="ncc", keep_n=5, n_per_iteration=700),
+        "ndp_k20": dict(metric="ndp", keep_n=20),
+        "ndp_k5_it1000": dict(metric="ndp", keep_n=5, n_per_iteration=1000),
+        "ncc_k20_circ": dict(metric="ncc", keep_n=20, signal_mask=np.asarray(circ)),
+        "ncc_k20_circ_it999": dict(metric="ncc", keep_n=20, signal_mask=np.asarray(circ),
+                                   n_per_iteration=999),
+        "ncc_k10_f64": dict(metric="ncc", keep_n=10, dtype=np.float64),
+        "ndp_k50": dict(metric="ndp", keep_n=50),
+    }
+    for name, kw in cases.items():
+        s, i, msg, rep = run_di(exp, dic, **kw)
+        out[f"{name}__scores"] = s
+        out[f"{name}__indices"] = i
+    # with navigation mask on a 2-D map
+    s, i, msg, rep = run_di(exp.reshape(6, 8, 60, 60), dic, metric="ncc", keep_n=7,
+                            navigation_mask=nav, n_per_iteration=1500)
+    out["ncc_k7_nav__scores"], out["ncc_k7_nav__indices"] = s, i
+    out["ncc_k7_nav__msg"] = np.array(msg)
+    # the survey's anchor
+    rng = np.random.default_rng(0)
+    e0 = rng.integers(0, 256, (3, 3, 60, 60)).astype(np.uint8)
+    d0 = rng.random((1000, 60, 60)).astype(np.float32)
+    for met in ("ncc", "ndp"):
+        s, i, _, _ = run_di(e0, d0, metric=met, keep_n=5)
+        out[f"anchor_{met}__scores"], out[f"anchor_{met}__indices"] = s, i
+    out["anchor_exp_sha"], out["anchor_dic_sha"] = np.array(sha(e0)), np.array(sha(d0))
+    np.savez_compressed(os.path.join(OUT, "di_synth.npz"), **out)
+    print("di_synth", len(out))
+
+
+# ------------------------------------------------------------------ Ni small (config 1)
+def load_ni():
+    import h5py
+
+    p = os.path.join(ref_shim.SRC, "data", "kikuchipy_h5ebsd", "patterns.h5")
+    with h5py.File(p, "r") as f:
+        pats = f["Scan 1/EBSD/Data/patterns"][()]
+        bg = f["Scan 1/EBSD/Header/static_background"][()]
+    return np.asarray(pats).reshape(3, 3, 60, 60), np.asarray(bg)
+
+
+def static_bg_ref(patterns, bg, operation, scale_bg):
+    """signals/ebsd.py:518-573 around the reference's per-pattern kernel."""
+    dtype_out = patterns.dtype.type
+    omin, omax = pat.dtype_range[dtype_out]
+    f = (pat._remove_static_background_subtract if operation == "subtract"
+         else pat._remove_static_background_divide)
+    bgf = bg.astype(np.float32)
+    flat = patterns.reshape((-1,) + patterns.shape[-2:])
+    out = np.stack([f(p, bgf, dtype_out, omin, omax, scale_bg) for p in flat])
+    return out.reshape(patterns.shape)
+
+
+def dynamic_bg_ref(patterns, operation, filter_domain, std, truncate):
+    """signals/ebsd.py:645-696 around the reference's per-pattern kernel."""
+    from scipy.ndimage import gaussian_filter
+
+    sy, sx = patterns.shape[-2:]
+    if std is None:
+        std = sx / 8
+    dtype_out = patterns.dtype.type
+    omin, omax = pat.dtype_range[dtype_out]
+    kw = {}
+    if filter_domain == "frequency":
+        func = ref["fft_barnes"]._fft_filter
+        (kw["fft_shape"], kw["window_shape"], kw["transfer_function"],
+         kw["offset_before_fft"], kw["offset_after_ifft"]) = \
+            pat._dynamic_background_frequency_space_setup((sy, sx), std, truncate)
+    else:
+        func = gaussian_filter
+        kw = {"sigma": std, "truncate": truncate}
+    flat = patterns.reshape((-1, sy, sx))
+    out = np.stack([
+        pat._remove_dynamic_background(p, func, operation, dtype_out, omin, omax, **kw)
+        for p in flat])
+    return out.reshape(patterns.shape)
+
+
+def gen_preproc():
+    ni, ni_bg = load_ni()
+    out = {"ni": ni, "ni_bg": ni_bg, "dummy": DUMMY, "dummy_bg": DUMMY_BG}
+    for name, data, bg in (("ni", ni, ni_bg), ("dummy", DUMMY, DUMMY_BG)):
+        for op in ("subtract", "divide"):
+            for sc in (False, True):
+                out[f"{name}__static_{op}_{int(sc)}"] = static_bg_ref(data, bg, op, sc)
+    # dynamic: default (frequency, std=w/8, truncate 4), then variants
+    dyn_cases = {
+        "freq_sub_default": ("subtract", "frequency", None, 4.0),
+        "freq_div_default": ("divide", "frequency", None, 4.0),
+        "freq_sub_std5": ("subtract", "frequency", 5, 4.0),
+        "freq_sub_std3_t3": ("subtract", "frequency", 3, 3.0),
+        "spat_sub_default": ("subtract", "spatial", None, 4.0),
+        "spat_div_std5": ("divide", "spatial", 5, 4.0),
+    }
+    for cname, (op, dom, std, tr) in dyn_cases.items():
+        out[f"ni__dyn_{cname}"] = dynamic_bg_ref(ni, op, dom, std, tr)
+    # dummy-signal dynamic cases pinned by tests/test_signals/test_ebsd.py:533-985
+    for cname, (op, dom, std, tr) in {
+        "spat_sub_std2": ("subtract", "spatial", 2, 4.0),
+        "freq_sub_std2": ("subtract", "frequency", 2, 4.0),
+        "freq_div_std2": ("divide", "frequency", 2, 4.0),
+        "freq_sub_std1_t3": ("subtract", "frequency", 1, 3.0),
+    }.items():
+        for dt in (np.uint8, np.uint16, np.float32):
+            d = DUMMY.astype(dt)
+            out[f"dummy__dyn_{cname}_{np.dtype(dt).name}"] = dynamic_bg_ref(d, op, dom, std, tr)
+    # the canonical pipeline (pattern_matching.ipynb cells 6/27/29): static -> dynamic
+    st = static_bg_ref(ni, ni_bg, "subtract", False)
+    dy = dynamic_bg_ref(st, "subtract", "frequency", None, 4.0)
+    out["ni__static_then_dynamic"] = dy
+    # uint16 Ni (scaled) to pin the wide integer path
+    ni16 = ni.astype(np.uint16) * 257
+    out["ni16"] = ni16
+    out["ni16__static_subtract_0"] = static_bg_ref(ni16, ni_bg.astype(np.uint16) * 257,
+                                                   "subtract", False)
+    out["ni16__dyn_freq_sub_default"] = dynamic_bg_ref(ni16, "subtract", "frequency", None, 4.0)
+    # windows / masks
+    out["circular_60"] = np.asarray(Window("circular", (60, 60)))
+    out["circular_5x7"] = np.asarray(Window("circular", (5, 7)))
+    w = Window("gaussian", std=7.5, shape=(30, 30))
+    out["gauss_30_std7p5"] = np.asarray(w)
+    (fs, ws, tf, ob, oa) = pat._dynamic_background_frequency_space_setup((60, 60), 7.5, 4.0)
+    out["dynsetup_60"] = np.array([fs[0], fs[1], ws[0], ws[1], ob[0], ob[1], oa[0], oa[1]])
+    # raw background estimate (float32) of Ni pattern 0, to bound FFT-vs-direct
+    out["ni0__fft_bg"] = ref["fft_barnes"]._fft_filter(
+        ni[0, 0].astype(np.float32), tf, fs, ws, ob, oa).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "preproc.npz"), **out)
+    print("preproc", len(out))
+
+    # ---- config 1: Ni small vs a ~1k dictionary (plumbing): pre-processed Ni
+    # patterns against a synthetic dictionary built from them (perturbed +
+    # random), ncc, keep_n=5.  Dictionary is regenerated from the seed.
+    rng = np.random.default_rng(7)
+    base = dy.reshape(9, 60, 60).astype(np.float32) / 255.0
+    # element-wise float32 only (no BLAS), so the dictionary regenerates bit-for-bit
+    # under any NumPy: pattern j%9 blended with noise at a weight that varies with j
+    noise = rng.random((1000, 60, 60)).astype(np.float32)
+    wgt = (np.float32(0.35) + np.float32(0.5) * rng.random(1000).astype(np.float32))
+    dic = base[np.arange(1000) % 9] * wgt[:, None, None] + noise * (np.float32(1) - wgt)[:, None, None]
+    dic[0:999:111] = base  # exact copies: 9 dictionary entries match perfectly
+    dic = dic.astype(np.float32)
+    o1 = {"exp": dy, "dic_sha": np.array(sha(dic)), "seed": 7}
+    circ = np.asarray(~Window("circular", (60, 60)).astype(bool))
+    for name, kw in {
+        "ncc_k5": dict(metric="ncc", keep_n=5),
+        "ncc_k5_circ_it300": dict(metric="ncc", keep_n=5, signal_mask=circ, n_per_iteration=300),
+    }.items():
+        s, i, msg, rep = run_di(dy, dic, **kw)
+        o1[f"{name}__scores"], o1[f"{name}__indices"] = s, i
+        o1[f"{name}__msg"] = np.array(msg)
+    np.savez_compressed(os.path.join(OUT, "config1_ni.npz"), **o1)
+    print("config1_ni", len(o1))
+
+
+# ------------------------------------------------------------------ the reference tests' own known answers
+def gen_refknown():
+    """Extract the hard-coded known-answer ARRAYS (data, not code) that the
+    reference's test-suite holds for the pre-processing path:
+    tests/test_signals/test_ebsd.py:245-443 (static), :534-916 (dynamic
+    spatial), :924-985 (dynamic frequency), :476-487 (scale_bg)."""
+    import ast
+
+    path = os.path.join(ref_shim.REF_ROOT, "tests", "test_signals", "test_ebsd.py")
+    tree = ast.parse(open(path).read())
+    wanted = {
+        "test_remove_static_background": "static",
+        "test_remove_dynamic_background_spatial": "dyn_spatial",
+        "test_remove_dynamic_background_frequency": "dyn_frequency",
+    }
+    out = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in wanted:
+            for dec in node.decorator_list:
+                if not (isinstance(dec, ast.Call) and getattr(dec.func, "attr", "") == "parametrize"):
+                    continue
+                names = ast.literal_eval(dec.args[0]).replace(" ", "").split(",")
+                cases = eval(compile(ast.Expression(dec.args[1]), path, "eval"), {"np": np})
+                for ci, case in enumerate(cases):
+                    tag = f"{wanted[node.name]}__{ci}"
+                    for nm, val in zip(names, case):
+                        if nm == "answer":
+                            out[f"{tag}__answer"] = np.asarray(val)
+                        else:
+                            out[f"{tag}__{nm}"] = np.array(val)
+    out["static_scalebg__answer"] = np.array([[15, 150, 15], [180, 255, 120], [150, 0, 75]])
+    np.savez_compressed(os.path.join(OUT, "refknown.npz"), **out)
+    print("refknown", sorted(out))
+
+
+if __name__ == "__main__":
+    gen_dummy_di()
+    gen_synth_di()
+    gen_preproc()
+    gen_refknown()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

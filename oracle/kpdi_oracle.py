@@ -1,0 +1,445 @@
+"""CPU restatement (NumPy) of kikuchipy's dictionary-indexing hot path.
+
+TEST INFRASTRUCTURE, NOT PRODUCT.  Only `tests/`, `__graft_entry__.smoke()` and
+`bench.py`'s `cpu_baseline` leg may import this module; `kikuchipy_amd/` never
+does (tests/test_no_oracle_in_product.py enforces it).
+
+Parity status: PINNED.  `oracle/gen_golden.py` ran the reference's own modules
+(loaded unmodified from /root/reference by `oracle/ref_shim.py`) in the build
+container and stored their inputs/outputs in `tests/golden/*.npz`;
+`tests/test_oracle_golden.py` checks every function here against those
+vectors and against the hard-coded known answers of the reference's own test
+suite (tests/test_signals/test_ebsd.py, tests/test_pattern/test_pattern.py,
+tests/test_filters/test_fft_barnes.py, tests/test_indexing/*).
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference/src/kikuchipy unless they start with tests/).
+
+Third-party arithmetic on the path that is NOT under /root/reference and is
+restated from its published behaviour:
+* dask.array.topk/argtopk (dask 2021.10.0, dask/array/chunk.py:167-258):
+  k largest along the axis, returned in descending order; order among equal
+  values unspecified.  Restated in `topk_desc` with the engine's documented
+  tie rule (lower dictionary index first).
+* numpy.einsum("ik,mk->im") -> BLAS sgemm: restated as `exp @ dic.T`.
+* scipy.signal.windows.gaussian, scipy.fft.rfft2/irfft2/next_fast_len,
+  scipy.ndimage.gaussian_filter: called directly (SciPy is importable both in
+  the build container and on the GPU box).
+* skimage.util.dtype.dtype_range: the table `DTYPE_RANGE` below.
+"""
+
+import numpy as np
+
+# skimage/util/dtype.py `dtype_range` (used at signals/ebsd.py:523, :676)
+DTYPE_RANGE = {
+    np.dtype(np.uint8): (0, 255),
+    np.dtype(np.uint16): (0, 65535),
+    np.dtype(np.uint32): (0, 2**32 - 1),
+    np.dtype(np.int8): (-128, 127),
+    np.dtype(np.int16): (-32768, 32767),
+    np.dtype(np.int32): (-(2**31), 2**31 - 1),
+    np.dtype(np.float16): (-1, 1),
+    np.dtype(np.float32): (-1, 1),
+    np.dtype(np.float64): (-1, 1),
+}
+
+ALLOWED_DTYPES = (np.dtype(np.float32), np.dtype(np.float64))
+
+
+# --------------------------------------------------------------------------
+# a4/a5/a6: pattern preparation
+# --------------------------------------------------------------------------
+def zero_mean_normalize(patterns):
+    """indexing/similarity_metrics/_normalized_cross_correlation.py:228-233
+    (`_zero_mean_normalize_patterns_numpy`); in place on a private copy."""
+    patterns_mean = np.mean(patterns, axis=1, keepdims=True)
+    patterns -= patterns_mean
+    patterns_norm = np.sqrt(np.sum(np.square(patterns), axis=1, keepdims=True))
+    patterns /= patterns_norm
+    return patterns
+
+
+def normalize(patterns):
+    """indexing/similarity_metrics/_normalized_dot_product.py:181-194
+    (`_normalize_patterns`): L2 only, no mean subtraction."""
+    patterns_norm = np.sqrt(np.sum(np.square(patterns), axis=1))[..., np.newaxis]
+    return patterns / patterns_norm
+
+
+def check_dtype(dtype):
+    """indexing/similarity_metrics/_similarity_metric.py:244-253."""
+    dtype = np.dtype(dtype)
+    if dtype not in ALLOWED_DTYPES:
+        raise ValueError(
+            f"Data type {dtype} not among supported data types "
+            f"{[np.float32, np.float64]}"
+        )
+    return dtype
+
+
+def prepare_experimental(
+    patterns, metric="ncc", n_experimental=None, navigation_mask=None,
+    signal_mask=None, dtype=np.float32,
+):
+    """_normalized_cross_correlation.py:88-128 / _normalized_dot_product.py:80-120.
+
+    cast -> reshape (M_all, -1) -> drop rows where nav mask is True -> drop
+    columns where signal mask is True -> normalise.  (Rechunking is a Dask
+    scheduling detail with no numerical effect.)"""
+    dtype = check_dtype(dtype)
+    patterns = np.asarray(patterns).astype(dtype)
+    if n_experimental is None:
+        n_experimental = max(int(np.prod(patterns.shape[:-2])), 1)
+    patterns = patterns.reshape((n_experimental, -1))
+    if navigation_mask is not None:
+        patterns = patterns[~np.asarray(navigation_mask).ravel()]
+    if signal_mask is not None:
+        patterns = patterns[:, ~np.asarray(signal_mask).ravel()]
+    if metric == "ncc":
+        return zero_mean_normalize(patterns)
+    return normalize(patterns)
+
+
+def prepare_dictionary(patterns, metric="ncc", signal_mask=None, dtype=np.float32):
+    """_normalized_cross_correlation.py:130-159 / _normalized_dot_product.py:122-150.
+    `astype` copies, so the caller's dictionary is never mutated
+    (tests/test_indexing/test_dictionary_indexing.py:41-43)."""
+    dtype = check_dtype(dtype)
+    patterns = np.asarray(patterns)
+    patterns = patterns.reshape((patterns.shape[0], -1)).astype(dtype)
+    if signal_mask is not None:
+        patterns = patterns[:, ~np.asarray(signal_mask).ravel()]
+    if metric == "ncc":
+        return zero_mean_normalize(patterns)
+    return normalize(patterns)
+
+
+# --------------------------------------------------------------------------
+# a7/a8: match + top-k
+# --------------------------------------------------------------------------
+def match(experimental, dictionary):
+    """_normalized_cross_correlation.py:161-183: einsum("ik,mk->im") == X @ Y.T."""
+    return experimental @ dictionary.T
+
+
+def topk_desc(similarities, k):
+    """indexing/_dictionary_indexing.py:197-198 (`argtopk`/`topk`, axis=-1).
+
+    Returns (indices int64, scores) of the k largest per row, descending.  Ties:
+    lower dictionary index first (the engine's documented rule; the reference's
+    own order among equal scores is unspecified)."""
+    n = similarities.shape[1]
+    k = min(k, n)
+    # stable argsort of -score keeps lower index first among equal scores
+    order = np.argsort(-similarities, axis=1, kind="stable")[:, :k]
+    scores = np.take_along_axis(similarities, order, axis=1)
+    return order.astype(np.int64), scores
+
+
+def merge_topk(scores, indices, scores_i, indices_i, keep_n):
+    """indexing/_dictionary_indexing.py:120-128: hstack running best with the
+    chunk's best, argsort descending, keep the first `keep_n`.  Tie rule as in
+    `topk_desc` (sort key = (-score, index))."""
+    all_scores = np.hstack((scores, scores_i))
+    all_idx = np.hstack((indices, indices_i))
+    order = np.lexsort((all_idx, -all_scores), axis=1)[:, :keep_n]
+    return (
+        np.take_along_axis(all_scores, order, axis=1),
+        np.take_along_axis(all_idx, order, axis=1),
+    )
+
+
+# --------------------------------------------------------------------------
+# a9: the chunk loop
+# --------------------------------------------------------------------------
+def dictionary_indexing(
+    experimental, dictionary, metric="ncc", keep_n=20, n_per_iteration=None,
+    navigation_mask=None, signal_mask=None, dtype=np.float32,
+):
+    """indexing/_dictionary_indexing.py:36-128 on plain arrays.
+
+    experimental: (..., sy, sx); dictionary: (N, sy, sx).  Returns
+    (scores (M, k) dtype, simulation_indices (M, k) int64) for the M patterns
+    where the navigation mask is False."""
+    dictionary = np.asarray(dictionary)
+    dictionary_size = dictionary.shape[0]
+    sig = experimental.shape[-2:]
+    n_exp_all = max(int(np.prod(experimental.shape[:-2])), 1)
+    if n_per_iteration is None:
+        n_per_iteration = dictionary_size  # signals/ebsd.py:1925-1929
+    keep_n = min(keep_n, dictionary_size)  # :67
+    n_iterations = int(np.ceil(dictionary_size / n_per_iteration))  # :68
+    exp = prepare_experimental(
+        experimental, metric, n_exp_all, navigation_mask, signal_mask, dtype
+    )  # :70
+    dictionary = dictionary.reshape((dictionary_size, -1))  # :71
+    if sig[0] * sig[1] != dictionary.shape[1]:
+        raise ValueError("signal shapes differ")
+    n_exp = exp.shape[0]
+
+    if dictionary_size == n_per_iteration:  # :88-93
+        sim = match(exp, prepare_dictionary(dictionary, metric, signal_mask, dtype))
+        idx, scores = topk_desc(sim, keep_n)
+        return scores, idx
+
+    sign = 1  # both metrics: greater is better
+    indices = np.zeros((n_exp, keep_n), dtype=np.int64)  # :97 (int32 there; hstack -> int64)
+    scores = np.full((n_exp, keep_n), -sign, dtype=dtype)  # :98  -1.0 sentinel
+    starts = np.cumsum([0] + [n_per_iteration] * (n_iterations - 1))  # :102
+    ends = np.cumsum([n_per_iteration] * n_iterations)  # :103
+    ends[-1] = max(ends[-1], dictionary_size)  # :104
+    for start, end in zip(starts, ends):
+        chunk = dictionary[start:end]
+        end = min(end, dictionary_size)
+        sim = match(exp, prepare_dictionary(chunk, metric, signal_mask, dtype))
+        idx_i, scores_i = topk_desc(sim, min(keep_n, end - start))  # :110-115
+        idx_i = idx_i + start  # :118
+        scores, indices = merge_topk(scores, indices, scores_i, idx_i, keep_n)
+    return scores, indices
+
+
+def scatter_navigation_mask(scores, indices, navigation_mask, keep_n):
+    """indexing/_dictionary_indexing.py:142-158: with a navigation mask the
+    results are scattered into (M_all, k) arrays (uninitialised elsewhere in
+    the reference; zero-filled here) and `keep_n == 1` squeezes to 1-D."""
+    in_data = ~np.asarray(navigation_mask).ravel()
+    n_all = in_data.size
+    scores_all = np.zeros((n_all, keep_n), dtype=scores.dtype)
+    idx_all = np.zeros((n_all, keep_n), dtype=indices.dtype)
+    scores_all[in_data] = scores
+    idx_all[in_data] = indices
+    if keep_n == 1:
+        scores_all = scores_all.squeeze()
+        idx_all = idx_all.squeeze()
+    return scores_all, idx_all, in_data
+
+
+# --------------------------------------------------------------------------
+# a-mask / windows
+# --------------------------------------------------------------------------
+def circular_window(shape):
+    """filters/window.py:163-187, :249-269 (`Window("circular", shape)`):
+    ones, zero where the distance to origin (shape//2) exceeds max(origin)."""
+    sy, sx = shape
+    oy, ox = sy // 2, sx // 2
+    yy, xx = np.ogrid[:sy, :sx]
+    dist = np.sqrt((yy - oy) ** 2 + (xx - ox) ** 2)
+    w = np.ones(shape, dtype=np.float64)
+    w[dist > max(oy, ox)] = 0
+    return w
+
+
+def gaussian_window_1d(n, std):
+    """scipy.signal.windows.gaussian(n, std, sym=True), as reached through
+    filters/window.py:167-174 with `fftbins=False`."""
+    x = np.arange(n, dtype=np.float64) - (n - 1.0) / 2.0
+    return np.exp(-0.5 * (x / std) ** 2)
+
+
+def dynamic_background_window(std, truncate):
+    """pattern/_pattern.py:604-613: n = int(truncate*std) per axis,
+    outer(g, g) / (2 pi std^2), then / sum."""
+    n = int(truncate * std)
+    g = gaussian_window_1d(n, std)
+    w = np.outer(g, g) / (2 * np.pi * std**2)
+    w /= np.sum(w)
+    return w
+
+
+# --------------------------------------------------------------------------
+# a-pre1: rescale + static background
+# --------------------------------------------------------------------------
+def rescale_with_min_max(pattern, imin, imax, omin, omax):
+    """pattern/_pattern.py:96-111, evaluated as the `.py_func` does under
+    NumPy: float32 throughout for a float32 pattern."""
+    rescaled = (pattern - imin) / float(imax - imin)
+    return rescaled * (omax - omin) + omin
+
+
+def remove_background_subtract(pattern, background, omin, omax):
+    """pattern/_pattern.py:484-495."""
+    pattern = pattern - background
+    return rescale_with_min_max(pattern, np.min(pattern), np.max(pattern), omin, omax)
+
+
+def remove_background_divide(pattern, background, omin, omax):
+    """pattern/_pattern.py:498-509."""
+    pattern = pattern / background
+    return rescale_with_min_max(pattern, np.min(pattern), np.max(pattern), omin, omax)
+
+
+def remove_static_background(
+    patterns, static_bg, operation="subtract", scale_bg=False, dtype_out=None
+):
+    """signals/ebsd.py:518-573 + pattern/_pattern.py:392-435, per pattern.
+
+    patterns (..., sy, sx) of an integer or float dtype; static_bg (sy, sx) of
+    the SAME dtype (ebsd.py:535-539).  Output dtype = input dtype, values
+    truncated toward zero by `.astype`."""
+    patterns = np.asarray(patterns)
+    dtype_out = np.dtype(dtype_out or patterns.dtype)
+    if np.dtype(static_bg.dtype) != patterns.dtype:
+        raise ValueError(
+            f"Static background dtype_out {static_bg.dtype} is not the same as "
+            f"pattern dtype_out {patterns.dtype}"
+        )
+    if static_bg.shape != patterns.shape[-2:]:
+        raise ValueError(
+            f"Signal {patterns.shape[-2:]} and static background {static_bg.shape} "
+            "shapes are not the same"
+        )
+    omin, omax = DTYPE_RANGE[dtype_out]
+    bg0 = static_bg.astype(np.float32)
+    flat = patterns.reshape((-1,) + patterns.shape[-2:])
+    out = np.empty(flat.shape, dtype=dtype_out)
+    op = remove_background_subtract if operation == "subtract" else remove_background_divide
+    for i, p in enumerate(flat):
+        p = p.astype(np.float32)
+        bg = bg0
+        if scale_bg:
+            bg = rescale_with_min_max(
+                bg0, np.min(bg0), np.max(bg0), np.min(p), np.max(p)
+            )
+        out[i] = op(p, bg, omin, omax).astype(dtype_out)
+    return out.reshape(patterns.shape)
+
+
+# --------------------------------------------------------------------------
+# a-pre2: dynamic background
+# --------------------------------------------------------------------------
+def fft_filter_setup(image_shape, window):
+    """filters/fft_barnes.py:29-51, :99-117."""
+    from scipy.fft import next_fast_len, rfft2
+
+    wy, wx = window.shape
+    fft_shape = (
+        next_fast_len(image_shape[0] + wy - 1, real=True),
+        next_fast_len(image_shape[1] + wx - 1, real=True),
+    )
+    window_pad = np.zeros(fft_shape, dtype=np.float32)
+    window_pad[:wy, :wx] = np.flipud(np.fliplr(window))
+    transfer_function = rfft2(window_pad)
+    offset_before = (wy - ((wy - 1) // 2) - 1, wx - ((wx - 1) // 2) - 1)
+    offset_after = ((wy - 1) // 2, (wx - 1) // 2)
+    return fft_shape, transfer_function, offset_before, offset_after
+
+
+def pad_image(image, fft_shape, window_shape, offset_before_fft):
+    """filters/fft_barnes.py:119-152: edge-replicating pad laid out for a
+    circular convolution."""
+    iy, ix = image.shape
+    wy, wx = window_shape
+    fy, fx = fft_shape
+    oy, ox = offset_before_fft
+    p = np.zeros(fft_shape, dtype=np.float32)
+    p[0:iy, 0:ix] = image
+    p[iy : iy + (wy - 1) // 2, :ix] = image[-1, :]
+    p[:iy, ix : ix + (wx - 1) // 2] = np.expand_dims(image[:, -1], axis=1)
+    p[fy - oy :, :ix] = image[0, :]
+    p[:iy, fx - ox :] = np.expand_dims(image[:, 0], axis=1)
+    p[iy : iy + (wy - 1) // 2, ix : ix + (wx - 1) // 2] = image[-1, -1]
+    p[fy - oy :, ix : ix + (wx - 1) // 2] = image[0, -1]
+    p[iy : iy + (wy - 1) // 2, fx - ox :] = image[-1, 0]
+    p[fy - oy :, fx - ox :] = image[0, 0]
+    return p
+
+
+def fft_filter(image, window):
+    """filters/fft_barnes.py:155-177 (`_fft_filter`) incl. its set-up."""
+    from scipy.fft import irfft2, rfft2
+
+    fft_shape, tf, ob, oa = fft_filter_setup(image.shape, window)
+    p = pad_image(image, fft_shape, window.shape, ob)
+    res = irfft2(rfft2(p) * tf, fft_shape)
+    iy, ix = image.shape
+    return np.real(res[oa[0] : oa[0] + iy, oa[1] : oa[1] + ix])
+
+
+def correlate_nearest(image, window):
+    """What `fft_filter` computes, written as a direct sum (the form the HIP
+    kernel evaluates): out[i,j] = sum_uv W[u,v] * I[clamp(i+u-cy), clamp(j+v-cx)]
+    with c = w - 1 - (w-1)//2.  Float64 accumulate; used by the tests to bound
+    the FFT-vs-direct difference (tests/test_filters/test_fft_barnes.py:135-173
+    pins `_fft_filter` == correlation with edge replication)."""
+    iy, ix = image.shape
+    wy, wx = window.shape
+    cy, cx = wy - 1 - (wy - 1) // 2, wx - 1 - (wx - 1) // 2
+    out = np.zeros((iy, ix), dtype=np.float64)
+    img = image.astype(np.float64)
+    for u in range(wy):
+        yy = np.clip(np.arange(iy) + u - cy, 0, iy - 1)
+        for v in range(wx):
+            xx = np.clip(np.arange(ix) + v - cx, 0, ix - 1)
+            out += window[u, v] * img[np.ix_(yy, xx)]
+    return out
+
+
+def remove_dynamic_background(
+    patterns, operation="subtract", filter_domain="frequency", std=None,
+    truncate=4.0, dtype_out=None,
+):
+    """signals/ebsd.py:645-696 + pattern/_pattern.py:438-481, per pattern."""
+    patterns = np.asarray(patterns)
+    dtype_out = np.dtype(dtype_out or patterns.dtype)
+    sy, sx = patterns.shape[-2:]
+    if std is None:
+        std = sx / 8  # ebsd.py:648-649: axes_manager.signal_shape[0] = n columns
+    omin, omax = DTYPE_RANGE[dtype_out]
+    if filter_domain == "frequency":
+        window = dynamic_background_window(std, truncate)
+
+        def filt(p):
+            return fft_filter(p, window)
+
+    elif filter_domain == "spatial":
+        from scipy.ndimage import gaussian_filter
+
+        def filt(p):
+            return gaussian_filter(p, sigma=std, truncate=truncate)
+
+    else:
+        raise ValueError(
+            f"{filter_domain} must be either of ['frequency', 'spatial']"
+        )
+    flat = patterns.reshape((-1, sy, sx))
+    out = np.empty(flat.shape, dtype=dtype_out)
+    op = remove_background_subtract if operation == "subtract" else remove_background_divide
+    for i, p in enumerate(flat):
+        p = p.astype(np.float32)
+        out[i] = op(p, filt(p), omin, omax).astype(dtype_out)
+    return out.reshape(patterns.shape)
+
+
+# --------------------------------------------------------------------------
+# comparison helper shared by the parity tests
+# --------------------------------------------------------------------------
+def assert_topk_parity(scores, indices, ref_scores, ref_indices, atol=1e-5, tie=2e-5):
+    """The parity contract of SURVEY.md section 8(a):
+
+    * |score - ref_score| <= atol element-wise,
+    * scores non-increasing along k,
+    * indices equal wherever the reference's neighbouring scores are more than
+      `tie` apart; inside a group of near-tied reference scores the index SETS
+      must agree (order inside a tie is unspecified in the reference).  A
+      group that touches the k-th place may differ in membership (the
+      (k+1)-th candidate is not visible), so there only the scores are
+      compared."""
+    scores = np.asarray(scores, dtype=np.float64)
+    ref_scores = np.asarray(ref_scores, dtype=np.float64)
+    assert scores.shape == ref_scores.shape, (scores.shape, ref_scores.shape)
+    assert indices.shape == ref_indices.shape
+    err = np.abs(scores - ref_scores)
+    assert np.all(err <= atol), f"max score error {err.max():.3e} > {atol}"
+    assert np.all(np.diff(scores, axis=1) <= 0), "scores not sorted descending"
+    k = scores.shape[1]
+    for m in np.nonzero(np.any(indices != ref_indices, axis=1))[0]:
+        rs = ref_scores[m]
+        # split into groups of near-tied neighbours
+        breaks = np.nonzero(-np.diff(rs) > tie)[0] + 1
+        groups = np.split(np.arange(k), breaks)
+        for g in groups:
+            if g[-1] == k - 1:
+                continue  # open-ended group: membership not decidable
+            assert set(indices[m, g]) == set(ref_indices[m, g]), (
+                f"row {m}: indices {indices[m, g]} vs reference {ref_indices[m, g]}"
+            )

@@ -1,0 +1,218 @@
+"""Load the reference's hot-path modules, unmodified, in THIS container only.
+
+TEST INFRASTRUCTURE - never imported by the product (kikuchipy_amd/).
+
+`import kikuchipy` is impossible here (no hyperspy/orix/numba/lazy_loader), but
+the modules on the dictionary-indexing path only need numpy/dask/scipy.  This
+shim (the recipe of SURVEY.md Appendix A) stubs the four things that are
+missing and loads each module BY FILE from /root/reference, so the code that
+runs is the reference's own:
+
+1. `numba` stub: `njit` returns the undecorated function (== the `.py_func`
+   the reference's own tests compare against, tests/test_pattern/test_pattern.py:169).
+2. `orix` stub: `CrystalMap`/`Rotation` record their arguments, so
+   `_dictionary_indexing()` (indexing/_dictionary_indexing.py:36) runs to the
+   end and hands back the `prop` dict with `scores` and `simulation_indices`.
+3. namespace-package stubs for `kikuchipy.*` so the packages' `__init__`
+   (lazy_loader, hyperspy) never run but intra-package imports resolve.
+4. a loader that compiles with postponed annotations (`X | Y` in signatures
+   is illegal at def time on Python 3.9).
+
+Must be run with /opt/conda/bin/python3.9 (numpy 1.26.4, dask 2021.10.0,
+scipy 1.7.1, h5py 3.3.0): inside the reference's supported range
+(pyproject.toml:44).  It reads /root/reference, so it can NOT run on the GPU
+box; only its outputs (tests/golden/*.npz) travel.
+"""
+
+import __future__
+
+import importlib.machinery
+import importlib.util
+import os
+import sys
+import types
+
+REF_ROOT = os.environ.get("KPDI_REFERENCE_ROOT", "/root/reference")
+SRC = os.path.join(REF_ROOT, "src", "kikuchipy")
+
+
+class _PostponedLoader(importlib.machinery.SourceFileLoader):
+    def source_to_code(self, data, path, *, _optimize=-1):
+        return compile(
+            data,
+            path,
+            "exec",
+            flags=__future__.annotations.compiler_flag,
+            dont_inherit=True,
+        )
+
+
+def _stub_numba():
+    nb = types.ModuleType("numba")
+
+    def njit(*args, **kwargs):
+        if len(args) == 1 and callable(args[0]) and not kwargs:
+            f = args[0]
+            f.py_func = f
+            return f
+
+        def deco(f):
+            f.py_func = f
+            return f
+
+        return deco
+
+    nb.njit = njit
+    nb.jit = njit
+    sys.modules["numba"] = nb
+
+
+class _Recorder:
+    """Stands in for orix CrystalMap / Rotation: records what it was given."""
+
+    def __init__(self, *args, **kwargs):
+        self.args = args
+        self.kw = kwargs
+
+    @classmethod
+    def identity(cls, shape):
+        return cls(identity=shape)
+
+    def __getitem__(self, item):
+        return _Recorder(parent=self, item=item)
+
+    def __setitem__(self, key, value):
+        self.kw.setdefault("set", []).append((key, value))
+
+    @property
+    def data(self):
+        return self
+
+    def flatten(self):
+        return self
+
+
+def _stub_orix():
+    orix = types.ModuleType("orix")
+    cm = types.ModuleType("orix.crystal_map")
+    qu = types.ModuleType("orix.quaternion")
+    cm.CrystalMap = _Recorder
+    cm.create_coordinate_arrays = lambda shape, step_sizes=None: ({}, None)
+    qu.Rotation = _Recorder
+    orix.crystal_map = cm
+    orix.quaternion = qu
+    sys.modules["orix"] = orix
+    sys.modules["orix.crystal_map"] = cm
+    sys.modules["orix.quaternion"] = qu
+
+
+def _stub_tqdm():
+    try:
+        import tqdm  # noqa: F401
+    except ImportError:
+        t = types.ModuleType("tqdm")
+        t.tqdm = lambda it, **kw: it
+        sys.modules["tqdm"] = t
+
+
+def _stub_skimage():
+    # pattern/_pattern.py imports dtype_range from skimage.util.dtype; the conda
+    # env has skimage 0.18.3, keep the real one if importable.
+    try:
+        from skimage.util.dtype import dtype_range  # noqa: F401
+    except Exception:
+        import numpy as np
+
+        sk = types.ModuleType("skimage")
+        sku = types.ModuleType("skimage.util")
+        skd = types.ModuleType("skimage.util.dtype")
+        skd.dtype_range = {
+            bool: (False, True),
+            np.bool_: (False, True),
+            float: (-1, 1),
+            np.float16: (-1, 1),
+            np.float32: (-1, 1),
+            np.float64: (-1, 1),
+            np.uint8: (0, 255),
+            np.uint16: (0, 65535),
+            np.uint32: (0, 2**32 - 1),
+            np.int8: (-128, 127),
+            np.int16: (-32768, 32767),
+            np.int32: (-(2**31), 2**31 - 1),
+        }
+        sys.modules["skimage"] = sk
+        sys.modules["skimage.util"] = sku
+        sys.modules["skimage.util.dtype"] = skd
+
+
+def _ns(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    sys.modules[name] = m
+    return m
+
+
+def _load(fullname, relpath):
+    path = os.path.join(SRC, relpath)
+    loader = _PostponedLoader(fullname, path)
+    spec = importlib.util.spec_from_file_location(fullname, path, loader=loader)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[fullname] = mod
+    loader.exec_module(mod)
+    return mod
+
+
+_loaded = {}
+
+
+def load_reference():
+    """Return a dict of the reference's hot-path modules."""
+    if _loaded:
+        return _loaded
+    _stub_numba()
+    _stub_orix()
+    _stub_tqdm()
+    _stub_skimage()
+    _ns("kikuchipy", SRC)
+    _ns("kikuchipy.indexing", os.path.join(SRC, "indexing"))
+    _ns(
+        "kikuchipy.indexing.similarity_metrics",
+        os.path.join(SRC, "indexing", "similarity_metrics"),
+    )
+    _ns("kikuchipy.filters", os.path.join(SRC, "filters"))
+    _ns("kikuchipy.pattern", os.path.join(SRC, "pattern"))
+
+    sm = "kikuchipy.indexing.similarity_metrics."
+    _loaded["similarity_metric"] = _load(
+        sm + "_similarity_metric", "indexing/similarity_metrics/_similarity_metric.py"
+    )
+    _loaded["ncc"] = _load(
+        sm + "_normalized_cross_correlation",
+        "indexing/similarity_metrics/_normalized_cross_correlation.py",
+    )
+    _loaded["ndp"] = _load(
+        sm + "_normalized_dot_product",
+        "indexing/similarity_metrics/_normalized_dot_product.py",
+    )
+    _loaded["di"] = _load(
+        "kikuchipy.indexing._dictionary_indexing", "indexing/_dictionary_indexing.py"
+    )
+    _loaded["window"] = _load("kikuchipy.filters.window", "filters/window.py")
+    # filters/__init__ re-exports Window; pattern/_pattern.py imports
+    # `from kikuchipy.filters.window import Window` and fft_barnes helpers.
+    sys.modules["kikuchipy.filters"].Window = _loaded["window"].Window
+    _loaded["fft_barnes"] = _load("kikuchipy.filters.fft_barnes", "filters/fft_barnes.py")
+    _loaded["pattern"] = _load("kikuchipy.pattern._pattern", "pattern/_pattern.py")
+    return _loaded
+
+
+class FakeDictionaryXmap:
+    """What `_dictionary_indexing` touches on `dictionary_xmap`
+    (indexing/_dictionary_indexing.py:79, :162-166)."""
+
+    class _Phases:
+        names = ["ni"]
+
+    phases = _Phases()
+    phases_in_data = None
+    rotations = _Recorder()
