@@ -1,0 +1,171 @@
+/* kpdi.h - C ABI of libkpdi.so, the MI355X (gfx950) dictionary-indexing engine.
+ *
+ * This is the drop-in boundary for ONE path of kikuchipy (reference =
+ * /root/reference, paths below relative to its src/kikuchipy/):
+ *
+ *   EBSD.dictionary_indexing()            signals/ebsd.py:1827-1984
+ *     -> _dictionary_indexing()           indexing/_dictionary_indexing.py:36-169
+ *        -> SimilarityMetric.prepare_*()  indexing/similarity_metrics/_normalized_cross_correlation.py:88-159
+ *                                         indexing/similarity_metrics/_normalized_dot_product.py:80-194
+ *        -> SimilarityMetric.match()      ..._normalized_cross_correlation.py:161-183
+ *        -> argtopk/topk + merge          indexing/_dictionary_indexing.py:172-203, :94-128
+ *   EBSD.remove_static_background()       signals/ebsd.py:442-573   + pattern/_pattern.py:392-435, :484-509, :96-111
+ *   EBSD.remove_dynamic_background()      signals/ebsd.py:575-696   + pattern/_pattern.py:438-481, :604-631,
+ *                                         filters/fft_barnes.py:29-177
+ *
+ * The reference has no FFI for this path (it is pure Python + NumPy/Dask/Numba);
+ * these entry points are what a ctypes binding inside a kikuchipy
+ * `SimilarityMetric` subclass calls (INTEGRATION.md shows that binding).
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no C++ or torch types; every function returns
+ *    0 on success or a negative KPDI_E* code, and kpdi_last_error() returns
+ *    the message for the calling thread's last failure.
+ *  - one context = one GPU = one HIP stream; one OS thread drives a context.
+ *  - the caller owns all host buffers; the library owns all device buffers.
+ *  - host inputs are never modified (tests/test_indexing/test_dictionary_indexing.py:41-43).
+ *  - masks follow the reference: nonzero = EXCLUDED (similarity_metrics/_similarity_metric.py:51-58).
+ *  - there is no CPU fallback: without a usable GPU kpdi_create() fails.
+ */
+#ifndef KPDI_H
+#define KPDI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kpdi_ctx kpdi_ctx;
+
+/* error codes */
+#define KPDI_OK 0
+#define KPDI_EINVAL (-1)  /* bad argument / call order */
+#define KPDI_EHIP (-2)    /* HIP runtime error */
+#define KPDI_ENODEV (-3)  /* no usable GPU */
+#define KPDI_ECOMM (-4)   /* RCCL error */
+#define KPDI_ENOMEM (-5)
+
+/* similarity metric: "ncc" / "ndp" of EBSD._prepare_metric (signals/ebsd.py:3058-3061) */
+#define KPDI_METRIC_NCC 0 /* zero-mean + L2 normalise, then dot product */
+#define KPDI_METRIC_NDP 1 /* L2 normalise only, then dot product */
+
+/* element type of a pattern array handed to the library */
+#define KPDI_U8 0
+#define KPDI_U16 1
+#define KPDI_F32 2
+#define KPDI_F64 3
+#define KPDI_I8 4
+#define KPDI_I16 5
+#define KPDI_I32 6
+#define KPDI_U32 7
+
+/* arithmetic of the match kernel */
+#define KPDI_COMPUTE_F32 0 /* exact f32 MFMA (v_mfma_f32_32x32x2_f32), f32 accumulate */
+
+/* background operations (`operation=` of remove_*_background) */
+#define KPDI_OP_SUBTRACT 0
+#define KPDI_OP_DIVIDE 1
+/* `filter_domain=` of remove_dynamic_background (signals/ebsd.py:652-672) */
+#define KPDI_DOMAIN_FREQUENCY 0 /* Barnes FFT filter == edge-replicating correlation */
+#define KPDI_DOMAIN_SPATIAL 1   /* scipy.ndimage.gaussian_filter (reflect boundary) */
+
+/* ---- library / device ---------------------------------------------------- */
+const char *kpdi_version(void);
+int kpdi_device_count(void);
+const char *kpdi_last_error(void);
+
+int kpdi_create(int device_id, kpdi_ctx **out);
+int kpdi_destroy(kpdi_ctx *ctx);
+int kpdi_synchronize(kpdi_ctx *ctx);
+
+/* ---- problem set-up -------------------------------------------------------
+ * Fixes what SimilarityMetric carries (similarity_metrics/_similarity_metric.py:69-86):
+ * detector shape, signal mask (sy*sx bytes or NULL), metric and keep_n
+ * (`keep_n = min(keep_n, dictionary_size)` is the caller's job,
+ * indexing/_dictionary_indexing.py:67).  Resets the running top-k. */
+int kpdi_set_problem(kpdi_ctx *ctx, int sy, int sx, const uint8_t *signal_mask,
+                     int metric, int compute_dtype, int keep_n);
+
+/* ---- experimental patterns (prepare_experimental, ..._cross_correlation.py:88-128)
+ * `patterns`: m_all x sy x sx, C order, HOST memory.  `nav_mask`: m_all bytes or
+ * NULL.  Uploads the raw patterns; they stay resident (and can be pre-processed
+ * in place with kpdi_remove_*_background) until the first dictionary chunk is
+ * pushed, when they are cast/masked/normalised once into the K-padded f32
+ * matrix the match kernel reads. */
+int kpdi_set_experimental(kpdi_ctx *ctx, const void *patterns, int dtype,
+                          int64_t m_all, const uint8_t *nav_mask);
+/* same, `patterns` already in DEVICE memory (copied device-to-device) */
+int kpdi_set_experimental_dev(kpdi_ctx *ctx, const void *d_patterns, int dtype,
+                              int64_t m_all, const uint8_t *nav_mask);
+/* number of patterns that will be matched (nav mask applied) */
+int64_t kpdi_n_experimental(kpdi_ctx *ctx);
+
+/* ---- pre-processing of the resident experimental patterns -------------------
+ * remove_static_background: pattern/_pattern.py:392-435 (+ :484-509, :96-111).
+ * `static_bg`: sy*sx float32 (the caller did `static_bg.astype(float32)`,
+ * signals/ebsd.py:547).  Output keeps the input dtype, truncated like `.astype`. */
+int kpdi_remove_static_background(kpdi_ctx *ctx, const float *static_bg,
+                                  int operation, int scale_bg);
+/* remove_dynamic_background: pattern/_pattern.py:438-481; std <= 0 selects the
+ * reference default sx/8 (signals/ebsd.py:648-649). */
+int kpdi_remove_dynamic_background(kpdi_ctx *ctx, int operation, int filter_domain,
+                                   double std, double truncate);
+/* copy the (pre-processed) resident patterns back: m_all*sy*sx elements of the
+ * dtype given to kpdi_set_experimental */
+int kpdi_get_experimental(kpdi_ctx *ctx, void *patterns_out);
+
+/* ---- dictionary sweep (_dictionary_indexing loop, indexing/_dictionary_indexing.py:94-128)
+ * One call = one loop iteration: prepare_dictionary (cast, mask, normalise) +
+ * match + top-k of the chunk + merge into the running best-k, all on the GPU.
+ * `global_start` is the dictionary index of the chunk's first pattern
+ * (`simulation_indices_i += start`, :118).  Chunks may arrive in any order and,
+ * with several ranks, each rank pushes only its own shard. */
+int kpdi_push_dictionary_chunk(kpdi_ctx *ctx, const void *patterns, int dtype,
+                               int64_t n_chunk, int64_t global_start);
+int kpdi_push_dictionary_chunk_dev(kpdi_ctx *ctx, const void *d_patterns, int dtype,
+                                   int64_t n_chunk, int64_t global_start);
+/* forget the running best-k (start another sweep over the same experimental set) */
+int kpdi_reset_topk(kpdi_ctx *ctx);
+/* scores: M x keep_n float32, descending; indices: M x keep_n int64 (the
+ * reference's `simulation_indices` end up int64).  Ties: lower
+ * dictionary index first.  With a communicator (kpdi_comm_init) every rank first
+ * all-gathers the per-shard lists over RCCL and merges them, so all ranks get
+ * the same, global result. */
+int kpdi_finalize(kpdi_ctx *ctx, float *scores_out, int64_t *indices_out);
+
+/* ---- multi-GPU: dictionary sharded over ranks, one process per GPU -------- */
+#define KPDI_UNIQUE_ID_BYTES 128
+int kpdi_comm_unique_id(uint8_t *id_out /* KPDI_UNIQUE_ID_BYTES */);
+int kpdi_comm_init(kpdi_ctx *ctx, int rank, int nranks, const uint8_t *id);
+
+/* ---- device buffers for callers that keep data resident (bench.py) -------- */
+int kpdi_dev_alloc(kpdi_ctx *ctx, size_t bytes, void **d_out);
+int kpdi_dev_free(kpdi_ctx *ctx, void *d_ptr);
+int kpdi_h2d(kpdi_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int kpdi_d2h(kpdi_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+
+/* ---- measurement ------------------------------------------------------------
+ * With profiling on, every match-kernel launch is bracketed by HIP events on
+ * the context's stream; kpdi_get_counters() synchronises and sums them. */
+typedef struct kpdi_counters {
+  double match_ms;      /* sum of match-kernel durations (HIP events) */
+  int64_t match_launches;
+  double match_flops;   /* 2 * M * n_chunk * K summed over launches (K = kept pixels) */
+  double prep_ms;       /* dictionary + experimental normalisation kernels */
+  double merge_ms;      /* top-k merge kernels */
+  double h2d_bytes;     /* bytes copied host->device by push/set calls */
+  int32_t match_grid;   /* workgroups of the last match launch */
+  int32_t match_nsplit; /* dictionary splits of the last match launch */
+  int32_t kpad;         /* padded reduction length */
+  int32_t k_kept;       /* kept pixels K */
+} kpdi_counters;
+int kpdi_set_profiling(kpdi_ctx *ctx, int on);
+int kpdi_get_counters(kpdi_ctx *ctx, kpdi_counters *out);
+int kpdi_reset_counters(kpdi_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KPDI_H */

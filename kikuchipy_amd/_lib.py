@@ -1,0 +1,276 @@
+"""ctypes binding of libkpdi.so (include/kpdi.h) - no PyTorch, no NumPy C-API.
+
+The library is built in-tree by `make -C kikuchipy_amd/csrc` (or
+`__graft_entry__.build()`).  There is no CPU fallback anywhere in this
+package: if the library is missing, or no gfx950 GPU is visible, calls raise.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libkpdi.so")
+
+METRIC_NCC, METRIC_NDP = 0, 1
+COMPUTE_F32 = 0
+OP_SUBTRACT, OP_DIVIDE = 0, 1
+DOMAIN_FREQUENCY, DOMAIN_SPATIAL = 0, 1
+UNIQUE_ID_BYTES = 128
+
+DTYPE_CODES = {
+    np.dtype(np.uint8): 0,
+    np.dtype(np.uint16): 1,
+    np.dtype(np.float32): 2,
+    np.dtype(np.float64): 3,
+    np.dtype(np.int8): 4,
+    np.dtype(np.int16): 5,
+    np.dtype(np.int32): 6,
+    np.dtype(np.uint32): 7,
+}
+
+
+class KpdiError(RuntimeError):
+    """A libkpdi call failed (message from kpdi_last_error())."""
+
+
+class Counters(C.Structure):
+    _fields_ = [
+        ("match_ms", C.c_double),
+        ("match_launches", C.c_int64),
+        ("match_flops", C.c_double),
+        ("prep_ms", C.c_double),
+        ("merge_ms", C.c_double),
+        ("h2d_bytes", C.c_double),
+        ("match_grid", C.c_int32),
+        ("match_nsplit", C.c_int32),
+        ("kpad", C.c_int32),
+        ("k_kept", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+# every symbol include/kpdi.h declares: (restype, argtypes)
+_vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+SIGNATURES = {
+    "kpdi_version": (C.c_char_p, []),
+    "kpdi_device_count": (_i, []),
+    "kpdi_last_error": (C.c_char_p, []),
+    "kpdi_create": (_i, [_i, C.POINTER(_vp)]),
+    "kpdi_destroy": (_i, [_vp]),
+    "kpdi_synchronize": (_i, [_vp]),
+    "kpdi_set_problem": (_i, [_vp, _i, _i, _vp, _i, _i, _i]),
+    "kpdi_set_experimental": (_i, [_vp, _vp, _i, _i64, _vp]),
+    "kpdi_set_experimental_dev": (_i, [_vp, _vp, _i, _i64, _vp]),
+    "kpdi_n_experimental": (_i64, [_vp]),
+    "kpdi_remove_static_background": (_i, [_vp, _vp, _i, _i]),
+    "kpdi_remove_dynamic_background": (_i, [_vp, _i, _i, C.c_double, C.c_double]),
+    "kpdi_get_experimental": (_i, [_vp, _vp]),
+    "kpdi_push_dictionary_chunk": (_i, [_vp, _vp, _i, _i64, _i64]),
+    "kpdi_push_dictionary_chunk_dev": (_i, [_vp, _vp, _i, _i64, _i64]),
+    "kpdi_reset_topk": (_i, [_vp]),
+    "kpdi_finalize": (_i, [_vp, _vp, _vp]),
+    "kpdi_comm_unique_id": (_i, [_vp]),
+    "kpdi_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "kpdi_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "kpdi_dev_free": (_i, [_vp, _vp]),
+    "kpdi_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "kpdi_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "kpdi_set_profiling": (_i, [_vp, _i]),
+    "kpdi_get_counters": (_i, [_vp, C.POINTER(Counters)]),
+    "kpdi_reset_counters": (_i, [_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libkpdi.so once; raise (never fall back) when it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KpdiError(
+                f"{LIB_PATH} not found: build it with `make -C kikuchipy_amd/csrc` "
+                "(python -c 'import __graft_entry__ as g; g.build()'). kikuchipy_amd has no "
+                "CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return (load().kpdi_last_error() or b"").decode()
+
+
+def check(rc):
+    if rc != 0:
+        raise KpdiError(f"libkpdi error {rc}: {last_error()}")
+
+
+def device_count():
+    return int(load().kpdi_device_count())
+
+
+def version():
+    return load().kpdi_version().decode()
+
+
+def dtype_code(dtype):
+    try:
+        return DTYPE_CODES[np.dtype(dtype)]
+    except KeyError:
+        raise KpdiError(f"pattern dtype {np.dtype(dtype)} is not supported by libkpdi") from None
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _mask_bytes(mask):
+    if mask is None:
+        return None
+    return np.ascontiguousarray(np.asarray(mask).ravel().astype(np.uint8))
+
+
+class Context:
+    """One GPU, one stream: thin object wrapper over a `kpdi_ctx*`."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(load().kpdi_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+        self._keep = {}  # host arrays the library may still be reading
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            load().kpdi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def synchronize(self):
+        check(load().kpdi_synchronize(self._h))
+
+    # -- set-up
+    def set_problem(self, sy, sx, signal_mask=None, metric=METRIC_NCC, keep_n=20):
+        sm = _mask_bytes(signal_mask)
+        if sm is not None and sm.size != sy * sx:
+            raise KpdiError(f"signal mask has {sm.size} elements, detector has {sy * sx}")
+        check(load().kpdi_set_problem(self._h, int(sy), int(sx), _ptr(sm), int(metric), COMPUTE_F32,
+                                      int(keep_n)))
+
+    def set_experimental(self, patterns, navigation_mask=None):
+        """patterns: (m_all, sy, sx) or (m_all, sy*sx), C-contiguous."""
+        p = np.ascontiguousarray(patterns)
+        nm = _mask_bytes(navigation_mask)
+        m_all = p.shape[0]
+        if nm is not None and nm.size != m_all:
+            raise KpdiError(f"navigation mask has {nm.size} elements, there are {m_all} patterns")
+        check(load().kpdi_set_experimental(self._h, _ptr(p), dtype_code(p.dtype), m_all, _ptr(nm)))
+        check(load().kpdi_synchronize(self._h))  # upload done: `p` may be a temporary
+        self._exp_shape, self._exp_dtype = p.shape, p.dtype
+
+    def set_experimental_dev(self, d_ptr, dtype, m_all, navigation_mask=None):
+        nm = _mask_bytes(navigation_mask)
+        check(load().kpdi_set_experimental_dev(self._h, C.c_void_p(d_ptr), dtype_code(dtype), int(m_all),
+                                               _ptr(nm)))
+
+    @property
+    def n_experimental(self):
+        return int(load().kpdi_n_experimental(self._h))
+
+    # -- pre-processing
+    def remove_static_background(self, static_bg_f32, operation=OP_SUBTRACT, scale_bg=False):
+        bg = np.ascontiguousarray(static_bg_f32, dtype=np.float32)
+        check(load().kpdi_remove_static_background(self._h, _ptr(bg), int(operation), int(bool(scale_bg))))
+
+    def remove_dynamic_background(self, operation=OP_SUBTRACT, filter_domain=DOMAIN_FREQUENCY, std=0.0,
+                                  truncate=4.0):
+        check(load().kpdi_remove_dynamic_background(self._h, int(operation), int(filter_domain),
+                                                    float(std), float(truncate)))
+
+    def get_experimental(self):
+        out = np.empty(self._exp_shape, dtype=self._exp_dtype)
+        check(load().kpdi_get_experimental(self._h, _ptr(out)))
+        return out
+
+    # -- sweep
+    def push_dictionary_chunk(self, patterns, global_start):
+        p = np.ascontiguousarray(patterns)
+        check(load().kpdi_push_dictionary_chunk(self._h, _ptr(p), dtype_code(p.dtype), p.shape[0],
+                                                int(global_start)))
+        check(load().kpdi_synchronize(self._h))  # the H2D copy has consumed `p`
+
+    def push_dictionary_chunk_dev(self, d_ptr, dtype, n_chunk, global_start):
+        check(load().kpdi_push_dictionary_chunk_dev(self._h, C.c_void_p(d_ptr), dtype_code(dtype),
+                                                    int(n_chunk), int(global_start)))
+
+    def reset_topk(self):
+        check(load().kpdi_reset_topk(self._h))
+
+    def finalize(self, keep_n):
+        m = self.n_experimental
+        scores = np.empty((m, keep_n), dtype=np.float32)
+        indices = np.empty((m, keep_n), dtype=np.int64)
+        check(load().kpdi_finalize(self._h, _ptr(scores), _ptr(indices)))
+        return scores, indices
+
+    # -- multi-GPU
+    @staticmethod
+    def comm_unique_id():
+        buf = np.zeros(UNIQUE_ID_BYTES, dtype=np.uint8)
+        check(load().kpdi_comm_unique_id(_ptr(buf)))
+        return buf.tobytes()
+
+    def comm_init(self, rank, nranks, unique_id):
+        buf = np.frombuffer(unique_id, dtype=np.uint8).copy()
+        if buf.size != UNIQUE_ID_BYTES:
+            raise KpdiError("unique id must be 128 bytes")
+        check(load().kpdi_comm_init(self._h, int(rank), int(nranks), _ptr(buf)))
+
+    # -- device buffers
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        check(load().kpdi_dev_alloc(self._h, int(nbytes), C.byref(p)))
+        return p.value
+
+    def dev_free(self, d_ptr):
+        check(load().kpdi_dev_free(self._h, C.c_void_p(d_ptr)))
+
+    def h2d(self, d_ptr, array):
+        a = np.ascontiguousarray(array)
+        check(load().kpdi_h2d(self._h, C.c_void_p(d_ptr), _ptr(a), a.nbytes))
+
+    def d2h(self, array, d_ptr):
+        check(load().kpdi_d2h(self._h, _ptr(array), C.c_void_p(d_ptr), array.nbytes))
+
+    # -- measurement
+    def set_profiling(self, on=True):
+        check(load().kpdi_set_profiling(self._h, int(bool(on))))
+
+    def counters(self):
+        c = Counters()
+        check(load().kpdi_get_counters(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def reset_counters(self):
+        check(load().kpdi_reset_counters(self._h))

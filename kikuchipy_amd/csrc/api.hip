@@ -1,0 +1,851 @@
+// api.hip - host side of libkpdi.so: the C ABI of include/kpdi.h on top of the
+// kernels in prep.hip / match.hip / merge.hip / preproc.hip.
+//
+// What one context holds (all in the HBM of ONE MI355X):
+//   raw experimental patterns (m_all x npix, caller's dtype)      - pre-processed in place
+//   prepared experimental matrix X (m_pad x kpad f32)             - built once per set
+//   raw + prepared dictionary chunk Y (n_pad x kpad f32)          - rebuilt per chunk
+//   per-lane partial lists of the match kernel                    - [m_pad][2*nsplit][len]
+//   running best-k (m x k: f32 score, i32 dictionary index)       - ping-pong pair
+// The running best-k is the whole state of the sweep, exactly as in the
+// reference's loop (indexing/_dictionary_indexing.py:97-98).
+#include "../../include/kpdi.h"
+#include "kernels.h"
+
+#include <dlfcn.h>
+#include <limits.h>
+#include <math.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail(KPDI_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) {
+      hipError_t e = hipFree(p);
+      p = nullptr;
+      cap = 0;
+      if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T *as() const { return (T *)p; }
+};
+
+struct Rccl {
+  void *lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool load() {
+    if (lib) return true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+      lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib) return false;
+#define KPDI_SYM(field, name)                        \
+  field = (decltype(field))dlsym(lib, name);         \
+  if (!field) return false;
+    KPDI_SYM(GetUniqueId, "ncclGetUniqueId")
+    KPDI_SYM(CommInitRank, "ncclCommInitRank")
+    KPDI_SYM(CommDestroy, "ncclCommDestroy")
+    KPDI_SYM(AllGather, "ncclAllGather")
+    KPDI_SYM(GroupStart, "ncclGroupStart")
+    KPDI_SYM(GroupEnd, "ncclGroupEnd")
+    KPDI_SYM(GetErrorString, "ncclGetErrorString")
+#undef KPDI_SYM
+    return true;
+  }
+};
+Rccl g_rccl;
+
+}  // namespace
+
+struct kpdi_ctx {
+  int device = 0;
+  int n_cu = 256;
+  hipStream_t stream = nullptr;
+
+  // problem
+  bool have_problem = false;
+  int sy = 0, sx = 0, npix = 0;
+  int k_kept = 0, kpad = 0;
+  bool have_sig_mask = false;
+  DevBuf pix_map;  // int[k_kept]
+  int metric = KPDI_METRIC_NCC;
+  int keep_n = 0;
+
+  // experimental
+  bool have_exp = false, exp_prepared = false;
+  int exp_dtype = KPDI_U8;
+  int64_t m_all = 0;
+  int m = 0, m_pad = 0;
+  bool have_nav_mask = false;
+  DevBuf exp_raw, row_map, exp_x;
+
+  // dictionary chunk
+  DevBuf dict_raw, dict_y;
+
+  // top-k state
+  DevBuf part_s, part_i;       // partial lists of one match launch
+  DevBuf run_s[2], run_i[2];   // running best-k ping-pong
+  int run_cur = 0;
+  bool run_valid = false;
+  DevBuf loc_s, loc_i, bound_s, bound_i;  // multi-pass (keep_n > 32)
+  DevBuf gather_s, gather_i;              // RCCL all-gather target
+
+  // pre-processing scratch
+  DevBuf bg, taps;
+
+  // comm
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+
+  // measurement
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_match, ev_prep, ev_merge;
+  std::vector<hipEvent_t> ev_pool;
+  kpdi_counters cnt{};
+
+  hipEvent_t get_event() {
+    if (!ev_pool.empty()) {
+      hipEvent_t e = ev_pool.back();
+      ev_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+};
+
+namespace {
+
+struct ScopedTimer {
+  kpdi_ctx *c;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> *list;
+  hipEvent_t a = nullptr, b = nullptr;
+  ScopedTimer(kpdi_ctx *ctx, std::vector<std::pair<hipEvent_t, hipEvent_t>> *l) : c(ctx), list(l) {
+    if (c->profiling) {
+      a = c->get_event();
+      b = c->get_event();
+      (void)hipEventRecord(a, c->stream);
+    }
+  }
+  ~ScopedTimer() {
+    if (c->profiling) {
+      (void)hipEventRecord(b, c->stream);
+      list->push_back({a, b});
+    }
+  }
+};
+
+int drain_events(kpdi_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> &list, double *ms_sum) {
+  for (auto &pr : list) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+    *ms_sum += ms;
+    c->ev_pool.push_back(pr.first);
+    c->ev_pool.push_back(pr.second);
+  }
+  list.clear();
+  return KPDI_OK;
+}
+
+void dtype_range(int dtype, float *omin, float *omax) {
+  // skimage.util.dtype.dtype_range, as used at signals/ebsd.py:523 and :676
+  switch (dtype) {
+    case KPDI_U8: *omin = 0.f; *omax = 255.f; break;
+    case KPDI_U16: *omin = 0.f; *omax = 65535.f; break;
+    case KPDI_I8: *omin = -128.f; *omax = 127.f; break;
+    case KPDI_I16: *omin = -32768.f; *omax = 32767.f; break;
+    default: *omin = -1.f; *omax = 1.f; break;  // float32 / float64
+  }
+}
+
+int use_device(kpdi_ctx *c) {
+  HIPCHK(hipSetDevice(c->device));
+  return KPDI_OK;
+}
+
+int choose_nsplit(const kpdi_ctx *c, int row_blocks, int n_tiles) {
+  // fill every CU with match_blocks_per_cu() workgroups; keep nsplit a multiple
+  // of 8 so that the workgroups of one XCD (block id % 8) share dictionary slabs
+  const int target = c->n_cu * kpdi::match_blocks_per_cu();
+  int ns = (target + row_blocks - 1) / row_blocks;
+  if (ns >= 8) ns = ((ns + 7) / 8) * 8;
+  ns = std::max(1, std::min(ns, n_tiles));
+  return ns;
+}
+
+int prepare_experimental(kpdi_ctx *c) {
+  if (c->exp_prepared) return KPDI_OK;
+  if (!c->have_exp) return fail(KPDI_EINVAL, "no experimental patterns set");
+  if (!c->have_problem) return fail(KPDI_EINVAL, "kpdi_set_problem has not been called");
+  HIPCHK(c->exp_x.reserve((size_t)c->m_pad * c->kpad * sizeof(float)));
+  HIPCHK(hipMemsetAsync(c->exp_x.p, 0, (size_t)c->m_pad * c->kpad * sizeof(float), c->stream));
+  kpdi::PrepLaunch p;
+  p.raw = c->exp_raw.p;
+  p.dtype = c->exp_dtype;
+  p.npix = c->npix;
+  p.row_map = c->have_nav_mask ? c->row_map.as<int>() : nullptr;
+  p.pix_map = c->have_sig_mask ? c->pix_map.as<int>() : nullptr;
+  p.k = c->k_kept;
+  p.kpad = c->kpad;
+  p.n_out = c->m;
+  p.metric = c->metric;
+  p.out = c->exp_x.as<float>();
+  {
+    ScopedTimer t(c, &c->ev_prep);
+    HIPCHK(kpdi::launch_prep(p, c->stream));
+  }
+  c->exp_prepared = true;
+  return KPDI_OK;
+}
+
+int ensure_running(kpdi_ctx *c) {
+  if (c->run_valid) return KPDI_OK;
+  const size_t n = (size_t)c->m * c->keep_n;
+  for (int j = 0; j < 2; ++j) {
+    HIPCHK(c->run_s[j].reserve(std::max<size_t>(n, 1) * sizeof(float)));
+    HIPCHK(c->run_i[j].reserve(std::max<size_t>(n, 1) * sizeof(int)));
+  }
+  c->run_cur = 0;
+  HIPCHK(kpdi::launch_fill_topk(c->run_s[0].as<float>(), c->run_i[0].as<int>(), (int64_t)n, c->stream));
+  c->run_valid = true;
+  return KPDI_OK;
+}
+
+// one match launch over the prepared chunk -> partial lists
+int run_match(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int list_len, int64_t global_start,
+              const float *bound_s, const int *bound_i) {
+  const size_t part = (size_t)c->m_pad * 2 * nsplit * list_len;
+  HIPCHK(c->part_s.reserve(part * sizeof(float)));
+  HIPCHK(c->part_i.reserve(part * sizeof(int)));
+  kpdi::MatchLaunch ml;
+  ml.dict = c->dict_y.as<float>();
+  ml.exp = c->exp_x.as<float>();
+  ml.kpad = c->kpad;
+  ml.n_tiles = n_tiles;
+  ml.n_valid = n_chunk;
+  ml.m_pad = c->m_pad;
+  ml.nsplit = nsplit;
+  ml.idx_base = (int)global_start;
+  ml.list_len = list_len;
+  ml.part_scores = c->part_s.as<float>();
+  ml.part_idx = c->part_i.as<int>();
+  ml.bound_score = bound_s;
+  ml.bound_idx = bound_i;
+  {
+    ScopedTimer t(c, &c->ev_match);
+    HIPCHK(kpdi::launch_match(ml, c->stream));
+  }
+  c->cnt.match_launches += 1;
+  c->cnt.match_flops += 2.0 * (double)c->m * (double)n_chunk * (double)c->k_kept;
+  c->cnt.match_grid = (c->m_pad / kpdi::TILE_EXP) * nsplit;
+  c->cnt.match_nsplit = nsplit;
+  return KPDI_OK;
+}
+
+int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start) {
+  if (!c->have_problem) return fail(KPDI_EINVAL, "kpdi_set_problem has not been called");
+  if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
+  if (n_chunk <= 0) return fail(KPDI_EINVAL, "dictionary chunk must hold at least one pattern");
+  if (kpdi::dtype_size(dtype) == 0) return fail(KPDI_EINVAL, "unknown dtype %d", dtype);
+  if (global_start < 0 || global_start + n_chunk >= (int64_t)INT_MAX)
+    return fail(KPDI_EINVAL, "dictionary indices must fit in int32");
+  if (c->m == 0) return KPDI_OK;
+  int rc = prepare_experimental(c);
+  if (rc) return rc;
+  rc = ensure_running(c);
+  if (rc) return rc;
+
+  const int n_pad = kpdi::round_up(n_chunk, kpdi::TILE_DICT);
+  const int n_tiles = n_pad / kpdi::TILE_DICT;
+  HIPCHK(c->dict_y.reserve((size_t)n_pad * c->kpad * sizeof(float)));
+  if (n_pad > n_chunk)
+    HIPCHK(hipMemsetAsync(c->dict_y.as<float>() + (size_t)n_chunk * c->kpad, 0,
+                          (size_t)(n_pad - n_chunk) * c->kpad * sizeof(float), c->stream));
+  kpdi::PrepLaunch p;
+  p.raw = d_patterns;
+  p.dtype = dtype;
+  p.npix = c->npix;
+  p.row_map = nullptr;
+  p.pix_map = c->have_sig_mask ? c->pix_map.as<int>() : nullptr;
+  p.k = c->k_kept;
+  p.kpad = c->kpad;
+  p.n_out = (int)n_chunk;
+  p.metric = c->metric;
+  p.out = c->dict_y.as<float>();
+  {
+    ScopedTimer t(c, &c->ev_prep);
+    HIPCHK(kpdi::launch_prep(p, c->stream));
+  }
+
+  const int row_blocks = c->m_pad / kpdi::TILE_EXP;
+  const int nsplit = choose_nsplit(c, row_blocks, n_tiles);
+  const int k = c->keep_n;
+  const int cur = c->run_cur, nxt = cur ^ 1;
+
+  kpdi::MergeLaunch mg{};
+  mg.m = c->m;
+  mg.out_scores = c->run_s[nxt].as<float>();
+  mg.out_idx = c->run_i[nxt].as<int>();
+  mg.out_stride = k;
+  mg.out_offset = 0;
+  mg.k = k;
+  // source 0: the running best-k
+  mg.src_scores[0] = c->run_s[cur].as<float>();
+  mg.src_idx[0] = c->run_i[cur].as<int>();
+  mg.src_lists[0] = 1;
+  mg.src_len[0] = k;
+  mg.src_row_stride[0] = k;
+  mg.src_list_stride[0] = k;
+
+  if (k <= kpdi::KMAX_LIMIT) {
+    const int len = kpdi::match_list_len(k);
+    rc = run_match(c, (int)n_chunk, n_tiles, nsplit, len, global_start, nullptr, nullptr);
+    if (rc) return rc;
+    mg.src_scores[1] = c->part_s.as<float>();
+    mg.src_idx[1] = c->part_i.as<int>();
+    mg.src_lists[1] = 2 * nsplit;
+    mg.src_len[1] = len;
+    mg.src_row_stride[1] = 2 * nsplit * len;
+    mg.src_list_stride[1] = len;
+    mg.n_src = 2;
+  } else {
+    // keep_n > 32: passes of 32 ranks; pass p only admits candidates ranked
+    // strictly after the last entry of pass p-1
+    const size_t n = (size_t)c->m * k;
+    HIPCHK(c->loc_s.reserve(n * sizeof(float)));
+    HIPCHK(c->loc_i.reserve(n * sizeof(int)));
+    HIPCHK(c->bound_s.reserve((size_t)c->m_pad * sizeof(float)));
+    HIPCHK(c->bound_i.reserve((size_t)c->m_pad * sizeof(int)));
+    HIPCHK(kpdi::launch_fill_topk(c->bound_s.as<float>(), c->bound_i.as<int>(), c->m_pad, c->stream));
+    const int kk = (int)std::min<int64_t>(k, n_chunk);
+    if (kk < k) HIPCHK(kpdi::launch_fill_topk(c->loc_s.as<float>(), c->loc_i.as<int>(), (int64_t)n, c->stream));
+    for (int done = 0; done < kk; done += kpdi::KMAX_LIMIT) {
+      const int kp = std::min(kpdi::KMAX_LIMIT, kk - done);
+      const int len = kpdi::match_list_len(kp);
+      rc = run_match(c, (int)n_chunk, n_tiles, nsplit, len, global_start,
+                     done ? c->bound_s.as<float>() : nullptr, done ? c->bound_i.as<int>() : nullptr);
+      if (rc) return rc;
+      kpdi::MergeLaunch pm{};
+      pm.m = c->m;
+      pm.k = kp;
+      pm.n_src = 1;
+      pm.src_scores[0] = c->part_s.as<float>();
+      pm.src_idx[0] = c->part_i.as<int>();
+      pm.src_lists[0] = 2 * nsplit;
+      pm.src_len[0] = len;
+      pm.src_row_stride[0] = 2 * nsplit * len;
+      pm.src_list_stride[0] = len;
+      pm.out_scores = c->loc_s.as<float>();
+      pm.out_idx = c->loc_i.as<int>();
+      pm.out_stride = k;
+      pm.out_offset = done;
+      {
+        ScopedTimer t(c, &c->ev_merge);
+        HIPCHK(kpdi::launch_merge(pm, c->stream));
+      }
+      HIPCHK(kpdi::launch_last_column(c->loc_s.as<float>(), c->loc_i.as<int>(), c->m, k, done + kp - 1,
+                                      c->bound_s.as<float>(), c->bound_i.as<int>(), c->stream));
+    }
+    mg.src_scores[1] = c->loc_s.as<float>();
+    mg.src_idx[1] = c->loc_i.as<int>();
+    mg.src_lists[1] = 1;
+    mg.src_len[1] = k;
+    mg.src_row_stride[1] = k;
+    mg.src_list_stride[1] = k;
+    mg.n_src = 2;
+  }
+  {
+    ScopedTimer t(c, &c->ev_merge);
+    HIPCHK(kpdi::launch_merge(mg, c->stream));
+  }
+  c->run_cur = nxt;
+  return KPDI_OK;
+}
+
+int set_experimental_common(kpdi_ctx *c, const void *src, bool src_on_device, int dtype, int64_t m_all,
+                            const uint8_t *nav_mask) {
+  if (!c->have_problem) return fail(KPDI_EINVAL, "kpdi_set_problem must be called before kpdi_set_experimental");
+  const size_t es = kpdi::dtype_size(dtype);
+  if (es == 0) return fail(KPDI_EINVAL, "unknown dtype %d", dtype);
+  if (m_all <= 0) return fail(KPDI_EINVAL, "need at least one experimental pattern");
+  if (!src) return fail(KPDI_EINVAL, "patterns pointer is NULL");
+  const size_t bytes = (size_t)m_all * c->npix * es;
+  HIPCHK(c->exp_raw.reserve(bytes));
+  HIPCHK(hipMemcpyAsync(c->exp_raw.p, src, bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                        c->stream));
+  if (!src_on_device) c->cnt.h2d_bytes += (double)bytes;
+  c->exp_dtype = dtype;
+  c->m_all = m_all;
+  c->have_nav_mask = nav_mask != nullptr;
+  if (nav_mask) {
+    std::vector<int> rows;
+    rows.reserve((size_t)m_all);
+    for (int64_t i = 0; i < m_all; ++i)
+      if (!nav_mask[i]) rows.push_back((int)i);
+    c->m = (int)rows.size();
+    HIPCHK(c->row_map.reserve(std::max<size_t>(rows.size(), 1) * sizeof(int)));
+    if (!rows.empty())
+      HIPCHK(hipMemcpyAsync(c->row_map.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // `rows` dies at scope exit
+  } else {
+    if (m_all >= (int64_t)INT_MAX) return fail(KPDI_EINVAL, "too many experimental patterns");
+    c->m = (int)m_all;
+  }
+  c->m_pad = kpdi::round_up(std::max(c->m, 1), kpdi::TILE_EXP);
+  c->have_exp = true;
+  c->exp_prepared = false;
+  c->run_valid = false;
+  return KPDI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *kpdi_version(void) { return "kpdi 0.1.0 (gfx950)"; }
+
+const char *kpdi_last_error(void) { return g_err.c_str(); }
+
+int kpdi_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int kpdi_create(int device_id, kpdi_ctx **out) {
+  if (!out) return fail(KPDI_EINVAL, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(KPDI_ENODEV, "no HIP device visible: libkpdi has no CPU fallback");
+  if (device_id < 0 || device_id >= n) return fail(KPDI_EINVAL, "device %d out of range [0, %d)", device_id, n);
+  HIPCHK(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(KPDI_ENODEV, "device %d is %s; libkpdi is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+  kpdi_ctx *c = new kpdi_ctx();
+  c->device = device_id;
+  c->n_cu = prop.multiProcessorCount;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(KPDI_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+  }
+  *out = c;
+  return KPDI_OK;
+}
+
+int kpdi_destroy(kpdi_ctx *c) {
+  if (!c) return KPDI_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  for (DevBuf *b : {&c->pix_map, &c->exp_raw, &c->row_map, &c->exp_x, &c->dict_raw, &c->dict_y, &c->part_s,
+                    &c->part_i, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
+                    &c->bound_s, &c->bound_i, &c->gather_s, &c->gather_i, &c->bg, &c->taps})
+    b->release();
+  for (auto *l : {&c->ev_match, &c->ev_prep, &c->ev_merge})
+    for (auto &pr : *l) {
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return KPDI_OK;
+}
+
+int kpdi_synchronize(kpdi_ctx *c) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KPDI_OK;
+}
+
+int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, int metric, int compute_dtype,
+                     int keep_n) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (sy <= 0 || sx <= 0) return fail(KPDI_EINVAL, "detector shape (%d, %d) must be positive", sy, sx);
+  if (metric != KPDI_METRIC_NCC && metric != KPDI_METRIC_NDP) return fail(KPDI_EINVAL, "unknown metric %d", metric);
+  if (compute_dtype != KPDI_COMPUTE_F32) return fail(KPDI_EINVAL, "unknown compute dtype %d", compute_dtype);
+  if (keep_n <= 0) return fail(KPDI_EINVAL, "keep_n must be >= 1");
+  int rc = use_device(c);
+  if (rc) return rc;
+  const int npix = sy * sx;
+  std::vector<int> keep;
+  if (signal_mask) {
+    for (int i = 0; i < npix; ++i)
+      if (!signal_mask[i]) keep.push_back(i);
+    if (keep.empty()) return fail(KPDI_EINVAL, "the signal mask excludes every pixel");
+    HIPCHK(c->pix_map.reserve(keep.size() * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(c->pix_map.p, keep.data(), keep.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  c->sy = sy;
+  c->sx = sx;
+  c->npix = npix;
+  c->have_sig_mask = signal_mask != nullptr;
+  c->k_kept = signal_mask ? (int)keep.size() : npix;
+  c->kpad = kpdi::round_up(c->k_kept, kpdi::TILE_K);
+  c->metric = metric;
+  c->keep_n = keep_n;
+  c->have_problem = true;
+  c->exp_prepared = false;
+  c->run_valid = false;
+  c->cnt.kpad = c->kpad;
+  c->cnt.k_kept = c->k_kept;
+  return KPDI_OK;
+}
+
+int kpdi_set_experimental(kpdi_ctx *c, const void *patterns, int dtype, int64_t m_all, const uint8_t *nav_mask) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  int rc = use_device(c);
+  if (rc) return rc;
+  return set_experimental_common(c, patterns, false, dtype, m_all, nav_mask);
+}
+
+int kpdi_set_experimental_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t m_all,
+                              const uint8_t *nav_mask) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  int rc = use_device(c);
+  if (rc) return rc;
+  return set_experimental_common(c, d_patterns, true, dtype, m_all, nav_mask);
+}
+
+int64_t kpdi_n_experimental(kpdi_ctx *c) { return c && c->have_exp ? c->m : 0; }
+
+int kpdi_remove_static_background(kpdi_ctx *c, const float *static_bg, int operation, int scale_bg) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
+  if (!static_bg) return fail(KPDI_EINVAL, "static_bg is NULL");
+  if (operation != KPDI_OP_SUBTRACT && operation != KPDI_OP_DIVIDE) return fail(KPDI_EINVAL, "unknown operation");
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(c->bg.reserve((size_t)c->npix * sizeof(float)));
+  HIPCHK(hipMemcpyAsync(c->bg.p, static_bg, (size_t)c->npix * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  kpdi::StaticBgLaunch a;
+  a.patterns = c->exp_raw.p;
+  a.dtype = c->exp_dtype;
+  a.n = c->m_all;
+  a.sy = c->sy;
+  a.sx = c->sx;
+  a.bg = c->bg.as<float>();
+  a.bg_min = *std::min_element(static_bg, static_bg + c->npix);
+  a.bg_max = *std::max_element(static_bg, static_bg + c->npix);
+  a.operation = operation;
+  a.scale_bg = scale_bg ? 1 : 0;
+  dtype_range(c->exp_dtype, &a.omin, &a.omax);
+  hipError_t e = kpdi::launch_static_bg(a, c->stream);
+  if (e != hipSuccess)
+    return fail(KPDI_EHIP, "static background kernel: %s (dtype %d, %dx%d)", hipGetErrorString(e), c->exp_dtype, c->sy, c->sx);
+  HIPCHK(hipStreamSynchronize(c->stream));  // static_bg may be freed by the caller after return
+  c->exp_prepared = false;
+  c->run_valid = false;
+  return KPDI_OK;
+}
+
+int kpdi_remove_dynamic_background(kpdi_ctx *c, int operation, int filter_domain, double std, double truncate) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
+  if (operation != KPDI_OP_SUBTRACT && operation != KPDI_OP_DIVIDE) return fail(KPDI_EINVAL, "unknown operation");
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (std <= 0) std = c->sx / 8.0;  // signals/ebsd.py:648-649
+  std::vector<double> taps;
+  int n, centre, reflect;
+  if (filter_domain == KPDI_DOMAIN_FREQUENCY) {
+    // pattern/_pattern.py:604-613: n = int(truncate*std) samples of
+    // scipy.signal.windows.gaussian, normalised; centre from filters/fft_barnes.py:106-117
+    n = (int)(truncate * std);
+    if (n < 1) return fail(KPDI_EINVAL, "Gaussian window of int(truncate*std) = %d samples", n);
+    taps.resize(n);
+    double sum = 0;
+    for (int i = 0; i < n; ++i) {
+      const double x = i - (n - 1) / 2.0;
+      taps[i] = exp(-0.5 * (x / std) * (x / std));
+      sum += taps[i];
+    }
+    for (double &t : taps) t /= sum;
+    centre = n - 1 - (n - 1) / 2;
+    reflect = 0;
+  } else if (filter_domain == KPDI_DOMAIN_SPATIAL) {
+    // scipy.ndimage.gaussian_filter(sigma=std, truncate=truncate), mode='reflect'
+    const int r = (int)(truncate * std + 0.5);
+    n = 2 * r + 1;
+    taps.resize(n);
+    double sum = 0;
+    for (int i = 0; i < n; ++i) {
+      const double x = i - r;
+      taps[i] = exp(-0.5 / (std * std) * x * x);
+      sum += taps[i];
+    }
+    for (double &t : taps) t /= sum;
+    centre = r;
+    reflect = 1;
+  } else {
+    return fail(KPDI_EINVAL, "unknown filter domain %d", filter_domain);
+  }
+  HIPCHK(c->taps.reserve(taps.size() * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(c->taps.p, taps.data(), taps.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  kpdi::DynamicBgLaunch a;
+  a.patterns = c->exp_raw.p;
+  a.dtype = c->exp_dtype;
+  a.n = c->m_all;
+  a.sy = c->sy;
+  a.sx = c->sx;
+  a.taps_y = a.taps_x = c->taps.as<double>();
+  a.ntaps_y = a.ntaps_x = n;
+  a.centre_y = a.centre_x = centre;
+  a.reflect = reflect;
+  a.operation = operation;
+  dtype_range(c->exp_dtype, &a.omin, &a.omax);
+  hipError_t e = kpdi::launch_dynamic_bg(a, c->stream);
+  if (e != hipSuccess)
+    return fail(KPDI_EHIP, "dynamic background kernel: %s (dtype %d, %dx%d)", hipGetErrorString(e), c->exp_dtype, c->sy, c->sx);
+  HIPCHK(hipStreamSynchronize(c->stream));  // `taps` dies at scope exit
+  c->exp_prepared = false;
+  c->run_valid = false;
+  return KPDI_OK;
+}
+
+int kpdi_get_experimental(kpdi_ctx *c, void *out) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
+  int rc = use_device(c);
+  if (rc) return rc;
+  const size_t bytes = (size_t)c->m_all * c->npix * kpdi::dtype_size(c->exp_dtype);
+  HIPCHK(hipMemcpyAsync(out, c->exp_raw.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KPDI_OK;
+}
+
+int kpdi_push_dictionary_chunk(kpdi_ctx *c, const void *patterns, int dtype, int64_t n_chunk, int64_t global_start) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!c->have_problem) return fail(KPDI_EINVAL, "kpdi_set_problem has not been called");
+  if (!patterns) return fail(KPDI_EINVAL, "patterns pointer is NULL");
+  const size_t es = kpdi::dtype_size(dtype);
+  if (es == 0) return fail(KPDI_EINVAL, "unknown dtype %d", dtype);
+  if (n_chunk <= 0) return fail(KPDI_EINVAL, "dictionary chunk must hold at least one pattern");
+  int rc = use_device(c);
+  if (rc) return rc;
+  const size_t bytes = (size_t)n_chunk * c->npix * es;
+  HIPCHK(c->dict_raw.reserve(bytes));
+  HIPCHK(hipMemcpyAsync(c->dict_raw.p, patterns, bytes, hipMemcpyHostToDevice, c->stream));
+  c->cnt.h2d_bytes += (double)bytes;
+  return push_chunk_dev(c, c->dict_raw.p, dtype, n_chunk, global_start);
+}
+
+int kpdi_push_dictionary_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk,
+                                   int64_t global_start) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!d_patterns) return fail(KPDI_EINVAL, "patterns pointer is NULL");
+  int rc = use_device(c);
+  if (rc) return rc;
+  return push_chunk_dev(c, d_patterns, dtype, n_chunk, global_start);
+}
+
+int kpdi_reset_topk(kpdi_ctx *c) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  c->run_valid = false;
+  return KPDI_OK;
+}
+
+int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!c->have_exp || !c->have_problem) return fail(KPDI_EINVAL, "nothing to finalise");
+  if (!scores_out || !indices_out) return fail(KPDI_EINVAL, "output pointer is NULL");
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (c->m == 0) return KPDI_OK;
+  rc = ensure_running(c);  // a rank that pushed nothing contributes empty lists
+  if (rc) return rc;
+  const int k = c->keep_n;
+  const size_t n = (size_t)c->m * k;
+  const float *d_s = c->run_s[c->run_cur].as<float>();
+  const int *d_i = c->run_i[c->run_cur].as<int>();
+  if (c->comm && c->nranks > 1) {
+    HIPCHK(c->gather_s.reserve(n * c->nranks * sizeof(float)));
+    HIPCHK(c->gather_i.reserve(n * c->nranks * sizeof(int)));
+    ncclResult_t r = g_rccl.GroupStart();
+    if (r == ncclSuccess) r = g_rccl.AllGather(d_s, c->gather_s.p, n, ncclFloat32, c->comm, c->stream);
+    if (r == ncclSuccess) r = g_rccl.AllGather(d_i, c->gather_i.p, n, ncclInt32, c->comm, c->stream);
+    ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) return fail(KPDI_ECOMM, "RCCL all-gather failed: %s", g_rccl.GetErrorString(r));
+    const int nxt = c->run_cur ^ 1;
+    kpdi::MergeLaunch mg{};
+    mg.m = c->m;
+    mg.k = k;
+    mg.n_src = 1;
+    mg.src_scores[0] = c->gather_s.as<float>();
+    mg.src_idx[0] = c->gather_i.as<int>();
+    mg.src_lists[0] = c->nranks;
+    mg.src_len[0] = k;
+    mg.src_row_stride[0] = k;
+    mg.src_list_stride[0] = (int)n;
+    mg.out_scores = c->run_s[nxt].as<float>();
+    mg.out_idx = c->run_i[nxt].as<int>();
+    mg.out_stride = k;
+    mg.out_offset = 0;
+    {
+      ScopedTimer t(c, &c->ev_merge);
+      HIPCHK(kpdi::launch_merge(mg, c->stream));
+    }
+    d_s = c->run_s[nxt].as<float>();
+    d_i = c->run_i[nxt].as<int>();
+    // the per-rank running list (run_cur) is left untouched: finalize is idempotent
+  }
+  std::vector<int> tmp(n);
+  HIPCHK(hipMemcpyAsync(scores_out, d_s, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(tmp.data(), d_i, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < n; ++i) indices_out[i] = (int64_t)tmp[i];
+  return KPDI_OK;
+}
+
+int kpdi_comm_unique_id(uint8_t *id_out) {
+  if (!id_out) return fail(KPDI_EINVAL, "id_out is NULL");
+  if (!g_rccl.load()) return fail(KPDI_ECOMM, "cannot load librccl: %s", dlerror());
+  static_assert(sizeof(ncclUniqueId) == KPDI_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  ncclResult_t r = g_rccl.GetUniqueId(&id);
+  if (r != ncclSuccess) return fail(KPDI_ECOMM, "ncclGetUniqueId: %s", g_rccl.GetErrorString(r));
+  memcpy(id_out, &id, sizeof id);
+  return KPDI_OK;
+}
+
+int kpdi_comm_init(kpdi_ctx *c, int rank, int nranks, const uint8_t *id) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(KPDI_EINVAL, "bad rank %d / %d", rank, nranks);
+  if (!id) return fail(KPDI_EINVAL, "id is NULL");
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (!g_rccl.load()) return fail(KPDI_ECOMM, "cannot load librccl: %s", dlerror());
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, uid, rank);
+  if (r != ncclSuccess) return fail(KPDI_ECOMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r));
+  c->rank = rank;
+  c->nranks = nranks;
+  return KPDI_OK;
+}
+
+int kpdi_dev_alloc(kpdi_ctx *c, size_t bytes, void **d_out) {
+  if (!c || !d_out) return fail(KPDI_EINVAL, "NULL argument");
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(hipMalloc(d_out, bytes));
+  return KPDI_OK;
+}
+
+int kpdi_dev_free(kpdi_ctx *c, void *d_ptr) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(d_ptr));
+  return KPDI_OK;
+}
+
+int kpdi_h2d(kpdi_ctx *c, void *d_dst, const void *src, size_t bytes) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KPDI_OK;
+}
+
+int kpdi_d2h(kpdi_ctx *c, void *dst, const void *d_src, size_t bytes) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KPDI_OK;
+}
+
+int kpdi_set_profiling(kpdi_ctx *c, int on) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  c->profiling = on != 0;
+  return KPDI_OK;
+}
+
+int kpdi_get_counters(kpdi_ctx *c, kpdi_counters *out) {
+  if (!c || !out) return fail(KPDI_EINVAL, "NULL argument");
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  rc = drain_events(c, c->ev_match, &c->cnt.match_ms);
+  if (rc) return rc;
+  rc = drain_events(c, c->ev_prep, &c->cnt.prep_ms);
+  if (rc) return rc;
+  rc = drain_events(c, c->ev_merge, &c->cnt.merge_ms);
+  if (rc) return rc;
+  *out = c->cnt;
+  return KPDI_OK;
+}
+
+int kpdi_reset_counters(kpdi_ctx *c) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  kpdi_counters tmp;
+  int rc = kpdi_get_counters(c, &tmp);  // recycles pending events
+  if (rc) return rc;
+  const int kpad = c->cnt.kpad, kk = c->cnt.k_kept;
+  c->cnt = kpdi_counters{};
+  c->cnt.kpad = kpad;
+  c->cnt.k_kept = kk;
+  return KPDI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// Internal launcher prototypes shared by the .hip translation units of libkpdi.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kpdi {
+
+// ---- tile geometry of the match kernel (match.hip) -------------------------
+constexpr int TILE_DICT = 128;  // dictionary patterns per tile (MFMA A operand, rows)
+constexpr int TILE_EXP = 128;   // experimental patterns per tile (MFMA B operand, columns)
+constexpr int TILE_K = 32;      // pixels per LDS slab
+constexpr int MATCH_THREADS = 256;
+constexpr int KMAX_LIMIT = 32;  // longest register-resident list of one pass
+
+inline int round_up(int64_t v, int64_t m) { return (int)(((v + m - 1) / m) * m); }
+
+// list length (template instantiation) used for a pass that needs `k` entries
+int match_list_len(int k);
+
+struct MatchLaunch {
+  const float *dict;  // (n_dict_pad, kpad) prepared, zero rows beyond n_valid
+  const float *exp;   // (m_pad, kpad) prepared, zero rows beyond M
+  int kpad;           // multiple of TILE_K
+  int n_tiles;        // n_dict_pad / TILE_DICT
+  int n_valid;        // valid dictionary patterns in this chunk
+  int m_pad;          // multiple of TILE_EXP
+  int nsplit;         // dictionary splits (lists per pattern = 2 * nsplit)
+  int idx_base;       // dictionary index of chunk row 0
+  int list_len;       // KMAX of the instantiation
+  float *part_scores; // [m_pad][2*nsplit][list_len]
+  int *part_idx;
+  // optional upper bound per experimental pattern (multi-pass for keep_n > 32):
+  // only candidates strictly after (bound_score, bound_idx) in the ranking count
+  const float *bound_score; // [m_pad] or nullptr
+  const int *bound_idx;
+};
+hipError_t launch_match(const MatchLaunch &a, hipStream_t s);
+int match_blocks_per_cu();
+
+// ---- pattern preparation (prep.hip): cast -> gather rows/pixels -> normalise --
+struct PrepLaunch {
+  const void *raw;     // (n_rows_in, npix) of `dtype`
+  int dtype;
+  int npix;            // sy*sx
+  const int *row_map;  // [n_out] source row per output row, or nullptr (identity)
+  const int *pix_map;  // [k] kept pixel indices, or nullptr (all pixels)
+  int k;               // kept pixels
+  int kpad;
+  int n_out;           // rows to produce
+  int metric;          // KPDI_METRIC_*
+  float *out;          // (>= n_out, kpad)
+};
+hipError_t launch_prep(const PrepLaunch &a, hipStream_t s);
+
+// ---- top-k merge (merge.hip) -------------------------------------------------
+struct MergeLaunch {
+  int m;                // experimental patterns
+  int k;                // entries to produce per pattern
+  // up to 3 candidate sources, each [m][lists][len] (stride between patterns = lists*len)
+  const float *src_scores[3];
+  const int *src_idx[3];
+  int src_lists[3];
+  int src_len[3];
+  int src_row_stride[3];  // elements between consecutive patterns
+  int src_list_stride[3]; // elements between consecutive lists of one pattern
+  int n_src;
+  float *out_scores;    // [m][out_stride] (must not alias a source)
+  int *out_idx;
+  int out_stride;
+  int out_offset;       // first output column
+};
+hipError_t launch_merge(const MergeLaunch &a, hipStream_t s);
+hipError_t launch_fill_topk(float *scores, int *idx, int64_t n, hipStream_t s);
+hipError_t launch_last_column(const float *scores, const int *idx, int m, int stride, int col,
+                              float *bound_score, int *bound_idx, hipStream_t s);
+
+// ---- pattern pre-processing (preproc.hip) ---------------------------------
+struct StaticBgLaunch {
+  void *patterns; int dtype; int64_t n; int sy, sx;
+  const float *bg;   // sy*sx
+  float bg_min, bg_max;
+  int operation, scale_bg;
+  float omin, omax;
+};
+hipError_t launch_static_bg(const StaticBgLaunch &a, hipStream_t s);
+struct DynamicBgLaunch {
+  void *patterns; int dtype; int64_t n; int sy, sx;
+  const double *taps_y, *taps_x; int ntaps_y, ntaps_x; int centre_y, centre_x;
+  int reflect;       // 0 = nearest (edge replicate), 1 = scipy 'reflect'
+  int operation;
+  float omin, omax;
+};
+hipError_t launch_dynamic_bg(const DynamicBgLaunch &a, hipStream_t s);
+size_t dtype_size(int dtype);
+
+}  // namespace kpdi

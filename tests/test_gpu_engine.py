@@ -1,0 +1,183 @@
+"""GPU parity tests of the C-ABI engine (libkpdi.so through ctypes) against the
+CPU oracle and the golden vectors made by the reference.  Tolerance: scores
+within 1e-5 absolute (BASELINE.json north_star), indices per
+`oracle.kpdi_oracle.assert_topk_parity`."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import kpdi_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from kikuchipy_amd import _lib
+
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def run_engine(ctx, exp, dic, metric="ncc", keep_n=20, chunk=None, signal_mask=None,
+               navigation_mask=None):
+    from kikuchipy_amd import _lib
+
+    sy, sx = exp.shape[-2:]
+    n = dic.shape[0]
+    keep_n = min(keep_n, n)
+    ctx.set_problem(sy, sx, signal_mask, {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[metric], keep_n)
+    ctx.set_experimental(exp.reshape(-1, sy, sx), navigation_mask)
+    chunk = chunk or n
+    for start in range(0, n, chunk):
+        ctx.push_dictionary_chunk(dic[start:start + chunk], start)
+    return ctx.finalize(keep_n)
+
+
+SYNTH_CASES = {
+    "ncc_k20": dict(metric="ncc", keep_n=20),
+    "ncc_k1": dict(metric="ncc", keep_n=1),
+    "ncc_k5_it700": dict(metric="ncc", keep_n=5, chunk=700),
+    "ndp_k20": dict(metric="ndp", keep_n=20),
+    "ndp_k5_it1000": dict(metric="ndp", keep_n=5, chunk=1000),
+    "ncc_k20_circ": dict(metric="ncc", keep_n=20, signal_mask="circ"),
+    "ncc_k20_circ_it999": dict(metric="ncc", keep_n=20, signal_mask="circ", chunk=999),
+    "ncc_k10_f64": dict(metric="ncc", keep_n=10),
+    "ndp_k50": dict(metric="ndp", keep_n=50),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SYNTH_CASES))
+def test_golden_synth(ctx, name, synth_inputs):
+    """The reference's own results (tests/golden/di_synth.npz)."""
+    exp, dic, g = synth_inputs
+    kw = dict(SYNTH_CASES[name])
+    if kw.get("signal_mask") == "circ":
+        kw["signal_mask"] = g["circular_mask"]
+    scores, idx = run_engine(ctx, exp, dic, **kw)
+    ko.assert_topk_parity(scores, idx, g[f"{name}__scores"], g[f"{name}__indices"], atol=ATOL)
+    assert scores.dtype == np.float32 and idx.dtype == np.int64
+
+
+def test_golden_navmask(ctx, synth_inputs):
+    exp, dic, g = synth_inputs
+    nav = g["nav_mask"]
+    scores, idx = run_engine(ctx, exp.reshape(6, 8, 60, 60), dic, metric="ncc", keep_n=7, chunk=1500,
+                             navigation_mask=nav)
+    assert scores.shape == (45, 7)
+    ko.assert_topk_parity(scores, idx, g["ncc_k7_nav__scores"][~nav.ravel()],
+                          g["ncc_k7_nav__indices"][~nav.ravel()], atol=ATOL)
+
+
+def test_golden_config1(ctx, config1_inputs):
+    """BASELINE.json configs[0]."""
+    exp, dic, g = config1_inputs
+    s, i = run_engine(ctx, exp, dic, metric="ncc", keep_n=5)
+    ko.assert_topk_parity(s, i, g["ncc_k5__scores"], g["ncc_k5__indices"], atol=ATOL)
+    assert np.allclose(s[:, 0], 1, atol=ATOL)
+    assert list(i[:, 0]) == list(range(0, 999, 111))
+    circ = ~ko.circular_window((60, 60)).astype(bool)
+    s, i = run_engine(ctx, exp, dic, metric="ncc", keep_n=5, signal_mask=circ, chunk=300)
+    ko.assert_topk_parity(s, i, g["ncc_k5_circ_it300__scores"], g["ncc_k5_circ_it300__indices"], atol=ATOL)
+
+
+@pytest.mark.parametrize("name", ["ndp_all", "ncc_all", "ndp_sigmask", "ndp_it2", "ncc_it4_k3"])
+def test_golden_dummy(ctx, name):
+    """3x3 detector, 9 patterns, dictionary == experimental
+    (tests/test_indexing/test_dictionary_indexing.py:27-66 of the reference)."""
+    g = load_golden("di_dummy.npz")
+    kw = {
+        "ndp_all": dict(metric="ndp"),
+        "ncc_all": dict(metric="ncc"),
+        "ndp_sigmask": dict(metric="ndp", signal_mask=g["sig_mask"]),
+        "ndp_it2": dict(metric="ndp", chunk=2),
+        "ncc_it4_k3": dict(metric="ncc", keep_n=3, chunk=4),
+    }[name]
+    dummy = g["dummy"]
+    s, i = run_engine(ctx, dummy, dummy.reshape(-1, 3, 3), **kw)
+    assert np.allclose(s[:, 0], 1, atol=ATOL)
+    ko.assert_topk_parity(s, i, g[f"{name}__scores"], g[f"{name}__indices"], atol=ATOL, tie=2e-5)
+
+
+@pytest.mark.parametrize("m,n,sy,sx,k,chunk,metric", [
+    (1, 1, 8, 8, 1, None, "ncc"),        # smallest problem
+    (3, 130, 16, 12, 20, None, "ncc"),   # ragged tile edges in every direction
+    (130, 257, 20, 20, 8, 100, "ndp"),   # two experimental row blocks, ragged chunks
+    (260, 1000, 31, 33, 20, 333, "ncc"), # K = 1023 -> padded to 1024
+    (17, 640, 60, 60, 33, 250, "ncc"),   # keep_n > 32: multi-pass path
+    (5, 70, 10, 10, 70, None, "ndp"),    # keep_n == dictionary size
+])
+def test_vs_oracle_shapes(ctx, m, n, sy, sx, k, chunk, metric):
+    rng = np.random.default_rng(m * 1000 + n)
+    exp = rng.integers(0, 256, (m, sy, sx)).astype(np.uint8)
+    dic = rng.random((n, sy, sx)).astype(np.float32)
+    s, i = run_engine(ctx, exp, dic, metric=metric, keep_n=k, chunk=chunk)
+    rs, ri = ko.dictionary_indexing(exp, dic, metric=metric, keep_n=k, n_per_iteration=chunk)
+    ko.assert_topk_parity(s, i, rs, ri, atol=ATOL)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32, np.float64])
+def test_input_dtypes(ctx, dtype):
+    rng = np.random.default_rng(5)
+    exp = (rng.random((40, 24, 24)) * 200).astype(dtype)
+    dic = (rng.random((300, 24, 24)) * 200).astype(dtype)
+    s, i = run_engine(ctx, exp, dic, keep_n=6)
+    rs, ri = ko.dictionary_indexing(exp, dic, keep_n=6)
+    ko.assert_topk_parity(s, i, rs, ri, atol=ATOL)
+
+
+def test_ties_lower_index_first(ctx):
+    """Exact duplicates in the dictionary: equal scores come out by ascending index."""
+    rng = np.random.default_rng(3)
+    base = rng.random((50, 16, 16)).astype(np.float32)
+    dic = np.concatenate([base, base, base])  # entries j, j+50, j+100 are identical
+    exp = (base[:10] * 255).astype(np.uint8)
+    s, i = run_engine(ctx, exp, dic, keep_n=6, chunk=64)
+    assert np.all(np.diff(s, axis=1) <= 0)
+    for row_s, row_i in zip(s, i):
+        for a in range(5):
+            if row_s[a] == row_s[a + 1]:
+                assert row_i[a] < row_i[a + 1]
+    # every pattern's best three are the three copies of its own source, in index order
+    assert np.array_equal(i[:, :3] % 50, np.repeat(np.arange(10)[:, None], 3, axis=1))
+    assert np.all(np.diff(i[:, :3], axis=1) > 0)
+
+
+def test_chunking_invariance(ctx, synth_inputs):
+    """Size-independent property: the result does not depend on how the
+    dictionary is cut into chunks nor on the order the chunks arrive in."""
+    exp, dic, g = synth_inputs
+    from kikuchipy_amd import _lib
+
+    ref = run_engine(ctx, exp, dic, keep_n=20)
+    ctx.set_problem(60, 60, None, _lib.METRIC_NCC, 20)
+    ctx.set_experimental(exp)
+    bounds = [0, 17, 900, 901, 2049, 3000]
+    for a, b in reversed(list(zip(bounds[:-1], bounds[1:]))):
+        ctx.push_dictionary_chunk(dic[a:b], a)
+    s, i = ctx.finalize(20)
+    assert np.array_equal(i, ref[1]) and np.array_equal(s, ref[0])
+
+
+def test_inputs_not_mutated(ctx):
+    rng = np.random.default_rng(1)
+    exp = rng.random((9, 12, 12)).astype(np.float32)
+    dic = rng.random((40, 12, 12)).astype(np.float32)
+    e0, d0 = exp.copy(), dic.copy()
+    run_engine(ctx, exp, dic, keep_n=3)
+    assert np.array_equal(exp, e0) and np.array_equal(dic, d0)
+
+
+def test_error_paths(ctx):
+    from kikuchipy_amd import _lib
+
+    with pytest.raises(_lib.KpdiError, match="keep_n"):
+        ctx.set_problem(4, 4, None, _lib.METRIC_NCC, 0)
+    with pytest.raises(_lib.KpdiError, match="every pixel"):
+        ctx.set_problem(2, 2, np.ones((2, 2), bool), _lib.METRIC_NCC, 1)
+    with pytest.raises(_lib.KpdiError, match="unknown metric"):
+        ctx.set_problem(2, 2, None, 7, 1)
