@@ -1,0 +1,255 @@
+"""bench.py - dictionary-indexing throughput on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+
+Workload = BASELINE.json configs[1]: 4096 synthetic experimental patterns
+(60x60, uint8) against a 100 000-pattern synthetic dictionary (float32), `ncc`,
+keep_n=20.  `--workload config3` adds the circular signal mask and the fused
+static + dynamic background pre-kernels (configs[2]).
+
+One step = one full pass of the hot path with the RAW inputs already resident
+in HBM: (optional pre-processing) -> cast/mask/normalise experimental patterns
+-> cast/mask/normalise this rank's dictionary shard -> f32 MFMA match with fused
+top-k -> merge -> (N > 1: RCCL all-gather of the per-shard best-k + merge) ->
+best-k scores/indices copied to the host.  With N ranks the SAME job is sharded
+over the dictionary axis (strong scaling); value = patterns indexed per second
+by the whole job.
+
+Prints ONE JSON line on rank 0.  torch is only imported for N > 1 (rendezvous,
+barrier and max-over-ranks through gloo); the data path is libkpdi + RCCL.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+WORKLOADS = {
+    "config2": dict(m=4096, n=100000, sy=60, sx=60, metric="ncc", keep_n=20, mask=False, preprocess=False,
+                    name="configs[1]: 4096 exp (60x60 u8) x 100k dict (f32), ncc, keep_n=20"),
+    "config3": dict(m=4096, n=100000, sy=60, sx=60, metric="ncc", keep_n=20, mask=True, preprocess=True,
+                    name="configs[2]: configs[1] + circular signal mask + static/dynamic background pre-kernels"),
+}
+
+
+def synth(w, seed=2024):
+    """SURVEY.md 8(d) config 2 generator."""
+    rng = np.random.default_rng(seed)
+    exp = rng.integers(0, 256, (w["m"], w["sy"], w["sx"]), dtype=np.uint8)
+    dic = rng.random((w["n"], w["sy"], w["sx"]), dtype=np.float32)
+    bg = rng.integers(1, 256, (w["sy"], w["sx"]), dtype=np.uint8)
+    return exp, dic, bg
+
+
+def circular_mask(sy, sx):
+    """`~Window("circular", (sy, sx)).astype(bool)` (filters/window.py:249-269)."""
+    yy, xx = np.ogrid[:sy, :sx]
+    return np.sqrt((yy - sy // 2) ** 2 + (xx - sx // 2) ** 2) > max(sy // 2, sx // 2)
+
+
+def cpu_baseline(w, exp, dic, bg, mask, n_sample):
+    """The CPU oracle (NumPy/BLAS restatement of the reference's chunked loop)
+    timed on this host, on a bounded sample: all M experimental patterns against
+    the first `n_sample` dictionary patterns, n_per_iteration=2000; the cost is
+    linear in the dictionary size, so patterns/s at the full N = rate * n_sample/N."""
+    from oracle import kpdi_oracle as ko
+
+    threads = os.cpu_count() or 1
+    try:
+        from threadpoolctl import threadpool_info
+
+        blas = [p["num_threads"] for p in threadpool_info() if p.get("user_api") == "blas"]
+        if blas:
+            threads = max(blas)
+    except Exception:
+        pass
+    e = exp
+    t0 = time.perf_counter()
+    if w["preprocess"]:
+        n_pp = min(256, e.shape[0])  # per-pattern Python loop: time a slice, scale linearly
+        tpp = time.perf_counter()
+        st = ko.remove_static_background(e[:n_pp], bg, "subtract")
+        ko.remove_dynamic_background(st, "subtract", "frequency")
+        pp_time = (time.perf_counter() - tpp) * e.shape[0] / n_pp
+    else:
+        pp_time = 0.0
+    t1 = time.perf_counter()
+    ko.dictionary_indexing(e, dic[:n_sample], metric=w["metric"], keep_n=w["keep_n"],
+                           n_per_iteration=2000, signal_mask=mask)
+    di_time = time.perf_counter() - t1
+    full = di_time * w["n"] / n_sample + pp_time
+    return {
+        "value": w["m"] / full,
+        "unit": "patterns/s",
+        "cores": int(threads),
+        "kind": "port",
+        "sample": (f"oracle/kpdi_oracle.py (NumPy+BLAS, {threads} threads of {os.cpu_count()} host cores): "
+                   f"{w['m']} exp x first {n_sample} dict patterns in {di_time:.1f} s, n_per_iteration=2000, "
+                   f"scaled linearly to N={w['n']}" + (f"; pre-processing timed on 256 patterns, scaled "
+                                                      f"({pp_time:.1f} s for all)" if w["preprocess"] else "")),
+        "measured_seconds": round(time.perf_counter() - t0, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="dictionary patterns in the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-pointer sweep")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("--gpus > 1 must be launched through `python -m torch.distributed.run` (one rank per GPU)")
+        a.gpus = world
+    dist = None
+    if world > 1:
+        from kikuchipy_amd.parallel import init_process_group
+
+        dist = init_process_group("gloo")
+
+    from kikuchipy_amd import _lib
+    from kikuchipy_amd.parallel import Communicator, shard_range
+
+    w = WORKLOADS[a.workload]
+    exp, dic, bg = synth(w)
+    mask = circular_mask(w["sy"], w["sx"]) if w["mask"] else None
+    lo, hi = shard_range(w["n"], rank, world)
+    n_local = hi - lo
+
+    ctx = _lib.Context(local_rank)
+    comm = Communicator(rank, world)
+    comm.attach(ctx)
+    metric = {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[w["metric"]]
+    ctx.set_problem(w["sy"], w["sx"], mask, metric, w["keep_n"])
+    # raw inputs resident in HBM before the timed region
+    d_exp = ctx.dev_alloc(exp.nbytes)
+    ctx.h2d(d_exp, exp)
+    shard = np.ascontiguousarray(dic[lo:hi])
+    d_dic = ctx.dev_alloc(shard.nbytes)
+    ctx.h2d(d_dic, shard)
+    bg_f32 = bg.astype(np.float32)
+
+    def step():
+        ctx.set_experimental_dev(d_exp, exp.dtype, w["m"])
+        if w["preprocess"]:
+            ctx.remove_static_background(bg_f32, _lib.OP_SUBTRACT, False)
+            ctx.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
+        ctx.push_dictionary_chunk_dev(d_dic, shard.dtype, n_local, lo)
+        return ctx.finalize(w["keep_n"])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    ctx.set_profiling(True)
+    ctx.reset_counters()
+    barrier()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        scores, indices = step()
+    ctx.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    cnt = ctx.counters()
+    ctx.set_profiling(False)
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    if rank != 0:
+        ctx.close()
+        return
+
+    ms_per_step = elapsed / a.steps * 1e3
+    value = w["m"] * a.steps / elapsed
+    k_kept = cnt["k_kept"]
+    launches = max(cnt["match_launches"], 1)
+    flops_per_launch = cnt["match_flops"] / launches
+    avg_ms = cnt["match_ms"] / launches
+    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    out = {
+        "metric": "experimental patterns indexed/sec (whole node), 60x60 px x 100k dict",
+        "value": round(value, 1),
+        "unit": "patterns/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (default_rng(2024): uint8 patterns, uniform float32 dictionary), raw inputs resident in HBM",
+        "config": {
+            "workload": w["name"],
+            "experimental_patterns": w["m"],
+            "dictionary_patterns": w["n"],
+            "detector": [w["sy"], w["sx"]],
+            "kept_pixels": k_kept,
+            "metric": w["metric"],
+            "keep_n": w["keep_n"],
+            "parallelism": f"dictionary sharded over {world} GPU(s)" + (", RCCL all-gather merge" if world > 1 else ""),
+        },
+        "roofline": {
+            "kernel": "kpdi::match_topk_kernel<20,false> (f32 MFMA GEMM + fused top-k), rank 0",
+            "bound": "mfma",
+            "achieved": round(achieved, 2),
+            "peak": F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": None,
+            "flops_per_launch": flops_per_launch,
+            "avg_launch_ms": round(avg_ms, 4),
+            "launches": int(cnt["match_launches"]),
+            "grid": int(cnt["match_grid"]),
+        },
+        "extra": {
+            "comparisons_per_s": round(value * w["n"], 1),
+            "prep_ms_per_step": round(cnt["prep_ms"] / a.steps, 4),
+            "merge_ms_per_step": round(cnt["merge_ms"] / a.steps, 4),
+            "best_score_mean": float(scores[:, 0].mean()),
+        },
+    }
+
+    if world == 1 and not a.no_pcie:
+        # informational: the same sweep with the dictionary handed over as a HOST
+        # buffer (pageable memory -> PCIe inside the step).  Never `value`.
+        ctx.set_experimental_dev(d_exp, exp.dtype, w["m"])
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        ctx.push_dictionary_chunk(dic, 0)
+        ctx.finalize(w["keep_n"])
+        out["extra"]["pcie_inclusive_patterns_per_s"] = round(w["m"] / (time.perf_counter() - t0), 1)
+
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w, exp, dic, bg, mask, min(a.cpu_sample, w["n"]))
+    ctx.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

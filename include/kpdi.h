@@ -88,6 +88,9 @@ int kpdi_synchronize(kpdi_ctx *ctx);
 int kpdi_set_problem(kpdi_ctx *ctx, int sy, int sx, const uint8_t *signal_mask,
                      int metric, int compute_dtype, int keep_n);
 
+/* change keep_n only (forgets the running best-k, keeps everything else) */
+int kpdi_set_keep_n(kpdi_ctx *ctx, int keep_n);
+
 /* ---- experimental patterns (prepare_experimental, ..._cross_correlation.py:88-128)
  * `patterns`: m_all x sy x sx, C order, HOST memory.  `nav_mask`: m_all bytes or
  * NULL.  Uploads the raw patterns; they stay resident (and can be pre-processed

@@ -1,0 +1,31 @@
+"""kikuchipy_amd - MI355X-native dictionary indexing for EBSD patterns.
+
+Accelerates ONE path of kikuchipy: `EBSD.dictionary_indexing()` with the
+`ncc`/`ndp` similarity metrics, plus the static/dynamic background removal
+that feeds it.  Python host code -> ctypes -> libkpdi.so (hand-written HIP for
+gfx950).  No PyTorch, no CPU fallback.
+"""
+
+__version__ = "0.1.0"
+
+from kikuchipy_amd.indexing import (  # noqa: E402,F401
+    DictionaryIndexingResult,
+    NormalizedCrossCorrelationMetric,
+    NormalizedDotProductMetric,
+    SimilarityMetric,
+    dictionary_indexing,
+)
+from kikuchipy_amd.pattern import remove_dynamic_background, remove_static_background  # noqa: E402,F401
+from kikuchipy_amd.signals import EBSD, DictionaryXmap  # noqa: E402,F401
+
+__all__ = [
+    "DictionaryIndexingResult",
+    "DictionaryXmap",
+    "EBSD",
+    "NormalizedCrossCorrelationMetric",
+    "NormalizedDotProductMetric",
+    "SimilarityMetric",
+    "dictionary_indexing",
+    "remove_dynamic_background",
+    "remove_static_background",
+]

@@ -63,6 +63,7 @@ SIGNATURES = {
     "kpdi_destroy": (_i, [_vp]),
     "kpdi_synchronize": (_i, [_vp]),
     "kpdi_set_problem": (_i, [_vp, _i, _i, _vp, _i, _i, _i]),
+    "kpdi_set_keep_n": (_i, [_vp, _i]),
     "kpdi_set_experimental": (_i, [_vp, _vp, _i, _i64, _vp]),
     "kpdi_set_experimental_dev": (_i, [_vp, _vp, _i, _i64, _vp]),
     "kpdi_n_experimental": (_i64, [_vp]),
@@ -177,6 +178,9 @@ class Context:
             raise KpdiError(f"signal mask has {sm.size} elements, detector has {sy * sx}")
         check(load().kpdi_set_problem(self._h, int(sy), int(sx), _ptr(sm), int(metric), COMPUTE_F32,
                                       int(keep_n)))
+
+    def set_keep_n(self, keep_n):
+        check(load().kpdi_set_keep_n(self._h, int(keep_n)))
 
     def set_experimental(self, patterns, navigation_mask=None):
         """patterns: (m_all, sy, sx) or (m_all, sy*sx), C-contiguous."""

@@ -531,6 +531,7 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
     HIPCHK(hipMemcpyAsync(c->pix_map.p, keep.data(), keep.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
+  if (npix != c->npix) c->have_exp = false;  // resident patterns belong to another detector shape
   c->sy = sy;
   c->sx = sx;
   c->npix = npix;
@@ -544,6 +545,15 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   c->run_valid = false;
   c->cnt.kpad = c->kpad;
   c->cnt.k_kept = c->k_kept;
+  return KPDI_OK;
+}
+
+int kpdi_set_keep_n(kpdi_ctx *c, int keep_n) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!c->have_problem) return fail(KPDI_EINVAL, "kpdi_set_problem has not been called");
+  if (keep_n <= 0) return fail(KPDI_EINVAL, "keep_n must be >= 1");
+  c->keep_n = keep_n;
+  c->run_valid = false;
   return KPDI_OK;
 }
 

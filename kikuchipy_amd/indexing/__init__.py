@@ -1,0 +1,9 @@
+from kikuchipy_amd.indexing._dictionary_indexing import (  # noqa: F401
+    DictionaryIndexingResult,
+    dictionary_indexing,
+)
+from kikuchipy_amd.indexing.similarity_metrics import (  # noqa: F401
+    NormalizedCrossCorrelationMetric,
+    NormalizedDotProductMetric,
+    SimilarityMetric,
+)

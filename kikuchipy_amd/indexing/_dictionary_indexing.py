@@ -1,0 +1,272 @@
+"""Stand-alone dictionary indexing on the GPU engine.
+
+Counterpart of `EBSD.dictionary_indexing` (signals/ebsd.py:1827-1984 of the
+reference) + `_dictionary_indexing` (indexing/_dictionary_indexing.py:36-169)
+for plain arrays: same keyword arguments, same validation and messages, same
+`scores` / `simulation_indices` outputs.  The difference to running the metric
+plugin inside kikuchipy's own loop is that here the running best-k stays on
+the GPU across dictionary chunks (the merge of :120-128 is a kernel) and, with
+a communicator, the dictionary can be sharded over several GPUs.
+"""
+
+import time
+
+import numpy as np
+
+from kikuchipy_amd.indexing.similarity_metrics import METRICS, SimilarityMetric, _HipMetric
+
+
+class DictionaryIndexingResult:
+    """What the reference stores in the returned `CrystalMap`
+    (indexing/_dictionary_indexing.py:141-167): `scores` and
+    `simulation_indices` of shape (n_points, keep_n) - squeezed to 1-D when
+    `keep_n == 1` and a navigation mask is used, as there - plus `is_in_data`
+    and, if dictionary rotations were given, `rotations` (quaternions of the
+    matched dictionary entries, identity where masked out)."""
+
+    def __init__(self, scores, simulation_indices, nav_shape, step_sizes, is_in_data, keep_n,
+                 rotations=None, phase_name=None, scan_unit=None, patterns_per_second=None,
+                 comparisons_per_second=None):
+        self.scores = scores
+        self.simulation_indices = simulation_indices
+        self.shape = tuple(nav_shape)
+        self.step_sizes = tuple(step_sizes)
+        self.is_in_data = is_in_data
+        self.rotations_per_point = keep_n
+        self.rotations = rotations
+        self.phase_name = phase_name
+        self.scan_unit = scan_unit
+        self.patterns_per_second = patterns_per_second
+        self.comparisons_per_second = comparisons_per_second
+
+    @property
+    def size(self):
+        """Number of indexed points (`xmap.size` in the reference's tests)."""
+        return int(np.count_nonzero(self.is_in_data))
+
+    @property
+    def prop(self):
+        return {"scores": self.scores, "simulation_indices": self.simulation_indices}
+
+    def to_crystal_map(self, phase_list=None):
+        """Build an `orix.crystal_map.CrystalMap` exactly as the reference does
+        (needs orix, which is not a dependency of this package)."""
+        from orix.crystal_map import CrystalMap, create_coordinate_arrays
+        from orix.quaternion import Rotation
+
+        kw, _ = create_coordinate_arrays(self.shape, self.step_sizes)
+        if self.rotations is None:
+            raise ValueError("dictionary_rotations were not given to dictionary_indexing()")
+        kw["rotations"] = Rotation(self.rotations)
+        kw["prop"] = self.prop
+        if not np.all(self.is_in_data):
+            kw["is_in_data"] = self.is_in_data
+        xmap = CrystalMap(phase_list=phase_list, **kw)
+        if self.scan_unit is not None:
+            xmap.scan_unit = self.scan_unit
+        return xmap
+
+
+def info_message(metric, n_experimental_all, dictionary_size, phase_name, n_experimental=None):
+    """Text of indexing/_dictionary_indexing.py:206-237."""
+    info = f"Dictionary indexing information:\n  Phase name: {phase_name}\n"
+    if n_experimental is not None and n_experimental != n_experimental_all:
+        info += f"  Matching {n_experimental}/{n_experimental_all} experimental pattern(s)"
+    else:
+        info += f"  Matching {n_experimental_all} experimental pattern(s)"
+    info += f" to {dictionary_size} dictionary pattern(s)\n  {metric}"
+    return info
+
+
+def _is_lazy(a):
+    return hasattr(a, "compute") and hasattr(a, "chunksize")
+
+
+def prepare_metric(metric, navigation_mask, signal_mask, dtype, rechunk, n_experimental,
+                   n_dictionary_patterns, device=0):
+    """EBSD._prepare_metric (signals/ebsd.py:3049-3088)."""
+    if isinstance(metric, str) and metric in METRICS:
+        metric = METRICS[metric](device=device)
+        metric.rechunk = rechunk
+    if not isinstance(metric, SimilarityMetric):
+        raise ValueError(
+            f"'{metric}' must be either of {METRICS.keys()} or a custom metric class "
+            "inheriting from SimilarityMetric. See kikuchipy.indexing.SimilarityMetric"
+        )
+    metric.n_experimental_patterns = max(n_experimental, 1)
+    metric.n_dictionary_patterns = max(n_dictionary_patterns, 1)
+    if navigation_mask is not None:
+        metric.navigation_mask = navigation_mask
+    if signal_mask is not None:
+        metric.signal_mask = signal_mask
+    if dtype is not None:
+        metric.dtype = dtype
+    metric.raise_error_if_invalid()
+    return metric
+
+
+def chunk_bounds(dictionary_size, n_per_iteration):
+    """Chunk starts/ends of indexing/_dictionary_indexing.py:100-104."""
+    n_iterations = int(np.ceil(dictionary_size / n_per_iteration))
+    starts = np.cumsum([0] + [n_per_iteration] * (n_iterations - 1))
+    ends = np.cumsum([n_per_iteration] * n_iterations)
+    ends[-1] = max(ends[-1], dictionary_size)
+    return [(int(s), int(min(e, dictionary_size))) for s, e in zip(starts, ends)]
+
+
+def dictionary_indexing(
+    experimental,
+    dictionary,
+    metric="ncc",
+    keep_n=20,
+    n_per_iteration=None,
+    navigation_mask=None,
+    signal_mask=None,
+    rechunk=False,
+    dtype=None,
+    *,
+    step_sizes=None,
+    dictionary_rotations=None,
+    phase_name="",
+    scan_unit=None,
+    device=0,
+    comm=None,
+    verbose=True,
+):
+    """Index experimental patterns against a dictionary of simulated patterns.
+
+    Parameters (the first nine are those of `EBSD.dictionary_indexing`,
+    signals/ebsd.py:1827-1918)
+    ----------
+    experimental
+        Array (..., sy, sx) with 0, 1 or 2 navigation axes.
+    dictionary
+        Array (N, sy, sx): NumPy, or lazy (Dask-like with `.chunksize` and
+        `.compute()`), in which case chunks are computed one at a time inside
+        the loop as in the reference (:106-108).
+    metric
+        "ncc", "ndp" or an instance of this package's metrics.
+    keep_n, n_per_iteration, navigation_mask, signal_mask, rechunk, dtype
+        As in the reference.  `n_per_iteration` bounds how many dictionary
+        patterns are uploaded and matched per iteration.
+    step_sizes, dictionary_rotations, phase_name, scan_unit
+        What the reference takes from the signals' axes managers and from
+        `dictionary.xmap` (rotations as an (N, 4) quaternion array).
+    comm
+        `kikuchipy_amd.parallel.Communicator` to shard the dictionary over
+        ranks (one process per GPU).  Every rank must pass the same arrays; each
+        matches its own contiguous block and all ranks return the global result.
+    """
+    experimental = experimental if _is_lazy(experimental) else np.asarray(experimental)
+    if experimental.ndim < 2 or experimental.ndim > 4:
+        raise ValueError("experimental patterns must have 0, 1 or 2 navigation axes and 2 signal axes")
+    if dictionary.ndim != 3:
+        raise ValueError(
+            "Dictionary signal must have a non-empty `EBSD.xmap` attribute of equal size as the "
+            "number of dictionary patterns, and both the signal and crystal map must have only one "
+            "navigation dimension"
+        )
+    dict_size = dictionary.shape[0]
+    nav_shape_exp = tuple(experimental.shape[:-2])
+
+    # ---- signals/ebsd.py:1925-1964
+    if n_per_iteration is None:
+        n_per_iteration = dictionary.chunksize[0] if _is_lazy(dictionary) else dict_size
+    if navigation_mask is not None:
+        if navigation_mask.shape != nav_shape_exp:
+            raise ValueError(
+                f"The navigation mask shape {navigation_mask.shape} and the "
+                f"signal's navigation shape {nav_shape_exp} must be identical"
+            )
+        elif navigation_mask.all():
+            raise ValueError(
+                "The navigation mask must allow for indexing of at least one "
+                "pattern (at least one value equal to `False`)"
+            )
+        elif not isinstance(navigation_mask, np.ndarray):
+            raise ValueError("The navigation mask must be a NumPy array")
+    if signal_mask is not None:
+        if not isinstance(signal_mask, np.ndarray):
+            raise ValueError("The signal mask must be a NumPy array")
+    sig_shape_exp = tuple(experimental.shape[-2:])
+    sig_shape_dict = tuple(dictionary.shape[-2:])
+    if sig_shape_exp != sig_shape_dict:
+        raise ValueError(
+            f"Experimental {sig_shape_exp} and dictionary {sig_shape_dict} signal "
+            "shapes must be identical"
+        )
+    if dictionary_rotations is not None:
+        dictionary_rotations = np.asarray(dictionary_rotations)
+        if dictionary_rotations.shape != (dict_size, 4):
+            raise ValueError(
+                "Dictionary signal must have a non-empty `EBSD.xmap` attribute of equal size as "
+                "the number of dictionary patterns, and both the signal and crystal map must have "
+                "only one navigation dimension"
+            )
+
+    n_experimental_all = int(np.prod(nav_shape_exp)) if nav_shape_exp else 1
+    metric = prepare_metric(metric, navigation_mask, signal_mask, dtype, rechunk, n_experimental_all,
+                            dict_size, device=device)
+    if not isinstance(metric, _HipMetric):
+        raise ValueError("the stand-alone driver runs the GPU metrics of kikuchipy_amd only")
+
+    # ---- indexing/_dictionary_indexing.py:66-128
+    keep_n = min(keep_n, dict_size)
+    prepared = metric.prepare_experimental(experimental)
+    n_experimental = prepared.shape[0]
+    if verbose:
+        print(info_message(metric, n_experimental_all, dict_size, phase_name, n_experimental))
+
+    ctx = metric.context
+    ctx.set_keep_n(keep_n)
+    rank, world = (comm.rank, comm.world_size) if comm is not None else (0, 1)
+    if comm is not None:
+        comm.attach(ctx)
+    from kikuchipy_amd.parallel import shard_range
+
+    lo, hi = shard_range(dict_size, rank, world)
+    time_start = time.time()
+    for start, end in chunk_bounds(dict_size, n_per_iteration):
+        start, end = max(start, lo), min(end, hi)  # this rank's part of the chunk
+        if start >= end:
+            continue
+        chunk = dictionary[start:end]
+        if _is_lazy(chunk):
+            chunk = chunk.compute()
+        ctx.push_dictionary_chunk(np.asarray(chunk), start)
+    scores, simulation_indices = ctx.finalize(keep_n)
+    total_time = time.time() - time_start
+    scores = scores.astype(metric.dtype, copy=False)
+    pps = n_experimental / total_time
+    cps = n_experimental * dict_size / total_time
+    if verbose:
+        print(f"  Indexing speed: {pps:.5f} patterns/s, {cps:.5f} comparisons/s")
+
+    # ---- indexing/_dictionary_indexing.py:141-167
+    if step_sizes is None:
+        step_sizes = (1,) * len(nav_shape_exp)
+    rotations = None
+    if metric.navigation_mask is not None:
+        in_data = ~np.asarray(metric.navigation_mask).ravel()
+        scores_all = np.zeros((n_experimental_all, keep_n), dtype=scores.dtype)
+        scores_all[in_data] = scores
+        indices_all = np.zeros((n_experimental_all, keep_n), dtype=simulation_indices.dtype)
+        indices_all[in_data] = simulation_indices
+        if dictionary_rotations is not None:
+            rotations = np.zeros((n_experimental_all, keep_n, 4), dtype=dictionary_rotations.dtype)
+            rotations[..., 0] = 1  # identity quaternion where masked out
+            rotations[in_data] = dictionary_rotations[simulation_indices]
+        if keep_n == 1:
+            scores_all = scores_all.squeeze()
+            indices_all = indices_all.squeeze()
+            if rotations is not None:
+                rotations = rotations.reshape(-1, 4)
+        scores, simulation_indices = scores_all, indices_all
+    else:
+        in_data = np.ones(n_experimental_all, dtype=bool)
+        if dictionary_rotations is not None:
+            rotations = dictionary_rotations[simulation_indices]
+    return DictionaryIndexingResult(
+        scores, simulation_indices, nav_shape_exp, step_sizes, in_data, keep_n, rotations=rotations,
+        phase_name=phase_name, scan_unit=scan_unit, patterns_per_second=pps, comparisons_per_second=cps,
+    )

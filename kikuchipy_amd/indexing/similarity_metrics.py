@@ -1,0 +1,253 @@
+"""Similarity metrics of the dictionary-indexing path, backed by libkpdi.
+
+Mirror of the reference's plugin interface (paths under
+/root/reference/src/kikuchipy/indexing/similarity_metrics/):
+
+* `SimilarityMetric`                      <- _similarity_metric.py:23-253
+* `NormalizedCrossCorrelationMetric`      <- _normalized_cross_correlation.py:26-226
+* `NormalizedDotProductMetric`            <- _normalized_dot_product.py:25-194
+
+Same attribute names, same `__repr__`, same error text, so the objects can be
+handed to an unmodified `kikuchipy.indexing._dictionary_indexing._dictionary_indexing`
+(which only needs `prepare_experimental`, `prepare_dictionary`, `match`, and on
+the result of `match`: `.argtopk(k, axis=-1)`, `.topk(k, axis=-1)`, then
+`.reshape`; indexing/_dictionary_indexing.py:193-201).  What differs is WHERE
+the work happens: `prepare_experimental` uploads the patterns to the GPU once,
+`match` returns a lazy proxy, and the first `argtopk`/`topk` call on it runs
+ONE fused launch sequence (normalise chunk -> f32 MFMA GEMM with in-register
+top-k -> merge) and memoises both results.  The (M x N) similarity matrix is
+never formed.
+
+Arithmetic is float32 on the MFMA pipe.  `dtype=float64` is accepted like in the
+reference; scores are then returned as float64 values of the float32
+computation (within the 1e-5 parity contract, not a float64 evaluation).
+"""
+
+import abc
+
+import numpy as np
+
+from kikuchipy_amd import _lib
+
+
+class SimilarityMetric(abc.ABC):
+    """Abstract similarity metric (interface of the reference's
+    `kikuchipy.indexing.SimilarityMetric`).
+
+    Masks follow the reference's convention: `True` = excluded, for both the
+    navigation mask (patterns) and the signal mask (detector pixels).
+    """
+
+    _allowed_dtypes = []
+    _sign = None
+
+    def __init__(self, n_experimental_patterns=None, n_dictionary_patterns=None, navigation_mask=None,
+                 signal_mask=None, dtype="float32", rechunk=False):
+        self.n_experimental_patterns = n_experimental_patterns
+        self.n_dictionary_patterns = n_dictionary_patterns
+        self.navigation_mask = navigation_mask
+        self.signal_mask = signal_mask
+        self.dtype = dtype
+        self.rechunk = rechunk
+
+    def __repr__(self):
+        better = {1: "greater is better", -1: "lower is better"}[self.sign]
+        return (
+            f"{type(self).__name__}: {np.dtype(self.dtype).name}, {better}, "
+            f"rechunk: {self.rechunk}, "
+            f"navigation mask: {self.navigation_mask is not None}, "
+            f"signal mask: {self.signal_mask is not None}"
+        )
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @dtype.setter
+    def dtype(self, value):
+        self._dtype = np.dtype(value)
+
+    @property
+    def allowed_dtypes(self):
+        return self._allowed_dtypes
+
+    @property
+    def sign(self):
+        return self._sign
+
+    @abc.abstractmethod
+    def prepare_experimental(self, *args, **kwargs):
+        return NotImplemented  # pragma: no cover
+
+    @abc.abstractmethod
+    def prepare_dictionary(self, *args, **kwargs):
+        return NotImplemented  # pragma: no cover
+
+    @abc.abstractmethod
+    def match(self, *args, **kwargs):
+        return NotImplemented  # pragma: no cover
+
+    def raise_error_if_invalid(self):
+        allowed = self.allowed_dtypes
+        if len(allowed) != 0 and self.dtype not in allowed:
+            raise ValueError(
+                f"Data type {self.dtype} not among supported data types {allowed}"
+            )
+
+
+class PreparedExperimental:
+    """Handle of the experimental patterns resident on the GPU.  Exposes
+    `.shape` because `_dictionary_indexing` reads `experimental.shape[0]`
+    (indexing/_dictionary_indexing.py:74)."""
+
+    def __init__(self, metric, n_patterns, n_pixels):
+        self.metric = metric
+        self.shape = (n_patterns, n_pixels)
+
+
+class DictionaryChunk:
+    """A dictionary chunk waiting to be matched (still on the host)."""
+
+    def __init__(self, patterns):
+        self.patterns = patterns
+        self.shape = patterns.shape
+
+
+class Similarities:
+    """Stands in for the (M x n_chunk) similarity matrix.  `argtopk`/`topk`
+    trigger one fused GPU sweep over the chunk and share its result."""
+
+    def __init__(self, metric, chunk):
+        self._metric = metric
+        self._chunk = chunk
+        self._cache = {}
+        self.shape = (metric._engine_m, chunk.shape[0])
+
+    def _run(self, k):
+        if k not in self._cache:
+            self._cache[k] = self._metric._match_chunk(self._chunk.patterns, int(k))
+        return self._cache[k]
+
+    @staticmethod
+    def _check_axis(axis):
+        if axis not in (-1, 1):
+            raise ValueError("the fused engine ranks along the dictionary axis (axis=-1) only")
+
+    def argtopk(self, k, axis=-1):
+        self._check_axis(axis)
+        return self._run(k)[1]
+
+    def topk(self, k, axis=-1):
+        self._check_axis(axis)
+        return self._run(k)[0]
+
+
+class _HipMetric(SimilarityMetric):
+    _allowed_dtypes = [np.float32, np.float64]
+    _sign = 1
+    _metric_code = None
+
+    def __init__(self, *args, device=0, context=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._device = device
+        self._ctx = context
+        self._engine_m = 0
+        self._problem = None
+
+    # ------------------------------------------------------------------ engine
+    @property
+    def context(self):
+        """The libkpdi context (created on first use: needs a GPU)."""
+        if self._ctx is None:
+            self._ctx = _lib.Context(self._device)
+        return self._ctx
+
+    def _set_problem(self, sig_shape, keep_n):
+        sm = None if self.signal_mask is None else np.asarray(self.signal_mask)
+        if sm is not None and sm.shape != tuple(sig_shape):
+            raise ValueError(
+                f"The signal mask shape {sm.shape} and the detector shape {tuple(sig_shape)} must be identical"
+            )
+        self.context.set_problem(sig_shape[0], sig_shape[1], sm, self._metric_code, keep_n)
+        self._problem = tuple(sig_shape)
+
+    def _match_chunk(self, patterns, k):
+        ctx = self.context
+        ctx.set_keep_n(k)
+        ctx.push_dictionary_chunk(patterns, 0)
+        scores, indices = ctx.finalize(k)
+        return scores.astype(self.dtype, copy=False), indices
+
+    # ------------------------------------------------------------------ plugin API
+    def __call__(self, experimental, dictionary):
+        """Full similarity matrix is not available from the fused engine; use
+        `dictionary_indexing` or `match(...).topk(k)`."""
+        experimental = self.prepare_experimental(experimental)
+        dictionary = np.asarray(dictionary).reshape((self.n_dictionary_patterns,) + self._problem)
+        return self.match(experimental, self.prepare_dictionary(dictionary))
+
+    def prepare_experimental(self, patterns):
+        """Upload and keep the experimental patterns resident; casting, masking
+        and normalisation (_normalized_cross_correlation.py:88-128) run on the GPU
+        when the first dictionary chunk arrives."""
+        self.raise_error_if_invalid()
+        if hasattr(patterns, "compute"):
+            patterns = patterns.compute()
+        patterns = np.asarray(patterns)
+        if patterns.ndim < 2:
+            raise ValueError("experimental patterns need at least the two detector axes")
+        sig_shape = patterns.shape[-2:]
+        n = self.n_experimental_patterns
+        if n is None:
+            n = max(int(np.prod(patterns.shape[:-2])), 1)
+        patterns = patterns.reshape((n,) + sig_shape)
+        self._set_problem(sig_shape, 1)
+        self.context.set_experimental(patterns, self.navigation_mask)
+        self._engine_m = self.context.n_experimental
+        n_pix = int(np.prod(sig_shape))
+        if self.signal_mask is not None:
+            n_pix = int((~np.asarray(self.signal_mask, dtype=bool)).sum())
+        return PreparedExperimental(self, self._engine_m, n_pix)
+
+    def prepare_dictionary(self, patterns):
+        """Nothing happens on the host (_normalized_cross_correlation.py:130-159
+        runs on the GPU inside the sweep); the caller's array is never modified."""
+        if hasattr(patterns, "compute"):
+            patterns = patterns.compute()
+        patterns = np.asarray(patterns)
+        if self._problem is not None:
+            patterns = patterns.reshape((patterns.shape[0],) + self._problem)
+        return DictionaryChunk(patterns)
+
+    def match(self, experimental, dictionary):
+        if not isinstance(experimental, PreparedExperimental) or experimental.metric is not self:
+            raise ValueError("`experimental` must come from this metric's prepare_experimental()")
+        if not isinstance(dictionary, DictionaryChunk):
+            dictionary = self.prepare_dictionary(dictionary)
+        return Similarities(self, dictionary)
+
+
+class NormalizedCrossCorrelationMetric(_HipMetric):
+    r"""Normalized cross-correlation (Pearson correlation coefficient)
+
+    .. math:: r = \frac{\sum_i (x_i - \bar{x})(y_i - \bar{y})}
+                       {\sqrt{\sum_i (x_i - \bar{x})^2}\sqrt{\sum_i (y_i - \bar{y})^2}}
+
+    evaluated as zero-mean/unit-norm rows and one f32 MFMA GEMM on the GPU
+    (reference: _normalized_cross_correlation.py:26-226)."""
+
+    _metric_code = _lib.METRIC_NCC
+
+
+class NormalizedDotProductMetric(_HipMetric):
+    r"""Normalized dot product
+
+    .. math:: \rho = \frac{\langle \mathbf{X}, \mathbf{Y} \rangle}{||\mathbf{X}|| \cdot ||\mathbf{Y}||}
+
+    (reference: _normalized_dot_product.py:25-194; only the L2 norm is removed,
+    not the mean)."""
+
+    _metric_code = _lib.METRIC_NDP
+
+
+METRICS = {"ncc": NormalizedCrossCorrelationMetric, "ndp": NormalizedDotProductMetric}

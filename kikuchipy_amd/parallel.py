@@ -1,0 +1,88 @@
+"""Dictionary sharding over the GPUs of one node: one process per GPU.
+
+The reference has no distributed layer; this is the
+MI355X-native counterpart of its `n_per_iteration` chunking.  Rank r matches the
+contiguous dictionary block `shard_range(N, r, R)` - so a global dictionary
+index is local index + block start, like `simulation_indices_i += start`
+(indexing/_dictionary_indexing.py:118) - against ALL experimental patterns
+(replicated, <= 576 MB prepared at 40k patterns).  The only exchange step is
+the merge of the per-rank best-k lists: one RCCL all-gather of M*k*(4+4) bytes
+per rank over xGMI inside `kpdi_finalize`, followed by the same (score desc,
+index asc) merge kernel used between chunks, so every rank ends with the
+bit-identical global result.
+
+Control plane (rank discovery, the 128-byte RCCL unique id, barriers) goes
+through `torch.distributed` (gloo), which is what `torchrun` sets up; the data
+path never touches torch.
+"""
+
+import os
+
+
+def shard_range(n_total, rank, world_size):
+    """Contiguous block [start, end) of rank `rank`: sizes differ by at most 1."""
+    if world_size < 1 or not 0 <= rank < world_size:
+        raise ValueError(f"bad rank {rank} / world size {world_size}")
+    base, rem = divmod(int(n_total), int(world_size))
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class Communicator:
+    """Rank/world bookkeeping + creation of the RCCL communicator inside a
+    libkpdi context.  `broadcast_bytes(payload_or_None, src) -> bytes` moves the
+    unique id from rank 0 to everybody (default: torch.distributed)."""
+
+    def __init__(self, rank, world_size, broadcast_bytes=None, barrier=None):
+        self.rank = int(rank)
+        self.world_size = int(world_size)
+        self._broadcast = broadcast_bytes or _torch_broadcast_bytes
+        self._barrier = barrier or _torch_barrier
+        self._attached = set()
+
+    @classmethod
+    def from_env(cls):
+        """RANK / WORLD_SIZE as exported by `python -m torch.distributed.run`."""
+        return cls(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+
+    def barrier(self):
+        if self.world_size > 1:
+            self._barrier()
+
+    def exchange_unique_id(self, make_id):
+        """Rank 0 creates the id with `make_id()`; every rank returns it."""
+        payload = make_id() if self.rank == 0 else None
+        if self.world_size == 1:
+            return payload
+        return self._broadcast(payload, 0)
+
+    def attach(self, ctx):
+        """Create the RCCL communicator of `ctx` once (collective call)."""
+        if self.world_size == 1 or id(ctx) in self._attached:
+            return
+        uid = self.exchange_unique_id(ctx.comm_unique_id)
+        ctx.comm_init(self.rank, self.world_size, uid)
+        self._attached.add(id(ctx))
+
+
+def init_process_group(backend="gloo"):
+    """Join the job `torchrun` started (MASTER_ADDR/PORT, RANK, WORLD_SIZE)."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend)
+    return dist
+
+
+def _torch_broadcast_bytes(payload, src):
+    import torch.distributed as dist
+
+    box = [payload]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def _torch_barrier():
+    import torch.distributed as dist
+
+    dist.barrier()

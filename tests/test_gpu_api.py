@@ -1,0 +1,326 @@
+"""GPU tests of the Python host layer (the mirror of the reference's API for
+this path), against golden vectors from the reference and the CPU oracle.
+They read like the reference's tests/test_indexing/test_dictionary_indexing.py
+and tests/test_signals/test_ebsd.py."""
+
+import numpy as np
+import pytest
+
+import kikuchipy_amd as kpa
+from conftest import load_golden
+from oracle import kpdi_oracle as ko
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-5
+
+
+@pytest.fixture
+def dummy_signal():
+    g = load_golden("di_dummy.npz")
+    return kpa.EBSD(g["dummy"].copy(), static_background=g["dummy_bg"].copy())
+
+
+def dict_from(signal):
+    d = kpa.EBSD(signal.data.reshape(-1, 3, 3))
+    d.xmap = kpa.DictionaryXmap.empty((9,))
+    return d
+
+
+class TestDictionaryIndexing:
+    def test_dictionary_indexing_doesnt_change_data(self, dummy_signal):
+        s_dict = dict_from(dummy_signal)
+        s2, d2 = dummy_signal.deepcopy(), s_dict.deepcopy()
+        d2.xmap = s_dict.xmap
+        xmap = s2.dictionary_indexing(d2, metric="ndp", rechunk=True)
+        assert isinstance(xmap, kpa.DictionaryIndexingResult)
+        assert np.allclose(xmap.scores[:, 0], 1, atol=ATOL)
+        assert np.array_equal(dummy_signal.data, s2.data)
+        assert np.array_equal(s_dict.data, d2.data)
+
+    def test_dictionary_indexing_signal_mask(self, dummy_signal):
+        s_dict = dict_from(dummy_signal)
+        signal_mask = np.array([[0, 0, 0], [0, 1, 0], [0, 0, 0]], dtype=bool)
+        xmap = dummy_signal.dictionary_indexing(s_dict, dtype=np.float64, n_per_iteration=2,
+                                                signal_mask=signal_mask, rechunk=True)
+        assert np.allclose(xmap.scores[:, 0], 1, atol=ATOL)
+        assert xmap.scores.dtype == np.float64
+        g = load_golden("di_dummy.npz")
+        ko.assert_topk_parity(xmap.scores, xmap.simulation_indices, g["ncc_sigmask_f64_it2__scores"],
+                              g["ncc_sigmask_f64_it2__indices"], atol=ATOL)
+
+    @pytest.mark.parametrize("nav_slice, nav_shape", [
+        ((0, slice(0, 1)), (1,)),
+        ((0, slice(0, 3)), (3,)),
+        ((slice(0, 3), slice(0, 2)), (3, 2)),
+    ])
+    def test_dictionary_indexing_nav_shape(self, dummy_signal, nav_slice, nav_shape):
+        s = kpa.EBSD(dummy_signal.data[nav_slice], scan_unit="um")
+        xmap = s.dictionary_indexing(dict_from(dummy_signal))
+        assert xmap.shape == nav_shape
+        assert np.allclose(xmap.scores[:, 0], 1, atol=ATOL)
+        assert xmap.scan_unit == "um"
+
+    def test_zero_navigation_axes(self, dummy_signal):
+        s = kpa.EBSD(dummy_signal.data[1, 2])
+        xmap = s.dictionary_indexing(dict_from(dummy_signal), keep_n=3)
+        assert xmap.shape == () and xmap.scores.shape == (1, 3)
+        assert xmap.simulation_indices[0, 0] == 5
+
+    def test_dictionary_indexing_navigation_mask(self, dummy_signal):
+        s = dummy_signal
+        s_dict = dict_from(s)
+        nav_mask = np.array([[0, 0, 0], [0, 1, 0], [0, 0, 0]], dtype=bool)
+        xmap1 = s.dictionary_indexing(s_dict, keep_n=1, navigation_mask=nav_mask)
+        xmap2 = s.dictionary_indexing(s_dict, metric="ndp", navigation_mask=~nav_mask)
+        assert xmap1.size == 8 and xmap1.rotations_per_point == 1
+        assert xmap2.size == 1 and xmap2.rotations_per_point == 9
+        assert xmap1.scores.shape == (9,) and xmap1.simulation_indices.shape == (9,)
+        g = load_golden("di_dummy.npz")
+        in_data = ~nav_mask.ravel()
+        assert np.array_equal(xmap1.simulation_indices[in_data], g["ncc_navmask_k1__indices"][in_data])
+        assert np.allclose(xmap1.scores[in_data], g["ncc_navmask_k1__scores"][in_data], atol=ATOL)
+        assert xmap1.rotations.shape == (9, 4)
+        ko.assert_topk_parity(xmap2.scores[~in_data], xmap2.simulation_indices[~in_data],
+                              g["ndp_navmask_inv__scores"][~in_data], g["ndp_navmask_inv__indices"][~in_data],
+                              atol=ATOL, tie=2e-5)
+
+    def test_messages(self, dummy_signal, capsys):
+        g = load_golden("di_dummy.npz")
+        dummy_signal.dictionary_indexing(dict_from(dummy_signal), metric="ncc")
+        out = capsys.readouterr().out
+        want = str(g["ncc_all__msg"]).split("\n")
+        assert "Dictionary indexing information:" in out
+        assert "  Matching 9 experimental pattern(s) to 9 dictionary pattern(s)" in out
+        assert want[3] in out  # the metric's repr line
+        assert "  Indexing speed: " in out and " patterns/s, " in out and " comparisons/s" in out
+
+    def test_lazy_dictionary(self, dummy_signal):
+        """n_per_iteration from the lazy dictionary's chunk size; chunks are
+        computed inside the loop (test_dictionary_indexing.py:68-88)."""
+
+        class Lazy:
+            def __init__(self, a, chunk):
+                self._a, self.shape, self.ndim, self.chunksize = a, a.shape, a.ndim, (chunk,) + a.shape[1:]
+                self.computed = 0
+
+            def __getitem__(self, sl):
+                out = Lazy(self._a[sl], self.chunksize[0])
+                out.parent = self
+                return out
+
+            def compute(self):
+                getattr(self, "parent", self).computed += 1
+                return self._a
+
+        lazy = Lazy(dummy_signal.data.reshape(-1, 3, 3), 4)
+        res = kpa.dictionary_indexing(dummy_signal.data, lazy, metric="ndp", verbose=False)
+        assert lazy.computed == 3  # chunks of 4, 4, 1
+        assert np.allclose(res.scores[:, 0], 1, atol=ATOL)
+
+
+SYNTH_CASES = {
+    "ncc_k20": dict(metric="ncc", keep_n=20),
+    "ncc_k5_it700": dict(metric="ncc", keep_n=5, n_per_iteration=700),
+    "ndp_k5_it1000": dict(metric="ndp", keep_n=5, n_per_iteration=1000),
+    "ncc_k20_circ_it999": dict(metric="ncc", keep_n=20, signal_mask="circ", n_per_iteration=999),
+    "ncc_k10_f64": dict(metric="ncc", keep_n=10, dtype=np.float64),
+    "ndp_k50": dict(metric="ndp", keep_n=50),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SYNTH_CASES))
+def test_standalone_vs_reference_golden(name, synth_inputs):
+    exp, dic, g = synth_inputs
+    kw = dict(SYNTH_CASES[name])
+    if kw.get("signal_mask") == "circ":
+        kw["signal_mask"] = g["circular_mask"]
+    res = kpa.dictionary_indexing(exp, dic, verbose=False, **kw)
+    ko.assert_topk_parity(res.scores, res.simulation_indices, g[f"{name}__scores"], g[f"{name}__indices"],
+                          atol=ATOL)
+    assert res.scores.dtype == g[f"{name}__scores"].dtype
+    assert res.simulation_indices.dtype == np.int64
+
+
+def test_standalone_navmask_2d(synth_inputs):
+    exp, dic, g = synth_inputs
+    nav = g["nav_mask"]
+    q = np.random.default_rng(0).normal(size=(len(dic), 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    res = kpa.dictionary_indexing(exp.reshape(6, 8, 60, 60), dic, keep_n=7, n_per_iteration=1500,
+                                  navigation_mask=nav, dictionary_rotations=q, verbose=False)
+    in_data = ~nav.ravel()
+    assert res.scores.shape == (48, 7) and np.array_equal(res.is_in_data, in_data)
+    ko.assert_topk_parity(res.scores[in_data], res.simulation_indices[in_data],
+                          g["ncc_k7_nav__scores"][in_data], g["ncc_k7_nav__indices"][in_data], atol=ATOL)
+    assert np.array_equal(res.rotations[in_data], q[res.simulation_indices[in_data]])
+    assert np.array_equal(res.rotations[~in_data], np.tile([1.0, 0, 0, 0], (3, 7, 1)))
+
+
+def test_metric_plugin_in_reference_loop(synth_inputs):
+    """Drive the metric exactly as the reference's `_dictionary_indexing` /
+    `_match_chunk` do (indexing/_dictionary_indexing.py:70, :106-128, :193-201):
+    prepare once, then per chunk prepare_dictionary -> match -> argtopk/topk ->
+    reshape -> `+= start` -> host merge."""
+    exp, dic, g = synth_inputs
+    keep_n, n_it = 5, 700
+    metric = kpa.NormalizedCrossCorrelationMetric(n_experimental_patterns=len(exp),
+                                                  n_dictionary_patterns=len(dic))
+    experimental = metric.prepare_experimental(exp)
+    dictionary = dic.reshape((len(dic), -1))
+    n_experimental = experimental.shape[0]
+    simulation_indices = np.zeros((n_experimental, keep_n), dtype=np.int32)
+    scores = np.full((n_experimental, keep_n), -metric.sign, dtype=metric.dtype)
+    for start in range(0, len(dic), n_it):
+        chunk = dictionary[start:start + n_it]
+        simulated = metric.prepare_dictionary(chunk)
+        similarities = metric.match(experimental, simulated)
+        k_i = min(keep_n, len(chunk))
+        idx_i = similarities.argtopk(k_i, axis=-1).reshape((-1, k_i))
+        sc_i = similarities.topk(k_i, axis=-1).reshape((-1, k_i))
+        idx_i = idx_i + start
+        all_scores = np.hstack((scores, sc_i))
+        all_idx = np.hstack((simulation_indices, idx_i))
+        best = np.argsort(-all_scores, axis=1, kind="stable")[:, :keep_n]
+        scores = np.take_along_axis(all_scores, best, axis=1)
+        simulation_indices = np.take_along_axis(all_idx, best, axis=1)
+    ko.assert_topk_parity(scores, simulation_indices, g["ncc_k5_it700__scores"], g["ncc_k5_it700__indices"],
+                          atol=ATOL)
+    assert simulation_indices.dtype == np.int64
+
+
+# ----------------------------------------------------------------- pre-processing
+def close_u8(out, ref, max_frac=1e-3):
+    d = np.abs(out.astype(np.int64) - ref.astype(np.int64))
+    assert out.dtype == ref.dtype
+    assert d.max() <= 1, f"max grey-level difference {d.max()}"
+    assert (d != 0).mean() <= max_frac, f"{(d != 0).mean():.2e} of pixels differ"
+
+
+@pytest.mark.parametrize("data", ["ni", "dummy"])
+@pytest.mark.parametrize("op", ["subtract", "divide"])
+@pytest.mark.parametrize("scale_bg", [False, True])
+def test_remove_static_background_golden(data, op, scale_bg):
+    g = load_golden("preproc.npz")
+    if data == "dummy" and op == "divide" and scale_bg:
+        pytest.skip("the scaled dummy background contains zeros: 0/0, undefined cast in the reference")
+    out = kpa.remove_static_background(g[data], g[f"{data}_bg"], op, scale_bg)
+    ref = g[f"{data}__static_{op}_{int(scale_bg)}"]
+    assert np.array_equal(out, ref)  # bit-exact against the reference's py_func
+
+
+def test_remove_static_background_reference_known_answers(dummy_signal):
+    """tests/test_signals/test_ebsd.py:244-443 and :476-487 of the reference."""
+    k = load_golden("refknown.npz")
+    for ci in (0, 1):
+        op = str(k[f"static__{ci}__operation"])
+        s = dummy_signal.deepcopy()
+        s.remove_static_background(operation=op)
+        ans = k[f"static__{ci}__answer"].reshape(3, 3, 3, 3).astype(np.uint8)
+        if op == "subtract":
+            assert np.array_equal(s.data, ans)
+        else:
+            d = np.abs(s.data.astype(int) - ans.astype(int))
+            assert d.max() <= 1 and (d != 0).sum() <= 2  # reference's fastmath vs its own py_func
+    s = dummy_signal.deepcopy()
+    s.remove_static_background(scale_bg=True)
+    assert np.array_equal(s.data[0, 0], k["static_scalebg__answer"])
+    s2 = dummy_signal.remove_static_background(inplace=False)
+    assert isinstance(s2, kpa.EBSD) and not np.array_equal(s2.data, dummy_signal.data)
+
+
+def test_remove_static_background_uint16():
+    g = load_golden("preproc.npz")
+    out = kpa.remove_static_background(g["ni16"], g["ni_bg"].astype(np.uint16) * 257)
+    assert np.array_equal(out, g["ni16__static_subtract_0"])
+
+
+DYN_NI = {
+    "freq_sub_default": ("subtract", "frequency", None, 4.0),
+    "freq_div_default": ("divide", "frequency", None, 4.0),
+    "freq_sub_std5": ("subtract", "frequency", 5, 4.0),
+    "freq_sub_std3_t3": ("subtract", "frequency", 3, 3.0),
+    "spat_sub_default": ("subtract", "spatial", None, 4.0),
+    "spat_div_std5": ("divide", "spatial", 5, 4.0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(DYN_NI))
+def test_remove_dynamic_background_golden(name):
+    """uint8 parity contract of SURVEY.md 8(a): <= 1 grey level on <= 1e-3 of pixels."""
+    g = load_golden("preproc.npz")
+    out = kpa.remove_dynamic_background(g["ni"], *DYN_NI[name])
+    close_u8(out, g[f"ni__dyn_{name}"])
+
+
+def test_pipeline_static_then_dynamic_then_index(config1_inputs):
+    """The canonical user pipeline (doc/tutorials/pattern_matching.ipynb):
+    static -> dynamic -> dictionary indexing, against the reference's results."""
+    g = load_golden("preproc.npz")
+    exp_ref, dic, g1 = config1_inputs
+    s = kpa.EBSD(g["ni"].copy(), static_background=g["ni_bg"])
+    s.remove_static_background()
+    s.remove_dynamic_background()
+    close_u8(s.data, g["ni__static_then_dynamic"])
+    assert list(s.data[0, 0].ravel()[:6]) == [108, 87, 93, 151, 159, 122]
+    # score parity when the match stage is fed the reference's own pre-processed patterns
+    res = kpa.dictionary_indexing(exp_ref, dic, keep_n=5, verbose=False)
+    ko.assert_topk_parity(res.scores, res.simulation_indices, g1["ncc_k5__scores"], g1["ncc_k5__indices"],
+                          atol=ATOL)
+    # end to end (one flipped grey level moves a score by up to ~1.6e-5)
+    res2 = kpa.dictionary_indexing(s.data, dic, keep_n=5, verbose=False)
+    assert np.abs(res2.scores - g1["ncc_k5__scores"]).max() < 5e-5
+    assert np.array_equal(res2.simulation_indices[:, 0], g1["ncc_k5__indices"][:, 0])
+
+
+@pytest.mark.parametrize("cname,args", [
+    ("spat_sub_std2", ("subtract", "spatial", 2, 4.0)),
+    ("freq_sub_std2", ("subtract", "frequency", 2, 4.0)),
+    ("freq_div_std2", ("divide", "frequency", 2, 4.0)),
+    ("freq_sub_std1_t3", ("subtract", "frequency", 1, 3.0)),
+])
+@pytest.mark.parametrize("dt", [np.uint8, np.uint16, np.float32])
+def test_remove_dynamic_background_dummy(cname, args, dt):
+    g = load_golden("preproc.npz")
+    out = kpa.remove_dynamic_background(g["dummy"].astype(dt), *args)
+    ref = g[f"dummy__dyn_{cname}_{np.dtype(dt).name}"]
+    assert out.dtype == ref.dtype
+    if dt == np.float32:
+        assert np.allclose(out, ref, atol=1e-4)
+    else:
+        # 3x3 patterns: every pixel is an extremum candidate, so allow +-1 anywhere
+        scale = 1 if dt == np.uint8 else 257
+        assert np.abs(out.astype(np.int64) - ref.astype(np.int64)).max() <= scale
+
+
+def test_remove_dynamic_background_reference_known_answers():
+    """tests/test_signals/test_ebsd.py:534-916 (spatial) and :924-985 (frequency)."""
+    g = load_golden("preproc.npz")
+    k = load_golden("refknown.npz")
+    for ci in range(4):
+        op, std = str(k[f"dyn_spatial__{ci}__operation"]), float(k[f"dyn_spatial__{ci}__std"])
+        ans = k[f"dyn_spatial__{ci}__answer"].reshape((3,) * 4).astype(np.uint8)
+        s = kpa.EBSD(g["dummy"].copy())
+        s.remove_dynamic_background(operation=op, std=std, filter_domain="spatial")
+        assert s.data.dtype == ans.dtype
+        assert np.abs(s.data.astype(int) - ans.astype(int)).max() <= 1
+    for ci in range(4):
+        op, std = str(k[f"dyn_frequency__{ci}__operation"]), float(k[f"dyn_frequency__{ci}__std"])
+        ans = k[f"dyn_frequency__{ci}__answer"]
+        s = kpa.EBSD(g["dummy"].astype(ans.dtype))
+        s.remove_dynamic_background(operation=op, std=std, filter_domain="frequency")
+        assert s.data.dtype == ans.dtype
+        if ans.dtype.kind == "f":
+            assert np.allclose(s.data[0, 0], ans, atol=2e-4)
+        else:
+            scale = 1 if ans.dtype == np.uint8 else 257
+            assert np.abs(s.data[0, 0].astype(np.int64) - ans.astype(np.int64)).max() <= scale
+
+
+def test_non_square_and_large_detector():
+    rng = np.random.default_rng(4)
+    pats = rng.integers(0, 256, (7, 50, 64), dtype=np.uint8)
+    bg = rng.integers(1, 256, (50, 64), dtype=np.uint8)
+    assert np.array_equal(kpa.remove_static_background(pats, bg), ko.remove_static_background(pats, bg))
+    close_u8(kpa.remove_dynamic_background(pats), ko.remove_dynamic_background(pats), max_frac=2e-3)
+    big = rng.integers(0, 256, (3, 120, 120), dtype=np.uint8)
+    close_u8(kpa.remove_dynamic_background(big), ko.remove_dynamic_background(big), max_frac=2e-3)

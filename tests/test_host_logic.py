@@ -1,0 +1,154 @@
+"""Host-side logic that must work without a GPU: the metric interface, argument
+validation and messages of dictionary_indexing (mirrors the reference's
+tests/test_indexing/test_dictionary_indexing.py:90-180 and
+tests/test_indexing/test_similarity_metrics.py:28-39), chunk/shard arithmetic."""
+
+import numpy as np
+import pytest
+
+import kikuchipy_amd as kpa
+from conftest import load_golden
+from kikuchipy_amd.indexing._dictionary_indexing import chunk_bounds, info_message
+from kikuchipy_amd.parallel import Communicator, shard_range
+
+
+@pytest.fixture
+def dummy():
+    g = load_golden("di_dummy.npz")
+    return g["dummy"], g["dummy_bg"], g
+
+
+class FakeDask:
+    """Quacks like a dask array for the `isinstance(..., np.ndarray)` checks."""
+
+    def __init__(self, a):
+        self._a = np.asarray(a)
+        self.shape = self._a.shape
+
+    def all(self):
+        return self._a.all()
+
+    def compute(self):
+        return self._a
+
+
+def test_metric_repr_and_dtype():
+    """Exact `repr` string and dtype error (test_similarity_metrics.py:28-39)."""
+    g = load_golden("di_dummy.npz")
+    m = kpa.NormalizedCrossCorrelationMetric()
+    assert repr(m) == (
+        "NormalizedCrossCorrelationMetric: float32, greater is better, "
+        "rechunk: False, navigation mask: False, signal mask: False"
+    )
+    assert repr(m) == str(g["ncc_all__repr"])
+    m2 = kpa.NormalizedDotProductMetric(rechunk=True, signal_mask=np.zeros((3, 3), bool), dtype=np.float64)
+    assert repr(m2) == (
+        "NormalizedDotProductMetric: float64, greater is better, "
+        "rechunk: True, navigation mask: False, signal mask: True"
+    )
+    assert m.sign == 1 and m.allowed_dtypes == [np.float32, np.float64]
+    with pytest.raises(ValueError, match="Data type float16 not among"):
+        kpa.NormalizedCrossCorrelationMetric(dtype=np.float16).raise_error_if_invalid()
+    assert issubclass(kpa.NormalizedCrossCorrelationMetric, kpa.SimilarityMetric)
+    with pytest.raises(TypeError):
+        kpa.SimilarityMetric()  # abstract
+
+
+def test_info_message_matches_reference(dummy):
+    data, _, g = dummy
+    m = kpa.NormalizedCrossCorrelationMetric()
+    msg = info_message(m, 9, 9, "ni", 9)
+    assert msg in str(g["ncc_all__msg"])
+    m.navigation_mask = g["nav_mask"]
+    m2 = kpa.NormalizedCrossCorrelationMetric(navigation_mask=g["nav_mask"])
+    assert "Matching 8/9 experimental pattern(s) to 9 dictionary pattern(s)" in info_message(m2, 9, 9, "ni", 8)
+    assert info_message(m2, 9, 9, "ni", 8) in str(g["ncc_navmask_k1__msg"])
+
+
+def test_invalid_metric(dummy):
+    data, _, _ = dummy
+    with pytest.raises(ValueError, match="'invalid' must be either of "):
+        kpa.dictionary_indexing(data, data.reshape(-1, 3, 3), metric="invalid")
+
+
+def test_invalid_signal_shapes(dummy):
+    data, _, _ = dummy
+    with pytest.raises(ValueError, match=r"Experimental \(3, 3\) and dictionary \(2, 2\) signal shapes"):
+        kpa.dictionary_indexing(data, data[:, :, :2, :2].reshape(-1, 2, 2))
+
+
+def test_invalid_dictionary(dummy):
+    data, _, _ = dummy
+    s = kpa.EBSD(data)
+    s_dict = kpa.EBSD(data)  # two navigation axes, no xmap
+    with pytest.raises(ValueError, match="Dictionary signal must have a non-empty"):
+        s.dictionary_indexing(s_dict)
+    s_dict.xmap = kpa.DictionaryXmap.empty((3, 3))
+    with pytest.raises(ValueError, match="Dictionary signal must have a non-empty"):
+        s.dictionary_indexing(s_dict)
+    with pytest.raises(ValueError, match="Dictionary signal must have a non-empty"):
+        kpa.dictionary_indexing(data, data.reshape(-1, 3, 3), dictionary_rotations=np.zeros((8, 4)))
+
+
+def test_navigation_mask_raises(dummy):
+    data, _, _ = dummy
+    dic = data.reshape(-1, 3, 3)
+    with pytest.raises(ValueError, match=r"The navigation mask shape \(8,\) and "):
+        kpa.dictionary_indexing(data, dic, navigation_mask=np.ones(8, dtype=bool))
+    with pytest.raises(ValueError, match=r"The navigation mask must allow for "):
+        kpa.dictionary_indexing(data, dic, navigation_mask=np.ones((3, 3), dtype=bool))
+    nav = np.ones((3, 3), dtype=bool)
+    nav[0, 0] = False
+    with pytest.raises(ValueError, match=r"The navigation mask must be a NumPy "):
+        kpa.dictionary_indexing(data, dic, navigation_mask=FakeDask(nav))
+
+
+def test_signal_mask_raises(dummy):
+    data, _, g = dummy
+    with pytest.raises(ValueError, match="The signal mask must be a NumPy array"):
+        kpa.dictionary_indexing(data, data.reshape(-1, 3, 3), signal_mask=FakeDask(g["sig_mask"]))
+
+
+def test_dtype_rejected_before_any_gpu_work(dummy):
+    data, _, _ = dummy
+    with pytest.raises(ValueError, match="Data type float16 not among"):
+        kpa.dictionary_indexing(data, data.reshape(-1, 3, 3), dtype=np.float16)
+
+
+def test_static_background_validation(dummy):
+    """tests/test_signals/test_ebsd.py:445-466 of the reference."""
+    data, bg, _ = dummy
+    with pytest.raises(ValueError, match="Static background dtype_out"):
+        kpa.remove_static_background(data, np.ones((3, 3), dtype=np.int8))
+    with pytest.raises(ValueError, match="Signal"):
+        kpa.remove_static_background(data, np.ones((3, 2), dtype=np.uint8))
+    with pytest.raises(ValueError, match="`EBSD.static_background` is not a valid array"):
+        kpa.EBSD(data).remove_static_background()
+    with pytest.raises(ValueError, match="must be either of"):
+        kpa.remove_dynamic_background(data, filter_domain="wrong")
+
+
+def test_chunk_bounds():
+    """Same starts/ends as indexing/_dictionary_indexing.py:100-104."""
+    assert chunk_bounds(9, 2) == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 9)]
+    assert chunk_bounds(9, 9) == [(0, 9)]
+    assert chunk_bounds(10, 4) == [(0, 4), (4, 8), (8, 10)]
+    assert chunk_bounds(3000, 999) == [(0, 999), (999, 1998), (1998, 2997), (2997, 3000)]
+    assert chunk_bounds(5, 100) == [(0, 5)]
+
+
+@pytest.mark.parametrize("n,world", [(100000, 8), (300000, 8), (10, 3), (7, 8), (1, 1), (0, 2)])
+def test_shard_range_partitions(n, world):
+    blocks = [shard_range(n, r, world) for r in range(world)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == n
+    assert all(a[1] == b[0] for a, b in zip(blocks[:-1], blocks[1:]))
+    sizes = [b - a for a, b in blocks]
+    assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(n, world, world)
+
+
+def test_communicator_single_rank_needs_no_torch():
+    c = Communicator(0, 1)
+    assert c.exchange_unique_id(lambda: b"x" * 128) == b"x" * 128
+    c.barrier()
