@@ -235,6 +235,20 @@ def main():
         },
     }
 
+    # HBM-side traffic of the match kernel cannot be read from inside the process; it comes from
+    # the committed rocprofv3 PMC passes of this same command (tools/summarize_pmc.py:
+    # FETCH_SIZE*1024*2 + WRITE_SIZE*1024 per launch, the gfx950 corrections of the microarch guide)
+    if a.workload == "config2" and world == 1:
+        import glob
+
+        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+        if pmc:
+            with open(pmc[-1]) as f:
+                prof = json.load(f)
+            out["roofline"]["traffic"] = prof.get("match_traffic_bytes_per_launch")
+            out["roofline"]["traffic_source"] = os.path.relpath(pmc[-1], ROOT)
+            out["roofline"]["algorithmic_operand_bytes"] = float(w["n"] * k_kept * 4 + w["m"] * k_kept * 4)
+
     if world == 1 and not a.no_pcie:
         # informational: the same sweep with the dictionary handed over as a HOST
         # buffer (pageable memory -> PCIe inside the step).  Never `value`.
