@@ -134,6 +134,7 @@ struct kpdi_ctx {
   DevBuf run_s[2], run_i[2];   // running best-k ping-pong
   int run_cur = 0;
   bool run_valid = false;
+  DevBuf gthr;                            // shared per-pattern threshold of the match kernel
   DevBuf loc_s, loc_i, bound_s, bound_i;  // multi-pass (keep_n > 32)
   DevBuf gather_s, gather_i;              // RCCL all-gather target
 
@@ -255,6 +256,8 @@ int ensure_running(kpdi_ctx *c) {
   }
   c->run_cur = 0;
   HIPCHK(kpdi::launch_fill_topk(c->run_s[0].as<float>(), c->run_i[0].as<int>(), (int64_t)n, c->stream));
+  HIPCHK(c->gthr.reserve((size_t)c->m_pad * sizeof(unsigned)));
+  HIPCHK(kpdi::launch_fill_u32(c->gthr.as<unsigned>(), kpdi::THRESHOLD_NONE, c->m_pad, c->stream));
   c->run_valid = true;
   return KPDI_OK;
 }
@@ -279,6 +282,7 @@ int run_match(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int list_len, i
   ml.part_idx = c->part_i.as<int>();
   ml.bound_score = bound_s;
   ml.bound_idx = bound_i;
+  ml.gthr = c->gthr.as<unsigned>();
   {
     ScopedTimer t(c, &c->ev_match);
     HIPCHK(kpdi::launch_match(ml, c->stream));
@@ -306,9 +310,9 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
   const int n_pad = kpdi::round_up(n_chunk, kpdi::TILE_DICT);
   const int n_tiles = n_pad / kpdi::TILE_DICT;
   HIPCHK(c->dict_y.reserve((size_t)n_pad * c->kpad * sizeof(float)));
-  if (n_pad > n_chunk)
-    HIPCHK(hipMemsetAsync(c->dict_y.as<float>() + (size_t)n_chunk * c->kpad, 0,
-                          (size_t)(n_pad - n_chunk) * c->kpad * sizeof(float), c->stream));
+  if (n_pad > n_chunk)  // rows of the last 128-pattern tile are interleaved: clear the whole tile
+    HIPCHK(hipMemsetAsync(c->dict_y.as<float>() + (size_t)(n_tiles - 1) * kpdi::TILE_DICT * c->kpad, 0,
+                          (size_t)kpdi::TILE_DICT * c->kpad * sizeof(float), c->stream));
   kpdi::PrepLaunch p;
   p.raw = d_patterns;
   p.dtype = dtype;
@@ -370,6 +374,8 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
     for (int done = 0; done < kk; done += kpdi::KMAX_LIMIT) {
       const int kp = std::min(kpdi::KMAX_LIMIT, kk - done);
       const int len = kpdi::match_list_len(kp);
+      // each pass ranks a different slice: its shared threshold starts from scratch
+      HIPCHK(kpdi::launch_fill_u32(c->gthr.as<unsigned>(), kpdi::THRESHOLD_NONE, c->m_pad, c->stream));
       rc = run_match(c, (int)n_chunk, n_tiles, nsplit, len, global_start,
                      done ? c->bound_s.as<float>() : nullptr, done ? c->bound_i.as<int>() : nullptr);
       if (rc) return rc;
@@ -491,7 +497,7 @@ int kpdi_destroy(kpdi_ctx *c) {
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   for (DevBuf *b : {&c->pix_map, &c->exp_raw, &c->row_map, &c->exp_x, &c->dict_raw, &c->dict_y, &c->part_s,
                     &c->part_i, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
-                    &c->bound_s, &c->bound_i, &c->gather_s, &c->gather_i, &c->bg, &c->taps})
+                    &c->bound_s, &c->bound_i, &c->gthr, &c->gather_s, &c->gather_i, &c->bg, &c->taps})
     b->release();
   for (auto *l : {&c->ev_match, &c->ev_prep, &c->ev_merge})
     for (auto &pr : *l) {

@@ -14,6 +14,21 @@ constexpr int KMAX_LIMIT = 32;  // longest register-resident list of one pass
 
 inline int round_up(int64_t v, int64_t m) { return (int)(((v + m - 1) / m) * m); }
 
+// ---- layout of a PREPARED pattern matrix (what prep.hip writes and match.hip reads).
+// Rows (patterns) are grouped in tiles of 128, the pixel axis in slabs of TILE_K = 32.
+// One (tile, slab) block = 128 x 32 floats = 16 KB is CONTIGUOUS in memory and is
+// already the LDS image of match.hip (bank swizzle included), so a slab is fetched with
+// 16 lane-linear 1 KB global_load_lds pieces = one sequential 16 KB burst:
+//   block(tile, slab) at float offset (tile * nslab + slab) * 4096
+//   inside: 16-byte slot p = (row>>1)*16 + (((row&1)<<3 | kq) ^ ((row>>1)&7)), kq = (c&31)>>2
+// Returns the float offset of element (row r, padded pixel c).
+__host__ __device__ inline size_t prepared_offset(int r, int c, int nslab) {
+  const int tile = r >> 7, row = r & 127, slab = c >> 5, kq = (c >> 2) & 7;
+  const int rp = row >> 1;
+  const int slot = rp * 16 + ((((row & 1) << 3) | kq) ^ (rp & 7));
+  return ((size_t)tile * nslab + slab) * 4096 + (size_t)slot * 4 + (c & 3);
+}
+
 // list length (template instantiation) used for a pass that needs `k` entries
 int match_list_len(int k);
 
@@ -33,7 +48,11 @@ struct MatchLaunch {
   // only candidates strictly after (bound_score, bound_idx) in the ranking count
   const float *bound_score; // [m_pad] or nullptr
   const int *bound_idx;
+  // [m_pad] shared per-pattern threshold keys (see match.hip); must hold
+  // KPDI_THRESHOLD_NONE at the start of a sweep (and of every bounded pass)
+  unsigned *gthr;
 };
+constexpr unsigned THRESHOLD_NONE = 0x007fffffu;  // key of -inf
 hipError_t launch_match(const MatchLaunch &a, hipStream_t s);
 int match_blocks_per_cu();
 
@@ -71,6 +90,7 @@ struct MergeLaunch {
 };
 hipError_t launch_merge(const MergeLaunch &a, hipStream_t s);
 hipError_t launch_fill_topk(float *scores, int *idx, int64_t n, hipStream_t s);
+hipError_t launch_fill_u32(unsigned *p, unsigned value, int64_t n, hipStream_t s);
 hipError_t launch_last_column(const float *scores, const int *idx, int m, int stride, int col,
                               float *bound_score, int *bound_idx, hipStream_t s);
 

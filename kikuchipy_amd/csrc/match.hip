@@ -10,8 +10,10 @@
 //
 // Design (gfx950 / CDNA4)
 //  * Operands are the PREPARED matrices (prep.hip): dictionary Y (n_pad x kpad)
-//    and experimental X (m_pad x kpad), f32, row-major with the pixel axis
-//    contiguous, zero-padded.  Both are "K-major", i.e. an NT GEMM.
+//    and experimental X (m_pad x kpad), f32, zero-padded, both "K-major" (an NT
+//    GEMM), stored tile/slab-blocked: every (128 patterns x 32 pixels) block is 16 KB
+//    contiguous and already in LDS order (kernels.h: prepared_offset), so a slab is
+//    one sequential 16 KB burst from HBM instead of 128 strided 128-byte rows.
 //  * The dictionary is the MFMA A operand (rows of the accumulator tile), the
 //    experimental patterns are the B operand (columns).  With
 //    v_mfma_f32_32x32x2_f32 the accumulator column is lane&31, so every lane owns
@@ -25,8 +27,8 @@
 //    best-KMAX lists in registers for the whole sweep.
 //  * HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two
 //    32 KB stages; one barrier per 32-pixel slab.  The LDS image is lane-linear
-//    (hardware rule), so the bank swizzle is applied to the per-lane SOURCE
-//    address and again on the ds_read_b128 fragment reads: 16-byte slot
+//    (hardware rule), so the bank swizzle lives in the prepared layout itself
+//    and is applied again on the ds_read_b128 fragment reads: 16-byte slot
 //    w = ((row&1)<<3 | kq) ^ ((row>>1)&7) inside the 256-byte line of a row pair
 //    -> conflict-free for the 16-lane groups of ds_read_b128.
 //  * Each ds_read_b128 hands a lane 4 consecutive pixels of its row; MFMA j of a
@@ -41,6 +43,7 @@
 #include "kernels.h"
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace kpdi {
 
@@ -55,11 +58,22 @@ struct MatchArgs {
   const float *dict;
   const float *exp;
   int kpad, n_tiles, n_valid, nsplit, idx_base;
+  int xcd_row_groups, rows_per_group, splits_per_group;  // XCD-aware block map (0 = plain)
   float *part_scores;
   int *part_idx;
   const float *bound_score;
   const int *bound_idx;
+  unsigned *gthr;  // [m_pad] shared lower bound of each pattern's k-th best score (monotone key)
 };
+
+// float <-> unsigned key, order preserving (same map as merge.hip)
+__device__ __forceinline__ unsigned score_key(float s) {
+  const unsigned u = __float_as_uint(s);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_score32(unsigned u) {
+  return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+}
 
 // Insert (v, idx) into a descending sorted list; precondition v > s[KMAX-1].
 // Equal scores keep arrival order (candidates arrive by increasing dictionary
@@ -84,30 +98,33 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int sp = blockIdx.x % a.nsplit;
-  const int rb = blockIdx.x / a.nsplit;
+  // Block -> (experimental row block rb, dictionary split sp).  The dispatcher puts
+  // block b on XCD b%8 (speed only, never correctness).  With the XCD-aware map each
+  // XCD owns a (row group) x (split group) rectangle of the work: a dictionary slab is
+  // then shared through that XCD's L2 by rows_per_group workgroups and an experimental
+  // slab by splits_per_group workgroups, instead of (all rows) x 2.
+  int sp, rb;
+  if (a.xcd_row_groups > 0) {
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xr = x % a.xcd_row_groups, xs = x / a.xcd_row_groups;
+    rb = xr * a.rows_per_group + j % a.rows_per_group;
+    sp = xs * a.splits_per_group + j / a.rows_per_group;
+  } else {
+    sp = blockIdx.x % a.nsplit;
+    rb = blockIdx.x / a.nsplit;
+  }
   const int t0 = (int)(((int64_t)sp * a.n_tiles) / a.nsplit);
   const int t1 = (int)(((int64_t)(sp + 1) * a.n_tiles) / a.nsplit);
   const int kpad = a.kpad;
   const int nslab = kpad / TILE_K;
   const int nsteps = (t1 - t0) * nslab;
 
-  // ---- global -> LDS staging: wave wv copies 1 KB pieces {wv, wv+4, wv+8, wv+12}
-  // of each operand's 16 KB slab.  Piece c covers rows 8c..8c+7; LDS slot p (16 B
-  // units) of the slab holds row = 2*(p>>4) + (w>>3), pixel quad kq = w&7 where
-  // w = (p&15) ^ ((p>>4)&7).
-  unsigned goff[4];  // byte offset of this lane's 16 B inside the operand tile (without k0)
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int piece = wv + 4 * c;
-    const int rp = piece * 4 + (lane >> 4);
-    const int w = (lane & 15) ^ (rp & 7);
-    const int row = rp * 2 + (w >> 3);
-    const int kq = w & 7;
-    goff[c] = (unsigned)(row * kpad + kq * 4) * 4u;
-  }
-  const char *exp_base = (const char *)(a.exp + (size_t)rb * TILE_EXP * kpad);
-  const size_t dict_tile_bytes = (size_t)TILE_DICT * kpad * 4;
+  // ---- global -> LDS staging.  A prepared (tile, slab) block is 16 KB contiguous in
+  // memory and already swizzled (kernels.h: prepared_offset), so wave wv just copies the
+  // 1 KB pieces {wv, wv+4, wv+8, wv+12} of each operand's slab, lane-linear.
+  const unsigned goff = (unsigned)lane * 16u;
+  const size_t tile_bytes = (size_t)(kpad / TILE_K) * SLAB_BYTES;  // one 128-row tile, all slabs
+  const char *exp_base = (const char *)a.exp + (size_t)rb * tile_bytes;
 
   // ---- LDS -> MFMA fragments.  Lane l reads row (l&31) of a 32-row tile, pixel
   // quad kg*2 + (l>>5) of the slab.
@@ -130,13 +147,20 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
     best[j] = -INFINITY;
     best_idx[j] = INT_MAX;
   }
+  const int m_lane = rb * TILE_EXP + wv * 32 + (lane & 31);
   float ub = INFINITY;
   int ub_idx = -1;
   if (BOUNDED) {
-    const int m = rb * TILE_EXP + wv * 32 + (lane & 31);
-    ub = a.bound_score[m];
-    ub_idx = a.bound_idx[m];
+    ub = a.bound_score[m_lane];
+    ub_idx = a.bound_idx[m_lane];
   }
+  // Shared threshold.  Every list's KMAX-th best score is a lower bound of the
+  // pattern's global KMAX-th best, so the maximum over all lists (other lanes, other
+  // workgroups, earlier chunks of the sweep) may be used to reject candidates: nothing
+  // strictly below it can be in the final top-k.  It is only a FILTER - monotone and
+  // valid however stale it is, so no ordering or coherence is required of it - and it
+  // cuts the insertions per lane from ~k*ln(n_lane/k) to ~k*ln(N/k)/lists.
+  unsigned gkey = 0x007fffffu;  // key(-inf)
 
   f32x16 acc[4];
 #pragma unroll
@@ -149,29 +173,30 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
   {
     // next slab to fetch
     int ld_tile = t0, ld_slab = 0;
-    auto issue = [&](int stage) {
-      const char *gd = (const char *)a.dict + (size_t)ld_tile * dict_tile_bytes + (size_t)ld_slab * (TILE_K * 4);
-      const char *ge = exp_base + (size_t)ld_slab * (TILE_K * 4);
-      char *ls = smem + stage * STAGE_BYTES;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)(gd + goff[c]),
-            (__attribute__((address_space(3))) void *)(ls + (wv + 4 * c) * 1024), 16, 0, 0);
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)(ge + goff[c]),
-            (__attribute__((address_space(3))) void *)(ls + SLAB_BYTES + (wv + 4 * c) * 1024), 16, 0, 0);
-      }
+    // One 1 KB piece of the next slab: pieces 0-3 dictionary, 4-7 experimental.  The
+    // pieces of a slab are issued ONE AT A TIME between MFMA groups (below): a
+    // global_load_lds costs the wave ~60-100 issue cycles, which are free while an MFMA
+    // it issued is still executing but dead time when 8 of them sit in front of the MFMAs.
+    const char *gd = nullptr, *ge = nullptr;
+    auto next_slab = [&]() {
+      gd = (const char *)a.dict + (size_t)ld_tile * tile_bytes + (size_t)ld_slab * SLAB_BYTES;
+      ge = exp_base + (size_t)ld_slab * SLAB_BYTES;
       if (++ld_slab == nslab) {
         ld_slab = 0;
         ++ld_tile;
       }
     };
+    auto issue_piece = [&](int stage, int piece) {
+      const int c = piece & 3;
+      const char *g = (piece < 4 ? gd : ge) + (wv + 4 * c) * 1024 + goff;
+      char *l = smem + stage * STAGE_BYTES + (piece < 4 ? 0 : SLAB_BYTES) + (wv + 4 * c) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                       (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+    };
 
-    issue(0);
+    next_slab();
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) issue_piece(0, pc);
     int tile = t0, slab = 0;
     for (int s = 0; s < nsteps; ++s) {
       const int stage = s & 1;
@@ -179,7 +204,10 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
       // every wave is done reading the other stage (it was computed on in step s-1)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (s + 1 < nsteps) issue(stage ^ 1);
+      const bool more = s + 1 < nsteps;
+      if (more) next_slab();
+      if (slab == nslab - 1)  // fetched now (L2, bypassing L1), consumed after this slab's MFMAs
+        gkey = __hip_atomic_load(&a.gthr[m_lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
       const char *ls = smem + stage * STAGE_BYTES;
       // fragments of pixel group kg+1 are fetched while the 16 MFMAs of group kg run
@@ -190,16 +218,25 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg) {
         const int cur = kg & 1;
-        if (kg < 3) {
-          fb[cur ^ 1] = *(const f32x4 *)(ls + exp_frag_base + frag[kg + 1]);
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) fa[cur ^ 1][rt] = *(const f32x4 *)(ls + rt * 4096 + frag[kg + 1]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt)
             acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][rt][j], fb[cur][j], acc[rt], 0, 0, 0);
+          // behind these 4 MFMAs (256 pipe cycles): next group's fragments (j = 0, 1) ...
+          if (kg < 3 && j == 0) {
+            fb[cur ^ 1] = *(const f32x4 *)(ls + exp_frag_base + frag[kg + 1]);
+            fa[cur ^ 1][0] = *(const f32x4 *)(ls + 0 * 4096 + frag[kg + 1]);
+            fa[cur ^ 1][1] = *(const f32x4 *)(ls + 1 * 4096 + frag[kg + 1]);
+          }
+          if (kg < 3 && j == 1) {
+            fa[cur ^ 1][2] = *(const f32x4 *)(ls + 2 * 4096 + frag[kg + 1]);
+            fa[cur ^ 1][3] = *(const f32x4 *)(ls + 3 * 4096 + frag[kg + 1]);
+          }
+          // ... and one piece of the next slab (all 8 go out in the first half of the step)
+          if (kg < 2 && more) issue_piece(stage ^ 1, kg * 4 + j);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
 
       if (++slab == nslab) {
@@ -208,20 +245,33 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
         // fetched with relative VGPR addressing, so there are 4 copies of the insertion
         // code instead of 64.
         const int row0 = tile * TILE_DICT + 4 * (lane >> 5);
+        const float gthr = key_score32(gkey);
+        const float kth_before = best[KMAX - 1];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
+          // cheap screen of the 16 candidates of this accumulator tile (thresholds as of
+          // now: a superset of what the exact loop below admits)
+          bool any = false;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) any = any || (acc[rt][r] >= gthr && acc[rt][r] > best[KMAX - 1]);
+          if (__builtin_amdgcn_ballot_w64(any) != 0) {
 #pragma unroll 1
-          for (int r = 0; r < 16; ++r) {
-            const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
-            const float v = acc[rt][r] + 0.f;  // -0 -> +0 so that ties compare as the merge does
-            const int idx = a.idx_base + lrow;
-            bool ok = lrow < a.n_valid;
-            if (BOUNDED) ok = ok && (v < ub || (v == ub && idx > ub_idx));
-            if (ok && v > best[KMAX - 1]) list_insert<KMAX>(best, best_idx, v, idx);
+            for (int r = 0; r < 16; ++r) {
+              const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
+              const float v = acc[rt][r] + 0.f;  // -0 -> +0 so that ties compare as the merge does
+              const int idx = a.idx_base + lrow;
+              bool ok = lrow < a.n_valid && v >= gthr;
+              if (BOUNDED) ok = ok && (v < ub || (v == ub && idx > ub_idx));
+              if (ok && v > best[KMAX - 1]) list_insert<KMAX>(best, best_idx, v, idx);
+            }
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
         }
+        // publish this list's KMAX-th best if it rose above the shared threshold
+        if (best[KMAX - 1] > kth_before && best[KMAX - 1] > gthr)
+          __hip_atomic_fetch_max(&a.gthr[m_lane], score_key(best[KMAX - 1]), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
         slab = 0;
         ++tile;
       }
@@ -229,7 +279,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
   }
 
 write_out : {
-  const int m = rb * TILE_EXP + wv * 32 + (lane & 31);
+  const int m = m_lane;
   const int lists = 2 * a.nsplit;
   const size_t o = ((size_t)m * lists + (size_t)(sp * 2 + (lane >> 5))) * KMAX;
 #pragma unroll
@@ -270,11 +320,33 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   g.n_tiles = a.n_tiles;
   g.n_valid = a.n_valid;
   g.nsplit = a.nsplit;
+  // choose (row groups) x (split groups) = 8 XCDs minimising rows_per_group + splits_per_group
+  g.xcd_row_groups = 0;
+  g.rows_per_group = g.splits_per_group = 0;
+  {
+    const int rbk = a.m_pad / TILE_EXP;
+    int best_cost = 1 << 30;
+    for (int gr = 1; gr <= 8; gr *= 2) {
+      const int gs = 8 / gr;
+      if (rbk % gr || a.nsplit % gs) continue;
+      const int cost = rbk / gr + a.nsplit / gs;
+      if (cost < best_cost) {
+        best_cost = cost;
+        g.xcd_row_groups = gr;
+        g.rows_per_group = rbk / gr;
+        g.splits_per_group = a.nsplit / gs;
+      }
+    }
+    if (const char *e = getenv("KPDI_PLAIN_BLOCK_MAP")) {
+      if (e[0] == '1') g.xcd_row_groups = 0;
+    }
+  }
   g.idx_base = a.idx_base;
   g.part_scores = a.part_scores;
   g.part_idx = a.part_idx;
   g.bound_score = a.bound_score;
   g.bound_idx = a.bound_idx;
+  g.gthr = a.gthr;
   const int grid = (a.m_pad / TILE_EXP) * a.nsplit;
   const bool bounded = a.bound_score != nullptr;
 #define KPDI_CASE(K)                                           \

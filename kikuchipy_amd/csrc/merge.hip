@@ -123,6 +123,17 @@ hipError_t launch_fill_topk(float *scores, int *idx, int64_t n, hipStream_t s) {
   return hipGetLastError();
 }
 
+__global__ void fill_u32_kernel(unsigned *p, unsigned value, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = value;
+}
+
+hipError_t launch_fill_u32(unsigned *p, unsigned value, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, value, n);
+  return hipGetLastError();
+}
+
 __global__ void last_column_kernel(const float *scores, const int *idx, int m, int stride, int col,
                                    float *bs, int *bi) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
