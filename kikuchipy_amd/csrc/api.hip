@@ -135,6 +135,7 @@ struct kpdi_ctx {
   int run_cur = 0;
   bool run_valid = false;
   DevBuf gthr;                            // shared per-pattern threshold of the match kernel
+  DevBuf tile_ctr;                        // dynamic tile counters of the match kernel
   DevBuf loc_s, loc_i, bound_s, bound_i;  // multi-pass (keep_n > 32)
   DevBuf gather_s, gather_i;              // RCCL all-gather target
 
@@ -283,6 +284,10 @@ int run_match(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int list_len, i
   ml.bound_score = bound_s;
   ml.bound_idx = bound_i;
   ml.gthr = c->gthr.as<unsigned>();
+  const size_t ctr_bytes = (size_t)(c->m_pad / kpdi::TILE_EXP) * sizeof(unsigned);
+  HIPCHK(c->tile_ctr.reserve(ctr_bytes));
+  HIPCHK(hipMemsetAsync(c->tile_ctr.p, 0, ctr_bytes, c->stream));
+  ml.tile_ctr = c->tile_ctr.as<unsigned>();
   {
     ScopedTimer t(c, &c->ev_match);
     HIPCHK(kpdi::launch_match(ml, c->stream));
@@ -497,7 +502,7 @@ int kpdi_destroy(kpdi_ctx *c) {
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   for (DevBuf *b : {&c->pix_map, &c->exp_raw, &c->row_map, &c->exp_x, &c->dict_raw, &c->dict_y, &c->part_s,
                     &c->part_i, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
-                    &c->bound_s, &c->bound_i, &c->gthr, &c->gather_s, &c->gather_i, &c->bg, &c->taps})
+                    &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps})
     b->release();
   for (auto *l : {&c->ev_match, &c->ev_prep, &c->ev_merge})
     for (auto &pr : *l) {

@@ -51,6 +51,7 @@ struct MatchLaunch {
   // [m_pad] shared per-pattern threshold keys (see match.hip); must hold
   // KPDI_THRESHOLD_NONE at the start of a sweep (and of every bounded pass)
   unsigned *gthr;
+  unsigned *tile_ctr;  // [m_pad / TILE_EXP] dynamic tile counters, zeroed before every launch
 };
 constexpr unsigned THRESHOLD_NONE = 0x007fffffu;  // key of -inf
 hipError_t launch_match(const MatchLaunch &a, hipStream_t s);

@@ -22,9 +22,10 @@
 //    no cross-lane traffic.
 //  * Workgroup = 4 waves, tile = 128 dictionary x 128 experimental patterns;
 //    wave w owns experimental columns [32w, 32w+32) and all 128 dictionary rows
-//    (4 accumulator tiles = 64 VGPRs).  A workgroup is persistent over a
-//    contiguous range of dictionary tiles ("split") and keeps its lanes' sorted
-//    best-KMAX lists in registers for the whole sweep.
+//    (4 accumulator tiles = 64 VGPRs).  A workgroup is persistent: it belongs to
+//    one block of 128 experimental patterns, draws dictionary tiles (ascending) from
+//    that block's counter and keeps its lanes' sorted best-KMAX lists in registers
+//    for the whole sweep.
 //  * HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two
 //    32 KB stages; one barrier per 32-pixel slab.  The LDS image is lane-linear
 //    (hardware rule), so the bank swizzle lives in the prepared layout itself
@@ -63,6 +64,7 @@ struct MatchArgs {
   int *part_idx;
   const float *bound_score;
   const int *bound_idx;
+  unsigned *tile_ctr;  // [row blocks] next dictionary tile to hand out, zero at launch
   unsigned *gthr;  // [m_pad] shared lower bound of each pattern's k-th best score (monotone key)
 };
 
@@ -79,16 +81,24 @@ __device__ __forceinline__ float key_score32(unsigned u) {
 // Equal scores keep arrival order (candidates arrive by increasing dictionary
 // index), which is the engine's tie rule: lower dictionary index first.
 // new s[j] = median(s[j-1], s[j], v) because s[j-1] >= s[j].
+// Branch-free: the index selects are written as bit blends (the compiler folds them to
+// v_cndmask; nested ?: on the indices came out as ~20 exec-mask branches per insertion).
+__device__ __forceinline__ int blend(int mask, int if_set, int if_clear) {
+  return (if_set & mask) | (if_clear & ~mask);
+}
+
 template <int KMAX>
 __device__ __forceinline__ void list_insert(float (&s)[KMAX], int (&id)[KMAX], float v, int idx) {
+  int above[KMAX];  // all ones where v ranks above entry j (monotone in j: 0..0 1..1)
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) above[j] = (v > s[j]) ? -1 : 0;
 #pragma unroll
   for (int j = KMAX - 1; j >= 1; --j) {
-    const bool below = v > s[j];       // v ranks above entry j
-    const bool below1 = v > s[j - 1];  // v ranks above entry j-1 as well -> shift
-    id[j] = below ? (below1 ? id[j - 1] : idx) : id[j];
+    // above entry j-1 too -> entry j-1 shifts down into j; else v lands in j (if above j)
+    id[j] = blend(above[j], blend(above[j - 1], id[j - 1], idx), id[j]);
     s[j] = __builtin_amdgcn_fmed3f(s[j - 1], s[j], v);
   }
-  id[0] = (v > s[0]) ? idx : id[0];
+  id[0] = blend(above[0], idx, id[0]);
   s[0] = fmaxf(s[0], v);
 }
 
@@ -113,11 +123,15 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
     sp = blockIdx.x % a.nsplit;
     rb = blockIdx.x / a.nsplit;
   }
-  const int t0 = (int)(((int64_t)sp * a.n_tiles) / a.nsplit);
-  const int t1 = (int)(((int64_t)(sp + 1) * a.n_tiles) / a.nsplit);
   const int kpad = a.kpad;
   const int nslab = kpad / TILE_K;
-  const int nsteps = (t1 - t0) * nslab;
+  // Dictionary tiles are handed out dynamically: the nsplit workgroups of a row block
+  // draw tile numbers from one counter, so all of them finish within one tile of each
+  // other however unevenly the CU's two resident workgroups share the MFMA pipe (static
+  // ranges left half of the workgroups idle for the last ~12 % of the launch).  Each
+  // workgroup still sees ascending tile numbers, which the tie rule relies on.
+  unsigned *tile_ctr = a.tile_ctr + rb;
+  volatile int *ctrl = (volatile int *)(smem + LDS_BYTES);  // 4 control words behind the stages
 
   // ---- global -> LDS staging.  A prepared (tile, slab) block is 16 KB contiguous in
   // memory and already swizzled (kernels.h: prepared_offset), so wave wv just copies the
@@ -168,11 +182,21 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
 
-  if (nsteps <= 0) goto write_out;
+  int tile, next_tile;
+  if (tid == 0) {
+    ctrl[0] = (int)atomicAdd(tile_ctr, 1u);
+    ctrl[1] = (int)atomicAdd(tile_ctr, 1u);
+  }
+  __syncthreads();
+  tile = __builtin_amdgcn_readfirstlane(ctrl[0]);
+  next_tile = __builtin_amdgcn_readfirstlane(ctrl[1]);
+  __syncthreads();
+  if (tile >= a.n_tiles) goto write_out;
 
   {
     // next slab to fetch
-    int ld_tile = t0, ld_slab = 0;
+    int ld_tile = tile, ld_slab = 0;
+    int fetched = 0;  // thread 0: the tile number drawn during the current tile
     // One 1 KB piece of the next slab: pieces 0-3 dictionary, 4-7 experimental.  The
     // pieces of a slab are issued ONE AT A TIME between MFMA groups (below): a
     // global_load_lds costs the wave ~60-100 issue cycles, which are free while an MFMA
@@ -183,7 +207,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
       ge = exp_base + (size_t)ld_slab * SLAB_BYTES;
       if (++ld_slab == nslab) {
         ld_slab = 0;
-        ++ld_tile;
+        ld_tile = next_tile;  // slab 0 of the following tile is fetched during this tile's last slab
       }
     };
     auto issue_piece = [&](int stage, int piece) {
@@ -197,15 +221,16 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
     next_slab();
 #pragma unroll
     for (int pc = 0; pc < 8; ++pc) issue_piece(0, pc);
-    int tile = t0, slab = 0;
-    for (int s = 0; s < nsteps; ++s) {
-      const int stage = s & 1;
-      // slab s has landed (this wave's pieces: vmcnt; the other waves': barrier) and
-      // every wave is done reading the other stage (it was computed on in step s-1)
+    int slab = 0, stage = 0;
+    for (;;) {
+      // the slab of this step has landed (this wave's pieces: vmcnt; the other waves':
+      // barrier) and every wave is done reading the other stage (computed on last step)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (slab == 1 && tid == 0) ctrl[2] = fetched;  // drawn at slab 0; the vmcnt above covers it
       __syncthreads();
-      const bool more = s + 1 < nsteps;
+      const bool more = slab + 1 < nslab || next_tile < a.n_tiles;
       if (more) next_slab();
+      if (slab == 0 && tid == 0) fetched = (int)atomicAdd(tile_ctr, 1u);
       if (slab == nslab - 1)  // fetched now (L2, bypassing L1), consumed after this slab's MFMAs
         gkey = __hip_atomic_load(&a.gthr[m_lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
@@ -273,8 +298,15 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
           __hip_atomic_fetch_max(&a.gthr[m_lane], score_key(best[KMAX - 1]), __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
         slab = 0;
-        ++tile;
+        if (nslab == 1) {  // single-slab detectors: no later step of this tile published it
+          if (tid == 0) ctrl[2] = fetched;
+          __syncthreads();
+        }
+        tile = next_tile;
+        next_tile = __builtin_amdgcn_readfirstlane(ctrl[2]);
+        if (tile >= a.n_tiles) break;
       }
+      stage ^= 1;
     }
   }
 
@@ -304,11 +336,11 @@ static hipError_t launch_t(const MatchArgs &args, int grid, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void *)match_topk_kernel<KMAX, BOUNDED>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 16);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((match_topk_kernel<KMAX, BOUNDED>), dim3(grid), dim3(MATCH_THREADS), LDS_BYTES, s, args);
+  hipLaunchKernelGGL((match_topk_kernel<KMAX, BOUNDED>), dim3(grid), dim3(MATCH_THREADS), LDS_BYTES + 16, s, args);
   return hipGetLastError();
 }
 
@@ -347,6 +379,7 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   g.bound_score = a.bound_score;
   g.bound_idx = a.bound_idx;
   g.gthr = a.gthr;
+  g.tile_ctr = a.tile_ctr;
   const int grid = (a.m_pad / TILE_EXP) * a.nsplit;
   const bool bounded = a.bound_score != nullptr;
 #define KPDI_CASE(K)                                           \
