@@ -734,7 +734,7 @@ int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
   const size_t n = (size_t)c->m * k;
   const float *d_s = c->run_s[c->run_cur].as<float>();
   const int *d_i = c->run_i[c->run_cur].as<int>();
-  if (c->comm && c->nranks > 1) {
+  if (c->comm) {  // also with one rank: keeps the RCCL path testable on a single GPU
     HIPCHK(c->gather_s.reserve(n * c->nranks * sizeof(float)));
     HIPCHK(c->gather_i.reserve(n * c->nranks * sizeof(int)));
     ncclResult_t r = g_rccl.GroupStart();

@@ -181,3 +181,43 @@ def test_error_paths(ctx):
         ctx.set_problem(2, 2, np.ones((2, 2), bool), _lib.METRIC_NCC, 1)
     with pytest.raises(_lib.KpdiError, match="unknown metric"):
         ctx.set_problem(2, 2, None, 7, 1)
+
+
+def test_rccl_path_single_rank(synth_inputs):
+    """The multi-GPU finalize (RCCL all-gather of the per-rank best-k + merge kernel)
+    with a one-rank communicator: must reproduce the plain result exactly."""
+    from kikuchipy_amd import _lib
+
+    exp, dic, g = synth_inputs
+    with _lib.Context(0) as c:
+        ref = run_engine(c, exp, dic, keep_n=20, chunk=1000)
+        c.comm_init(0, 1, _lib.Context.comm_unique_id())
+        out = run_engine(c, exp, dic, keep_n=20, chunk=1000)
+        again = c.finalize(20)  # finalize is idempotent
+    assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
+    assert np.array_equal(again[0], ref[0]) and np.array_equal(again[1], ref[1])
+
+
+def test_sharded_sweep_equals_full_sweep(synth_inputs):
+    """What N ranks do, on one GPU: each 'rank' sweeps only its dictionary block
+    (kikuchipy_amd.parallel.shard_range); merging the per-rank lists with the
+    engine's merge order gives the single-GPU result bit for bit."""
+    from kikuchipy_amd import _lib
+    from kikuchipy_amd.parallel import shard_range
+
+    exp, dic, g = synth_inputs
+    k = 20
+    with _lib.Context(0) as c:
+        ref_s, ref_i = run_engine(c, exp, dic, keep_n=k)
+        parts = []
+        for r in range(4):
+            lo, hi = shard_range(len(dic), r, 4)
+            c.set_problem(60, 60, None, _lib.METRIC_NCC, k)
+            c.set_experimental(exp)
+            c.push_dictionary_chunk(dic[lo:hi], lo)
+            parts.append(c.finalize(k))
+    s = np.concatenate([p[0] for p in parts], axis=1)
+    i = np.concatenate([p[1] for p in parts], axis=1)
+    order = np.lexsort((i, -s), axis=1)[:, :k]
+    assert np.array_equal(np.take_along_axis(i, order, 1), ref_i)
+    assert np.array_equal(np.take_along_axis(s, order, 1), ref_s)
