@@ -26,8 +26,9 @@
 //    one block of 128 experimental patterns, draws dictionary tiles (ascending) from
 //    that block's counter and keeps its lanes' sorted best-KMAX lists in registers
 //    for the whole sweep.
-//  * HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two
-//    32 KB stages; one barrier per 32-pixel slab.  The LDS image is lane-linear
+//  * Dictionary slabs: HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round
+//    trip), two 16 KB stages, one barrier per 32-pixel slab.  Experimental slabs are
+//    not shared between waves and go straight to VGPRs (see exp_base below).  The LDS image is lane-linear
 //    (hardware rule), so the bank swizzle lives in the prepared layout itself
 //    and is applied again on the ds_read_b128 fragment reads: 16-byte slot
 //    w = ((row&1)<<3 | kq) ^ ((row>>1)&7) inside the 256-byte line of a row pair
@@ -51,9 +52,9 @@ namespace kpdi {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SLAB_BYTES = TILE_DICT * TILE_K * 4;  // 16 KB per operand per stage
-constexpr int STAGE_BYTES = 2 * SLAB_BYTES;          // dictionary slab + experimental slab
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;           // double buffered: 64 KB -> 2 workgroups / CU
+constexpr int SLAB_BYTES = TILE_DICT * TILE_K * 4;  // one dictionary slab: 16 KB
+constexpr int STAGE_BYTES = SLAB_BYTES;              // only the dictionary goes through LDS
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;           // double buffered: 32 KB per workgroup
 
 struct MatchArgs {
   const float *dict;
@@ -138,7 +139,11 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
   // 1 KB pieces {wv, wv+4, wv+8, wv+12} of each operand's slab, lane-linear.
   const unsigned goff = (unsigned)lane * 16u;
   const size_t tile_bytes = (size_t)(kpad / TILE_K) * SLAB_BYTES;  // one 128-row tile, all slabs
-  const char *exp_base = (const char *)a.exp + (size_t)rb * tile_bytes;
+  // The experimental operand is NOT shared between waves (wave wv only ever needs its own
+  // 32 patterns), so it skips LDS: the prepared layout (kernels.h: prepared_exp_offset)
+  // stores, per (32 patterns, slab), the four MFMA B fragments lane-linear - each one a
+  // fully coalesced 1 KB global_load_dwordx4 straight into VGPRs, one slab ahead.
+  const f32x4 *exp_base = (const f32x4 *)a.exp + ((size_t)rb * 4 + wv) * (size_t)nslab * 256 + lane;
 
   // ---- LDS -> MFMA fragments.  Lane l reads row (l&31) of a 32-row tile, pixel
   // quad kg*2 + (l>>5) of the slab.
@@ -151,7 +156,6 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
       frag[kg] = (unsigned)((lr >> 1) * 256 + w * 16);
     }
   }
-  const unsigned exp_frag_base = SLAB_BYTES + wv * 4096;
 
   // ---- per-lane running best lists for experimental pattern rb*128 + wv*32 + (lane&31)
   float best[KMAX];
@@ -197,30 +201,33 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
     // next slab to fetch
     int ld_tile = tile, ld_slab = 0;
     int fetched = 0;  // thread 0: the tile number drawn during the current tile
-    // One 1 KB piece of the next slab: pieces 0-3 dictionary, 4-7 experimental.  The
-    // pieces of a slab are issued ONE AT A TIME between MFMA groups (below): a
-    // global_load_lds costs the wave ~60-100 issue cycles, which are free while an MFMA
-    // it issued is still executing but dead time when 8 of them sit in front of the MFMAs.
-    const char *gd = nullptr, *ge = nullptr;
+    // The next slab = four 1 KB LDS-DMA pieces of the dictionary slab + the four B
+    // fragments of the experimental slab.  They are issued ONE AT A TIME between MFMA
+    // groups (below): the issue cycles of a memory instruction are free while an MFMA the
+    // wave issued is still executing, but dead time when 8 of them sit in front of the MFMAs.
+    const char *gd = nullptr;
+    const f32x4 *ge = nullptr;
+    f32x4 eb[4], eb_next[4];  // experimental fragments of this / the next slab
     auto next_slab = [&]() {
       gd = (const char *)a.dict + (size_t)ld_tile * tile_bytes + (size_t)ld_slab * SLAB_BYTES;
-      ge = exp_base + (size_t)ld_slab * SLAB_BYTES;
+      ge = exp_base + (size_t)ld_slab * 256;
       if (++ld_slab == nslab) {
         ld_slab = 0;
         ld_tile = next_tile;  // slab 0 of the following tile is fetched during this tile's last slab
       }
     };
-    auto issue_piece = [&](int stage, int piece) {
-      const int c = piece & 3;
-      const char *g = (piece < 4 ? gd : ge) + (wv + 4 * c) * 1024 + goff;
-      char *l = smem + stage * STAGE_BYTES + (piece < 4 ? 0 : SLAB_BYTES) + (wv + 4 * c) * 1024;
+    auto issue_piece = [&](int stage, int c) {
+      const char *g = gd + (wv + 4 * c) * 1024 + goff;
+      char *l = smem + stage * STAGE_BYTES + (wv + 4 * c) * 1024;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                        (__attribute__((address_space(3))) void *)l, 16, 0, 0);
     };
 
     next_slab();
 #pragma unroll
-    for (int pc = 0; pc < 8; ++pc) issue_piece(0, pc);
+    for (int pc = 0; pc < 4; ++pc) issue_piece(0, pc);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) eb_next[kg] = ge[kg * 64];
     int slab = 0, stage = 0;
     for (;;) {
       // the slab of this step has landed (this wave's pieces: vmcnt; the other waves':
@@ -235,9 +242,10 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
         gkey = __hip_atomic_load(&a.gthr[m_lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
       const char *ls = smem + stage * STAGE_BYTES;
-      // fragments of pixel group kg+1 are fetched while the 16 MFMAs of group kg run
-      f32x4 fa[2][4], fb[2];
-      fb[0] = *(const f32x4 *)(ls + exp_frag_base + frag[0]);
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) eb[kg] = eb_next[kg];
+      // dictionary fragments of pixel group kg+1 are fetched while the 16 MFMAs of group kg run
+      f32x4 fa[2][4];
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) fa[0][rt] = *(const f32x4 *)(ls + rt * 4096 + frag[0]);
 #pragma unroll
@@ -247,10 +255,9 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt)
-            acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][rt][j], fb[cur][j], acc[rt], 0, 0, 0);
+            acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][rt][j], eb[kg][j], acc[rt], 0, 0, 0);
           // behind these 4 MFMAs (256 pipe cycles): next group's fragments (j = 0, 1) ...
           if (kg < 3 && j == 0) {
-            fb[cur ^ 1] = *(const f32x4 *)(ls + exp_frag_base + frag[kg + 1]);
             fa[cur ^ 1][0] = *(const f32x4 *)(ls + 0 * 4096 + frag[kg + 1]);
             fa[cur ^ 1][1] = *(const f32x4 *)(ls + 1 * 4096 + frag[kg + 1]);
           }
@@ -258,8 +265,9 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
             fa[cur ^ 1][2] = *(const f32x4 *)(ls + 2 * 4096 + frag[kg + 1]);
             fa[cur ^ 1][3] = *(const f32x4 *)(ls + 3 * 4096 + frag[kg + 1]);
           }
-          // ... and one piece of the next slab (all 8 go out in the first half of the step)
-          if (kg < 2 && more) issue_piece(stage ^ 1, kg * 4 + j);
+          // ... and one eighth of the next slab (all of it goes out in the first half of the step)
+          if (kg == 0 && more) issue_piece(stage ^ 1, j);
+          if (kg == 1 && more) eb_next[j] = ge[j * 64];
           __builtin_amdgcn_sched_barrier(0);
         }
       }

@@ -31,6 +31,10 @@ size_t dtype_size(int dtype) {
   return 0;
 }
 
+__device__ __forceinline__ size_t out_offset(int exp_layout, int r, int c, int nslab) {
+  return exp_layout ? prepared_exp_offset(r, c, nslab) : prepared_offset(r, c, nslab);
+}
+
 constexpr int PREP_THREADS = 256;
 constexpr int PREP_VPT = 16;  // values per thread held in registers
 
@@ -55,7 +59,7 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 template <typename T>
 __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const T *raw, int npix, const int *row_map,
                                                             const int *pix_map, int k, int kpad,
-                                                            int metric, float *out) {
+                                                            int metric, int exp_layout, float *out) {
   __shared__ float red[PREP_THREADS / 64];
   const int r = blockIdx.x;
   const int64_t src = row_map ? row_map[r] : r;
@@ -89,10 +93,10 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const T *raw, int np
 #pragma unroll
     for (int i = 0; i < PREP_VPT; ++i) {
       const int c = tid + i * PREP_THREADS;
-      if (c < kpad) out[prepared_offset(r, c, nslab)] = (c < k) ? v[i] * inv : 0.f;
+      if (c < kpad) out[out_offset(exp_layout, r, c, nslab)] = (c < k) ? v[i] * inv : 0.f;
     }
     for (int c = tid + PREP_VPT * PREP_THREADS; c < kpad; c += PREP_THREADS)
-      out[prepared_offset(r, c, nslab)] = 0.f;
+      out[out_offset(exp_layout, r, c, nslab)] = 0.f;
   } else {
     float s = 0.f;
     for (int c = tid; c < k; c += PREP_THREADS) s += (float)p[pix_map ? pix_map[c] : c];
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const T *raw, int np
     const float norm = sqrtf(block_sum(q, red));
     const float inv = norm > 0.f ? 1.f / norm : 0.f;
     for (int c = tid; c < kpad; c += PREP_THREADS)
-      out[prepared_offset(r, c, nslab)] = (c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv : 0.f;
+      out[out_offset(exp_layout, r, c, nslab)] = (c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv : 0.f;
   }
 }
 
@@ -122,7 +126,7 @@ struct alignas(sizeof(T) * 4) Quad {
 template <typename T, int VEC>
 __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, int npix, const int *row_map,
                                                                  const int *pix_map, int k, int kpad,
-                                                                 int metric, int n_out, float *out) {
+                                                                 int metric, int exp_layout, int n_out, float *out) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * (PREP_THREADS / 64) + (threadIdx.x >> 6);
   if (r >= n_out) return;
@@ -179,14 +183,14 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, i
         w.y = v[4 * i + 1] * inv;
         w.z = v[4 * i + 2] * inv;
         w.w = v[4 * i + 3] * inv;
-        *reinterpret_cast<float4 *>(out + prepared_offset(r, c, nslab)) = w;
+        *reinterpret_cast<float4 *>(out + out_offset(exp_layout, r, c, nslab)) = w;
       }
     }
   } else {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int c = lane + 64 * i;
-      if (c < kpad) out[prepared_offset(r, c, nslab)] = v[i] * inv;
+      if (c < kpad) out[out_offset(exp_layout, r, c, nslab)] = v[i] * inv;
     }
   }
 }
@@ -201,13 +205,13 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
 #define KPDI_PREP(T)                                                                                   \
   if (vec4)                                                                                            \
     hipLaunchKernelGGL((prep_wave_kernel<T, 4>), grid, block, 0, s, (const T *)a.raw, a.npix,         \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out);                   \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.exp_layout, a.n_out, a.out);                   \
   else if (wave_path)                                                                                  \
     hipLaunchKernelGGL((prep_wave_kernel<T, 1>), grid, block, 0, s, (const T *)a.raw, a.npix,         \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out);                   \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.exp_layout, a.n_out, a.out);                   \
   else                                                                                                 \
     hipLaunchKernelGGL((prep_kernel<T>), grid, block, 0, s, (const T *)a.raw, a.npix, a.row_map,      \
-                       a.pix_map, a.k, a.kpad, a.metric, a.out);                                       \
+                       a.pix_map, a.k, a.kpad, a.metric, a.exp_layout, a.out);                                       \
   break;
   switch (a.dtype) {
     case KPDI_U8: KPDI_PREP(uint8_t)
