@@ -239,7 +239,7 @@ int prepare_experimental(kpdi_ctx *c) {
   p.kpad = c->kpad;
   p.n_out = c->m;
   p.metric = c->metric;
-  p.exp_layout = 1;
+  p.exp_layout = 0;
   p.out = c->exp_x.as<float>();
   {
     ScopedTimer t(c, &c->ev_prep);

@@ -7,7 +7,7 @@ namespace kpdi {
 
 // ---- tile geometry of the match kernel (match.hip) -------------------------
 constexpr int TILE_DICT = 128;  // dictionary patterns per tile (MFMA A operand, rows)
-constexpr int TILE_EXP = 128;   // experimental patterns per tile (MFMA B operand, columns)
+constexpr int TILE_EXP = 256;   // experimental patterns per workgroup tile (MFMA B operand, columns)
 constexpr int TILE_K = 32;      // pixels per LDS slab
 constexpr int MATCH_THREADS = 256;
 constexpr int KMAX_LIMIT = 32;  // longest register-resident list of one pass

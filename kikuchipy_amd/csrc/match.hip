@@ -9,37 +9,34 @@
 // argtopk/topk (indexing/_dictionary_indexing.py:193-203).
 //
 // Design (gfx950 / CDNA4)
-//  * Operands are the PREPARED matrices (prep.hip): dictionary Y (n_pad x kpad)
-//    and experimental X (m_pad x kpad), f32, zero-padded, both "K-major" (an NT
-//    GEMM), stored tile/slab-blocked: every (128 patterns x 32 pixels) block is 16 KB
-//    contiguous and already in LDS order (kernels.h: prepared_offset), so a slab is
-//    one sequential 16 KB burst from HBM instead of 128 strided 128-byte rows.
-//  * The dictionary is the MFMA A operand (rows of the accumulator tile), the
-//    experimental patterns are the B operand (columns).  With
-//    v_mfma_f32_32x32x2_f32 the accumulator column is lane&31, so every lane owns
-//    ONE experimental pattern per 32x32 tile and sees 16 dictionary candidates
-//    for it in its registers: top-k becomes a lane-local streaming insertion with
-//    no cross-lane traffic.
-//  * Workgroup = 4 waves, tile = 128 dictionary x 128 experimental patterns;
-//    wave w owns experimental columns [32w, 32w+32) and all 128 dictionary rows
-//    (4 accumulator tiles = 64 VGPRs).  A workgroup is persistent: it belongs to
-//    one block of 128 experimental patterns, draws dictionary tiles (ascending) from
-//    that block's counter and keeps its lanes' sorted best-KMAX lists in registers
-//    for the whole sweep.
-//  * Dictionary slabs: HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round
-//    trip), two 16 KB stages, one barrier per 32-pixel slab.  Experimental slabs are
-//    not shared between waves and go straight to VGPRs (see exp_base below).  The LDS image is lane-linear
-//    (hardware rule), so the bank swizzle lives in the prepared layout itself
-//    and is applied again on the ds_read_b128 fragment reads: 16-byte slot
-//    w = ((row&1)<<3 | kq) ^ ((row>>1)&7) inside the 256-byte line of a row pair
-//    -> conflict-free for the 16-lane groups of ds_read_b128.
-//  * Each ds_read_b128 hands a lane 4 consecutive pixels of its row; MFMA j of a
-//    group uses element j as the k-operand for both A and B, i.e. lanes 0-31
-//    carry pixel j and lanes 32-63 pixel 4+j.  A and B use the same assignment,
-//    which only permutes the summation order.
-//  * Grid = row_blocks x nsplit with split = blockIdx % nsplit: hardware places
-//    block b on XCD b%8, so (nsplit % 8 == 0) all workgroups of an XCD sweep the
-//    same dictionary range at the same time and share its slabs in that XCD's L2.
+//  * ONE WAVE PER SIMD.  Measured on MI355X (tools/ubench/mfma_f32.hip):
+//    v_mfma_f32_32x32x2_f32 sustains 99 % of the 157.3 TFLOP/s f32 peak from one wave
+//    per SIMD, but only 66 % when two waves share a SIMD's matrix pipe.  So a
+//    workgroup is 4 waves = one per SIMD, one workgroup per CU, up to 512 VGPRs per
+//    lane, and every latency is hidden inside the wave's own instruction stream
+//    (memory instructions are issued in the shadow of MFMAs already in the pipe).
+//  * Operands are the PREPARED matrices (prep.hip), f32, zero padded, both K-major
+//    (an NT GEMM): dictionary Y = MFMA A operand (accumulator rows), experimental X =
+//    B operand (columns).  Both are stored tile/slab-blocked: a (128 patterns x 32
+//    pixels) block is 16 KB contiguous and already in LDS order incl. bank swizzle
+//    (kernels.h: prepared_offset), so a slab is a sequential burst of lane-linear
+//    1 KB global_load_lds pieces.
+//  * Workgroup tile = 128 dictionary x 256 experimental patterns; wave w owns columns
+//    [64w, 64w+64) x all 128 rows = 8 accumulators (128 VGPRs).  With 32x32x2 the
+//    accumulator column is lane&31: every lane owns ONE experimental pattern per 32-wide
+//    column group and sees 16 dictionary candidates per accumulator in its registers,
+//    so top-k is a lane-local streaming insertion into two sorted register lists.
+//  * The workgroup is persistent: it belongs to one block of 256 experimental patterns
+//    and draws dictionary tiles (ascending) from that block's counter (dynamic balance).
+//  * Step = one 32-pixel slab = 128 MFMAs per wave (8192 pipe cycles).  LDS is a ring
+//    of three 48 KB stages (16 KB dictionary slab + 32 KB experimental slab) filled by
+//    global_load_lds_dwordx4 two slabs ahead (144 KB: the CU's LDS is there to be used).
+//    ONE barrier per step, in the MIDDLE of the step: after it the next slab is
+//    complete in LDS, so its first fragments are read during the second half of the
+//    current step and no wave ever waits on LDS or memory at a step boundary.
+//  * ds_read_b128 hands a lane 4 consecutive pixels of its row; MFMA j of a group
+//    takes element j for both operands (lanes 0-31 pixel j, lanes 32-63 pixel 4+j):
+//    a permutation of the summation order only.  16 LDS reads per 128 MFMAs.
 //
 // Algorithmic work per launch: 2 * M * n_chunk * K flops (K = kept pixels).
 #include "kernels.h"
@@ -52,21 +49,21 @@ namespace kpdi {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SLAB_BYTES = TILE_DICT * TILE_K * 4;  // one dictionary slab: 16 KB
-constexpr int STAGE_BYTES = SLAB_BYTES;              // only the dictionary goes through LDS
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;           // double buffered: 32 KB per workgroup
+constexpr int SLAB_BYTES = TILE_DICT * TILE_K * 4;  // 128 patterns x 32 pixels: 16 KB
+constexpr int STAGE_BYTES = 3 * SLAB_BYTES;          // dictionary slab + 2 experimental slabs
+constexpr int NSTAGE = 3;
+constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;      // 144 KB ring (+ 32 B control words)
 
 struct MatchArgs {
   const float *dict;
   const float *exp;
   int kpad, n_tiles, n_valid, nsplit, idx_base;
-  int xcd_row_groups, rows_per_group, splits_per_group;  // XCD-aware block map (0 = plain)
   float *part_scores;
   int *part_idx;
   const float *bound_score;
   const int *bound_idx;
   unsigned *tile_ctr;  // [row blocks] next dictionary tile to hand out, zero at launch
-  unsigned *gthr;  // [m_pad] shared lower bound of each pattern's k-th best score (monotone key)
+  unsigned *gthr;      // [m_pad] shared lower bound of each pattern's k-th best score (monotone key)
 };
 
 // float <-> unsigned key, order preserving (same map as merge.hip)
@@ -81,9 +78,9 @@ __device__ __forceinline__ float key_score32(unsigned u) {
 // Insert (v, idx) into a descending sorted list; precondition v > s[KMAX-1].
 // Equal scores keep arrival order (candidates arrive by increasing dictionary
 // index), which is the engine's tie rule: lower dictionary index first.
-// new s[j] = median(s[j-1], s[j], v) because s[j-1] >= s[j].
-// Branch-free: the index selects are written as bit blends (the compiler folds them to
-// v_cndmask; nested ?: on the indices came out as ~20 exec-mask branches per insertion).
+// new s[j] = median(s[j-1], s[j], v) because s[j-1] >= s[j].  Branch-free: the index
+// selects are bit blends the compiler folds to v_cndmask (nested ?: came out as ~20
+// exec-mask branches per insertion).
 __device__ __forceinline__ int blend(int mask, int if_set, int if_clear) {
   return (if_set & mask) | (if_clear & ~mask);
 }
@@ -95,7 +92,6 @@ __device__ __forceinline__ void list_insert(float (&s)[KMAX], int (&id)[KMAX], f
   for (int j = 0; j < KMAX; ++j) above[j] = (v > s[j]) ? -1 : 0;
 #pragma unroll
   for (int j = KMAX - 1; j >= 1; --j) {
-    // above entry j-1 too -> entry j-1 shifts down into j; else v lands in j (if above j)
     id[j] = blend(above[j], blend(above[j - 1], id[j - 1], idx), id[j]);
     s[j] = __builtin_amdgcn_fmed3f(s[j - 1], s[j], v);
   }
@@ -103,50 +99,84 @@ __device__ __forceinline__ void list_insert(float (&s)[KMAX], int (&id)[KMAX], f
   s[0] = fmaxf(s[0], v);
 }
 
+// One accumulator column group (32 patterns) of the epilogue: 64 candidates per lane by
+// increasing dictionary index.  The register index r is a scalar loop counter (relative
+// VGPR addressing), so there is one copy of the insertion code per accumulator.
 template <int KMAX, bool BOUNDED>
-__global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs a) {
+__device__ __forceinline__ void scan_tile(f32x16 (&acc)[4], float (&best)[KMAX], int (&best_idx)[KMAX],
+                                          float gthr, float ub, int ub_idx, int row0, int n_valid,
+                                          int idx_base) {
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    // cheap screen of the 16 candidates (thresholds as of now: a superset of what the
+    // exact loop admits)
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) any = any || (acc[rt][r] >= gthr && acc[rt][r] > best[KMAX - 1]);
+    if (__builtin_amdgcn_ballot_w64(any) != 0) {
+#pragma unroll 1
+      for (int r = 0; r < 16; ++r) {
+        const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
+        const float v = acc[rt][r] + 0.f;  // -0 -> +0 so that ties compare as the merge does
+        const int idx = idx_base + lrow;
+        bool ok = lrow < n_valid && v >= gthr;
+        if (BOUNDED) ok = ok && (v < ub || (v == ub && idx > ub_idx));
+        if (ok && v > best[KMAX - 1]) list_insert<KMAX>(best, best_idx, v, idx);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+  }
+}
+
+// acc += A x B with the accumulator pinned to the accumulation registers ("a" class).
+// Written as asm because with > 256 live registers the register allocator otherwise keeps
+// parts of the accumulators in VGPRs and shuttles them (hundreds of v_accvgpr moves per
+// step).  `s_nop 1` covers the VALU-write -> MFMA-operand hazard, which hipcc does not pad
+// for instructions inside an asm statement.
+__device__ __forceinline__ void mfma_acc(f32x16 &c, float a, float b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+// One of a wave's twelve 1 KB LDS-DMA pieces of a stage: 0-3 dictionary slab, 4-7 / 8-11
+// the two experimental slabs.  `gd`/`ge` already include the lane's 16-byte offset.
+__device__ __forceinline__ void issue_piece(const char *gd, const char *ge, size_t tile_bytes, char *stage_base,
+                                            int wv, int p) {
+  const int c = p & 3, part = p >> 2;
+  const char *g = (part == 0 ? gd : ge + (size_t)(part - 1) * tile_bytes) + (wv + 4 * c) * 1024;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                   (__attribute__((address_space(3))) void *)(stage_base + part * SLAB_BYTES +
+                                                                              (wv + 4 * c) * 1024),
+                                   16, 0, 0);
+}
+
+template <int KMAX, bool BOUNDED>
+__global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Block -> (experimental row block rb, dictionary split sp).  The dispatcher puts
-  // block b on XCD b%8 (speed only, never correctness).  With the XCD-aware map each
-  // XCD owns a (row group) x (split group) rectangle of the work: a dictionary slab is
-  // then shared through that XCD's L2 by rows_per_group workgroups and an experimental
-  // slab by splits_per_group workgroups, instead of (all rows) x 2.
-  int sp, rb;
-  if (a.xcd_row_groups > 0) {
-    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int xr = x % a.xcd_row_groups, xs = x / a.xcd_row_groups;
-    rb = xr * a.rows_per_group + j % a.rows_per_group;
-    sp = xs * a.splits_per_group + j / a.rows_per_group;
-  } else {
-    sp = blockIdx.x % a.nsplit;
-    rb = blockIdx.x / a.nsplit;
-  }
+  // block -> (block of 256 experimental patterns rb, list slot sp); block b sits on XCD
+  // b%8 (speed only): consecutive blocks of one XCD share rb, i.e. the experimental slabs
+  const int sp = blockIdx.x % a.nsplit;
+  const int rb = blockIdx.x / a.nsplit;
+  // kernel arguments into locals (nothing below takes the address of `a`)
+  const float *a_dict = a.dict;
+  const int n_tiles = a.n_tiles, n_valid = a.n_valid, idx_base = a.idx_base;
+  unsigned *gthr_arr = a.gthr;
   const int kpad = a.kpad;
   const int nslab = kpad / TILE_K;
-  // Dictionary tiles are handed out dynamically: the nsplit workgroups of a row block
-  // draw tile numbers from one counter, so all of them finish within one tile of each
-  // other however unevenly the CU's two resident workgroups share the MFMA pipe (static
-  // ranges left half of the workgroups idle for the last ~12 % of the launch).  Each
-  // workgroup still sees ascending tile numbers, which the tie rule relies on.
   unsigned *tile_ctr = a.tile_ctr + rb;
-  volatile int *ctrl = (volatile int *)(smem + LDS_BYTES);  // 4 control words behind the stages
+  volatile int *ctrl = (volatile int *)(smem + LDS_BYTES);  // control words behind the ring
 
-  // ---- global -> LDS staging.  A prepared (tile, slab) block is 16 KB contiguous in
-  // memory and already swizzled (kernels.h: prepared_offset), so wave wv just copies the
-  // 1 KB pieces {wv, wv+4, wv+8, wv+12} of each operand's slab, lane-linear.
   const unsigned goff = (unsigned)lane * 16u;
-  const size_t tile_bytes = (size_t)(kpad / TILE_K) * SLAB_BYTES;  // one 128-row tile, all slabs
-  // The experimental operand is NOT shared between waves (wave wv only ever needs its own
-  // 32 patterns), so it skips LDS: the prepared layout (kernels.h: prepared_exp_offset)
-  // stores, per (32 patterns, slab), the four MFMA B fragments lane-linear - each one a
-  // fully coalesced 1 KB global_load_dwordx4 straight into VGPRs, one slab ahead.
-  const f32x4 *exp_base = (const f32x4 *)a.exp + ((size_t)rb * 4 + wv) * (size_t)nslab * 256 + lane;
+  const size_t tile_bytes = (size_t)nslab * SLAB_BYTES;  // one 128-pattern dictionary tile, all slabs
+  // the workgroup's 256 experimental patterns = prepared tiles 2*rb and 2*rb+1
+  const char *exp_base = (const char *)a.exp + (size_t)rb * 2 * tile_bytes + goff;
+  // wave wv's two column groups inside a stage: rows wv*64 + c*32 + (lane&31) of the 256
+  const unsigned exp_frag = SLAB_BYTES + (wv >> 1) * SLAB_BYTES + ((wv & 1) * 2) * 4096;
 
-  // ---- LDS -> MFMA fragments.  Lane l reads row (l&31) of a 32-row tile, pixel
-  // quad kg*2 + (l>>5) of the slab.
+  // LDS -> MFMA A fragments: lane l reads row (l&31) of a 32-row tile, pixel quad kg*2 + (l>>5)
   unsigned frag[4];
   {
     const int lr = lane & 31;
@@ -157,175 +187,191 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_topk_kernel(MatchArgs 
     }
   }
 
-  // ---- per-lane running best lists for experimental pattern rb*128 + wv*32 + (lane&31)
-  float best[KMAX];
-  int best_idx[KMAX];
+  // per-lane running best lists: pattern rb*256 + wv*64 + c*32 + (lane&31), c = 0, 1
+  float best0[KMAX], best1[KMAX];
+  int bidx0[KMAX], bidx1[KMAX];
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) {
-    best[j] = -INFINITY;
-    best_idx[j] = INT_MAX;
+    best0[j] = best1[j] = -INFINITY;
+    bidx0[j] = bidx1[j] = INT_MAX;
   }
-  const int m_lane = rb * TILE_EXP + wv * 32 + (lane & 31);
-  float ub = INFINITY;
-  int ub_idx = -1;
+  const int m_lane = rb * TILE_EXP + wv * 64 + (lane & 31);  // column group 0; group 1 = +32
+  float ub0 = INFINITY, ub1 = INFINITY;
+  int ubi0 = -1, ubi1 = -1;
   if (BOUNDED) {
-    ub = a.bound_score[m_lane];
-    ub_idx = a.bound_idx[m_lane];
+    ub0 = a.bound_score[m_lane];
+    ubi0 = a.bound_idx[m_lane];
+    ub1 = a.bound_score[m_lane + 32];
+    ubi1 = a.bound_idx[m_lane + 32];
   }
-  // Shared threshold.  Every list's KMAX-th best score is a lower bound of the
-  // pattern's global KMAX-th best, so the maximum over all lists (other lanes, other
-  // workgroups, earlier chunks of the sweep) may be used to reject candidates: nothing
-  // strictly below it can be in the final top-k.  It is only a FILTER - monotone and
-  // valid however stale it is, so no ordering or coherence is required of it - and it
-  // cuts the insertions per lane from ~k*ln(n_lane/k) to ~k*ln(N/k)/lists.
-  unsigned gkey = 0x007fffffu;  // key(-inf)
+  // Shared threshold.  Every list's KMAX-th best score is a lower bound of the pattern's
+  // global KMAX-th best, so the maximum over all lists (other lanes, other workgroups,
+  // earlier chunks of the sweep) may be used to reject candidates.  It is only a FILTER -
+  // monotone and valid however stale - so it needs no ordering or coherence.
+  unsigned gkey0 = THRESHOLD_NONE, gkey1 = THRESHOLD_NONE;
 
-  f32x16 acc[4];
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
 
-  int tile, next_tile;
+  // ---- dictionary tiles are handed out dynamically; t0 = tile being computed, t1/t2 the
+  // next two (the loads run two slabs ahead, which can reach two tiles ahead)
+  int t0, t1, t2;
   if (tid == 0) {
     ctrl[0] = (int)atomicAdd(tile_ctr, 1u);
     ctrl[1] = (int)atomicAdd(tile_ctr, 1u);
+    ctrl[2] = (int)atomicAdd(tile_ctr, 1u);
   }
   __syncthreads();
-  tile = __builtin_amdgcn_readfirstlane(ctrl[0]);
-  next_tile = __builtin_amdgcn_readfirstlane(ctrl[1]);
+  t0 = __builtin_amdgcn_readfirstlane(ctrl[0]);
+  t1 = __builtin_amdgcn_readfirstlane(ctrl[1]);
+  t2 = __builtin_amdgcn_readfirstlane(ctrl[2]);
   __syncthreads();
-  if (tile >= a.n_tiles) goto write_out;
+  if (t0 >= n_tiles) goto write_out;
 
   {
-    // next slab to fetch
-    int ld_tile = tile, ld_slab = 0;
-    int fetched = 0;  // thread 0: the tile number drawn during the current tile
-    // The next slab = four 1 KB LDS-DMA pieces of the dictionary slab + the four B
-    // fragments of the experimental slab.  They are issued ONE AT A TIME between MFMA
-    // groups (below): the issue cycles of a memory instruction are free while an MFMA the
-    // wave issued is still executing, but dead time when 8 of them sit in front of the MFMAs.
-    const char *gd = nullptr;
-    const f32x4 *ge = nullptr;
-    f32x4 eb[4], eb_next[4];  // experimental fragments of this / the next slab
-    auto next_slab = [&]() {
-      gd = (const char *)a.dict + (size_t)ld_tile * tile_bytes + (size_t)ld_slab * SLAB_BYTES;
-      ge = exp_base + (size_t)ld_slab * 256;
-      if (++ld_slab == nslab) {
-        ld_slab = 0;
-        ld_tile = next_tile;  // slab 0 of the following tile is fetched during this tile's last slab
-      }
-    };
-    auto issue_piece = [&](int stage, int c) {
-      const char *g = gd + (wv + 4 * c) * 1024 + goff;
-      char *l = smem + stage * STAGE_BYTES + (wv + 4 * c) * 1024;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                       (__attribute__((address_space(3))) void *)l, 16, 0, 0);
-    };
-
-    next_slab();
+    const int last_tile = n_tiles - 1;
+    // load cursor: the slab that is fetched next (two ahead of the one being computed)
+    int ld_pos = 0, ld_slab = 0, ld_stage = 0;
+    int fetched = 0;  // thread 0: tile number drawn during the current tile
+    int tp = 0;       // tile parity: the drawn number is handed over through ctrl[4 + tp]
+    const char *gd = nullptr, *ge = nullptr;
+    const char *dict_base = (const char *)a_dict + goff;
+    // (plain macros instead of lambdas: by-reference captures put the whole state in scratch)
+#define KPDI_CURSOR_SET()                                                                        \
+  {                                                                                              \
+    int t_ = ld_pos == 0 ? t0 : (ld_pos == 1 ? t1 : t2);                                         \
+    t_ = t_ < last_tile ? t_ : last_tile; /* past the end: harmless re-load, no branch */        \
+    gd = dict_base + (size_t)t_ * tile_bytes + (size_t)ld_slab * SLAB_BYTES;                     \
+    ge = exp_base + (size_t)ld_slab * SLAB_BYTES;                                                \
+  }
+#define KPDI_CURSOR_ADVANCE()                                  \
+  {                                                            \
+    if (++ld_slab == nslab) {                                  \
+      ld_slab = 0;                                             \
+      ++ld_pos;                                                \
+    }                                                          \
+    ld_stage = ld_stage == NSTAGE - 1 ? 0 : ld_stage + 1;      \
+  }
+    // ---- prologue: slabs 0 and 1 in flight, then everything landed and visible
+    KPDI_CURSOR_SET();
 #pragma unroll
-    for (int pc = 0; pc < 4; ++pc) issue_piece(0, pc);
+    for (int p = 0; p < 12; ++p) issue_piece(gd, ge, tile_bytes, smem + ld_stage * STAGE_BYTES, wv, p);
+    KPDI_CURSOR_ADVANCE();
+    KPDI_CURSOR_SET();
 #pragma unroll
-    for (int kg = 0; kg < 4; ++kg) eb_next[kg] = ge[kg * 64];
-    int slab = 0, stage = 0;
-    for (;;) {
-      // the slab of this step has landed (this wave's pieces: vmcnt; the other waves':
-      // barrier) and every wave is done reading the other stage (computed on last step)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (slab == 1 && tid == 0) ctrl[2] = fetched;  // drawn at slab 0; the vmcnt above covers it
-      __syncthreads();
-      const bool more = slab + 1 < nslab || next_tile < a.n_tiles;
-      if (more) next_slab();
-      if (slab == 0 && tid == 0) fetched = (int)atomicAdd(tile_ctr, 1u);
-      if (slab == nslab - 1)  // fetched now (L2, bypassing L1), consumed after this slab's MFMAs
-        gkey = __hip_atomic_load(&a.gthr[m_lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int p = 0; p < 12; ++p) issue_piece(gd, ge, tile_bytes, smem + ld_stage * STAGE_BYTES, wv, p);
+    KPDI_CURSOR_ADVANCE();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
+    // A (dictionary) and B (experimental) fragments, double buffered by pixel group
+    f32x4 fa[2][4], fb[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) fa[0][rt] = *(const f32x4 *)(smem + rt * 4096 + frag[0]);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) fb[0][c] = *(const f32x4 *)(smem + exp_frag + c * 4096 + frag[0]);
+
+    int stage = 0;
+#pragma clang loop unroll(disable)
+    for (;;) {  // dictionary tiles
+      // accumulators are born here and die in this tile's epilogue: inside the slab loop
+      // they are only ever touched by MFMAs (keeps them in the accumulation registers
+      // instead of being shuttled between register classes every step)
+      f32x16 acc0[4], acc1[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[rt][r] = acc1[rt][r] = 0.f;
+#pragma clang loop unroll(disable)
+      for (int slab = 0; slab < nslab; ++slab) {
       const char *ls = smem + stage * STAGE_BYTES;
-#pragma unroll
-      for (int kg = 0; kg < 4; ++kg) eb[kg] = eb_next[kg];
-      // dictionary fragments of pixel group kg+1 are fetched while the 16 MFMAs of group kg run
-      f32x4 fa[2][4];
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) fa[0][rt] = *(const f32x4 *)(ls + rt * 4096 + frag[0]);
+      const int nstage = stage == NSTAGE - 1 ? 0 : stage + 1;
+      const char *ls_next = smem + nstage * STAGE_BYTES;
+      if (slab == 0 && tid == 0) fetched = (int)atomicAdd(tile_ctr, 1u);
+      if (slab == nslab - 1) {  // L2 (bypassing L1); landed by the mid-step wait, used in the epilogue
+        gkey0 = __hip_atomic_load(&gthr_arr[m_lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gkey1 = __hip_atomic_load(&gthr_arr[m_lane + 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      KPDI_CURSOR_SET();
+      char *ld_base = smem + ld_stage * STAGE_BYTES;
+
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg) {
         const int cur = kg & 1;
+        if (kg == 2) {
+          // ---- the step's only synchronisation point.  Everything this wave issued during
+          // the second half of the previous step has landed (its pieces of slab+1, the tile
+          // counter); after the barrier (a) slab+1 is complete in LDS, (b) every wave is past
+          // the previous step, whose stage is refilled below.
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (slab == 0 && tid == 0) ctrl[4 + tp] = fetched;
+          __syncthreads();
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt)
-            acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][rt][j], eb[kg][j], acc[rt], 0, 0, 0);
-          // behind these 4 MFMAs (256 pipe cycles): next group's fragments (j = 0, 1) ...
-          if (kg < 3 && j == 0) {
-            fa[cur ^ 1][0] = *(const f32x4 *)(ls + 0 * 4096 + frag[kg + 1]);
-            fa[cur ^ 1][1] = *(const f32x4 *)(ls + 1 * 4096 + frag[kg + 1]);
+          for (int rt = 0; rt < 4; ++rt) {
+            mfma_acc(acc0[rt], fa[cur][rt][j], fb[cur][0][j]);
+            mfma_acc(acc1[rt], fa[cur][rt][j], fb[cur][1][j]);
           }
-          if (kg < 3 && j == 1) {
-            fa[cur ^ 1][2] = *(const f32x4 *)(ls + 2 * 4096 + frag[kg + 1]);
-            fa[cur ^ 1][3] = *(const f32x4 *)(ls + 3 * 4096 + frag[kg + 1]);
+          // in the shadow of these 8 MFMAs (512 pipe cycles):
+          // ... the fragments of the next pixel group (for kg = 3: of the next slab)
+          if (j < 2) {
+            const char *src = kg < 3 ? ls + frag[kg + 1] : ls_next + frag[0];
+            fa[cur ^ 1][2 * j] = *(const f32x4 *)(src + (2 * j) * 4096);
+            fa[cur ^ 1][2 * j + 1] = *(const f32x4 *)(src + (2 * j + 1) * 4096);
+            fb[cur ^ 1][j] = *(const f32x4 *)(src + exp_frag + j * 4096);
           }
-          // ... and one eighth of the next slab (all of it goes out in the first half of the step)
-          if (kg == 0 && more) issue_piece(stage ^ 1, j);
-          if (kg == 1 && more) eb_next[j] = ge[j * 64];
+          // ... and the slab two steps ahead: this wave's 12 LDS-DMA pieces
+          if (kg == 2) {
+            issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * j);
+            issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * j + 1);
+          }
+          if (kg == 3) issue_piece(gd, ge, tile_bytes, ld_base, wv, 8 + j);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-
-      if (++slab == nslab) {
-        // ---- epilogue: 64 candidates per lane, by increasing dictionary index.
-        // The register index r is a (scalar) loop counter: the accumulator element is
-        // fetched with relative VGPR addressing, so there are 4 copies of the insertion
-        // code instead of 64.
-        const int row0 = tile * TILE_DICT + 4 * (lane >> 5);
-        const float gthr = key_score32(gkey);
-        const float kth_before = best[KMAX - 1];
+      KPDI_CURSOR_ADVANCE();
+      stage = nstage;
+      }  // slabs
+      // the last MFMAs (16 passes) must have written the accumulators before they are read
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-          // cheap screen of the 16 candidates of this accumulator tile (thresholds as of
-          // now: a superset of what the exact loop below admits)
-          bool any = false;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) any = any || (acc[rt][r] >= gthr && acc[rt][r] > best[KMAX - 1]);
-          if (__builtin_amdgcn_ballot_w64(any) != 0) {
-#pragma unroll 1
-            for (int r = 0; r < 16; ++r) {
-              const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
-              const float v = acc[rt][r] + 0.f;  // -0 -> +0 so that ties compare as the merge does
-              const int idx = a.idx_base + lrow;
-              bool ok = lrow < a.n_valid && v >= gthr;
-              if (BOUNDED) ok = ok && (v < ub || (v == ub && idx > ub_idx));
-              if (ok && v > best[KMAX - 1]) list_insert<KMAX>(best, best_idx, v, idx);
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
-        }
-        // publish this list's KMAX-th best if it rose above the shared threshold
-        if (best[KMAX - 1] > kth_before && best[KMAX - 1] > gthr)
-          __hip_atomic_fetch_max(&a.gthr[m_lane], score_key(best[KMAX - 1]), __ATOMIC_RELAXED,
+      for (int rt = 0; rt < 4; ++rt)
+        asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc0[rt]), "+a"(acc1[rt]));
+      {
+        // ---- epilogue of the tile
+        const int row0 = t0 * TILE_DICT + 4 * (lane >> 5);
+        const float g0 = key_score32(gkey0), g1 = key_score32(gkey1);
+        const float kth0 = best0[KMAX - 1], kth1 = best1[KMAX - 1];
+        scan_tile<KMAX, BOUNDED>(acc0, best0, bidx0, g0, ub0, ubi0, row0, n_valid, idx_base);
+        scan_tile<KMAX, BOUNDED>(acc1, best1, bidx1, g1, ub1, ubi1, row0, n_valid, idx_base);
+        // publish a list's KMAX-th best if it rose above the shared threshold
+        if (best0[KMAX - 1] > kth0 && best0[KMAX - 1] > g0)
+          __hip_atomic_fetch_max(&gthr_arr[m_lane], score_key(best0[KMAX - 1]), __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
-        slab = 0;
-        if (nslab == 1) {  // single-slab detectors: no later step of this tile published it
-          if (tid == 0) ctrl[2] = fetched;
-          __syncthreads();
-        }
-        tile = next_tile;
-        next_tile = __builtin_amdgcn_readfirstlane(ctrl[2]);
-        if (tile >= a.n_tiles) break;
+        if (best1[KMAX - 1] > kth1 && best1[KMAX - 1] > g1)
+          __hip_atomic_fetch_max(&gthr_arr[m_lane + 32], score_key(best1[KMAX - 1]), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+        t0 = t1;
+        t1 = t2;
+        // published at this tile's first barrier; the slot alternates so that a wave still in
+        // its epilogue cannot see the next tile's number
+        t2 = __builtin_amdgcn_readfirstlane(ctrl[4 + tp]);
+        tp ^= 1;
+        --ld_pos;
+        if (t0 >= n_tiles) break;
       }
-      stage ^= 1;
     }
   }
 
 write_out : {
-  const int m = m_lane;
   const int lists = 2 * a.nsplit;
-  const size_t o = ((size_t)m * lists + (size_t)(sp * 2 + (lane >> 5))) * KMAX;
+  const size_t o0 = ((size_t)m_lane * lists + (size_t)(sp * 2 + (lane >> 5))) * KMAX;
+  const size_t o1 = ((size_t)(m_lane + 32) * lists + (size_t)(sp * 2 + (lane >> 5))) * KMAX;
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) {
-    a.part_scores[o + j] = best[j];
-    a.part_idx[o + j] = best_idx[j];
+    a.part_scores[o0 + j] = best0[j];
+    a.part_idx[o0 + j] = bidx0[j];
+    a.part_scores[o1 + j] = best1[j];
+    a.part_idx[o1 + j] = bidx1[j];
   }
 }
 }
@@ -337,18 +383,18 @@ int match_list_len(int k) {
   return 32;
 }
 
-int match_blocks_per_cu() { return 2; }
+int match_blocks_per_cu() { return 1; }
 
 template <int KMAX, bool BOUNDED>
 static hipError_t launch_t(const MatchArgs &args, int grid, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void *)match_topk_kernel<KMAX, BOUNDED>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 16);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 32);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((match_topk_kernel<KMAX, BOUNDED>), dim3(grid), dim3(MATCH_THREADS), LDS_BYTES + 16, s, args);
+  hipLaunchKernelGGL((match_topk_kernel<KMAX, BOUNDED>), dim3(grid), dim3(MATCH_THREADS), LDS_BYTES + 32, s, args);
   return hipGetLastError();
 }
 
@@ -360,27 +406,6 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   g.n_tiles = a.n_tiles;
   g.n_valid = a.n_valid;
   g.nsplit = a.nsplit;
-  // choose (row groups) x (split groups) = 8 XCDs minimising rows_per_group + splits_per_group
-  g.xcd_row_groups = 0;
-  g.rows_per_group = g.splits_per_group = 0;
-  {
-    const int rbk = a.m_pad / TILE_EXP;
-    int best_cost = 1 << 30;
-    for (int gr = 1; gr <= 8; gr *= 2) {
-      const int gs = 8 / gr;
-      if (rbk % gr || a.nsplit % gs) continue;
-      const int cost = rbk / gr + a.nsplit / gs;
-      if (cost < best_cost) {
-        best_cost = cost;
-        g.xcd_row_groups = gr;
-        g.rows_per_group = rbk / gr;
-        g.splits_per_group = a.nsplit / gs;
-      }
-    }
-    if (const char *e = getenv("KPDI_PLAIN_BLOCK_MAP")) {
-      if (e[0] == '1') g.xcd_row_groups = 0;
-    }
-  }
   g.idx_base = a.idx_base;
   g.part_scores = a.part_scores;
   g.part_idx = a.part_idx;
