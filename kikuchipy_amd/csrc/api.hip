@@ -134,7 +134,8 @@ struct kpdi_ctx {
   DevBuf run_s[2], run_i[2];   // running best-k ping-pong
   int run_cur = 0;
   bool run_valid = false;
-  DevBuf gthr;                            // shared per-pattern threshold of the match kernel
+  DevBuf gthr;                            // shared rejection bound of the match kernel
+  int bound_key = -1;                     // plan the bound array was initialised for (-1: none)
   DevBuf tile_ctr;                        // dynamic tile counters of the match kernel
   DevBuf loc_s, loc_i, bound_s, bound_i;  // multi-pass (keep_n > 32)
   DevBuf gather_s, gather_i;              // RCCL all-gather target
@@ -258,8 +259,7 @@ int ensure_running(kpdi_ctx *c) {
   }
   c->run_cur = 0;
   HIPCHK(kpdi::launch_fill_topk(c->run_s[0].as<float>(), c->run_i[0].as<int>(), (int64_t)n, c->stream));
-  HIPCHK(c->gthr.reserve((size_t)c->m_pad * sizeof(unsigned)));
-  HIPCHK(kpdi::launch_fill_u32(c->gthr.as<unsigned>(), kpdi::THRESHOLD_NONE, c->m_pad, c->stream));
+  c->bound_key = -1;  // a new sweep starts without a shared bound
   c->run_valid = true;
   return KPDI_OK;
 }
@@ -284,6 +284,19 @@ int run_match(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int list_len, i
   ml.part_idx = c->part_i.as<int>();
   ml.bound_score = bound_s;
   ml.bound_idx = bound_i;
+  {
+    // the published ranks are only comparable under one plan: (re)initialise when it changes
+    int rank, grouped, used;
+    kpdi::bound_plan(2 * nsplit, list_len, &rank, &grouped, &used);
+    const int key = (rank << 8) | (grouped << 7) | used;
+    if (key != c->bound_key || bound_s != nullptr) {
+      HIPCHK(c->gthr.reserve((size_t)c->m_pad * kpdi::BOUND_SLOTS * sizeof(unsigned)));
+      HIPCHK(kpdi::launch_init_bound(c->gthr.as<unsigned>(), c->m_pad, used, c->stream));
+      c->bound_key = bound_s != nullptr ? -1 : key;  // bounded passes always start from scratch
+    }
+    ml.bound_rank = rank;
+    ml.bound_grouped = grouped;
+  }
   ml.gthr = c->gthr.as<unsigned>();
   const size_t ctr_bytes = (size_t)(c->m_pad / kpdi::TILE_EXP) * sizeof(unsigned);
   HIPCHK(c->tile_ctr.reserve(ctr_bytes));
@@ -381,8 +394,7 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
     for (int done = 0; done < kk; done += kpdi::KMAX_LIMIT) {
       const int kp = std::min(kpdi::KMAX_LIMIT, kk - done);
       const int len = kpdi::match_list_len(kp);
-      // each pass ranks a different slice: its shared threshold starts from scratch
-      HIPCHK(kpdi::launch_fill_u32(c->gthr.as<unsigned>(), kpdi::THRESHOLD_NONE, c->m_pad, c->stream));
+      c->bound_key = -1;  // each pass ranks a different slice: its shared bound starts from scratch
       rc = run_match(c, (int)n_chunk, n_tiles, nsplit, len, global_start,
                      done ? c->bound_s.as<float>() : nullptr, done ? c->bound_i.as<int>() : nullptr);
       if (rc) return rc;

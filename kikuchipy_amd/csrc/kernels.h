@@ -48,12 +48,28 @@ struct MatchLaunch {
   // only candidates strictly after (bound_score, bound_idx) in the ranking count
   const float *bound_score; // [m_pad] or nullptr
   const int *bound_idx;
-  // [m_pad] shared per-pattern threshold keys (see match.hip); must hold
-  // KPDI_THRESHOLD_NONE at the start of a sweep (and of every bounded pass)
+  // [m_pad][BOUND_SLOTS] published list ranks (see match.hip: shared_bound); prepared by
+  // launch_init_bound at the start of a sweep (and of every bounded pass)
   unsigned *gthr;
+  int bound_rank, bound_grouped;  // from bound_plan()
   unsigned *tile_ctr;  // [m_pad / TILE_EXP] dynamic tile counters, zeroed before every launch
 };
 constexpr unsigned THRESHOLD_NONE = 0x007fffffu;  // key of -inf
+constexpr int BOUND_SLOTS = 32;
+// how the lists of one pattern share their rejection bound: lists = 2 * nsplit
+inline void bound_plan(int lists, int list_len, int *rank, int *grouped, int *used_slots) {
+  if (lists >= BOUND_SLOTS) {
+    *rank = 1;
+    *grouped = 1;
+    *used_slots = BOUND_SLOTS;
+  } else {
+    *rank = (list_len + lists - 1) / lists;  // rank * lists >= list_len
+    *grouped = 0;
+    *used_slots = lists;
+  }
+}
+// slots [0, used) <- key(-inf), slots [used, 32) <- key(+inf), for m_pad patterns
+hipError_t launch_init_bound(unsigned *gthr, int m_pad, int used_slots, hipStream_t s);
 hipError_t launch_match(const MatchLaunch &a, hipStream_t s);
 int match_blocks_per_cu();
 

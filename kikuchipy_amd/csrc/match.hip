@@ -54,6 +54,8 @@ constexpr int STAGE_BYTES = 3 * SLAB_BYTES;          // dictionary slab + 2 expe
 constexpr int NSTAGE = 3;
 constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;      // 144 KB ring (+ 32 B control words)
 
+__device__ __forceinline__ float key_score32(unsigned u);
+
 struct MatchArgs {
   const float *dict;
   const float *exp;
@@ -63,8 +65,58 @@ struct MatchArgs {
   const float *bound_score;
   const int *bound_idx;
   unsigned *tile_ctr;  // [row blocks] next dictionary tile to hand out, zero at launch
-  unsigned *gthr;      // [m_pad] shared lower bound of each pattern's k-th best score (monotone key)
+  unsigned *gthr;      // [m_pad][BOUND_SLOTS] published list ranks (monotone keys), see shared_bound()
+  int bound_rank;      // which entry (1-based) of its list a workgroup lane publishes
+  int bound_grouped;   // 1: all 32 slots are in use and bound_rank == 1 (grouped form)
 };
+
+// ---- shared rejection bound -------------------------------------------------------------
+// A score T may be used to reject candidates (v < T cannot enter the final top-KMAX) whenever
+// at least KMAX candidates >= T are known to exist.  Lists cover disjoint candidates, and a
+// list whose j-th best is b holds j candidates >= b.  Every list publishes its j-th best
+// (key, atomic max) into slot (list % 32) of its pattern's 128-byte line; then
+//   * plain form   (fewer than 32 lists, j = ceil(KMAX / lists)): T = min over the used slots
+//     (j * lists >= KMAX candidates); unused slots hold the key of +inf;
+//   * grouped form (>= 32 lists, j = 1): the slots are split into >= KMAX groups; every group
+//     maximum is one list's best, so T = min over groups of the group maximum is backed by
+//     >= KMAX distinct candidates.  This is far tighter than any single list's KMAX-th best:
+//     it sits near the true global KMAX-th best instead of ~lists*KMAX places below it.
+// The bound is only a FILTER: monotone and valid however stale, no ordering or coherence
+// needed, and it persists across the chunks of a sweep.
+template <int KMAX>
+__device__ __forceinline__ float shared_bound(const unsigned *line, bool grouped) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  unsigned k[BOUND_SLOTS];
+#pragma unroll
+  for (int c = 0; c < BOUND_SLOTS / 4; ++c) {
+    const u32x4 q = __builtin_nontemporal_load((const u32x4 *)line + c);  // L2, not the stale L1
+#pragma unroll
+    for (int e = 0; e < 4; ++e) k[4 * c + e] = q[e];
+  }
+  unsigned t = 0xffffffffu;
+  if (grouped) {
+    // G groups, G = smallest supported count >= KMAX: 1, 8, 20 (12 pairs + 8 singles), 32
+    constexpr int G = KMAX <= 1 ? 1 : (KMAX <= 8 ? 8 : (KMAX <= 20 ? 20 : 32));
+    if (G == 20) {
+#pragma unroll
+      for (int g = 0; g < 12; ++g) t = min(t, max(k[2 * g], k[2 * g + 1]));
+#pragma unroll
+      for (int i = 24; i < 32; ++i) t = min(t, k[i]);
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        unsigned m = 0;
+#pragma unroll
+        for (int i = g; i < BOUND_SLOTS; i += G) m = max(m, k[i]);
+        t = min(t, m);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < BOUND_SLOTS; ++i) t = min(t, k[i]);
+  }
+  return key_score32(t);
+}
 
 // float <-> unsigned key, order preserving (same map as merge.hip)
 __device__ __forceinline__ unsigned score_key(float s) {
@@ -99,29 +151,39 @@ __device__ __forceinline__ void list_insert(float (&s)[KMAX], int (&id)[KMAX], f
   s[0] = fmaxf(s[0], v);
 }
 
+// smallest float above f (f finite or -inf)
+__device__ __forceinline__ float next_up(float f) {
+  const unsigned u = __float_as_uint(f);
+  if (f == 0.f) return __uint_as_float(1u);
+  return __uint_as_float((u & 0x80000000u) ? u - 1u : u + 1u);
+}
+
 // One accumulator column group (32 patterns) of the epilogue: 64 candidates per lane by
-// increasing dictionary index.  The register index r is a scalar loop counter (relative
-// VGPR addressing), so there is one copy of the insertion code per accumulator.
+// increasing dictionary index.  Steady state is ONE compare + branch per accumulator
+// register: a candidate has to reach thr = max(shared bound, next float above the list's
+// last entry), and only a register in which some lane does takes the exact path (valid
+// row, multi-pass bound, insertion).  The register index r is a scalar loop counter
+// (relative VGPR addressing), so there is one copy of the insertion code per accumulator.
 template <int KMAX, bool BOUNDED>
 __device__ __forceinline__ void scan_tile(f32x16 (&acc)[4], float (&best)[KMAX], int (&best_idx)[KMAX],
                                           float gthr, float ub, int ub_idx, int row0, int n_valid,
                                           int idx_base) {
+  // v > best[KMAX-1]  <=>  v >= nextafter(best[KMAX-1], +inf)   (scores are finite)
+  float thr = fmaxf(gthr, next_up(best[KMAX - 1]));
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
-    // cheap screen of the 16 candidates (thresholds as of now: a superset of what the
-    // exact loop admits)
-    bool any = false;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) any = any || (acc[rt][r] >= gthr && acc[rt][r] > best[KMAX - 1]);
-    if (__builtin_amdgcn_ballot_w64(any) != 0) {
 #pragma unroll 1
-      for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc[rt][r] + 0.f;  // -0 -> +0 so that ties compare as the merge does
+      if (__builtin_amdgcn_ballot_w64(v >= thr) != 0) {
         const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
-        const float v = acc[rt][r] + 0.f;  // -0 -> +0 so that ties compare as the merge does
         const int idx = idx_base + lrow;
-        bool ok = lrow < n_valid && v >= gthr;
+        bool ok = lrow < n_valid && v >= thr;
         if (BOUNDED) ok = ok && (v < ub || (v == ub && idx > ub_idx));
-        if (ok && v > best[KMAX - 1]) list_insert<KMAX>(best, best_idx, v, idx);
+        if (ok) {
+          list_insert<KMAX>(best, best_idx, v, idx);
+          thr = fmaxf(gthr, next_up(best[KMAX - 1]));
+        }
       }
     }
 #pragma unroll
@@ -132,8 +194,9 @@ __device__ __forceinline__ void scan_tile(f32x16 (&acc)[4], float (&best)[KMAX],
 // acc += A x B with the accumulator pinned to the accumulation registers ("a" class).
 // Written as asm because with > 256 live registers the register allocator otherwise keeps
 // parts of the accumulators in VGPRs and shuttles them (hundreds of v_accvgpr moves per
-// step).  `s_nop 1` covers the VALU-write -> MFMA-operand hazard, which hipcc does not pad
-// for instructions inside an asm statement.
+// step); accumulators in architectural VGPRs measured 4 % slower (they compete with the LDS
+// returns and VALU for the VGPR ports).  `s_nop 1` covers the VALU-write -> MFMA-operand
+// hazard, which hipcc does not pad for instructions inside an asm statement.
 __device__ __forceinline__ void mfma_acc(f32x16 &c, float a, float b) {
   asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
@@ -204,11 +267,13 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
     ub1 = a.bound_score[m_lane + 32];
     ubi1 = a.bound_idx[m_lane + 32];
   }
-  // Shared threshold.  Every list's KMAX-th best score is a lower bound of the pattern's
-  // global KMAX-th best, so the maximum over all lists (other lanes, other workgroups,
-  // earlier chunks of the sweep) may be used to reject candidates.  It is only a FILTER -
-  // monotone and valid however stale - so it needs no ordering or coherence.
-  unsigned gkey0 = THRESHOLD_NONE, gkey1 = THRESHOLD_NONE;
+  // shared rejection bound (see shared_bound above): this lane's two pattern lines and slot
+  const unsigned *line0 = gthr_arr + (size_t)m_lane * BOUND_SLOTS;
+  const unsigned *line1 = line0 + 32 * BOUND_SLOTS;
+  const int my_slot = (sp * 2 + (lane >> 5)) & (BOUND_SLOTS - 1);
+  const int bound_rank = a.bound_rank;
+  const bool bound_grouped = a.bound_grouped != 0;
+  float g0 = -INFINITY, g1 = -INFINITY;
 
 
   // ---- dictionary tiles are handed out dynamically; t0 = tile being computed, t1/t2 the
@@ -286,9 +351,9 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
       const int nstage = stage == NSTAGE - 1 ? 0 : stage + 1;
       const char *ls_next = smem + nstage * STAGE_BYTES;
       if (slab == 0 && tid == 0) fetched = (int)atomicAdd(tile_ctr, 1u);
-      if (slab == nslab - 1) {  // L2 (bypassing L1); landed by the mid-step wait, used in the epilogue
-        gkey0 = __hip_atomic_load(&gthr_arr[m_lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        gkey1 = __hip_atomic_load(&gthr_arr[m_lane + 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (slab == nslab - 1) {  // landed by the mid-step wait, used in the epilogue
+        g0 = shared_bound<KMAX>(line0, bound_grouped);
+        g1 = shared_bound<KMAX>(line1, bound_grouped);
       }
       KPDI_CURSOR_SET();
       char *ld_base = smem + ld_stage * STAGE_BYTES;
@@ -339,16 +404,26 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
       {
         // ---- epilogue of the tile
         const int row0 = t0 * TILE_DICT + 4 * (lane >> 5);
-        const float g0 = key_score32(gkey0), g1 = key_score32(gkey1);
-        const float kth0 = best0[KMAX - 1], kth1 = best1[KMAX - 1];
+        float pub0 = best0[0], pub1 = best1[0];  // entry bound_rank-1 before the scan
+#pragma unroll
+        for (int j = 1; j < KMAX; ++j) {
+          pub0 = j == bound_rank - 1 ? best0[j] : pub0;
+          pub1 = j == bound_rank - 1 ? best1[j] : pub1;
+        }
         scan_tile<KMAX, BOUNDED>(acc0, best0, bidx0, g0, ub0, ubi0, row0, n_valid, idx_base);
         scan_tile<KMAX, BOUNDED>(acc1, best1, bidx1, g1, ub1, ubi1, row0, n_valid, idx_base);
-        // publish a list's KMAX-th best if it rose above the shared threshold
-        if (best0[KMAX - 1] > kth0 && best0[KMAX - 1] > g0)
-          __hip_atomic_fetch_max(&gthr_arr[m_lane], score_key(best0[KMAX - 1]), __ATOMIC_RELAXED,
+        // publish the list entry the bound is built from, if it rose
+        float now0 = best0[0], now1 = best1[0];
+#pragma unroll
+        for (int j = 1; j < KMAX; ++j) {
+          now0 = j == bound_rank - 1 ? best0[j] : now0;
+          now1 = j == bound_rank - 1 ? best1[j] : now1;
+        }
+        if (now0 > pub0)
+          __hip_atomic_fetch_max(const_cast<unsigned *>(line0) + my_slot, score_key(now0), __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
-        if (best1[KMAX - 1] > kth1 && best1[KMAX - 1] > g1)
-          __hip_atomic_fetch_max(&gthr_arr[m_lane + 32], score_key(best1[KMAX - 1]), __ATOMIC_RELAXED,
+        if (now1 > pub1)
+          __hip_atomic_fetch_max(const_cast<unsigned *>(line1) + my_slot, score_key(now1), __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
         t0 = t1;
         t1 = t2;
@@ -412,6 +487,8 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   g.bound_score = a.bound_score;
   g.bound_idx = a.bound_idx;
   g.gthr = a.gthr;
+  g.bound_rank = a.bound_rank;
+  g.bound_grouped = a.bound_grouped;
   g.tile_ctr = a.tile_ctr;
   const int grid = (a.m_pad / TILE_EXP) * a.nsplit;
   const bool bounded = a.bound_score != nullptr;

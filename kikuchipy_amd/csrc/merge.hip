@@ -134,6 +134,18 @@ hipError_t launch_fill_u32(unsigned *p, unsigned value, int64_t n, hipStream_t s
   return hipGetLastError();
 }
 
+__global__ void init_bound_kernel(unsigned *gthr, int64_t n, int used) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) gthr[i] = (int)(i & (BOUND_SLOTS - 1)) < used ? THRESHOLD_NONE : 0xffffffffu;
+}
+
+hipError_t launch_init_bound(unsigned *gthr, int m_pad, int used_slots, hipStream_t s) {
+  const int64_t n = (int64_t)m_pad * BOUND_SLOTS;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(init_bound_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gthr, n, used_slots);
+  return hipGetLastError();
+}
+
 __global__ void last_column_kernel(const float *scores, const int *idx, int m, int stride, int col,
                                    float *bs, int *bi) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
