@@ -240,7 +240,6 @@ int prepare_experimental(kpdi_ctx *c) {
   p.kpad = c->kpad;
   p.n_out = c->m;
   p.metric = c->metric;
-  p.exp_layout = 0;
   p.out = c->exp_x.as<float>();
   {
     ScopedTimer t(c, &c->ev_prep);
@@ -342,7 +341,6 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
   p.kpad = c->kpad;
   p.n_out = (int)n_chunk;
   p.metric = c->metric;
-  p.exp_layout = 0;
   p.out = c->dict_y.as<float>();
   {
     ScopedTimer t(c, &c->ev_prep);

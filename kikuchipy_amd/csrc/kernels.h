@@ -73,16 +73,6 @@ hipError_t launch_init_bound(unsigned *gthr, int m_pad, int used_slots, hipStrea
 hipError_t launch_match(const MatchLaunch &a, hipStream_t s);
 int match_blocks_per_cu();
 
-// Layout of the prepared EXPERIMENTAL matrix (MFMA B operand, read straight into VGPRs):
-// per (32 patterns = one wave's columns, slab) the four pixel-group fragments, each
-// lane-linear: float offset ((((r>>5) * nslab + slab) * 4 + kg) * 64 + lane) * 4 + (c&3)
-// with kq = (c&31)>>2, kg = kq>>1, lane = (kq&1)*32 + (r&31)  [B[k = lane>>5][col = lane&31]].
-__host__ __device__ inline size_t prepared_exp_offset(int r, int c, int nslab) {
-  const int slab = c >> 5, kq = (c >> 2) & 7;
-  const int lane = (kq & 1) * 32 + (r & 31);
-  return ((((size_t)(r >> 5) * nslab + slab) * 4 + (kq >> 1)) * 64 + lane) * 4 + (c & 3);
-}
-
 // ---- pattern preparation (prep.hip): cast -> gather rows/pixels -> normalise --
 struct PrepLaunch {
   const void *raw;     // (n_rows_in, npix) of `dtype`
@@ -94,7 +84,6 @@ struct PrepLaunch {
   int kpad;
   int n_out;           // rows to produce
   int metric;          // KPDI_METRIC_*
-  int exp_layout;      // 0: dictionary layout (prepared_offset), 1: prepared_exp_offset
   float *out;          // (>= n_out, kpad)
 };
 hipError_t launch_prep(const PrepLaunch &a, hipStream_t s);

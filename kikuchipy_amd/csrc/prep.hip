@@ -6,18 +6,27 @@
 // Reference: similarity_metrics/_normalized_cross_correlation.py:88-159, :228-241
 //            similarity_metrics/_normalized_dot_product.py:80-150, :181-194
 //
-// K <= 4096 kept pixels (up to 64x64 detectors): one WAVE per pattern, values
-// in registers, shuffle reductions, vector loads/stores when unmasked.  Larger
-// detectors: one workgroup per pattern re-reading the pattern from L2.  Output:
-// the K-padded f32 row (zero tail), scattered into the tiled/swizzled layout
-// match.hip streams (kernels.h: prepared_offset; 128-byte pieces = full lines).  HBM-bound: algorithmic bytes =
-// npix*sizeof(in) read + kpad*4 written per pattern.
+// Output: the K-padded f32 row (zero tail) of every pattern, scattered into the
+// tiled / swizzled layout match.hip streams (kernels.h: prepared_offset; the pieces of
+// one pattern are full 128-byte lines).  HBM-bound: algorithmic bytes per pattern =
+// npix*sizeof(in) read + kpad*4 written.
+//
+//   K <= 4096 kept pixels (up to 64x64 detectors): ONE WAVE per pattern, 64 values per
+//   lane in VGPRs, all loads in flight before the first use, shuffle reductions.
+//     unmasked:  4-element vector loads straight to registers      (prep_wave_kernel<T,4>)
+//     masked:    the raw row is staged in LDS with vector loads, the kept pixels are
+//                gathered from LDS through the LDS copy of the pixel map
+//                                                                   (prep_wave_masked_kernel)
+//     otherwise: scalar gather from global memory                   (prep_wave_kernel<T,1>)
+//   larger detectors: one workgroup per pattern re-reading the pattern from L2 (prep_kernel).
 //
 // A pattern with zero norm (constant pattern; 0/0 = NaN in the reference, out of
 // contract per SURVEY.md 8(a)) becomes an all-zero row: it scores exactly 0
 // against everything.
 #include "kernels.h"
 #include "../../include/kpdi.h"
+
+#include <algorithm>
 
 namespace kpdi {
 
@@ -31,12 +40,8 @@ size_t dtype_size(int dtype) {
   return 0;
 }
 
-__device__ __forceinline__ size_t out_offset(int exp_layout, int r, int c, int nslab) {
-  return exp_layout ? prepared_exp_offset(r, c, nslab) : prepared_offset(r, c, nslab);
-}
-
 constexpr int PREP_THREADS = 256;
-constexpr int PREP_VPT = 16;  // values per thread held in registers
+constexpr int WAVE_VALUES = 64;  // values per lane of the wave-per-pattern kernels (K <= 4096)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -57,9 +62,15 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 }
 
 template <typename T>
+struct alignas(sizeof(T) * 4) Quad {
+  T v[4];
+};
+
+// ---- large detectors: one workgroup per pattern ----------------------------------------
+template <typename T>
 __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const T *raw, int npix, const int *row_map,
                                                             const int *pix_map, int k, int kpad,
-                                                            int metric, int exp_layout, float *out) {
+                                                            int metric, float *out) {
   __shared__ float red[PREP_THREADS / 64];
   const int r = blockIdx.x;
   const int64_t src = row_map ? row_map[r] : r;
@@ -67,78 +78,97 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const T *raw, int np
   const int nslab = kpad / TILE_K;
   const int tid = threadIdx.x;
 
-  if (k <= PREP_THREADS * PREP_VPT) {
-    float v[PREP_VPT];
-    float s = 0.f;
+  float s = 0.f;
+  for (int c = tid; c < k; c += PREP_THREADS) s += (float)p[pix_map ? pix_map[c] : c];
+  float mean = 0.f;
+  if (metric == KPDI_METRIC_NCC) mean = block_sum(s, red) / (float)k;
+  float q = 0.f;
+  for (int c = tid; c < k; c += PREP_THREADS) {
+    const float d = (float)p[pix_map ? pix_map[c] : c] - mean;
+    q += d * d;
+  }
+  const float norm = sqrtf(block_sum(q, red));
+  const float inv = norm > 0.f ? 1.f / norm : 0.f;
+  for (int c = tid; c < kpad; c += PREP_THREADS)
+    out[prepared_offset(r, c, nslab)] = (c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv : 0.f;
+}
+
+// ---- shared tail of the wave-per-pattern kernels: v[i] holds kept pixel lane + 64*i -----
+__device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], float s, int lane, int r, int k,
+                                                    int kpad, int metric, float *out) {
+  const int nslab = kpad / TILE_K;
+  float mean = 0.f;
+  if (metric == KPDI_METRIC_NCC) mean = wave_sum(s) / (float)k;
+  float q2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < PREP_VPT; ++i) {
-      const int c = tid + i * PREP_THREADS;
+  for (int i = 0; i < WAVE_VALUES; ++i) {
+    const int c = lane + 64 * i;
+    if (c < k) {
+      v[i] -= mean;
+      q2 += v[i] * v[i];
+    } else {
       v[i] = 0.f;
-      if (c < k) v[i] = (float)p[pix_map ? pix_map[c] : c];
-      s += v[i];
     }
-    float mean = 0.f;
-    if (metric == KPDI_METRIC_NCC) mean = block_sum(s, red) / (float)k;
-    float q = 0.f;
+  }
+  const float norm = sqrtf(wave_sum(q2));
+  const float inv = norm > 0.f ? 1.f / norm : 0.f;
 #pragma unroll
-    for (int i = 0; i < PREP_VPT; ++i) {
-      const int c = tid + i * PREP_THREADS;
-      if (c < k) {
-        v[i] -= mean;
-        q += v[i] * v[i];
-      }
-    }
-    const float norm = sqrtf(block_sum(q, red));
-    const float inv = norm > 0.f ? 1.f / norm : 0.f;
-#pragma unroll
-    for (int i = 0; i < PREP_VPT; ++i) {
-      const int c = tid + i * PREP_THREADS;
-      if (c < kpad) out[out_offset(exp_layout, r, c, nslab)] = (c < k) ? v[i] * inv : 0.f;
-    }
-    for (int c = tid + PREP_VPT * PREP_THREADS; c < kpad; c += PREP_THREADS)
-      out[out_offset(exp_layout, r, c, nslab)] = 0.f;
-  } else {
-    float s = 0.f;
-    for (int c = tid; c < k; c += PREP_THREADS) s += (float)p[pix_map ? pix_map[c] : c];
-    float mean = 0.f;
-    if (metric == KPDI_METRIC_NCC) mean = block_sum(s, red) / (float)k;
-    float q = 0.f;
-    for (int c = tid; c < k; c += PREP_THREADS) {
-      const float d = (float)p[pix_map ? pix_map[c] : c] - mean;
-      q += d * d;
-    }
-    const float norm = sqrtf(block_sum(q, red));
-    const float inv = norm > 0.f ? 1.f / norm : 0.f;
-    for (int c = tid; c < kpad; c += PREP_THREADS)
-      out[out_offset(exp_layout, r, c, nslab)] = (c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv : 0.f;
+  for (int i = 0; i < WAVE_VALUES; ++i) {
+    const int c = lane + 64 * i;
+    if (c < kpad) out[prepared_offset(r, c, nslab)] = v[i] * inv;
   }
 }
 
-// ---- fast path: ONE WAVE per pattern, K <= 4096 kept pixels (up to 64x64 detectors).
-// All of a lane's loads are issued before the first use (64 values in VGPRs), the two
-// reductions are wave shuffles (no LDS, no barrier), 4 patterns per workgroup.
-// VEC = 4: no signal mask and K % 4 == 0 -> 4-element vector loads / float4 stores.
-template <typename T>
-struct alignas(sizeof(T) * 4) Quad {
-  T v[4];
-};
+// same, v[4*i + e] holds kept pixel 4*(lane + 64*i) + e: float4 stores (full 16-byte slots)
+__device__ __forceinline__ void normalise_and_store_quads(float (&v)[WAVE_VALUES], float s, int lane, int r, int k,
+                                                          int kpad, int metric, float *out) {
+  const int nslab = kpad / TILE_K;
+  float mean = 0.f;
+  if (metric == KPDI_METRIC_NCC) mean = wave_sum(s) / (float)k;
+  float q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < WAVE_VALUES; ++i) {
+    const int c = 4 * (lane + 64 * (i / 4)) + (i & 3);
+    if (c < k) {
+      v[i] -= mean;
+      q2 += v[i] * v[i];
+    } else {
+      v[i] = 0.f;
+    }
+  }
+  const float norm = sqrtf(wave_sum(q2));
+  const float inv = norm > 0.f ? 1.f / norm : 0.f;
+#pragma unroll
+  for (int i = 0; i < WAVE_VALUES / 4; ++i) {
+    const int c = 4 * (lane + 64 * i);
+    if (c < kpad) {
+      float4 w;
+      w.x = v[4 * i] * inv;
+      w.y = v[4 * i + 1] * inv;
+      w.z = v[4 * i + 2] * inv;
+      w.w = v[4 * i + 3] * inv;
+      *reinterpret_cast<float4 *>(out + prepared_offset(r, c, nslab)) = w;
+    }
+  }
+}
 
+// ---- one wave per pattern, values straight from global memory ---------------------------
+// VEC = 4: no signal mask and K % 4 == 0 -> 4-element vector loads / float4 stores.
+// VEC = 1: scalar gather through the pixel map.
 template <typename T, int VEC>
 __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, int npix, const int *row_map,
                                                                  const int *pix_map, int k, int kpad,
-                                                                 int metric, int exp_layout, int n_out, float *out) {
+                                                                 int metric, int n_out, float *out) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * (PREP_THREADS / 64) + (threadIdx.x >> 6);
   if (r >= n_out) return;
   const int64_t src = row_map ? row_map[r] : r;
   const T *p = raw + src * (int64_t)npix;
-  const int nslab = kpad / TILE_K;
-  constexpr int N = 64;  // values per lane
-  float v[N];
+  float v[WAVE_VALUES];
   float s = 0.f;
   if (VEC == 4) {
 #pragma unroll
-    for (int i = 0; i < N / 4; ++i) {
+    for (int i = 0; i < WAVE_VALUES / 4; ++i) {
       const int c = 4 * (lane + 64 * i);
       Quad<T> q;
       q.v[0] = q.v[1] = q.v[2] = q.v[3] = (T)0;
@@ -149,69 +179,103 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, i
         s += v[4 * i + e];
       }
     }
+    normalise_and_store_quads(v, s, lane, r, k, kpad, metric, out);
   } else {
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
+    for (int i = 0; i < WAVE_VALUES; ++i) {
       const int c = lane + 64 * i;
       v[i] = 0.f;
       if (c < k) v[i] = (float)p[pix_map ? pix_map[c] : c];
       s += v[i];
     }
+    normalise_and_store(v, s, lane, r, k, kpad, metric, out);
   }
-  float mean = 0.f;
-  if (metric == KPDI_METRIC_NCC) mean = wave_sum(s) / (float)k;
-  float q2 = 0.f;
+}
+
+// ---- one wave per pattern, signal mask, row staged in LDS -------------------------------
+// LDS: [k ints pixel map][4 waves x npix floats].  Workgroups are persistent over groups of
+// 4 patterns, so the pixel map is staged once per workgroup.
+template <typename T>
+__global__ __launch_bounds__(PREP_THREADS) void prep_wave_masked_kernel(const T *raw, int npix, const int *row_map,
+                                                                        const int *pix_map, int k, int kpad,
+                                                                        int metric, int n_out, float *out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int *map = (int *)smem_raw;
+  const int map_words = (k + 3) & ~3;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float *row = (float *)smem_raw + map_words + wv * npix;
+  for (int c = threadIdx.x; c < map_words; c += PREP_THREADS) map[c] = c < k ? pix_map[c] : 0;
+  __syncthreads();
+  const int ngroups = (n_out + 3) / 4;
+  for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int r = g * 4 + wv;
+    const bool live = r < n_out;
+    if (live) {
+      const int64_t src = row_map ? row_map[r] : r;
+      const T *p = raw + src * (int64_t)npix;
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const int c = VEC == 4 ? 4 * (lane + 64 * (i / 4)) + (i & 3) : lane + 64 * i;
-    if (c < k) {
-      v[i] -= mean;
-      q2 += v[i] * v[i];
-    } else {
-      v[i] = 0.f;
-    }
-  }
-  const float norm = sqrtf(wave_sum(q2));
-  const float inv = norm > 0.f ? 1.f / norm : 0.f;
-  if (VEC == 4) {
-#pragma unroll
-    for (int i = 0; i < N / 4; ++i) {
-      const int c = 4 * (lane + 64 * i);
-      if (c < kpad) {
-        float4 w;
-        w.x = v[4 * i] * inv;
-        w.y = v[4 * i + 1] * inv;
-        w.z = v[4 * i + 2] * inv;
-        w.w = v[4 * i + 3] * inv;
-        *reinterpret_cast<float4 *>(out + out_offset(exp_layout, r, c, nslab)) = w;
+      for (int i = 0; i < WAVE_VALUES / 4; ++i) {
+        const int c = 4 * (lane + 64 * i);
+        if (c < npix) {
+          const Quad<T> q = *reinterpret_cast<const Quad<T> *>(p + c);
+          float4 w;
+          w.x = (float)q.v[0];
+          w.y = (float)q.v[1];
+          w.z = (float)q.v[2];
+          w.w = (float)q.v[3];
+          *reinterpret_cast<float4 *>(row + c) = w;
+        }
       }
     }
-  } else {
+    __syncthreads();  // rows staged (also orders this wave's own LDS writes before its gathers)
+    if (live) {
+      float v[WAVE_VALUES];
+      float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int c = lane + 64 * i;
-      if (c < kpad) out[out_offset(exp_layout, r, c, nslab)] = v[i] * inv;
+      for (int i = 0; i < WAVE_VALUES / 4; ++i) {
+        const int c = 4 * (lane + 64 * i);
+        int4 px = make_int4(0, 0, 0, 0);
+        if (c < k) px = *reinterpret_cast<const int4 *>(map + c);
+        v[4 * i] = c < k ? row[px.x] : 0.f;
+        v[4 * i + 1] = c + 1 < k ? row[px.y] : 0.f;
+        v[4 * i + 2] = c + 2 < k ? row[px.z] : 0.f;
+        v[4 * i + 3] = c + 3 < k ? row[px.w] : 0.f;
+        s += (v[4 * i] + v[4 * i + 1]) + (v[4 * i + 2] + v[4 * i + 3]);
+      }
+      normalise_and_store_quads(v, s, lane, r, k, kpad, metric, out);
     }
+    __syncthreads();  // rows are overwritten by the next group
   }
 }
 
 hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   if (a.n_out <= 0) return hipSuccess;
-  const bool wave_path = a.k <= 4096;
-  const bool vec4 = wave_path && a.pix_map == nullptr && (a.k % 4) == 0 && (a.npix % 4) == 0 &&
-                    ((uintptr_t)a.raw % (4 * dtype_size(a.dtype))) == 0;
+  const bool wave_path = a.k <= 64 * WAVE_VALUES;
+  const bool vec_ok = (a.npix % 4) == 0 && ((uintptr_t)a.raw % (4 * dtype_size(a.dtype))) == 0;
+  const bool vec4 = wave_path && a.pix_map == nullptr && (a.k % 4) == 0 && vec_ok;
+  const bool staged = wave_path && a.pix_map != nullptr && vec_ok && a.npix <= 64 * WAVE_VALUES;
+  const size_t staged_lds = (size_t)(((a.k + 3) & ~3) + 4 * a.npix) * 4;
   dim3 block(PREP_THREADS);
   dim3 grid(wave_path ? (a.n_out + 3) / 4 : a.n_out);
-#define KPDI_PREP(T)                                                                                   \
-  if (vec4)                                                                                            \
-    hipLaunchKernelGGL((prep_wave_kernel<T, 4>), grid, block, 0, s, (const T *)a.raw, a.npix,         \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.exp_layout, a.n_out, a.out);                   \
-  else if (wave_path)                                                                                  \
-    hipLaunchKernelGGL((prep_wave_kernel<T, 1>), grid, block, 0, s, (const T *)a.raw, a.npix,         \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.exp_layout, a.n_out, a.out);                   \
-  else                                                                                                 \
-    hipLaunchKernelGGL((prep_kernel<T>), grid, block, 0, s, (const T *)a.raw, a.npix, a.row_map,      \
-                       a.pix_map, a.k, a.kpad, a.metric, a.exp_layout, a.out);                                       \
+  if (staged) grid = dim3(std::min((a.n_out + 3) / 4, 2048));
+#define KPDI_PREP(T)                                                                                     \
+  if (vec4)                                                                                              \
+    hipLaunchKernelGGL((prep_wave_kernel<T, 4>), grid, block, 0, s, (const T *)a.raw, a.npix,           \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out);                     \
+  else if (staged) {                                                                                     \
+    if (staged_lds > 64 * 1024) {                                                                        \
+      hipError_t e = hipFuncSetAttribute((const void *)prep_wave_masked_kernel<T>,                       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)staged_lds);   \
+      if (e != hipSuccess) return e;                                                                     \
+    }                                                                                                    \
+    hipLaunchKernelGGL((prep_wave_masked_kernel<T>), grid, block, staged_lds, s, (const T *)a.raw,      \
+                       a.npix, a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out);             \
+  } else if (wave_path)                                                                                  \
+    hipLaunchKernelGGL((prep_wave_kernel<T, 1>), grid, block, 0, s, (const T *)a.raw, a.npix,           \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out);                     \
+  else                                                                                                   \
+    hipLaunchKernelGGL((prep_kernel<T>), grid, block, 0, s, (const T *)a.raw, a.npix, a.row_map,        \
+                       a.pix_map, a.k, a.kpad, a.metric, a.out);                                         \
   break;
   switch (a.dtype) {
     case KPDI_U8: KPDI_PREP(uint8_t)
