@@ -281,6 +281,116 @@ def gen_preproc():
     print("config1_ni", len(o1))
 
 
+# ------------------------------------------------------------------ master-pattern projection (8(f1))
+def load_ni_master_pattern():
+    """The Lambert master pattern the reference ships for its own tests
+    (data/emsoft_ebsd_master_pattern/, uint8, 401 x 401 per hemisphere)."""
+    import h5py
+
+    p = os.path.join(ref_shim.SRC, "data", "emsoft_ebsd_master_pattern",
+                     "ni_mc_mp_20kv_uint8_gzip_opts9.h5")
+    with h5py.File(p, "r") as f:
+        up = np.asarray(f["EMData/EBSDmaster/mLPNH"][()]).reshape(401, 401)
+        lo = np.asarray(f["EMData/EBSDmaster/mLPSH"][()]).reshape(401, 401)
+    return up, lo
+
+
+def random_quaternions(rng, n):
+    q = rng.standard_normal((n, 4))
+    q /= np.sqrt(np.sum(q**2, axis=1))[:, None]
+    q[q[:, 0] < 0] *= -1
+    return q
+
+
+DETECTORS = {
+    # name: shape, Bruker PC, sample_tilt, tilt, azimuthal, twist (degrees)
+    "det60": ((60, 60), (0.4210, 0.7794, 0.5049), 70.0, 0.0, 0.0, 0.0),
+    "det48x60": ((48, 60), (0.52, 0.71, 0.63), 69.5, 5.0, 3.0, 1.5),
+}
+
+
+def gen_projection():
+    r = ref_shim.load_reference_projection()
+    mpm = r["master_pattern"]
+    s2d = ref_shim.load_function_source("detectors/_ebsd_detector.py", "_sample_to_detector_matrix")
+    up, lo = load_ni_master_pattern()
+    out = {"mp_upper": up, "mp_lower": lo}
+    rng = np.random.default_rng(11)
+
+    # reference tests' known answers for the Lambert projection
+    # (tests/test_signals/test_ebsd_master_pattern.py:746-775) + awkward vectors
+    vec = np.array([[0, 0, 1], [0, 1, 0], [2, 0, 0], [0, 0, -3], [0, 0, -1], [0, -1, 0], [-2, 0, 0],
+                    [0, 0, 3], [1, 1, 0], [1, -1, 0.5], [-1, 1, -0.5], [-3, -3, 1e-9], [1e-12, 2e-12, 1],
+                    [0.3, -0.7, 0.2], [-0.6, 0.1, -0.9], [1, 0, 1e-17], [0, 1e-300, -1]], dtype=np.float64)
+    out["vec"] = vec
+    out["vec__lambert"] = mpm._vector2lambert(vec)
+    for name, val in zip(("nii", "nij", "niip", "nijp", "di", "dj", "dim", "djm"),
+                         mpm._get_lambert_interpolation_parameters(v=vec, npx=401, npy=401, scale=200.0)):
+        out[f"vec__{name}"] = val
+
+    dcs = {}
+    for name, (shape, pc, sigma, theta, omega, gamma) in DETECTORS.items():
+        m = s2d(*np.deg2rad([sigma, theta, omega, gamma]))
+        out[f"{name}__s2d"] = m
+        aspect = shape[1] / shape[0]
+        # EBSDDetector.gnomonic_bounds (detectors/_ebsd_detector.py:731-818), Bruker PC
+        bounds = np.array([-aspect * (pc[0] / pc[2]), aspect * (1 - pc[0]) / pc[2],
+                           -(1 - pc[1]) / pc[2], pc[1] / pc[2]], dtype=np.float64)
+        # (~Rotation.from_matrix(m)).to_matrix() == m.T for a rotation matrix
+        dc = mpm._get_direction_cosines_for_fixed_pc(
+            gnomonic_bounds=bounds, pcz=np.float64(pc[2]), nrows=shape[0], ncols=shape[1],
+            om_detector_to_sample=np.ascontiguousarray(m.T), signal_mask=np.ones(shape[0] * shape[1], bool))
+        out[f"{name}__dc"] = dc
+        dcs[name] = dc
+    circ_keep = np.asarray(Window("circular", (60, 60)).astype(bool))
+    out["det60__dc_circ"] = mpm._get_direction_cosines_for_fixed_pc(
+        gnomonic_bounds=np.array([-(0.4210 / 0.5049), (1 - 0.4210) / 0.5049, -(1 - 0.7794) / 0.5049,
+                                  0.7794 / 0.5049]),
+        pcz=np.float64(0.5049), nrows=60, ncols=60,
+        om_detector_to_sample=np.ascontiguousarray(out["det60__s2d"].T), signal_mask=circ_keep.ravel())
+
+    def project(rot, dc, mu, ml, rescale, omin, omax, dtype_out):
+        return mpm._project_patterns_from_master_pattern_with_fixed_pc(
+            rotations=rot, direction_cosines=dc, master_upper=mu, master_lower=ml, npx=401, npy=401,
+            scale=200.0, rescale=rescale, out_min=omin, out_max=omax, dtype_out=dtype_out)
+
+    rot = random_quaternions(rng, 8)
+    rot[0] = [1, 0, 0, 0]
+    rot[1] = np.array([1, 1, 0, 0]) / np.sqrt(2)
+    out["rot8"] = rot
+    upf, lof = up.astype(np.float32), lo.astype(np.float32)
+    inv = (255 - up).astype(np.uint8)
+    # get_patterns' rescale rule (signals/ebsd_master_pattern.py:225-233)
+    out["u8mp_f32__patterns"] = project(rot, dcs["det60"], up, lo, True, -1, 1, np.float32)
+    out["f32mp_f32__patterns"] = project(rot, dcs["det60"], upf, lof, False, 1, 2, np.float32)
+    out["f32mp_u8__patterns"] = project(rot, dcs["det60"], upf, lof, True, 0, 255, np.uint8)
+    out["u8mp_u8__patterns"] = project(rot, dcs["det60"], up, lo, False, 1, 2, np.uint8)
+    out["hemis_f32__patterns"] = project(rot, dcs["det60"], upf, inv.astype(np.float32), False, 1, 2,
+                                         np.float32)
+    out["det48x60_f32__patterns"] = project(rot[:4], dcs["det48x60"], upf, lof, False, 1, 2, np.float32)
+
+    # ---- end to end: dictionary of 1200 projected patterns -> reference DI
+    n_dict = 1200
+    rot_d = random_quaternions(rng, n_dict)
+    dic = project(rot_d, dcs["det60"], up, lo, True, -1, 1, np.float32).reshape(n_dict, 60, 60)
+    picks = rng.choice(n_dict, 24, replace=False)
+    noisy = dic[picks] + 0.25 * rng.standard_normal((24, 60, 60)).astype(np.float32)
+    exp = np.clip((noisy + 1.5) * 80, 0, 255).astype(np.uint8)
+    out["di_rot"] = rot_d
+    out["di_exp"] = exp
+    out["di_picks"] = picks
+    out["di_dic_sample"] = dic[::100]
+    out["di_dic_sha"] = np.array(sha(dic))
+    for name, kw in {
+        "di_ncc_k10": dict(metric="ncc", keep_n=10, n_per_iteration=500),
+        "di_ndp_k10_circ": dict(metric="ndp", keep_n=10, signal_mask=~circ_keep),
+    }.items():
+        s, i, msg, rep = run_di(exp, dic, **kw)
+        out[f"{name}__scores"], out[f"{name}__indices"] = s, i
+    np.savez_compressed(os.path.join(OUT, "projection.npz"), **out)
+    print("projection", len(out))
+
+
 # ------------------------------------------------------------------ the reference tests' own known answers
 def gen_refknown():
     """Extract the hard-coded known-answer ARRAYS (data, not code) that the
@@ -317,9 +427,14 @@ def gen_refknown():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # e.g. `gen_golden.py projection`: only the named fixtures
+        for name in sys.argv[1:]:
+            globals()[f"gen_{name}"]()
+        sys.exit(0)
     gen_dummy_di()
     gen_synth_di()
     gen_preproc()
     gen_refknown()
+    gen_projection()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

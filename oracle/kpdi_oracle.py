@@ -411,6 +411,157 @@ def remove_dynamic_background(
 
 
 # --------------------------------------------------------------------------
+# dictionary generation: projection of a master pattern onto the detector
+# (all f64 like the reference)
+# --------------------------------------------------------------------------
+SQRT_PI = np.sqrt(np.pi)
+SQRT_PI_HALF = np.sqrt(np.pi / 2)
+SQRT_PI_OVER_2 = SQRT_PI / 2
+TWO_OVER_SQRT_PI = 2 / SQRT_PI
+
+
+def sample_to_detector_matrix(sample_tilt=70.0, tilt=0.0, azimuthal=0.0, twist=0.0):
+    """detectors/_ebsd_detector.py:100-150 (+ :836-845): rows are the detector
+    axes (X_d, Y_d, Z_d) in sample coordinates, starting from (Y_s, Z_s, X_s)
+    and turned, in this order, about the current X_d by -sample_tilt, about X_d
+    by +tilt, about Y_d by -azimuthal, about Z_d by -twist (Rodrigues formula,
+    all three rows turned by each step).  Angles in degrees."""
+    basis = np.array([[0, 1, 0], [0, 0, 1], [1, 0, 0]], dtype=np.float64)
+    angles = np.deg2rad(np.array([-sample_tilt, tilt, -azimuthal, -twist], dtype=np.float64))
+    for axis_row, angle in zip((0, 0, 1, 2), angles):
+        u = basis[axis_row] / np.sqrt(np.sum(basis[axis_row] ** 2))
+        c, s = np.cos(angle), np.sin(angle)
+        for j in range(3):
+            v = basis[j].copy()
+            basis[j] = v * c + np.cross(u, v) * s + u * np.dot(u, v) * (1.0 - c)
+    return basis
+
+
+def gnomonic_bounds(shape, pc):
+    """detectors/_ebsd_detector.py:731-818: (x_min, x_max, y_min, y_max) of the
+    detector in gnomonic coordinates for a Bruker-convention PC (pcx, pcy, pcz)."""
+    nrows, ncols = shape
+    pcx, pcy, pcz = (np.float64(v) for v in pc)
+    aspect = ncols / nrows
+    return np.array(
+        [-aspect * (pcx / pcz), aspect * (1 - pcx) / pcz, -(1 - pcy) / pcz, pcy / pcz],
+        dtype=np.float64,
+    )
+
+
+def direction_cosines_fixed_pc(bounds, pcz, nrows, ncols, om_detector_to_sample, signal_mask=None):
+    """signals/util/_master_pattern.py:133-204: unit vectors from the source
+    point through the centre of every (kept) detector pixel, in the sample
+    frame.  `signal_mask` follows that function's convention: True = keep."""
+    x_scale = (bounds[1] - bounds[0]) / ncols
+    y_scale = (bounds[3] - bounds[2]) / nrows
+    det_gn_x = bounds[0] + np.arange(ncols) * x_scale      # np.arange(start, stop, step)
+    det_gn_y = bounds[3] + np.arange(nrows) * (-y_scale)
+    idx = np.arange(nrows * ncols)
+    if signal_mask is not None:
+        idx = idx[np.asarray(signal_mask, dtype=bool).ravel()]
+    rows, cols = idx // ncols, idx % ncols
+    r_g = np.empty((idx.size, 3), dtype=np.float64)
+    r_g[:, 0] = (det_gn_x[cols] + x_scale / 2) * pcz
+    r_g[:, 1] = (det_gn_y[rows] - y_scale / 2) * pcz
+    r_g[:, 2] = pcz
+    r_g = r_g @ np.asarray(om_detector_to_sample, dtype=np.float64).T
+    return r_g / np.sqrt(np.sum(r_g**2, axis=-1))[:, None]
+
+
+def detector_direction_cosines(shape, pc, sample_tilt=70.0, tilt=0.0, azimuthal=0.0, twist=0.0,
+                               signal_mask=None):
+    """signals/util/_master_pattern.py:83-124 for one PC: detector -> sample
+    matrix is the inverse (transpose) of `sample_to_detector_matrix`."""
+    m = sample_to_detector_matrix(sample_tilt, tilt, azimuthal, twist)
+    return direction_cosines_fixed_pc(gnomonic_bounds(shape, pc), np.float64(pc[2]), shape[0], shape[1],
+                                      m.T, signal_mask)
+
+
+def rotate_vector(rotation, vector):
+    """_utils/numba.py:59-81: passive rotation of (n, 3) vectors by the unit
+    quaternion (a, b, c, d)."""
+    a, b, c, d = (np.float64(v) for v in rotation)
+    x, y, z = vector[:, 0], vector[:, 1], vector[:, 2]
+    aa, bb, cc, dd = a * a, b * b, c * c, d * d
+    ac, ab, ad, bc, bd, cd = a * c, a * b, a * d, b * c, b * d, c * d
+    out = np.empty(vector.shape, dtype=np.float64)
+    out[:, 0] = (aa + bb - cc - dd) * x + 2 * ((ac + bd) * z + (bc - ad) * y)
+    out[:, 1] = (aa - bb + cc - dd) * y + 2 * ((ad + bc) * x + (cd - ab) * z)
+    out[:, 2] = (aa - bb - cc + dd) * z + 2 * ((ab + cd) * y + (bd - ac) * x)
+    return out
+
+
+def vector2lambert(v):
+    """signals/util/_master_pattern.py:530-568: square Lambert (X, Y) of (n, 3)
+    vectors (normalised first); (0, 0) at the poles."""
+    w = v / np.sqrt(np.sum(v**2, axis=1))[:, None]
+    x, y, z = w[:, 0], w[:, 1], w[:, 2]
+    abs_z = np.abs(z)
+    sqrt_z = np.sqrt(2 * (1 - abs_z))
+    out = np.zeros((v.shape[0], 2), dtype=np.float64)
+    pole = abs_z == 1
+    xdom = (np.abs(y) <= np.abs(x)) & ~pole
+    ydom = ~xdom & ~pole
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sx, sy = np.sign(x), np.sign(y)
+        out[xdom, 0] = (sx * sqrt_z * SQRT_PI_OVER_2)[xdom]
+        out[xdom, 1] = (sx * sqrt_z * TWO_OVER_SQRT_PI * np.arctan(y / x))[xdom]
+        out[ydom, 0] = (sy * sqrt_z * TWO_OVER_SQRT_PI * np.arctan(x / y))[ydom]
+        out[ydom, 1] = (sy * sqrt_z * SQRT_PI_OVER_2)[ydom]
+    return out
+
+
+def lambert_interpolation_parameters(v, npx, npy, scale):
+    """signals/util/_master_pattern.py:580-678: the four neighbouring master-
+    pattern pixels of every vector and their bilinear weights.  The row index
+    comes from Lambert Y, the column index from Lambert X; `int32()` truncates
+    toward zero."""
+    xy = scale * vector2lambert(v) / SQRT_PI_HALF
+    i, j = xy[:, 1], xy[:, 0]
+    nii = np.trunc(i + scale).astype(np.int32)
+    nij = np.trunc(j + scale).astype(np.int32)
+    niip, nijp = nii + 1, nij + 1
+    niip = np.where(niip >= npx, nii, niip)
+    nijp = np.where(nijp >= npy, nij, nijp)
+    nii = np.where(nii < 0, niip, nii)
+    nij = np.where(nij < 0, nijp, nij)
+    di = i - nii + scale
+    dj = j - nij + scale
+    return nii, nij, niip, nijp, di, dj, 1 - di, 1 - dj
+
+
+def project_patterns(rotations, direction_cosines, master_upper, master_lower, rescale=False,
+                     out_min=-1, out_max=1, dtype_out=np.float32):
+    """signals/util/_master_pattern.py:299-370, :449-527: one simulated pattern
+    per unit quaternion: rotate the direction cosines, bilinear interpolation in
+    the square-Lambert master pattern of the hemisphere the rotated vector
+    points into (z >= 0: upper), optional min-max rescale of each pattern
+    (pattern/_pattern.py:97-111), cast (integers truncate)."""
+    rotations = np.asarray(rotations, dtype=np.float64).reshape(-1, 4)
+    npy, npx = master_upper.shape  # axes_manager.signal_shape = (npx, npy), square in practice
+    scale = float((npx - 1) / 2)
+    out = np.empty((rotations.shape[0], direction_cosines.shape[0]), dtype=dtype_out)
+    for n, rot in enumerate(rotations):
+        v = rotate_vector(rot, direction_cosines)
+        nii, nij, niip, nijp, di, dj, dim, djm = lambert_interpolation_parameters(v, npx, npy, scale)
+        up = v[:, 2] >= 0
+        pattern = np.empty(v.shape[0], dtype=np.float64)
+        for sel, mp in ((up, master_upper), (~up, master_lower)):
+            pattern[sel] = (
+                mp[nii[sel], nij[sel]] * dim[sel] * djm[sel]
+                + mp[niip[sel], nij[sel]] * di[sel] * djm[sel]
+                + mp[nii[sel], nijp[sel]] * dim[sel] * dj[sel]
+                + mp[niip[sel], nijp[sel]] * di[sel] * dj[sel]
+            )
+        if rescale:
+            imin, imax = np.min(pattern), np.max(pattern)
+            pattern = (pattern - imin) / float(imax - imin) * (out_max - out_min) + out_min
+        out[n] = pattern.astype(dtype_out)
+    return out
+
+
+# --------------------------------------------------------------------------
 # comparison helper shared by the parity tests
 # --------------------------------------------------------------------------
 def assert_topk_parity(scores, indices, ref_scores, ref_indices, atol=1e-5, tie=2e-5):

@@ -64,6 +64,7 @@ def _stub_numba():
 
     nb.njit = njit
     nb.jit = njit
+    nb.prange = range
     sys.modules["numba"] = nb
 
 
@@ -204,6 +205,47 @@ def load_reference():
     _loaded["fft_barnes"] = _load("kikuchipy.filters.fft_barnes", "filters/fft_barnes.py")
     _loaded["pattern"] = _load("kikuchipy.pattern._pattern", "pattern/_pattern.py")
     return _loaded
+
+
+def load_reference_projection():
+    """The master-pattern projection modules:
+    `_utils/numba.py` (rotate_vector) and `signals/util/_master_pattern.py`
+    (direction cosines, Lambert interpolation, pattern projection).  Under the
+    numba stub every function is its `.py_func`."""
+    ref = load_reference()
+    if "master_pattern" in ref:
+        return ref
+    _ns("kikuchipy._utils", os.path.join(SRC, "_utils"))
+    _ns("kikuchipy.signals", os.path.join(SRC, "signals"))
+    _ns("kikuchipy.signals.util", os.path.join(SRC, "signals", "util"))
+    ref["numba_utils"] = _load("kikuchipy._utils.numba", "_utils/numba.py")
+    ref["master_pattern"] = _load(
+        "kikuchipy.signals.util._master_pattern", "signals/util/_master_pattern.py"
+    )
+    return ref
+
+
+def load_function_source(relpath, name, extra_globals=None):
+    """Execute ONE top-level function of a reference module that cannot be
+    imported as a whole here (e.g. detectors/_ebsd_detector.py needs orix and
+    matplotlib) and return it."""
+    import ast
+
+    import numpy as np
+
+    path = os.path.join(SRC, relpath)
+    tree = ast.parse(open(path).read())
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            mod = ast.Module(body=[node], type_ignores=[])
+            code = compile(
+                mod, path, "exec", flags=__future__.annotations.compiler_flag, dont_inherit=True
+            )
+            g = {"np": np, "nb": sys.modules.get("numba")}
+            g.update(extra_globals or {})
+            exec(code, g)
+            return g[name]
+    raise KeyError(name)
 
 
 class FakeDictionaryXmap:
