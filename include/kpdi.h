@@ -138,6 +138,41 @@ int kpdi_reset_topk(kpdi_ctx *ctx);
  * the same, global result. */
 int kpdi_finalize(kpdi_ctx *ctx, float *scores_out, int64_t *indices_out);
 
+/* ---- dictionary generation on the device ------------------
+ * EBSDMasterPattern.get_patterns (signals/ebsd_master_pattern.py:95-330): project a
+ * square-Lambert master pattern onto the detector, one simulated pattern per
+ * rotation, without the dictionary ever existing in host memory.
+ *
+ * kpdi_set_master_pattern: the arrays `_get_master_pattern_arrays_from_energy`
+ * returns (signals/_kikuchi_master_pattern.py:303-345): npy rows x npx columns per
+ * hemisphere, dtype U8 / U16 / F32 (F64 is rounded to F32).  `lower` may be NULL
+ * (hemisphere != "both": lower = upper). */
+int kpdi_set_master_pattern(kpdi_ctx *ctx, const void *upper, const void *lower,
+                            int dtype, int npx, int npy);
+/* kpdi_set_detector: arguments of `_get_direction_cosines_for_fixed_pc`
+ * (signals/util/_master_pattern.py:133-204) for the whole detector:
+ * gnomonic_bounds = (x_min, x_max, y_min, y_max), om_detector_to_sample = 3x3
+ * row-major.  The direction cosines (nrows*ncols x 3 f64) are computed on the host
+ * in that function's operation order and kept on the device. */
+int kpdi_set_detector(kpdi_ctx *ctx, const double *gnomonic_bounds, double pcz,
+                      int nrows, int ncols, const double *om_detector_to_sample);
+/* alternative: hand over direction cosines computed elsewhere (npix x 3 f64) */
+int kpdi_set_direction_cosines(kpdi_ctx *ctx, const double *direction_cosines, int64_t npix);
+/* the resident direction cosines, npix*3 doubles */
+int kpdi_get_direction_cosines(kpdi_ctx *ctx, double *out);
+/* `_project_patterns_from_master_pattern_with_fixed_pc` (:299-370): `rotations` =
+ * n x 4 unit quaternions (a, b, c, d) f64; out = n x npix of `dtype_out` (F32, F64,
+ * U8, U16; integers truncate like ndarray.astype) in HOST memory.  `rescale` != 0:
+ * every pattern is min-max rescaled to [out_min, out_max] (pattern/_pattern.py:97-111). */
+int kpdi_project_patterns(kpdi_ctx *ctx, const double *rotations, int64_t n, int rescale,
+                          double out_min, double out_max, int dtype_out, void *out);
+/* generate + match in one call: the chunk of the dictionary belonging to
+ * `rotations` is projected as float32 straight into device memory and swept like
+ * kpdi_push_dictionary_chunk(..., KPDI_F32, n, global_start); the detector must have
+ * sy*sx pixels (kpdi_set_problem). */
+int kpdi_push_rotations_chunk(kpdi_ctx *ctx, const double *rotations, int64_t n,
+                              int64_t global_start, int rescale, double out_min, double out_max);
+
 /* ---- multi-GPU: dictionary sharded over ranks, one process per GPU -------- */
 #define KPDI_UNIQUE_ID_BYTES 128
 int kpdi_comm_unique_id(uint8_t *id_out /* KPDI_UNIQUE_ID_BYTES */);
@@ -163,6 +198,7 @@ typedef struct kpdi_counters {
   int32_t match_nsplit; /* dictionary splits of the last match launch */
   int32_t kpad;         /* padded reduction length */
   int32_t k_kept;       /* kept pixels K */
+  double project_ms;    /* master-pattern projection kernels */
 } kpdi_counters;
 int kpdi_set_profiling(kpdi_ctx *ctx, int on);
 int kpdi_get_counters(kpdi_ctx *ctx, kpdi_counters *out);

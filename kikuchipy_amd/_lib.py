@@ -47,6 +47,7 @@ class Counters(C.Structure):
         ("match_nsplit", C.c_int32),
         ("kpad", C.c_int32),
         ("k_kept", C.c_int32),
+        ("project_ms", C.c_double),
     ]
 
     def as_dict(self):
@@ -72,6 +73,12 @@ SIGNATURES = {
     "kpdi_get_experimental": (_i, [_vp, _vp]),
     "kpdi_push_dictionary_chunk": (_i, [_vp, _vp, _i, _i64, _i64]),
     "kpdi_push_dictionary_chunk_dev": (_i, [_vp, _vp, _i, _i64, _i64]),
+    "kpdi_set_master_pattern": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "kpdi_set_detector": (_i, [_vp, _vp, C.c_double, _i, _i, _vp]),
+    "kpdi_set_direction_cosines": (_i, [_vp, _vp, _i64]),
+    "kpdi_get_direction_cosines": (_i, [_vp, _vp]),
+    "kpdi_project_patterns": (_i, [_vp, _vp, _i64, _i, C.c_double, C.c_double, _i, _vp]),
+    "kpdi_push_rotations_chunk": (_i, [_vp, _vp, _i64, _i64, _i, C.c_double, C.c_double]),
     "kpdi_reset_topk": (_i, [_vp]),
     "kpdi_finalize": (_i, [_vp, _vp, _vp]),
     "kpdi_comm_unique_id": (_i, [_vp]),
@@ -227,6 +234,46 @@ class Context:
     def push_dictionary_chunk_dev(self, d_ptr, dtype, n_chunk, global_start):
         check(load().kpdi_push_dictionary_chunk_dev(self._h, C.c_void_p(d_ptr), dtype_code(dtype),
                                                     int(n_chunk), int(global_start)))
+
+    # -- dictionary generation on the device
+    def set_master_pattern(self, upper, lower=None):
+        """upper / lower: (npy, npx) arrays of one dtype (uint8, uint16, float32, float64)."""
+        up = np.ascontiguousarray(upper)
+        lo = None if lower is None else np.ascontiguousarray(lower, dtype=up.dtype)
+        if up.ndim != 2 or (lo is not None and lo.shape != up.shape):
+            raise KpdiError("master pattern hemispheres must be 2D arrays of equal shape")
+        check(load().kpdi_set_master_pattern(self._h, _ptr(up), _ptr(lo), dtype_code(up.dtype),
+                                             up.shape[1], up.shape[0]))
+
+    def set_detector(self, gnomonic_bounds, pcz, nrows, ncols, om_detector_to_sample):
+        gb = np.ascontiguousarray(gnomonic_bounds, dtype=np.float64).ravel()
+        om = np.ascontiguousarray(om_detector_to_sample, dtype=np.float64).ravel()
+        if gb.size != 4 or om.size != 9:
+            raise KpdiError("gnomonic_bounds must have 4 and om_detector_to_sample 9 elements")
+        check(load().kpdi_set_detector(self._h, _ptr(gb), float(pcz), int(nrows), int(ncols), _ptr(om)))
+        self._dc_npix = int(nrows) * int(ncols)
+
+    def set_direction_cosines(self, direction_cosines):
+        dc = np.ascontiguousarray(direction_cosines, dtype=np.float64).reshape(-1, 3)
+        check(load().kpdi_set_direction_cosines(self._h, _ptr(dc), dc.shape[0]))
+        self._dc_npix = dc.shape[0]
+
+    def get_direction_cosines(self):
+        out = np.empty((self._dc_npix, 3), dtype=np.float64)
+        check(load().kpdi_get_direction_cosines(self._h, _ptr(out)))
+        return out
+
+    def project_patterns(self, rotations, rescale=False, out_min=-1.0, out_max=1.0, dtype_out=np.float32):
+        rot = np.ascontiguousarray(rotations, dtype=np.float64).reshape(-1, 4)
+        out = np.empty((rot.shape[0], self._dc_npix), dtype=dtype_out)
+        check(load().kpdi_project_patterns(self._h, _ptr(rot), rot.shape[0], int(bool(rescale)),
+                                           float(out_min), float(out_max), dtype_code(out.dtype), _ptr(out)))
+        return out
+
+    def push_rotations_chunk(self, rotations, global_start, rescale=False, out_min=-1.0, out_max=1.0):
+        rot = np.ascontiguousarray(rotations, dtype=np.float64).reshape(-1, 4)
+        check(load().kpdi_push_rotations_chunk(self._h, _ptr(rot), rot.shape[0], int(global_start),
+                                               int(bool(rescale)), float(out_min), float(out_max)))
 
     def reset_topk(self):
         check(load().kpdi_reset_topk(self._h))

@@ -143,13 +143,19 @@ struct kpdi_ctx {
   // pre-processing scratch
   DevBuf bg, taps;
 
+  // dictionary generation (project.hip)
+  bool have_master = false, have_dc = false;
+  int mp_npx = 0, mp_npy = 0;
+  int64_t dc_npix = 0;
+  DevBuf mp_packed, dcos, rot, proj_out;
+
   // comm
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
 
   // measurement
   bool profiling = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_match, ev_prep, ev_merge;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_match, ev_prep, ev_merge, ev_proj;
   std::vector<hipEvent_t> ev_pool;
   kpdi_counters cnt{};
 
@@ -514,9 +520,10 @@ int kpdi_destroy(kpdi_ctx *c) {
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   for (DevBuf *b : {&c->pix_map, &c->exp_raw, &c->row_map, &c->exp_x, &c->dict_raw, &c->dict_y, &c->part_s,
                     &c->part_i, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
-                    &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps})
+                    &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps,
+                    &c->mp_packed, &c->dcos, &c->rot, &c->proj_out})
     b->release();
-  for (auto *l : {&c->ev_match, &c->ev_prep, &c->ev_merge})
+  for (auto *l : {&c->ev_match, &c->ev_prep, &c->ev_merge, &c->ev_proj})
     for (auto &pr : *l) {
       (void)hipEventDestroy(pr.first);
       (void)hipEventDestroy(pr.second);
@@ -727,6 +734,163 @@ int kpdi_push_dictionary_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtyp
   return push_chunk_dev(c, d_patterns, dtype, n_chunk, global_start);
 }
 
+// ---- dictionary generation --------------------------------------------------
+int kpdi_set_master_pattern(kpdi_ctx *c, const void *upper, const void *lower, int dtype, int npx, int npy) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!upper) return fail(KPDI_EINVAL, "upper hemisphere pointer is NULL");
+  if (npx < 2 || npy < 2) return fail(KPDI_EINVAL, "master pattern must be at least 2 x 2 pixels");
+  if (dtype != KPDI_U8 && dtype != KPDI_U16 && dtype != KPDI_F32 && dtype != KPDI_F64)
+    return fail(KPDI_EINVAL, "master pattern dtype must be uint8, uint16, float32 or float64");
+  int rc = use_device(c);
+  if (rc) return rc;
+  const size_t n = (size_t)npx * npy;
+  std::vector<float> up(n), lo;
+  auto convert = [&](const void *src, std::vector<float> &dst) {
+    switch (dtype) {
+      case KPDI_U8: for (size_t i = 0; i < n; ++i) dst[i] = (float)((const uint8_t *)src)[i]; break;
+      case KPDI_U16: for (size_t i = 0; i < n; ++i) dst[i] = (float)((const uint16_t *)src)[i]; break;
+      case KPDI_F32: for (size_t i = 0; i < n; ++i) dst[i] = ((const float *)src)[i]; break;
+      default: for (size_t i = 0; i < n; ++i) dst[i] = (float)((const double *)src)[i]; break;
+    }
+  };
+  convert(upper, up);
+  if (lower && lower != upper) {
+    lo.resize(n);
+    convert(lower, lo);
+  }
+  std::vector<float> packed(kpdi::packed_master_floats(npx, npy));
+  kpdi::pack_master_pattern(up.data(), lo.empty() ? up.data() : lo.data(), npx, npy, packed.data());
+  HIPCHK(c->mp_packed.reserve(packed.size() * sizeof(float)));
+  HIPCHK(hipMemcpyAsync(c->mp_packed.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice,
+                        c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->cnt.h2d_bytes += (double)(packed.size() * sizeof(float));
+  c->mp_npx = npx;
+  c->mp_npy = npy;
+  c->have_master = true;
+  return KPDI_OK;
+}
+
+int kpdi_set_direction_cosines(kpdi_ctx *c, const double *dc, int64_t npix) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!dc) return fail(KPDI_EINVAL, "direction cosines pointer is NULL");
+  if (npix <= 0 || npix >= (int64_t)INT_MAX / 3) return fail(KPDI_EINVAL, "bad number of detector pixels");
+  int rc = use_device(c);
+  if (rc) return rc;
+  const size_t bytes = (size_t)npix * 3 * sizeof(double);
+  HIPCHK(c->dcos.reserve(bytes));
+  HIPCHK(hipMemcpyAsync(c->dcos.p, dc, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->dc_npix = npix;
+  c->have_dc = true;
+  return KPDI_OK;
+}
+
+int kpdi_set_detector(kpdi_ctx *c, const double *gb, double pcz, int nrows, int ncols, const double *om) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!gb || !om) return fail(KPDI_EINVAL, "gnomonic bounds / orientation matrix pointer is NULL");
+  if (nrows <= 0 || ncols <= 0) return fail(KPDI_EINVAL, "detector must have at least one pixel");
+  // _get_direction_cosines_for_fixed_pc (signals/util/_master_pattern.py:175-203)
+  const double x_scale = (gb[1] - gb[0]) / ncols;
+  const double y_scale = (gb[3] - gb[2]) / nrows;
+  const double x_half = x_scale / 2, y_half = y_scale / 2;
+  std::vector<double> dc((size_t)nrows * ncols * 3);
+  for (int r = 0; r < nrows; ++r) {
+    const double gy = gb[3] + r * (-y_scale);  // np.arange(y_max, y_min, -y_scale)[r]
+    for (int col = 0; col < ncols; ++col) {
+      const double gx = gb[0] + col * x_scale;  // np.arange(x_min, x_max, x_scale)[col]
+      const double v[3] = {(gx + x_half) * pcz, (gy - y_half) * pcz, pcz};
+      double w[3];
+      for (int a = 0; a < 3; ++a) w[a] = v[0] * om[3 * a] + v[1] * om[3 * a + 1] + v[2] * om[3 * a + 2];
+      const double norm = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+      double *o = &dc[((size_t)r * ncols + col) * 3];
+      o[0] = w[0] / norm;
+      o[1] = w[1] / norm;
+      o[2] = w[2] / norm;
+    }
+  }
+  return kpdi_set_direction_cosines(c, dc.data(), (int64_t)nrows * ncols);
+}
+
+int kpdi_get_direction_cosines(kpdi_ctx *c, double *out) {
+  if (!c || !out) return fail(KPDI_EINVAL, "NULL argument");
+  if (!c->have_dc) return fail(KPDI_EINVAL, "no detector set");
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->dcos.p, (size_t)c->dc_npix * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KPDI_OK;
+}
+
+namespace {
+// rotations (host) -> device, then one pattern per rotation into `d_out`
+int project_to_device(kpdi_ctx *c, const double *rotations, int64_t n, int rescale, double out_min, double out_max,
+                      int dtype_out, void *d_out) {
+  if (!c->have_master) return fail(KPDI_EINVAL, "kpdi_set_master_pattern has not been called");
+  if (!c->have_dc) return fail(KPDI_EINVAL, "kpdi_set_detector has not been called");
+  if (!rotations) return fail(KPDI_EINVAL, "rotations pointer is NULL");
+  if (n <= 0 || n >= (int64_t)INT_MAX) return fail(KPDI_EINVAL, "need between 1 and 2^31-1 rotations per call");
+  if (rescale && !(out_max > out_min)) return fail(KPDI_EINVAL, "rescale needs out_max > out_min");
+  HIPCHK(c->rot.reserve((size_t)n * 4 * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(c->rot.p, rotations, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  c->cnt.h2d_bytes += (double)n * 4 * sizeof(double);
+  kpdi::ProjectLaunch p;
+  p.rotations = c->rot.as<double>();
+  p.n = n;
+  p.direction_cosines = c->dcos.as<double>();
+  p.npix = (int)c->dc_npix;
+  p.master_packed = c->mp_packed.as<float>();
+  p.npx = c->mp_npx;
+  p.npy = c->mp_npy;
+  p.rescale = rescale;
+  p.out_min = out_min;
+  p.out_max = out_max;
+  p.dtype_out = dtype_out;
+  p.out = d_out;
+  {
+    ScopedTimer t(c, &c->ev_proj);
+    HIPCHK(kpdi::launch_project(p, c->stream));
+  }
+  // the rotations buffer may be a temporary of the caller's binding: it must have been read
+  // before we return (pageable memory is staged synchronously, pinned memory is not)
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KPDI_OK;
+}
+}  // namespace
+
+int kpdi_project_patterns(kpdi_ctx *c, const double *rotations, int64_t n, int rescale, double out_min,
+                          double out_max, int dtype_out, void *out) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!out) return fail(KPDI_EINVAL, "output pointer is NULL");
+  if (dtype_out != KPDI_F32 && dtype_out != KPDI_F64 && dtype_out != KPDI_U8 && dtype_out != KPDI_U16)
+    return fail(KPDI_EINVAL, "dtype_out must be float32, float64, uint8 or uint16");
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (!c->have_dc) return fail(KPDI_EINVAL, "kpdi_set_detector has not been called");
+  const size_t bytes = (size_t)n * c->dc_npix * kpdi::dtype_size(dtype_out);
+  if (n > 0) HIPCHK(c->proj_out.reserve(bytes));
+  rc = project_to_device(c, rotations, n, rescale, out_min, out_max, dtype_out, c->proj_out.p);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->proj_out.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KPDI_OK;
+}
+
+int kpdi_push_rotations_chunk(kpdi_ctx *c, const double *rotations, int64_t n, int64_t global_start, int rescale,
+                              double out_min, double out_max) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!c->have_problem) return fail(KPDI_EINVAL, "kpdi_set_problem has not been called");
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (c->have_dc && c->dc_npix != c->npix)
+    return fail(KPDI_EINVAL, "detector has %lld pixels but the problem's signal shape has %d", (long long)c->dc_npix,
+                c->npix);
+  if (n > 0) HIPCHK(c->dict_raw.reserve((size_t)n * c->npix * sizeof(float)));
+  rc = project_to_device(c, rotations, n, rescale, out_min, out_max, KPDI_F32, c->dict_raw.p);
+  if (rc) return rc;
+  return push_chunk_dev(c, c->dict_raw.p, KPDI_F32, n, global_start);
+}
+
 int kpdi_reset_topk(kpdi_ctx *c) {
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
   c->run_valid = false;
@@ -864,6 +1028,8 @@ int kpdi_get_counters(kpdi_ctx *c, kpdi_counters *out) {
   rc = drain_events(c, c->ev_prep, &c->cnt.prep_ms);
   if (rc) return rc;
   rc = drain_events(c, c->ev_merge, &c->cnt.merge_ms);
+  if (rc) return rc;
+  rc = drain_events(c, c->ev_proj, &c->cnt.project_ms);
   if (rc) return rc;
   *out = c->cnt;
   return KPDI_OK;

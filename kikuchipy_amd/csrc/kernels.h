@@ -130,4 +130,22 @@ struct DynamicBgLaunch {
 hipError_t launch_dynamic_bg(const DynamicBgLaunch &a, hipStream_t s);
 size_t dtype_size(int dtype);
 
+// ---- master-pattern projection (project.hip) --------------------------------
+struct ProjectLaunch {
+  const double *rotations;          // [n][4] unit quaternions
+  int64_t n;
+  const double *direction_cosines;  // [npix][3]
+  int npix;
+  const float *master_packed;       // pack_master_pattern() layout
+  int npx, npy;
+  int rescale;
+  double out_min, out_max;
+  int dtype_out;
+  void *out;                        // [n][npix] of dtype_out
+};
+hipError_t launch_project(const ProjectLaunch &a, hipStream_t s);
+// host: upper/lower [npy][npx] f32 -> [2][npy][npx + 1] float2 {m[r][c], m[r+1][c]}, edges repeated
+size_t packed_master_floats(int npx, int npy);
+void pack_master_pattern(const float *upper, const float *lower, int npx, int npy, float *out);
+
 }  // namespace kpdi
