@@ -2,7 +2,8 @@
 
 Accelerates ONE path of kikuchipy: `EBSD.dictionary_indexing()` with the
 `ncc`/`ndp` similarity metrics, plus the static/dynamic background removal
-that feeds it.  Python host code -> ctypes -> libkpdi.so (hand-written HIP for
+that feeds it, and the on-device generation of the dictionary from a master
+pattern (`EBSDMasterPattern.get_patterns`).  Python host code -> ctypes -> libkpdi.so (hand-written HIP for
 gfx950).  No PyTorch, no CPU fallback.
 """
 
@@ -16,12 +17,17 @@ from kikuchipy_amd.indexing import (  # noqa: E402,F401
     dictionary_indexing,
 )
 from kikuchipy_amd.pattern import remove_dynamic_background, remove_static_background  # noqa: E402,F401
-from kikuchipy_amd.signals import EBSD, DictionaryXmap  # noqa: E402,F401
+from kikuchipy_amd.detectors import EBSDDetector  # noqa: E402,F401
+from kikuchipy_amd.signals import EBSD, DictionaryXmap, EBSDMasterPattern  # noqa: E402,F401
+from kikuchipy_amd.simulations import ProjectedDictionary  # noqa: E402,F401
 
 __all__ = [
     "DictionaryIndexingResult",
     "DictionaryXmap",
     "EBSD",
+    "EBSDDetector",
+    "EBSDMasterPattern",
+    "ProjectedDictionary",
     "NormalizedCrossCorrelationMetric",
     "NormalizedDotProductMetric",
     "SimilarityMetric",

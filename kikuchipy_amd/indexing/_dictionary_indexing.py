@@ -143,7 +143,9 @@ def dictionary_indexing(
     dictionary
         Array (N, sy, sx): NumPy, or lazy (Dask-like with `.chunksize` and
         `.compute()`), in which case chunks are computed one at a time inside
-        the loop as in the reference (:106-108).
+        the loop as in the reference (:106-108), or the `ProjectedDictionary`
+        of `EBSDMasterPattern.get_patterns()`, whose chunks are simulated
+        directly in device memory.
     metric
         "ncc", "ndp" or an instance of this package's metrics.
     keep_n, n_per_iteration, navigation_mask, signal_mask, rechunk, dtype
@@ -231,6 +233,11 @@ def dictionary_indexing(
         if start >= end:
             continue
         chunk = dictionary[start:end]
+        if hasattr(chunk, "push_to_engine"):
+            # simulated on the device from (master pattern, detector, rotations): the chunk
+            # never exists on the host (kikuchipy_amd.simulations.ProjectedDictionary)
+            chunk.push_to_engine(ctx, start)
+            continue
         if _is_lazy(chunk):
             chunk = chunk.compute()
         ctx.push_dictionary_chunk(np.asarray(chunk), start)

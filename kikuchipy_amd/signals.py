@@ -1,4 +1,4 @@
-"""A minimal `EBSD` holder with the three methods of the accelerated path.
+"""Minimal `EBSD` / `EBSDMasterPattern` holders with the methods of the accelerated path.
 
 NOT a re-implementation of kikuchipy's HyperSpy signal (out of scope): just
 enough object surface - `data`, `static_background`, `xmap` (dictionary
@@ -8,6 +8,7 @@ the reference's:
 * `EBSD.remove_static_background`   signals/ebsd.py:442-573
 * `EBSD.remove_dynamic_background`  signals/ebsd.py:575-696
 * `EBSD.dictionary_indexing`        signals/ebsd.py:1827-1984
+* `EBSDMasterPattern.get_patterns`  signals/ebsd_master_pattern.py:95-330
 
 Like the reference's methods, each call hands back host data (`self.data` is
 replaced by the pre-processed array); callers that want the whole chain
@@ -22,6 +23,7 @@ import numpy as np
 from kikuchipy_amd import _lib
 from kikuchipy_amd.indexing._dictionary_indexing import dictionary_indexing as _dictionary_indexing
 from kikuchipy_amd.pattern import _pattern
+from kikuchipy_amd.simulations import DTYPE_RANGE, ProjectedDictionary
 
 
 class DictionaryXmap:
@@ -51,7 +53,8 @@ class EBSD:
     def __init__(self, data, static_background=None, xmap=None, step_sizes=None, scan_unit="px",
                  device=0):
         self.data = data
-        if np.ndim(data) < 2 or np.ndim(data) > 4:
+        ndim = data.ndim if hasattr(data, "ndim") else np.ndim(data)  # lazy data is not touched
+        if ndim < 2 or ndim > 4:
             raise ValueError("EBSD data must have 0, 1 or 2 navigation axes and 2 signal axes")
         self.static_background = static_background
         self.xmap = xmap
@@ -135,3 +138,126 @@ class EBSD:
             phase_name=dict_xmap.phase_name, scan_unit=self.scan_unit, device=self._device, comm=comm,
             verbose=verbose,
         )
+
+
+class EBSDMasterPattern:
+    """Master pattern in the square Lambert projection: the surface of
+    `kikuchipy.signals.EBSDMasterPattern` that `get_patterns` reads.
+
+    Parameters
+    ----------
+    data
+        (npy, npx), (2, npy, npx) [hemisphere], (n_energies, npy, npx) [energy]
+        or (2, n_energies, npy, npx) [hemisphere, energy], as HyperSpy orders the
+        reference's navigation axes.
+    projection
+        Must be "lambert" for `get_patterns` (as in the reference).
+    hemisphere
+        "upper", "lower" or "both"; "both" needs the leading axis of size 2.
+    energies
+        Energy axis values in kV when `data` has an energy axis.
+    has_inversion_symmetry
+        Whether the phase's point group contains inversion
+        (`phase.point_group.contains_inversion`; orix is not a dependency here).
+        `None` = no valid point group.
+    """
+
+    def __init__(self, data, projection="lambert", hemisphere=None, energies=None, phase_name="",
+                 has_inversion_symmetry=True, device=0):
+        self.data = np.asarray(data)
+        if self.data.ndim < 2 or self.data.ndim > 4:
+            raise ValueError("master pattern data must have 2 signal axes and at most 2 navigation axes")
+        self.projection = projection
+        self.energies = None if energies is None else np.asarray(energies, dtype=np.float64)
+        n_nav = self.data.ndim - 2
+        has_energy = self.energies is not None
+        if hemisphere is None:
+            hemisphere = "both" if n_nav - int(has_energy) == 1 else "upper"
+        self.hemisphere = hemisphere
+        expected_nav = int(hemisphere == "both") + int(has_energy)
+        if expected_nav != n_nav or (hemisphere == "both" and self.data.shape[0] != 2):
+            raise ValueError(
+                f"data of shape {self.data.shape} does not match hemisphere='{hemisphere}' and "
+                f"{'an' if has_energy else 'no'} energy axis"
+            )
+        if has_energy and self.data.shape[n_nav - 1] != self.energies.size:
+            raise ValueError("`energies` must have one value per master pattern along the energy axis")
+        self.phase_name = phase_name
+        self.has_inversion_symmetry = has_inversion_symmetry
+        self._device = device
+
+    @property
+    def _has_multiple_energies(self):
+        return self.energies is not None
+
+    # signals/ebsd_master_pattern.py:331-377
+    def _is_suitable_for_projection(self, raise_if_not=False):
+        error = None
+        if self.projection != "lambert":
+            error = NotImplementedError("Master pattern must be in the square Lambert projection")
+        if self.has_inversion_symmetry is None:
+            error = AttributeError("Master pattern `phase` attribute must have a valid point group")
+        elif self.hemisphere != "both" and not self.has_inversion_symmetry:
+            error = AttributeError(
+                "For point groups without inversion symmetry, both hemispheres must be present in the "
+                "master pattern signal"
+            )
+        if error is not None and raise_if_not:
+            raise error
+        return error is None
+
+    # signals/_kikuchi_master_pattern.py:303-345
+    def _get_master_pattern_arrays_from_energy(self, energy=None):
+        data = self.data
+        if self._has_multiple_energies:
+            if energy is None:
+                energy = self.energies[-1]
+            # HyperSpy float indexing (`inav[float]`): the axis value closest to `energy`
+            idx = int(np.argmin(np.abs(self.energies - float(energy))))
+            data = data[:, idx] if self.hemisphere == "both" else data[idx]
+        if self.hemisphere == "both":
+            return data[0], data[1]
+        return data, data
+
+    def get_patterns(self, rotations, detector, energy=None, dtype_out="float32", compute=False,
+                     show_progressbar=None, **kwargs):
+        """Patterns projected onto `detector`, one per rotation.
+
+        `rotations`: (..., 4) unit quaternions (a, b, c, d) with at most two
+        leading axes (an orix `Rotation`'s `.data` works as is).  Returns an
+        `EBSD` whose `data` is a NumPy array (`compute=True`) or a lazy
+        `ProjectedDictionary` (`compute=False`, the default, like the
+        reference's `LazyEBSD`), with `xmap` holding the rotations.  `chunk_shape`
+        in `kwargs` sets the number of patterns per lazy chunk."""
+        self._is_suitable_for_projection(raise_if_not=True)
+        rot = np.asarray(getattr(rotations, "data", rotations), dtype=np.float64)
+        if rot.shape[-1] != 4:
+            raise ValueError("`rotations` must be an array of quaternions with a last axis of size 4")
+        nav_shape = rot.shape[:-1] if rot.ndim > 1 else (1,)
+        if len(nav_shape) > 2:
+            raise ValueError(
+                "`rotations` can only have one or two dimensions, but an instance with "
+                f"{len(nav_shape)} dimensions was passed"
+            )
+        dtype_out = np.dtype(dtype_out)
+        # signals/ebsd_master_pattern.py:224-233
+        if dtype_out != self.data.dtype:
+            rescale = True
+            out_min, out_max = DTYPE_RANGE[dtype_out]
+        else:
+            rescale = False
+            out_min, out_max = 1, 2
+        master_upper, master_lower = self._get_master_pattern_arrays_from_energy(energy)
+        lazy = ProjectedDictionary(np.ascontiguousarray(master_upper), np.ascontiguousarray(master_lower),
+                                   rot.reshape(-1, 4), detector, rescale, out_min, out_max, dtype_out,
+                                   device=self._device, chunk=kwargs.get("chunk_shape"))
+        xmap = DictionaryXmap(rot.reshape(-1, 4), self.phase_name)
+        if compute:
+            data = lazy.compute().reshape(nav_shape + detector.shape)
+        elif len(nav_shape) == 1:
+            data = lazy
+        else:
+            raise NotImplementedError("lazy output needs a 1D array of rotations (pass compute=True)")
+        out = EBSD(data, xmap=xmap, device=self._device)
+        out.detector = detector
+        return out

@@ -170,3 +170,52 @@ def test_error_paths(g):
         c.set_experimental(np.ones((2, 30, 30), np.uint8))
         with pytest.raises(_lib.KpdiError, match="3600 pixels"):
             c.push_rotations_chunk(g["rot8"], 0)
+
+
+# ------------------------------------------------------------------ Python interface
+def test_get_patterns_and_dictionary_indexing_api(g):
+    """`mp.get_patterns(rot, det)` -> `s.dictionary_indexing(sim)` as a kikuchipy
+    user writes it; the lazy dictionary is generated chunk by chunk in HBM."""
+    import kikuchipy_amd as ka
+
+    det = ka.EBSDDetector(**DET60)
+    mp = ka.EBSDMasterPattern(np.stack([g["mp_upper"], g["mp_lower"]]), phase_name="ni")
+    sim = mp.get_patterns(g["di_rot"], det, chunk_shape=500)
+    assert isinstance(sim.data, ka.ProjectedDictionary)
+    s = ka.EBSD(g["di_exp"])
+    res = s.dictionary_indexing(sim, keep_n=10, verbose=False)
+    ko.assert_topk_parity(res.scores, res.simulation_indices, g["di_ncc_k10__scores"],
+                          g["di_ncc_k10__indices"], atol=ATOL)
+    assert res.phase_name == "ni"
+    assert np.array_equal(res.rotations, g["di_rot"][res.simulation_indices])
+    # n_per_iteration overrides the lazy chunk size; signal mask + ndp
+    mask = ~ko.circular_window((60, 60)).astype(bool)
+    res = s.dictionary_indexing(sim, metric="ndp", keep_n=10, n_per_iteration=333, signal_mask=mask,
+                                verbose=False)
+    ko.assert_topk_parity(res.scores, res.simulation_indices, g["di_ndp_k10_circ__scores"],
+                          g["di_ndp_k10_circ__indices"], atol=ATOL)
+    # compute=True gives the patterns themselves
+    pats = mp.get_patterns(g["di_rot"][::100], det, compute=True).data
+    assert pats.shape == (12, 60, 60) and pats.dtype == np.float32
+    assert np.allclose(pats, g["di_dic_sample"], rtol=3e-7, atol=3e-7)
+    # 2D rotation array, integer output dtype (materialised, truncated)
+    p2 = mp.get_patterns(g["rot8"].reshape(2, 4, 4), det, dtype_out=np.uint8, compute=True).data
+    assert p2.shape == (2, 4, 60, 60)
+    diff = np.abs(p2.reshape(8, -1).astype(int) - g["u8mp_u8__patterns"].astype(int))
+    assert diff.max() <= 1
+
+
+def test_uint8_dictionary_takes_the_materialised_route(g):
+    """A dictionary asked for as uint8 is generated, truncated and then matched
+    like any other uint8 dictionary."""
+    import kikuchipy_amd as ka
+
+    det = ka.EBSDDetector(**DET60)
+    mp = ka.EBSDMasterPattern(g["mp_upper"].astype(np.float32))
+    rot = g["di_rot"][:300]
+    sim = mp.get_patterns(rot, det, dtype_out=np.uint8)
+    res = ka.EBSD(g["di_exp"]).dictionary_indexing(sim, keep_n=5, verbose=False)
+    dic = sim.data.compute()
+    assert dic.dtype == np.uint8 and dic.min() == 0 and dic.max() >= 254
+    rs, ri = ko.dictionary_indexing(g["di_exp"], dic, keep_n=5)
+    ko.assert_topk_parity(res.scores, res.simulation_indices, rs, ri, atol=ATOL)
