@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20000, help="dictionary patterns in the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-pointer sweep")
+    ap.add_argument("--no-generation", action="store_true",
+                    help="skip the informational sweep with the dictionary simulated on the device")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -258,6 +260,40 @@ def main():
         ctx.push_dictionary_chunk(dic, 0)
         ctx.finalize(w["keep_n"])
         out["extra"]["pcie_inclusive_patterns_per_s"] = round(w["m"] / (time.perf_counter() - t0), 1)
+
+    if world == 1 and not a.no_generation:
+        # informational: the dictionary is SIMULATED on the device inside the step
+        # from n rotations (32 B each over PCIe) and a 401 x 401 x 2 synthetic master pattern, then
+        # swept as above.  Never `value`.
+        rng = np.random.default_rng(7)
+        quat = rng.standard_normal((w["n"], 4))
+        quat /= np.linalg.norm(quat, axis=1)[:, None]
+        ctx.set_master_pattern(rng.random((401, 401), dtype=np.float32), rng.random((401, 401), dtype=np.float32))
+        pc = (0.421, 0.7794, 0.5049)
+        aspect = w["sx"] / w["sy"]
+        bounds = [-aspect * pc[0] / pc[2], aspect * (1 - pc[0]) / pc[2], -(1 - pc[1]) / pc[2], pc[1] / pc[2]]
+        ct, st = np.cos(np.deg2rad(70.0)), np.sin(np.deg2rad(70.0))
+        det_to_sample = np.array([[0, 1, 0], [-st, 0, ct], [ct, 0, st]], dtype=np.float64).T
+        ctx.set_detector(bounds, pc[2], w["sy"], w["sx"], det_to_sample)
+        ctx.set_profiling(True)
+        reps = 3
+        for r in range(reps + 1):
+            if r == 1:
+                ctx.reset_counters()
+                ctx.synchronize()
+                t0 = time.perf_counter()
+            ctx.set_experimental_dev(d_exp, exp.dtype, w["m"])
+            ctx.push_rotations_chunk(quat, 0, True, -1.0, 1.0)
+            ctx.finalize(w["keep_n"])
+        dt = (time.perf_counter() - t0) / reps
+        pj = ctx.counters()["project_ms"] / reps
+        ctx.set_profiling(False)
+        out["extra"]["dictionary_generation"] = {
+            "what": "100k patterns projected from a 2x401x401 master pattern inside the step (kpdi::project_kernel)",
+            "project_ms_per_step": round(pj, 3),
+            "gpixel_per_s": round(w["n"] * w["sy"] * w["sx"] / (pj * 1e-3) / 1e9, 1),
+            "patterns_per_s_including_generation": round(w["m"] / dt, 1),
+        }
 
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, exp, dic, bg, mask, min(a.cpu_sample, w["n"]))

@@ -3,6 +3,7 @@
 TEST INFRASTRUCTURE.  Run with:
 
     /opt/conda/bin/python3.9 -W ignore oracle/gen_golden.py
+    python -W ignore oracle/gen_golden.py refinement     # SciPy 1.15 solver results, see gen_refinement
 
 It loads the reference's modules unmodified through `oracle/ref_shim.py` and
 stores inputs + the reference's outputs as small fixtures.  The fixtures are
@@ -285,7 +286,11 @@ def gen_preproc():
 def load_ni_master_pattern():
     """The Lambert master pattern the reference ships for its own tests
     (data/emsoft_ebsd_master_pattern/, uint8, 401 x 401 per hemisphere)."""
-    import h5py
+    try:
+        import h5py
+    except ImportError:  # system interpreter: the same arrays, as stored by gen_projection()
+        g = np.load(os.path.join(OUT, "projection.npz"))
+        return g["mp_upper"], g["mp_lower"]
 
     p = os.path.join(ref_shim.SRC, "data", "emsoft_ebsd_master_pattern",
                      "ni_mc_mp_20kv_uint8_gzip_opts9.h5")
@@ -391,6 +396,129 @@ def gen_projection():
     print("projection", len(out))
 
 
+# ------------------------------------------------------------------ refinement (8(f2))
+def gen_refinement():
+    """Objective functions and SciPy Nelder-Mead solvers of the reference
+    (indexing/_refinement/_objective_functions.py, _solvers.py) on synthetic
+    experiments: Ni master pattern, 60 x 60 detector, one PC per pattern.
+
+    Run under BOTH interpreters: /opt/conda/bin/python3.9 (SciPy 1.7.1) writes
+    refinement.npz; the system python (SciPy 1.15.3, the version on the GPU box)
+    writes refinement_scipy115.npz with the solver results only - Nelder-Mead's
+    handling of bounds changed between these SciPy versions."""
+    import scipy
+    import scipy.optimize
+
+    r = ref_shim.load_reference_refinement()
+    mpm, sol, obj, nbu = r["master_pattern"], r["solvers"], r["objective_functions"], r["numba_utils"]
+    s2d = ref_shim.load_function_source("detectors/_ebsd_detector.py", "_sample_to_detector_matrix")
+    modern = tuple(int(v) for v in scipy.__version__.split(".")[:2]) >= (1, 11)
+    up, lo = load_ni_master_pattern()
+    # _get_master_pattern_data (indexing/_refinement/_refinement.py:1288-1320)
+    mpu = pat.rescale_intensity(up, dtype_out=np.float32)
+    mpl = pat.rescale_intensity(lo, dtype_out=np.float32)
+    fixed_mp = (mpu, mpl, 401, 401, 200.0)
+    nrows = ncols = 60
+    om = np.ascontiguousarray(s2d(*np.deg2rad([70.0, 0.0, 0.0, 0.0])).T)
+    rng = np.random.default_rng(21)
+    n = 4
+    eu_true = np.column_stack([rng.uniform(0.3, 6.0, n), rng.uniform(0.3, 2.8, n), rng.uniform(0.3, 6.0, n)])
+    pc_true = np.array([0.42, 0.78, 0.50]) + rng.uniform(-0.01, 0.01, (n, 3))
+    keep = np.asarray(Window("circular", (60, 60)).astype(bool)).ravel()
+    all_px = np.ones(3600, dtype=bool)
+
+    def dc_for(pc, mask):
+        return mpm._get_direction_cosines_for_fixed_pc(
+            gnomonic_bounds=r["gnomonic_bounds"].get_gnomonic_bounds(nrows, ncols, *pc), pcz=pc[2],
+            nrows=nrows, ncols=ncols, om_detector_to_sample=om, signal_mask=mask)
+
+    pats = np.empty((n, 3600), dtype=np.uint8)
+    for i in range(n):
+        sim = mpm._project_single_pattern_from_master_pattern(
+            rotation=nbu.rotation_from_euler(*eu_true[i]), direction_cosines=dc_for(pc_true[i], all_px),
+            master_upper=mpu, master_lower=mpl, npx=401, npy=401, scale=200.0, rescale=False, out_min=0,
+            out_max=1, dtype_out=np.float32)
+        noisy = sim + 0.15 * rng.standard_normal(3600).astype(np.float32)
+        pats[i] = np.clip((noisy + 1.3) * 98, 0, 255).astype(np.uint8)
+    eu0 = eu_true + np.deg2rad(rng.uniform(-1.0, 1.0, (n, 3)))
+    pc0 = pc_true + rng.uniform(-0.004, 0.004, (n, 3))
+    out = {"patterns": pats, "eu_true": eu_true, "pc_true": pc_true, "eu0": eu0, "pc0": pc0,
+           "om_detector_to_sample": om, "scipy_version": np.array(scipy.__version__)}
+
+    nm = {"method": "Nelder-Mead"}
+    if not modern:
+        # ---- _prepare_pattern, uint8 (no rescale) and float32 (rescale), masked / unmasked
+        p8, sq8 = sol._prepare_pattern(pats[0], False)
+        pf, sqf = sol._prepare_pattern(pats[1][keep].astype(np.float32) * 0.37, True)
+        out.update(prep_u8=p8, prep_u8_sqnorm=np.float64(sq8), prep_f32_masked=pf, prep_f32_masked_sqnorm=np.float64(sqf))
+        out["mp_f32_upper_sample"] = mpu[::40, ::40]
+        # ---- objective values at the starts and at a few offsets
+        offs = np.array([[0, 0, 0, 0, 0, 0], [0.01, -0.02, 0.005, 0, 0, 0], [0, 0, 0, 0.003, -0.002, 0.004],
+                         [-0.03, 0.01, 0.02, -0.005, 0.005, 0.002]])
+        vals = np.empty((n, len(offs), 3))
+        for i in range(n):
+            for mask_name, mask in (("all", all_px),):
+                p, sq = sol._prepare_pattern(pats[i][mask], False)
+                for j, o in enumerate(offs):
+                    x = np.concatenate([eu0[i], pc0[i]]) + o
+                    vals[i, j, 0] = obj._refine_orientation_objective_function(
+                        x[:3], p, dc_for(pc0[i], mask), *fixed_mp, sq)
+                    vals[i, j, 1] = obj._refine_pc_objective_function(
+                        x[3:], p, nbu.rotation_from_euler(*eu0[i]), *fixed_mp, mask, nrows, ncols, om, sq)
+                    vals[i, j, 2] = obj._refine_orientation_pc_objective_function(
+                        x, p, *fixed_mp, mask, nrows, ncols, om, sq)
+        out["objective_offsets"] = offs
+        out["objective_values"] = vals
+        p, sq = sol._prepare_pattern(pats[2][keep], False)
+        out["objective_masked"] = np.float64(obj._refine_orientation_pc_objective_function(
+            np.concatenate([eu0[2], pc0[2]]), p, *fixed_mp, keep, nrows, ncols, om, sq))
+
+    # ---- solvers (scipy.optimize.minimize, Nelder-Mead)
+    def ori(i, bounds=None, starts=None, mask=all_px, mk=None):
+        rot = eu0[i][None] if starts is None else starts
+        kw = dict(mk or nm)
+        b = np.zeros((len(rot), 3, 2)) if bounds is None else bounds
+        return np.array(sol._refine_orientation_solver_scipy(
+            pattern=pats[i][mask], rotation=rot, bounds=b, signal_mask=mask, rescale=False,
+            method=scipy.optimize.minimize, method_kwargs=kw, trust_region_passed=bounds is not None,
+            fixed_parameters=fixed_mp, pcx=pc0[i][0], pcy=pc0[i][1], pcz=pc0[i][2], nrows=nrows, ncols=ncols,
+            om_detector_to_sample=om, n_pseudo_symmetry_ops=len(rot) - 1), dtype=np.float64)
+
+    tr = np.deg2rad(2.0)
+    out["ori_nm"] = np.stack([ori(i) for i in range(n)])
+    out["ori_nm_masked"] = np.stack([ori(i, mask=keep) for i in range(2)])
+    out["ori_nm_maxfev30"] = np.stack([ori(i, mk=dict(method="Nelder-Mead", options=dict(maxfev=30))) for i in range(2)])
+    bnd = np.stack([np.stack([eu0[i] - tr, eu0[i] + tr], axis=1)[None] for i in range(n)])
+    out["ori_nm_bounds"] = np.stack([ori(i, bounds=bnd[i]) for i in range(n)])
+    # pseudo-symmetry: start 1 = a copy displaced by 3 degrees about phi1 (only the bookkeeping matters)
+    starts = np.stack([np.stack([eu0[i] + [np.deg2rad(3), 0, 0], eu0[i]]) for i in range(2)])
+    out["ori_nm_ps_starts"] = starts
+    out["ori_nm_ps"] = np.stack([ori(i, starts=starts[i]) for i in range(2)])
+
+    fixed_pc = fixed_mp + (all_px, nrows, ncols, om)
+    res = []
+    for i in range(2):
+        res.append(sol._refine_pc_solver_scipy(
+            pattern=pats[i], rotation=nbu.rotation_from_euler(*eu0[i]), pc=pc0[i], bounds=np.zeros((3, 2)),
+            rescale=False, method=scipy.optimize.minimize, method_kwargs=dict(nm), fixed_parameters=fixed_pc,
+            trust_region_passed=False))
+    out["pc_nm"] = np.array(res, dtype=np.float64)
+    res = []
+    for i in range(2):
+        x0 = np.concatenate([eu0[i], pc0[i]])[None]
+        tr6 = np.array([tr, tr, tr, 0.02, 0.02, 0.02])
+        b = np.stack([x0[0] - tr6, x0[0] + tr6], axis=1)[None]
+        res.append(sol._refine_orientation_pc_solver_scipy(
+            pattern=pats[i], rot_pc=x0, bounds=b, rescale=False, method=scipy.optimize.minimize,
+            method_kwargs=dict(nm), fixed_parameters=fixed_pc, trust_region_passed=True))
+    out["ori_pc_nm_bounds"] = np.array(res, dtype=np.float64)
+    name = "refinement_scipy115.npz" if modern else "refinement.npz"
+    if modern:
+        out = {k: v for k, v in out.items() if k.startswith(("ori_", "pc_nm", "scipy_version"))}
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, sorted(out))
+
+
 # ------------------------------------------------------------------ the reference tests' own known answers
 def gen_refknown():
     """Extract the hard-coded known-answer ARRAYS (data, not code) that the
@@ -436,5 +564,6 @@ if __name__ == "__main__":
     gen_preproc()
     gen_refknown()
     gen_projection()
+    gen_refinement()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -562,6 +562,104 @@ def project_patterns(rotations, direction_cosines, master_upper, master_lower, r
 
 
 # --------------------------------------------------------------------------
+# orientation / projection-centre refinement: objective functions and the
+# SciPy Nelder-Mead solver chunk
+# --------------------------------------------------------------------------
+def rotation_from_euler(phi1, Phi, phi2):
+    """_utils/numba.py:43-57: Bunge Euler angles (radians) -> unit quaternion
+    with a non-negative scalar part."""
+    sigma = 0.5 * (phi1 + phi2)
+    delta = 0.5 * (phi1 - phi2)
+    c, s = np.cos(0.5 * Phi), np.sin(0.5 * Phi)
+    rot = np.array([c * np.cos(sigma), -s * np.cos(delta), -s * np.sin(delta), -c * np.sin(sigma)],
+                   dtype=np.float64)
+    return -rot if rot[0] < 0 else rot
+
+
+def refinement_master_pattern(master_upper, master_lower):
+    """indexing/_refinement/_refinement.py:1288-1320: hemispheres as float32;
+    anything else is rescaled to [-1, 1] over its own min/max
+    (pattern/_pattern.py:66-93, `rescale_intensity(mp, dtype_out=float32)`)."""
+    out = []
+    for mp in (master_upper, master_lower):
+        if mp.dtype != np.float32:
+            imin, imax = np.nanmin(mp), np.nanmax(mp)
+            mp = ((mp - imin) / float(imax - imin) * 2 + -1).astype(np.float32)
+        out.append(mp)
+    return out
+
+
+def prepare_refinement_pattern(pattern, rescale):
+    """indexing/_refinement/_solvers.py:51-74: float32 cast, optional rescale
+    to [-1, 1] (float32 arithmetic, pattern/_pattern.py:125-133), centring, and
+    the squared norm of the centred pattern (pattern/_pattern.py:136-139)."""
+    pattern = pattern.astype(np.float32)
+    if rescale:
+        imin, imax = np.min(pattern), np.max(pattern)
+        pattern = (pattern - imin) / float(imax - imin) * 2 + -1
+    pattern = pattern - np.mean(pattern)
+    return pattern, np.square(pattern).sum()
+
+
+def ncc_exp_centered(exp, sim, exp_squared_norm):
+    """similarity_metrics/_normalized_cross_correlation.py:200-225."""
+    sim = sim - np.mean(sim)
+    return np.divide(np.sum(exp * sim), np.sqrt(exp_squared_norm * np.sum(np.square(sim))))
+
+
+def refinement_objective(x, mode, pattern, squared_norm, master_upper, master_lower, *, direction_cosines=None,
+                         rotation=None, signal_mask_keep=None, nrows=None, ncols=None,
+                         om_detector_to_sample=None):
+    """indexing/_refinement/_objective_functions.py:36-190: 1 - NCC between the
+    centred experimental pattern and the pattern projected for the control
+    variables `x`:  mode "ori": x = Euler angles, fixed `direction_cosines`;
+    "pc": x = (PCx, PCy, PCz), fixed quaternion `rotation`;  "ori_pc": x =
+    Euler angles + PC.  `signal_mask_keep`: 1D, True = pixel is used."""
+    if mode == "ori":
+        rot, dc = rotation_from_euler(*x[:3]), direction_cosines
+    else:
+        pc = x if mode == "pc" else x[3:]
+        rot = rotation if mode == "pc" else rotation_from_euler(*x[:3])
+        dc = direction_cosines_fixed_pc(gnomonic_bounds((nrows, ncols), pc), pc[2], nrows, ncols,
+                                        om_detector_to_sample, signal_mask_keep)
+    sim = project_patterns(rot, dc, master_upper, master_lower, False, 0, 1, np.float32)[0]
+    return 1 - ncc_exp_centered(pattern, sim, squared_norm)
+
+
+def refine_solver(pattern, mode, x0, master_upper, master_lower, rescale, bounds=None, method_kwargs=None,
+                  **fixed):
+    """indexing/_refinement/_solvers.py:79-250 (orientation), :253-330 (PC),
+    :333-460 (both) with `method=scipy.optimize.minimize`: one SciPy
+    Nelder-Mead run per row of `x0` (row 0 = the indexed orientation, further
+    rows = its pseudo-symmetry equivalents); the best run wins (first maximum).
+    SciPy is the reference's own third-party optimiser (pyproject: scipy >= 1.7)
+    and is called here as there.  Returns (ncc, num_evals, *x[, best_index])."""
+    import scipy.optimize
+
+    pattern, squared_norm = prepare_refinement_pattern(pattern, rescale)
+    kwargs = {"method": "Nelder-Mead"}
+    kwargs.update(method_kwargs or {})
+    x0 = np.atleast_2d(np.asarray(x0, dtype=np.float64))
+    rotations = fixed.pop("rotation", None)
+    results = []
+    for i, start in enumerate(x0):
+        kw = dict(kwargs)
+        if bounds is not None:
+            kw["bounds"] = np.atleast_3d(bounds)[i] if np.ndim(bounds) == 3 else bounds
+        extra = dict(fixed)
+        if rotations is not None:
+            extra["rotation"] = np.atleast_2d(rotations)[i]
+        res = scipy.optimize.minimize(
+            fun=lambda x: refinement_objective(x, mode, pattern, squared_norm, master_upper, master_lower, **extra),
+            x0=start, **kw)
+        results.append(res)
+    ncc_all = [1 - r.fun for r in results]
+    best = int(np.argmax(ncc_all))
+    out = (ncc_all[best], results[best].nfev) + tuple(results[best].x)
+    return out + (best,) if len(results) > 1 else out
+
+
+# --------------------------------------------------------------------------
 # comparison helper shared by the parity tests
 # --------------------------------------------------------------------------
 def assert_topk_parity(scores, indices, ref_scores, ref_indices, atol=1e-5, tie=2e-5):

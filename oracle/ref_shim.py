@@ -141,9 +141,40 @@ def _stub_skimage():
             np.int16: (-32768, 32767),
             np.int32: (-(2**31), 2**31 - 1),
         }
+        sk.__path__ = []
+        sku.__path__ = []
+        ske = types.ModuleType("skimage.exposure")
+        ske.equalize_adapthist = None  # imported by pattern/_pattern.py, never called here
+        sk.util, sk.exposure, sku.dtype = sku, ske, skd
         sys.modules["skimage"] = sk
         sys.modules["skimage.util"] = sku
         sys.modules["skimage.util.dtype"] = skd
+        sys.modules["skimage.exposure"] = ske
+
+
+def _stub_dask_if_missing():
+    # the system interpreter (python3.10, scipy 1.15) has no dask; the refinement
+    # functions loaded there never touch it, the modules only import it
+    try:
+        import dask.array  # noqa: F401
+    except ImportError:
+        d = types.ModuleType("dask")
+        da = types.ModuleType("dask.array")
+        da.Array = type("Array", (), {})
+        d.array = da
+        d.delayed = lambda f: f
+        d.__path__ = []
+        diag = types.ModuleType("dask.diagnostics")
+        diag.__path__ = []
+        prog = types.ModuleType("dask.diagnostics.progress")
+        prog.ProgressBar = type("ProgressBar", (), {})
+        diag.progress = prog
+        diag.ProgressBar = prog.ProgressBar
+        d.diagnostics = diag
+        sys.modules["dask"] = d
+        sys.modules["dask.array"] = da
+        sys.modules["dask.diagnostics"] = diag
+        sys.modules["dask.diagnostics.progress"] = prog
 
 
 def _ns(name, path):
@@ -174,6 +205,7 @@ def load_reference():
     _stub_orix()
     _stub_tqdm()
     _stub_skimage()
+    _stub_dask_if_missing()
     _ns("kikuchipy", SRC)
     _ns("kikuchipy.indexing", os.path.join(SRC, "indexing"))
     _ns(
@@ -221,6 +253,27 @@ def load_reference_projection():
     ref["numba_utils"] = _load("kikuchipy._utils.numba", "_utils/numba.py")
     ref["master_pattern"] = _load(
         "kikuchipy.signals.util._master_pattern", "signals/util/_master_pattern.py"
+    )
+    return ref
+
+
+def load_reference_refinement():
+    """The refinement objective functions and SciPy solvers:
+    `_utils/_gnonomic_bounds.py`, `indexing/_refinement/__init__.py` (the table
+    of supported methods), `_objective_functions.py`, `_solvers.py`."""
+    ref = load_reference_projection()
+    if "solvers" in ref:
+        return ref
+    ref["gnomonic_bounds"] = _load("kikuchipy._utils._gnonomic_bounds", "_utils/_gnonomic_bounds.py")
+    pkg = _ns("kikuchipy.indexing._refinement", os.path.join(SRC, "indexing", "_refinement"))
+    init = os.path.join(SRC, "indexing", "_refinement", "__init__.py")
+    exec(compile(open(init).read(), init, "exec"), pkg.__dict__)
+    ref["objective_functions"] = _load(
+        "kikuchipy.indexing._refinement._objective_functions",
+        "indexing/_refinement/_objective_functions.py",
+    )
+    ref["solvers"] = _load(
+        "kikuchipy.indexing._refinement._solvers", "indexing/_refinement/_solvers.py"
     )
     return ref
 
