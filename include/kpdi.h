@@ -173,6 +173,47 @@ int kpdi_project_patterns(kpdi_ctx *ctx, const double *rotations, int64_t n, int
 int kpdi_push_rotations_chunk(kpdi_ctx *ctx, const double *rotations, int64_t n,
                               int64_t global_start, int rescale, double out_min, double out_max);
 
+/* ---- refinement of orientations / projection centres ---------
+ * EBSD.refine_orientation / refine_projection_center / refine_orientation_projection_center
+ * with the default optimiser (scipy.optimize.minimize, Nelder-Mead): the chunk functions
+ * `_refine_*_chunk_scipy` (indexing/_refinement/_refinement.py:441-503, :642-668, :779-809),
+ * i.e. `_prepare_pattern` + the objective functions
+ * (indexing/_refinement/_objective_functions.py:36-190) + the simplex search, all on the GPU:
+ * one workgroup per (pattern, start) runs the whole optimisation.
+ * The master pattern is the one given to kpdi_set_master_pattern (the caller passes the
+ * float32 hemispheres of `_get_master_pattern_data`, _refinement.py:1288-1320). */
+#define KPDI_REFINE_ORI 0     /* x = (phi1, Phi, phi2) [rad];            fixed = (PCx, PCy, PCz)   */
+#define KPDI_REFINE_PC 1      /* x = (PCx, PCy, PCz) Bruker convention;  fixed = quaternion (a,b,c,d) */
+#define KPDI_REFINE_ORI_PC 2  /* x = (phi1, Phi, phi2, PCx, PCy, PCz);   no fixed values            */
+#define KPDI_REFINE_RESULT_STRIDE 9  /* result row: fun (= 1 - NCC), nfev, nit, x[0..nvar), padding */
+/* Patterns to refine: `n` patterns of nrows x ncols `dtype` values in host memory.
+ * signal_mask: nonzero = pixel NOT used, or NULL.  `rescale` != 0: intensities are rescaled
+ * to [-1, 1] first (the reference does so exactly when the patterns are float32,
+ * _refinement.py:956).  om_detector_to_sample: 3x3 row-major. */
+int kpdi_refine_set_patterns(kpdi_ctx *ctx, const void *patterns, int dtype, int64_t n,
+                             int nrows, int ncols, const uint8_t *signal_mask, int rescale,
+                             const double *om_detector_to_sample);
+/* the prepared patterns (n x k float32, centred) and their squared norms (n float64) */
+int kpdi_refine_get_prepared(kpdi_ctx *ctx, float *patterns_out, double *sqnorm_out);
+/* Objective values: out[e] = 1 - NCC(pattern[pattern_index[e]], projection(x[e], fixed[e])).
+ * x: n_eval x nvar, fixed: n_eval x nfixed (nvar/nfixed = 3/3, 3/4, 6/0 for the three modes). */
+int kpdi_refine_objective(kpdi_ctx *ctx, int mode, int64_t n_eval, const int32_t *pattern_index,
+                          const double *x, const double *fixed, double *out);
+/* Nelder-Mead from every start of every pattern.  x0 / fixed / lower / upper:
+ * n_patterns x n_starts x (nvar | nfixed); lower/upper NULL = unbounded (no trust region).
+ * maxiter / maxfev <= 0 select SciPy's defaults (200 * nvar each when both are unset, else
+ * unlimited).  results: n_patterns x n_starts x KPDI_REFINE_RESULT_STRIDE doubles. */
+int kpdi_refine_solve(kpdi_ctx *ctx, int mode, int64_t n_patterns, int n_starts,
+                      const double *x0, const double *fixed, const double *lower,
+                      const double *upper, double xatol, double fatol, int maxiter, int maxfev,
+                      double *results);
+/* The optimiser alone on an analytic f64 objective (kind 0: Rosenbrock, 1: weighted bowl),
+ * nvar <= 6: lets a test compare the device's simplex path with SciPy's bit for bit.
+ * result: fun, nfev, nit, x[0..nvar). */
+int kpdi_nelder_mead_selftest(kpdi_ctx *ctx, int kind, int nvar, const double *x0,
+                              const double *lower, const double *upper, double xatol,
+                              double fatol, int maxiter, int maxfev, double *result);
+
 /* ---- multi-GPU: dictionary sharded over ranks, one process per GPU -------- */
 #define KPDI_UNIQUE_ID_BYTES 128
 int kpdi_comm_unique_id(uint8_t *id_out /* KPDI_UNIQUE_ID_BYTES */);
@@ -199,6 +240,7 @@ typedef struct kpdi_counters {
   int32_t kpad;         /* padded reduction length */
   int32_t k_kept;       /* kept pixels K */
   double project_ms;    /* master-pattern projection kernels */
+  double refine_ms;     /* refinement solve kernels */
 } kpdi_counters;
 int kpdi_set_profiling(kpdi_ctx *ctx, int on);
 int kpdi_get_counters(kpdi_ctx *ctx, kpdi_counters *out);

@@ -18,6 +18,9 @@ COMPUTE_F32 = 0
 OP_SUBTRACT, OP_DIVIDE = 0, 1
 DOMAIN_FREQUENCY, DOMAIN_SPATIAL = 0, 1
 UNIQUE_ID_BYTES = 128
+REFINE_ORI, REFINE_PC, REFINE_ORI_PC = 0, 1, 2
+REFINE_SIZES = {REFINE_ORI: (3, 3), REFINE_PC: (3, 4), REFINE_ORI_PC: (6, 0)}  # (control variables, fixed values)
+REFINE_RESULT_STRIDE = 9
 
 DTYPE_CODES = {
     np.dtype(np.uint8): 0,
@@ -48,6 +51,7 @@ class Counters(C.Structure):
         ("kpad", C.c_int32),
         ("k_kept", C.c_int32),
         ("project_ms", C.c_double),
+        ("refine_ms", C.c_double),
     ]
 
     def as_dict(self):
@@ -79,6 +83,11 @@ SIGNATURES = {
     "kpdi_get_direction_cosines": (_i, [_vp, _vp]),
     "kpdi_project_patterns": (_i, [_vp, _vp, _i64, _i, C.c_double, C.c_double, _i, _vp]),
     "kpdi_push_rotations_chunk": (_i, [_vp, _vp, _i64, _i64, _i, C.c_double, C.c_double]),
+    "kpdi_refine_set_patterns": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _i, _vp]),
+    "kpdi_refine_get_prepared": (_i, [_vp, _vp, _vp]),
+    "kpdi_refine_objective": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp]),
+    "kpdi_refine_solve": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, C.c_double, C.c_double, _i, _i, _vp]),
+    "kpdi_nelder_mead_selftest": (_i, [_vp, _i, _i, _vp, _vp, _vp, C.c_double, C.c_double, _i, _i, _vp]),
     "kpdi_reset_topk": (_i, [_vp]),
     "kpdi_finalize": (_i, [_vp, _vp, _vp]),
     "kpdi_comm_unique_id": (_i, [_vp]),
@@ -274,6 +283,63 @@ class Context:
         rot = np.ascontiguousarray(rotations, dtype=np.float64).reshape(-1, 4)
         check(load().kpdi_push_rotations_chunk(self._h, _ptr(rot), rot.shape[0], int(global_start),
                                                int(bool(rescale)), float(out_min), float(out_max)))
+
+    # -- refinement
+    def refine_set_patterns(self, patterns, signal_mask=None, rescale=False, om_detector_to_sample=None):
+        """patterns: (n, nrows, ncols); signal_mask: True = pixel not used."""
+        p = np.ascontiguousarray(patterns)
+        if p.ndim != 3:
+            raise KpdiError("patterns must have shape (n, nrows, ncols)")
+        sm = _mask_bytes(signal_mask)
+        om = np.ascontiguousarray(om_detector_to_sample, dtype=np.float64).ravel()
+        if om.size != 9:
+            raise KpdiError("om_detector_to_sample must have 9 elements")
+        check(load().kpdi_refine_set_patterns(self._h, _ptr(p), dtype_code(p.dtype), p.shape[0], p.shape[1],
+                                              p.shape[2], _ptr(sm), int(bool(rescale)), _ptr(om)))
+        self._ref_n = p.shape[0]
+        self._ref_k = p.shape[1] * p.shape[2] if sm is None else int(np.count_nonzero(sm == 0))
+
+    def refine_get_prepared(self):
+        pat = np.empty((self._ref_n, self._ref_k), dtype=np.float32)
+        sqn = np.empty(self._ref_n, dtype=np.float64)
+        check(load().kpdi_refine_get_prepared(self._h, _ptr(pat), _ptr(sqn)))
+        return pat, sqn
+
+    def refine_objective(self, mode, pattern_index, x, fixed=None):
+        idx = np.ascontiguousarray(pattern_index, dtype=np.int32).ravel()
+        nvar, nfixed = REFINE_SIZES[mode]
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(idx.size, nvar)
+        f = None if nfixed == 0 else np.ascontiguousarray(fixed, dtype=np.float64).reshape(idx.size, nfixed)
+        out = np.empty(idx.size, dtype=np.float64)
+        check(load().kpdi_refine_objective(self._h, int(mode), idx.size, _ptr(idx), _ptr(x), _ptr(f), _ptr(out)))
+        return out
+
+    def refine_solve(self, mode, x0, fixed=None, lower=None, upper=None, xatol=1e-4, fatol=1e-4, maxiter=0,
+                     maxfev=0):
+        """x0: (n_patterns, n_starts, nvar).  Returns (n_patterns, n_starts, 3 + nvar):
+        fun, nfev, nit, x."""
+        nvar, nfixed = REFINE_SIZES[mode]
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        if x0.ndim != 3 or x0.shape[2] != nvar:
+            raise KpdiError(f"x0 must have shape (n_patterns, n_starts, {nvar})")
+        n, starts = x0.shape[:2]
+        f = None if nfixed == 0 else np.ascontiguousarray(fixed, dtype=np.float64).reshape(n, starts, nfixed)
+        lo = None if lower is None else np.ascontiguousarray(lower, dtype=np.float64).reshape(x0.shape)
+        hi = None if upper is None else np.ascontiguousarray(upper, dtype=np.float64).reshape(x0.shape)
+        res = np.empty((n, starts, REFINE_RESULT_STRIDE), dtype=np.float64)
+        check(load().kpdi_refine_solve(self._h, int(mode), n, starts, _ptr(x0), _ptr(f), _ptr(lo), _ptr(hi),
+                                       float(xatol), float(fatol), int(maxiter or 0), int(maxfev or 0), _ptr(res)))
+        return res[:, :, :3 + nvar]
+
+    def nelder_mead_selftest(self, kind, x0, lower=None, upper=None, xatol=1e-4, fatol=1e-4, maxiter=0, maxfev=0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).ravel()
+        lo = None if lower is None else np.ascontiguousarray(lower, dtype=np.float64).ravel()
+        hi = None if upper is None else np.ascontiguousarray(upper, dtype=np.float64).ravel()
+        res = np.empty(3 + x0.size, dtype=np.float64)
+        check(load().kpdi_nelder_mead_selftest(self._h, int(kind), x0.size, _ptr(x0), _ptr(lo), _ptr(hi),
+                                               float(xatol), float(fatol), int(maxiter or 0), int(maxfev or 0),
+                                               _ptr(res)))
+        return res
 
     def reset_topk(self):
         check(load().kpdi_reset_topk(self._h))

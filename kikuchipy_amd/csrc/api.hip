@@ -149,6 +149,13 @@ struct kpdi_ctx {
   int64_t dc_npix = 0;
   DevBuf mp_packed, dcos, rot, proj_out;
 
+  // refinement (refine.hip)
+  bool have_ref = false;
+  int ref_nrows = 0, ref_ncols = 0, ref_k = 0;
+  int64_t ref_n = 0;
+  double ref_om[9] = {};
+  DevBuf ref_raw, ref_map, ref_rowcol, ref_pat, ref_sqn, ref_in, ref_out, ref_idx;
+
   // comm
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
@@ -521,7 +528,9 @@ int kpdi_destroy(kpdi_ctx *c) {
   for (DevBuf *b : {&c->pix_map, &c->exp_raw, &c->row_map, &c->exp_x, &c->dict_raw, &c->dict_y, &c->part_s,
                     &c->part_i, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
                     &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps,
-                    &c->mp_packed, &c->dcos, &c->rot, &c->proj_out})
+                    &c->mp_packed, &c->dcos, &c->rot, &c->proj_out,
+                    &c->ref_raw, &c->ref_map, &c->ref_rowcol, &c->ref_pat, &c->ref_sqn, &c->ref_in, &c->ref_out,
+                    &c->ref_idx})
     b->release();
   for (auto *l : {&c->ev_match, &c->ev_prep, &c->ev_merge, &c->ev_proj})
     for (auto &pr : *l) {
@@ -889,6 +898,228 @@ int kpdi_push_rotations_chunk(kpdi_ctx *c, const double *rotations, int64_t n, i
   rc = project_to_device(c, rotations, n, rescale, out_min, out_max, KPDI_F32, c->dict_raw.p);
   if (rc) return rc;
   return push_chunk_dev(c, c->dict_raw.p, KPDI_F32, n, global_start);
+}
+
+// ---- refinement ---------------------------------------------------------------
+namespace {
+int refine_mode_sizes(int mode, int *nvar, int *nfixed) {
+  switch (mode) {
+    case KPDI_REFINE_ORI: *nvar = 3; *nfixed = 3; return KPDI_OK;
+    case KPDI_REFINE_PC: *nvar = 3; *nfixed = 4; return KPDI_OK;
+    case KPDI_REFINE_ORI_PC: *nvar = 6; *nfixed = 0; return KPDI_OK;
+  }
+  return fail(KPDI_EINVAL, "unknown refinement mode %d", mode);
+}
+
+int refine_fill_launch(kpdi_ctx *c, int mode, kpdi::RefineLaunch *a) {
+  if (!c->have_ref) return fail(KPDI_EINVAL, "kpdi_refine_set_patterns has not been called");
+  if (!c->have_master) return fail(KPDI_EINVAL, "kpdi_set_master_pattern has not been called");
+  int rc = refine_mode_sizes(mode, &a->nvar, &a->nfixed);
+  if (rc) return rc;
+  a->mode = mode;
+  a->nrows = c->ref_nrows;
+  a->ncols = c->ref_ncols;
+  a->k = c->ref_k;
+  a->rowcol = c->ref_rowcol.as<unsigned>();
+  for (int i = 0; i < 9; ++i) a->om[i] = c->ref_om[i];
+  a->master_packed = c->mp_packed.as<float>();
+  a->npx = c->mp_npx;
+  a->npy = c->mp_npy;
+  a->patterns = c->ref_pat.as<float>();
+  a->sqnorm = c->ref_sqn.as<double>();
+  return KPDI_OK;
+}
+}  // namespace
+
+int kpdi_refine_set_patterns(kpdi_ctx *c, const void *patterns, int dtype, int64_t n, int nrows, int ncols,
+                             const uint8_t *signal_mask, int rescale, const double *om) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!patterns || !om) return fail(KPDI_EINVAL, "patterns / orientation matrix pointer is NULL");
+  const size_t es = kpdi::dtype_size(dtype);
+  if (es == 0) return fail(KPDI_EINVAL, "unknown dtype %d", dtype);
+  if (n <= 0 || n >= (int64_t)INT_MAX) return fail(KPDI_EINVAL, "need between 1 and 2^31-1 patterns");
+  if (nrows <= 0 || ncols <= 0 || nrows > 65535 || ncols > 65535)
+    return fail(KPDI_EINVAL, "detector shape must be within 1..65535 pixels per side");
+  int rc = use_device(c);
+  if (rc) return rc;
+  const int npix = nrows * ncols;
+  std::vector<int> map;
+  std::vector<unsigned> rowcol;
+  for (int i = 0; i < npix; ++i)
+    if (!signal_mask || !signal_mask[i]) {
+      map.push_back(i);
+      rowcol.push_back(((unsigned)(i / ncols) << 16) | (unsigned)(i % ncols));
+    }
+  const int k = (int)map.size();
+  if (k < 2) return fail(KPDI_EINVAL, "the signal mask must leave at least two pixels");
+  const size_t bytes = (size_t)n * npix * es;
+  HIPCHK(c->ref_raw.reserve(bytes));
+  HIPCHK(c->ref_map.reserve((size_t)k * sizeof(int)));
+  HIPCHK(c->ref_rowcol.reserve((size_t)k * sizeof(unsigned)));
+  HIPCHK(c->ref_pat.reserve((size_t)n * k * sizeof(float)));
+  HIPCHK(c->ref_sqn.reserve((size_t)n * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(c->ref_raw.p, patterns, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->ref_map.p, map.data(), (size_t)k * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->ref_rowcol.p, rowcol.data(), (size_t)k * sizeof(unsigned), hipMemcpyHostToDevice,
+                        c->stream));
+  c->cnt.h2d_bytes += (double)bytes;
+  HIPCHK(kpdi::launch_refine_prep(c->ref_raw.p, dtype, n, npix, signal_mask ? c->ref_map.as<int>() : nullptr, k,
+                                  rescale, c->ref_pat.as<float>(), c->ref_sqn.as<double>(), c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));  // `map`, `rowcol` and the caller's buffer have been consumed
+  c->ref_nrows = nrows;
+  c->ref_ncols = ncols;
+  c->ref_k = k;
+  c->ref_n = n;
+  for (int i = 0; i < 9; ++i) c->ref_om[i] = om[i];
+  c->have_ref = true;
+  return KPDI_OK;
+}
+
+int kpdi_refine_get_prepared(kpdi_ctx *c, float *patterns_out, double *sqnorm_out) {
+  if (!c || !patterns_out || !sqnorm_out) return fail(KPDI_EINVAL, "NULL argument");
+  if (!c->have_ref) return fail(KPDI_EINVAL, "kpdi_refine_set_patterns has not been called");
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(patterns_out, c->ref_pat.p, (size_t)c->ref_n * c->ref_k * sizeof(float), hipMemcpyDeviceToHost,
+                        c->stream));
+  HIPCHK(hipMemcpyAsync(sqnorm_out, c->ref_sqn.p, (size_t)c->ref_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KPDI_OK;
+}
+
+int kpdi_refine_objective(kpdi_ctx *c, int mode, int64_t n_eval, const int32_t *pattern_index, const double *x,
+                          const double *fixed, double *out) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!pattern_index || !x || !out) return fail(KPDI_EINVAL, "NULL argument");
+  if (n_eval <= 0 || n_eval >= (int64_t)INT_MAX) return fail(KPDI_EINVAL, "need between 1 and 2^31-1 evaluations");
+  int rc = use_device(c);
+  if (rc) return rc;
+  kpdi::RefineLaunch a{};
+  rc = refine_fill_launch(c, mode, &a);
+  if (rc) return rc;
+  if (a.nfixed > 0 && !fixed) return fail(KPDI_EINVAL, "this mode needs the `fixed` array");
+  for (int64_t e = 0; e < n_eval; ++e)
+    if (pattern_index[e] < 0 || pattern_index[e] >= c->ref_n)
+      return fail(KPDI_EINVAL, "pattern index %d out of range at evaluation %lld", pattern_index[e], (long long)e);
+  const size_t nx = (size_t)n_eval * a.nvar, nf = (size_t)n_eval * a.nfixed;
+  HIPCHK(c->ref_in.reserve((nx + nf + 1) * sizeof(double)));
+  HIPCHK(c->ref_idx.reserve((size_t)n_eval * sizeof(int)));
+  HIPCHK(c->ref_out.reserve((size_t)n_eval * sizeof(double)));
+  double *d_x = c->ref_in.as<double>(), *d_f = d_x + nx;
+  HIPCHK(hipMemcpyAsync(d_x, x, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (nf) HIPCHK(hipMemcpyAsync(d_f, fixed, nf * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->ref_idx.p, pattern_index, (size_t)n_eval * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  a.n_jobs = n_eval;
+  a.x0 = d_x;
+  a.fixed = d_f;
+  HIPCHK(kpdi::launch_refine_objective(a, c->ref_idx.as<int>(), c->ref_out.as<double>(), c->stream));
+  HIPCHK(hipMemcpyAsync(out, c->ref_out.p, (size_t)n_eval * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KPDI_OK;
+}
+
+namespace {
+// SciPy's resolution of maxiter / maxfev (scipy/optimize/_optimize.py, _minimize_neldermead)
+void resolve_budget(int nvar, int maxiter, int maxfev, int *it, int *fev) {
+  const bool no_it = maxiter <= 0, no_fev = maxfev <= 0;
+  if (no_it && no_fev) {
+    *it = nvar * 200;
+    *fev = nvar * 200;
+  } else if (no_it) {
+    *it = INT_MAX;
+    *fev = maxfev;
+  } else if (no_fev) {
+    *it = maxiter;
+    *fev = INT_MAX;
+  } else {
+    *it = maxiter;
+    *fev = maxfev;
+  }
+}
+}  // namespace
+
+int kpdi_refine_solve(kpdi_ctx *c, int mode, int64_t n_patterns, int n_starts, const double *x0, const double *fixed,
+                      const double *lower, const double *upper, double xatol, double fatol, int maxiter, int maxfev,
+                      double *results) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!x0 || !results) return fail(KPDI_EINVAL, "NULL argument");
+  if ((lower == nullptr) != (upper == nullptr)) return fail(KPDI_EINVAL, "give both bounds or neither");
+  if (n_starts <= 0) return fail(KPDI_EINVAL, "need at least one start per pattern");
+  int rc = use_device(c);
+  if (rc) return rc;
+  kpdi::RefineLaunch a{};
+  rc = refine_fill_launch(c, mode, &a);
+  if (rc) return rc;
+  if (n_patterns != c->ref_n)
+    return fail(KPDI_EINVAL, "%lld patterns were set but starts for %lld were given", (long long)c->ref_n,
+                (long long)n_patterns);
+  if (a.nfixed > 0 && !fixed) return fail(KPDI_EINVAL, "this mode needs the `fixed` array");
+  const int64_t jobs = n_patterns * n_starts;
+  if (jobs >= (int64_t)INT_MAX) return fail(KPDI_EINVAL, "too many (pattern, start) pairs");
+  const size_t nx = (size_t)jobs * a.nvar, nf = (size_t)jobs * a.nfixed;
+  if (lower)
+    for (size_t i = 0; i < nx; ++i)
+      if (lower[i] > upper[i])
+        return fail(KPDI_EINVAL, "Nelder Mead - one of the lower bounds is greater than an upper bound.");
+  const size_t total = nx * (lower ? 3 : 1) + nf + 1;
+  HIPCHK(c->ref_in.reserve(total * sizeof(double)));
+  HIPCHK(c->ref_out.reserve((size_t)jobs * kpdi::REFINE_RESULT_STRIDE * sizeof(double)));
+  double *d_x = c->ref_in.as<double>(), *d_f = d_x + nx, *d_lo = d_f + nf, *d_hi = d_lo + nx;
+  HIPCHK(hipMemcpyAsync(d_x, x0, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (nf) HIPCHK(hipMemcpyAsync(d_f, fixed, nf * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (lower) {
+    HIPCHK(hipMemcpyAsync(d_lo, lower, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_hi, upper, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(hipMemsetAsync(c->ref_out.p, 0, (size_t)jobs * kpdi::REFINE_RESULT_STRIDE * sizeof(double), c->stream));
+  a.n_jobs = jobs;
+  a.n_starts = n_starts;
+  a.x0 = d_x;
+  a.fixed = d_f;
+  a.lower = lower ? d_lo : nullptr;
+  a.upper = lower ? d_hi : nullptr;
+  a.xatol = xatol;
+  a.fatol = fatol;
+  resolve_budget(a.nvar, maxiter, maxfev, &a.maxiter, &a.maxfun);
+  a.results = c->ref_out.as<double>();
+  hipEvent_t e0 = c->get_event(), e1 = c->get_event();
+  HIPCHK(hipEventRecord(e0, c->stream));
+  HIPCHK(kpdi::launch_refine_solve(a, c->stream));
+  HIPCHK(hipEventRecord(e1, c->stream));
+  HIPCHK(hipMemcpyAsync(results, c->ref_out.p, (size_t)jobs * kpdi::REFINE_RESULT_STRIDE * sizeof(double),
+                        hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  c->cnt.refine_ms += ms;
+  c->ev_pool.push_back(e0);
+  c->ev_pool.push_back(e1);
+  return KPDI_OK;
+}
+
+int kpdi_nelder_mead_selftest(kpdi_ctx *c, int kind, int nvar, const double *x0, const double *lower,
+                              const double *upper, double xatol, double fatol, int maxiter, int maxfev,
+                              double *result) {
+  if (!c || !x0 || !result) return fail(KPDI_EINVAL, "NULL argument");
+  if (nvar < 1 || nvar > 6) return fail(KPDI_EINVAL, "nvar must be within 1..6");
+  if ((lower == nullptr) != (upper == nullptr)) return fail(KPDI_EINVAL, "give both bounds or neither");
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(c->ref_in.reserve((size_t)(3 * nvar + 1) * sizeof(double)));
+  HIPCHK(c->ref_out.reserve((size_t)kpdi::REFINE_RESULT_STRIDE * sizeof(double)));
+  double *d_x = c->ref_in.as<double>(), *d_lo = d_x + nvar, *d_hi = d_lo + nvar;
+  HIPCHK(hipMemcpyAsync(d_x, x0, nvar * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (lower) {
+    HIPCHK(hipMemcpyAsync(d_lo, lower, nvar * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_hi, upper, nvar * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  int it, fev;
+  resolve_budget(nvar, maxiter, maxfev, &it, &fev);
+  HIPCHK(kpdi::launch_nelder_mead_selftest(kind, nvar, d_x, lower ? d_lo : nullptr, lower ? d_hi : nullptr, xatol,
+                                           fatol, it, fev, c->ref_out.as<double>(), c->stream));
+  HIPCHK(hipMemcpyAsync(result, c->ref_out.p, (size_t)(3 + nvar) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KPDI_OK;
 }
 
 int kpdi_reset_topk(kpdi_ctx *c) {

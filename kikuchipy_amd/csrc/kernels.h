@@ -148,4 +148,31 @@ hipError_t launch_project(const ProjectLaunch &a, hipStream_t s);
 size_t packed_master_floats(int npx, int npy);
 void pack_master_pattern(const float *upper, const float *lower, int npx, int npy, float *out);
 
+// ---- refinement (refine.hip) -------------------------------------------------
+struct RefineLaunch {
+  int mode, nvar, nfixed, n_starts;
+  int64_t n_jobs;        // solve: patterns * starts; objective: evaluations
+  const double *x0;      // [n_jobs][nvar]
+  const double *fixed;   // [n_jobs][nfixed]
+  const double *lower, *upper;  // [n_jobs][nvar] or nullptr
+  int nrows, ncols, k;
+  const unsigned *rowcol;       // [k] row << 16 | col of the kept pixels
+  double om[9];
+  const float *master_packed;
+  int npx, npy;
+  const float *patterns;        // [n][k] centred float32
+  const double *sqnorm;         // [n]
+  double xatol, fatol;
+  int maxiter, maxfun;
+  double *results;              // [n_jobs][REFINE_RESULT_STRIDE]: fun, nfev, nit, x[nvar]
+};
+constexpr int REFINE_RESULT_STRIDE = 9;
+hipError_t launch_refine_prep(const void *raw, int dtype, int64_t n, int npix, const int *pix_map, int k, int rescale,
+                              float *out, double *sqnorm, hipStream_t s);
+hipError_t launch_refine_solve(const RefineLaunch &a, hipStream_t s);
+hipError_t launch_refine_objective(const RefineLaunch &a, const int *pattern_index, double *out, hipStream_t s);
+hipError_t launch_nelder_mead_selftest(int kind, int nvar, const double *x0, const double *lower, const double *upper,
+                                       double xatol, double fatol, int maxiter, int maxfun, double *result,
+                                       hipStream_t s);
+
 }  // namespace kpdi
