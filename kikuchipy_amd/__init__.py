@@ -13,6 +13,7 @@ from kikuchipy_amd.indexing import (  # noqa: E402,F401
     DictionaryIndexingResult,
     NormalizedCrossCorrelationMetric,
     NormalizedDotProductMetric,
+    RefinementResult,
     SimilarityMetric,
     dictionary_indexing,
 )
@@ -28,6 +29,7 @@ __all__ = [
     "EBSDDetector",
     "EBSDMasterPattern",
     "ProjectedDictionary",
+    "RefinementResult",
     "NormalizedCrossCorrelationMetric",
     "NormalizedDotProductMetric",
     "SimilarityMetric",

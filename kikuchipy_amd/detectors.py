@@ -5,9 +5,10 @@ sample-to-detector orientation matrix that
 `_get_direction_cosines_for_fixed_pc` takes
 (signals/util/_master_pattern.py:83-124).
 
-One PC per detector only: the dictionary-indexing path uses a single PC for the
-whole dictionary; per-pattern PCs belong to refinement (8(f2)).
-Plotting, calibration, PC fitting/extrapolation and file I/O are out of scope.
+One PC, or one PC per map point (`pc` of shape navigation shape + (3,)):
+dictionary generation uses a single PC for the whole dictionary (SURVEY.md
+8(f1)), refinement takes either (8(f2)).  Plotting, calibration, PC
+fitting/extrapolation and file I/O are out of scope.
 """
 
 import numpy as np
@@ -39,7 +40,7 @@ def sample_to_detector_matrix(sample_tilt, tilt, azimuthal, twist):
 
 
 class EBSDDetector:
-    """EBSD detector with a single projection centre.
+    """EBSD detector with one projection centre, or one per map point.
 
     Parameters mirror the reference's constructor
     (detectors/_ebsd_detector.py:282-318): `shape` = (rows, columns), `px_size`
@@ -58,13 +59,13 @@ class EBSDDetector:
         self.azimuthal = float(azimuthal)
         self.twist = float(twist)
         self.sample_tilt = float(sample_tilt)
-        pc = np.asarray(pc, dtype=np.float64)
-        if pc.size != 3:
-            raise NotImplementedError(
-                "kikuchipy_amd.EBSDDetector holds exactly one projection centre (3 values), got an "
-                f"array of shape {pc.shape}"
+        pc = np.atleast_2d(np.asarray(pc, dtype=np.float64))
+        if pc.shape[-1] != 3 or pc.ndim > 3:
+            raise ValueError(
+                "`pc` must be (PCx, PCy, PCz) or an array of such triplets with at most two "
+                f"navigation axes, got shape {pc.shape}"
             )
-        self._pc = self._to_bruker(pc.reshape(3), convention)
+        self._pc = self._to_bruker(pc, convention)
 
     # detectors/_ebsd_detector.py:2207-2248, :2295-2315
     def _to_bruker(self, pc, convention):
@@ -77,20 +78,20 @@ class EBSDDetector:
             raise ValueError(
                 f"Invalid projection/pattern center convention {convention!r}. Options are {options}."
             )
-        pcx, pcy, pcz = pc
+        pcx, pcy, pcz = pc[..., 0], pc[..., 1], pc[..., 2]
         if conv == "tsl":
-            return np.array([pcx, 1 - pcy, pcz * min(self.nrows, self.ncols) / self.nrows])
+            return np.stack([pcx, 1 - pcy, pcz * min(self.nrows, self.ncols) / self.nrows], axis=-1)
         if conv == "oxford":
-            return np.array([pcx, 1 - pcy * self.aspect_ratio, pcz * self.aspect_ratio])
+            return np.stack([pcx, 1 - pcy * self.aspect_ratio, pcz * self.aspect_ratio], axis=-1)
         if conv == "emsoft":
             version = int(convention[-1]) if convention[-1].isdigit() else 5
             if version < 5:
                 pcx = -pcx
-            return np.array([
+            return np.stack([
                 0.5 - (pcx / (self.ncols * self._binning)),
                 0.5 - (pcy / (self.nrows * self._binning)),
                 pcz / (self.nrows * self._binning * self.px_size),
-            ])
+            ], axis=-1)
         return pc.copy()
 
     # ---- shape (detectors/_ebsd_detector.py:640-668)
@@ -116,24 +117,47 @@ class EBSDDetector:
 
     @property
     def navigation_shape(self):
-        return (1,)
+        return self._pc.shape[:-1]
 
-    # ---- PC (Bruker convention)
+    @property
+    def navigation_size(self):
+        return int(np.prod(self.navigation_shape))
+
+    # ---- PC (Bruker convention); scalars for a single PC, arrays otherwise
     @property
     def pc(self):
-        return self._pc.reshape(1, 3)
+        return self._pc
+
+    @pc.setter
+    def pc(self, value):
+        value = np.atleast_2d(np.asarray(value, dtype=np.float64))
+        if value.shape[-1] != 3:
+            raise ValueError("`pc` must have a last axis of size 3")
+        self._pc = value
+
+    @property
+    def pc_flattened(self):
+        return self._pc.reshape(-1, 3)
+
+    @property
+    def pc_average(self):
+        return np.nanmean(self.pc_flattened, axis=0)
+
+    def _component(self, i):
+        v = self._pc[..., i]
+        return v[0] if v.shape == (1,) else v
 
     @property
     def pcx(self):
-        return self._pc[0]
+        return self._component(0)
 
     @property
     def pcy(self):
-        return self._pc[1]
+        return self._component(1)
 
     @property
     def pcz(self):
-        return self._pc[2]
+        return self._component(2)
 
     # ---- gnomonic coordinates (detectors/_ebsd_detector.py:731-818)
     @property
@@ -154,7 +178,8 @@ class EBSDDetector:
 
     @property
     def gnomonic_bounds(self):
-        return np.array([self.x_min, self.x_max, self.y_min, self.y_max], dtype=np.float64)
+        """(x_min, x_max, y_min, y_max): shape (4,) for one PC, else navigation shape + (4,)."""
+        return np.stack([self.x_min, self.x_max, self.y_min, self.y_max], axis=-1).astype(np.float64)
 
     # ---- orientation
     @property
@@ -172,7 +197,7 @@ class EBSDDetector:
                             self.sample_tilt, self._pc.copy(), "bruker")
 
     def __repr__(self):
-        pc = tuple(float(v) for v in np.round(self._pc, 3))
+        pc = tuple(float(v) for v in np.round(self.pc_average, 3))
         return (f"EBSDDetector(shape={self.shape}, pc={pc}, sample_tilt={self.sample_tilt}, "
                 f"tilt={self.tilt}, azimuthal={self.azimuthal}, twist={self.twist}, "
                 f"binning={self.binning}, px_size={self.px_size} um)")

@@ -7,3 +7,4 @@ from kikuchipy_amd.indexing.similarity_metrics import (  # noqa: F401
     NormalizedDotProductMetric,
     SimilarityMetric,
 )
+from kikuchipy_amd.indexing._refinement import RefinementResult, refine  # noqa: F401

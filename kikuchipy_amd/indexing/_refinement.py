@@ -1,0 +1,297 @@
+"""Refinement of orientations and/or projection centres on the GPU engine.
+
+Counterpart of `EBSD.refine_orientation`, `EBSD.refine_projection_center` and
+`EBSD.refine_orientation_projection_center` (signals/ebsd.py:1986-2700 of the
+reference) with their set-up (`_RefinementSetup`,
+indexing/_refinement/_refinement.py:851-1286) for the default optimiser,
+`scipy.optimize.minimize(method="Nelder-Mead")`.  The reference hands every
+pattern to SciPy, which calls a Numba objective a few hundred times; here the
+whole map is ONE kernel launch (`kpdi_refine_solve`): a workgroup per (pattern,
+start) evaluates the objective and walks SciPy's simplex on the device.
+
+The other optimisers the reference can dispatch to (NLopt's LN_NELDERMEAD and
+SciPy's global methods) are not part of this path and raise
+`NotImplementedError`.
+"""
+
+import time
+
+import numpy as np
+
+from kikuchipy_amd import _lib
+
+MODES = {"ori": _lib.REFINE_ORI, "pc": _lib.REFINE_PC, "ori_pc": _lib.REFINE_ORI_PC}
+# indexing/_refinement/__init__.py:33-66
+SUPPORTED_OPTIMIZATION_METHODS = ["minimize", "ln_neldermead", "basinhopping", "differential_evolution",
+                                  "dual_annealing", "shgo"]
+
+
+# --------------------------------------------------------------------------- rotations
+def rotation_from_euler(euler):
+    """(..., 3) Bunge Euler angles in radians -> (..., 4) unit quaternions with a
+    non-negative scalar part (_utils/numba.py:43-57; `Rotation.from_euler`)."""
+    euler = np.asarray(euler, dtype=np.float64)
+    sigma = 0.5 * (euler[..., 0] + euler[..., 2])
+    delta = 0.5 * (euler[..., 0] - euler[..., 2])
+    c, s = np.cos(0.5 * euler[..., 1]), np.sin(0.5 * euler[..., 1])
+    q = np.stack([c * np.cos(sigma), -s * np.cos(delta), -s * np.sin(delta), -c * np.sin(sigma)], axis=-1)
+    return np.where(q[..., :1] < 0, -q, q)
+
+
+def euler_from_rotation(q):
+    """(..., 4) unit quaternions -> (..., 3) Bunge Euler angles, phi1 and phi2 in
+    [0, 2 pi), Phi in [0, pi]: the inverse of `rotation_from_euler`, i.e. what
+    orix's `Rotation.to_euler()` returns (un-vendored third party; eq. A.6 of
+    Rowenhorst et al. 2015 with orix's passive convention).  phi2 = 0 where Phi
+    is 0 or pi."""
+    q = np.asarray(q, dtype=np.float64)
+    a, b, c, d = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    q03, q12 = a * a + d * d, b * b + c * c
+    chi = np.sqrt(q03 * q12)
+    sigma = np.arctan2(-d, a)   # (phi1 + phi2) / 2
+    delta = np.arctan2(-c, -b)  # (phi1 - phi2) / 2
+    phi1 = np.where(chi == 0, np.where(q12 == 0, 2 * sigma, 2 * delta), sigma + delta)
+    Phi = np.where(chi == 0, np.where(q12 == 0, 0.0, np.pi), 2 * np.arctan2(np.sqrt(q12), np.sqrt(q03)))
+    phi2 = np.where(chi == 0, 0.0, sigma - delta)
+    two_pi = 2 * np.pi
+    out = np.stack([np.mod(phi1, two_pi), Phi, np.mod(phi2, two_pi)], axis=-1)
+    out[out == two_pi] = 0.0  # np.mod of a tiny negative number
+    return out
+
+
+def quaternion_multiply(p, q):
+    """Hamilton product p * q, broadcasting (orix `Quaternion.__mul__`)."""
+    p, q = np.asarray(p, dtype=np.float64), np.asarray(q, dtype=np.float64)
+    a1, b1, c1, d1 = p[..., 0], p[..., 1], p[..., 2], p[..., 3]
+    a2, b2, c2, d2 = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    return np.stack([
+        a1 * a2 - b1 * b2 - c1 * c2 - d1 * d2,
+        a1 * b2 + b1 * a2 + c1 * d2 - d1 * c2,
+        a1 * c2 - b1 * d2 + c1 * a2 + d1 * b2,
+        a1 * d2 + b1 * c2 - c1 * b2 + d1 * a2,
+    ], axis=-1)
+
+
+# --------------------------------------------------------------------------- results
+class RefinementResult:
+    """What the reference puts into the refined `CrystalMap`
+    (indexing/_refinement/_refinement.py:58-131): per refined point the
+    `scores` (NCC), `num_evals`, `rotations` (quaternions from the refined Euler
+    angles) and, with pseudo-symmetry operators, `pseudo_symmetry_index`
+    (0 = the indexed orientation itself).  `is_in_data` marks the refined points
+    in the flattened map."""
+
+    def __init__(self, scores, num_evals, euler, is_in_data, nav_shape, pseudo_symmetry_index=None,
+                 patterns_per_second=None):
+        self.scores = scores
+        self.num_evals = num_evals
+        self.euler = euler
+        self.rotations = None if euler is None else rotation_from_euler(euler)
+        self.is_in_data = is_in_data
+        self.shape = tuple(nav_shape)
+        self.pseudo_symmetry_index = pseudo_symmetry_index
+        self.patterns_per_second = patterns_per_second
+
+    @property
+    def size(self):
+        return int(np.count_nonzero(self.is_in_data))
+
+    @property
+    def prop(self):
+        out = {"scores": self.scores, "num_evals": self.num_evals}
+        if self.pseudo_symmetry_index is not None:
+            out["pseudo_symmetry_index"] = self.pseudo_symmetry_index
+        return out
+
+
+# --------------------------------------------------------------------------- set-up
+def _nelder_mead_options(method, method_kwargs, initial_step, maxeval):
+    """`_RefinementSetup.set_optimization_parameters`
+    (indexing/_refinement/_refinement.py:1053-1139) for the one supported method."""
+    method = (method or "minimize").lower()
+    if method not in SUPPORTED_OPTIMIZATION_METHODS:
+        raise ValueError(
+            f"Method {method!r} not in the list of supported methods {SUPPORTED_OPTIMIZATION_METHODS}"
+        )
+    if method != "minimize":
+        raise NotImplementedError(
+            f"Method {method!r} is not available on the GPU engine; only 'minimize' with SciPy's "
+            "Nelder-Mead (the reference's default) is"
+        )
+    kwargs = dict(method_kwargs or {})
+    name = kwargs.pop("method", "Nelder-Mead")
+    if str(name).lower() not in ("nelder-mead", "neldermead"):
+        raise NotImplementedError(f"minimize(method={name!r}) is not available on the GPU engine, only 'Nelder-Mead'")
+    options = dict(kwargs.pop("options", None) or {})
+    tol = kwargs.pop("tol", None)
+    if kwargs:
+        raise NotImplementedError(f"unsupported keyword argument(s) to minimize: {sorted(kwargs)}")
+    if tol is not None:  # scipy.optimize.minimize: tol sets xatol and fatol of Nelder-Mead
+        options.setdefault("xatol", tol)
+        options.setdefault("fatol", tol)
+    unknown = set(options) - {"xatol", "fatol", "maxiter", "maxfev", "disp", "adaptive", "return_all"}
+    if unknown or options.get("adaptive") or options.get("return_all"):
+        raise NotImplementedError(f"unsupported Nelder-Mead option(s): {sorted(unknown) or ['adaptive/return_all']}")
+    shown = {"method": "Nelder-Mead"}
+    if method_kwargs:
+        shown.update({k: v for k, v in method_kwargs.items() if k != "method"})
+    return dict(xatol=float(options.get("xatol", 1e-4)), fatol=float(options.get("fatol", 1e-4)),
+                maxiter=options.get("maxiter"), maxfev=options.get("maxfev")), shown
+
+
+def _bounds(mode, x0, trust_region):
+    """`_RefinementSetup.get_bound_constraints` (:1178-1242)."""
+    if trust_region is None:
+        return None, None
+    angle_leeway = np.deg2rad(5)
+    eu_lower = 3 * [-angle_leeway]
+    eu_upper = [2 * np.pi + angle_leeway, np.pi + angle_leeway, 2 * np.pi + angle_leeway]
+    pc_lower, pc_upper = 3 * [-2], 3 * [2]
+    trust_region = np.asarray(trust_region, dtype=np.float64).copy()
+    if mode == "ori":
+        trust_region = np.deg2rad(trust_region)
+        lower_abs, upper_abs = eu_lower, eu_upper
+    elif mode == "pc":
+        lower_abs, upper_abs = pc_lower, pc_upper
+    else:
+        trust_region[:3] = np.deg2rad(trust_region[:3])
+        lower_abs, upper_abs = eu_lower + pc_lower, eu_upper + pc_upper
+    return np.fmax(x0 - trust_region, lower_abs), np.fmin(x0 + trust_region, upper_abs)
+
+
+def _info_message(mode, trust_region, shown_kwargs, n_pseudo):
+    """`_RefinementSetup.get_info_message` (:1244-1286)."""
+    info = "Refinement information:\n  Method: Nelder-Mead (local) from SciPy"
+    tr_str = np.array_str(np.asarray(trust_region), precision=5)
+    info += "\n  Trust region (+/-): " + tr_str
+    info += f"\n  Keyword arguments passed to method: {shown_kwargs}"
+    if n_pseudo > 0:
+        info += f"\n  No. pseudo-symmetry operators: {n_pseudo}"
+    return info
+
+
+def _master_pattern_data(master_pattern, energy):
+    """`_get_master_pattern_data` (:1288-1320): float32 hemispheres; other data
+    types are rescaled to [-1, 1] over each hemisphere's own range
+    (pattern/_pattern.py:66-93)."""
+    out = []
+    for mp in master_pattern._get_master_pattern_arrays_from_energy(energy):
+        if mp.dtype != np.float32:
+            imin, imax = np.nanmin(mp), np.nanmax(mp)
+            mp = ((mp - imin) / float(imax - imin) * 2 + -1).astype(np.float32)
+        out.append(np.ascontiguousarray(mp))
+    return out
+
+
+def refine(mode, patterns, rotations, detector, master_pattern, energy=None, navigation_mask=None,
+           signal_mask=None, pseudo_symmetry_ops=None, method="minimize", method_kwargs=None, trust_region=None,
+           initial_step=None, rtol=1e-4, maxeval=None, context=None, device=0, verbose=True):
+    """Shared driver of the three refinements.
+
+    patterns
+        (..., rows, cols) experimental patterns with 0-2 navigation axes.
+    rotations
+        Quaternions of the indexed orientations, navigation shape + (4,) or
+        navigation shape + (k, 4) (best match first, as dictionary indexing
+        returns them; only the best is refined, _refinement.py:963-966).
+    detector
+        `EBSDDetector` with one PC or one PC per navigation point.
+    Returns `(RefinementResult, new_detector)`; `new_detector` is None in
+    mode "ori".
+    """
+    if mode not in MODES:
+        raise ValueError(f"mode must be one of {sorted(MODES)}")
+    nm, shown = _nelder_mead_options(method, method_kwargs, initial_step, maxeval)
+    master_pattern._is_suitable_for_projection(raise_if_not=True)
+    patterns = np.asarray(patterns)
+    if patterns.ndim < 2 or patterns.ndim > 4:
+        raise ValueError("patterns must have 0, 1 or 2 navigation axes and 2 signal axes")
+    nav_shape, sig_shape = patterns.shape[:-2], patterns.shape[-2:]
+    nav_size = int(np.prod(nav_shape)) if nav_shape else 1
+    if sig_shape != detector.shape:
+        raise ValueError(f"Detector shape {detector.shape} must be equal to the signal shape {sig_shape}")
+    if detector.navigation_size not in (1, nav_size):
+        raise ValueError(
+            f"Detector must have exactly one projection center (PC), or one PC per pattern in an array of shape "
+            f"signal's navigation shape + (3,) {nav_shape + (3,)}, but was {detector.pc.shape}"
+        )
+    if signal_mask is not None and signal_mask.shape != sig_shape:
+        raise ValueError(
+            f"Signal mask shape {signal_mask.shape} and signal's signal shape {sig_shape} must be the same shape"
+        )
+    rot = np.asarray(getattr(rotations, "data", rotations), dtype=np.float64)
+    if rot.shape[-1] != 4:
+        raise ValueError("`rotations` must be quaternions with a last axis of size 4")
+    if rot.ndim == len(nav_shape) + 2:  # several rotations per point: refine the best
+        rot = rot[..., 0, :]
+    if rot.size != nav_size * 4:
+        raise ValueError(f"need one rotation per pattern ({nav_size}), got an array of shape {rot.shape}")
+    rot = rot.reshape(nav_size, 4)
+    if navigation_mask is not None:
+        if navigation_mask.shape != (nav_shape or (1,)):
+            raise ValueError(
+                f"Navigation mask shape {navigation_mask.shape} and crystal map shape {nav_shape} must be the same"
+            )
+        points = ~np.asarray(navigation_mask, dtype=bool).ravel()
+        if not points.any():
+            raise ValueError("The navigation mask must allow refinement of at least one pattern")
+    else:
+        points = np.ones(nav_size, dtype=bool)
+    n = int(points.sum())
+    rot = rot[points]
+    pats = patterns.reshape((nav_size,) + sig_shape)[points]
+    pc = detector.pc_flattened[points] if detector.navigation_size > 1 else np.tile(detector.pc_flattened, (n, 1))
+    pc = pc.astype(np.float64)
+
+    # starts: the indexed orientation, then its pseudo-symmetry equivalents (_refinement.py:968-973)
+    n_pseudo = 0
+    if pseudo_symmetry_ops is not None and mode != "pc":
+        ops = np.asarray(getattr(pseudo_symmetry_ops, "data", pseudo_symmetry_ops), dtype=np.float64).reshape(-1, 4)
+        n_pseudo = ops.shape[0]
+        rot_starts = np.concatenate([rot[:, None, :], quaternion_multiply(ops[None, :, :], rot[:, None, :])], axis=1)
+    else:
+        rot_starts = rot[:, None, :]
+    starts = rot_starts.shape[1]
+    pc_starts = np.repeat(pc[:, None, :], starts, axis=1)
+    if mode == "ori":
+        x0, fixed = euler_from_rotation(rot_starts), pc_starts
+    elif mode == "pc":
+        x0, fixed = pc_starts, rot_starts
+    else:
+        x0, fixed = np.concatenate([euler_from_rotation(rot_starts), pc_starts], axis=2), None
+    lower, upper = _bounds(mode, x0, trust_region)
+    if verbose:
+        print(_info_message(mode, trust_region, shown, n_pseudo))
+        what = {"ori": "orientation(s)", "pc": "projection center(s)", "ori_pc": "orientation(s) and projection center(s)"}
+        print(f"Refining {n} {what[mode]}:")
+
+    ctx = context if context is not None else _lib.Context(device)
+    try:
+        ctx.set_master_pattern(*_master_pattern_data(master_pattern, energy))
+        # rescale exactly when the patterns are float32 (_refinement.py:956)
+        ctx.refine_set_patterns(pats, signal_mask, pats.dtype == np.float32, detector.detector_to_sample)
+        t0 = time.time()
+        res = ctx.refine_solve(MODES[mode], x0, fixed, lower, upper, nm["xatol"], nm["fatol"], nm["maxiter"] or 0,
+                               nm["maxfev"] or 0)
+        total = time.time() - t0
+    finally:
+        if context is None:
+            ctx.close()
+    if verbose:
+        print(f"Refinement speed: {n / total:.5f} patterns/s")
+
+    ncc = 1 - res[:, :, 0]
+    best = np.argmax(ncc, axis=1)  # first maximum, like int(np.argmax(ncc_all)) in the solvers
+    pick = res[np.arange(n), best]
+    scores, num_evals, x = ncc[np.arange(n), best], pick[:, 1].astype(np.int32), pick[:, 3:]
+    ps_index = best.astype(np.int32) if n_pseudo > 0 else None
+    euler = x[:, :3] if mode != "pc" else None
+    result = RefinementResult(scores, num_evals, euler, points, nav_shape or (1,), ps_index, n / total)
+    new_detector = None
+    if mode != "ori":
+        new_pc = x[:, -3:]
+        new_detector = detector.deepcopy()
+        if navigation_mask is None and nav_shape:
+            new_pc = new_pc.reshape(nav_shape + (3,))
+        new_detector.pc = new_pc
+    return result, new_detector

@@ -9,6 +9,8 @@ the reference's:
 * `EBSD.remove_dynamic_background`  signals/ebsd.py:575-696
 * `EBSD.dictionary_indexing`        signals/ebsd.py:1827-1984
 * `EBSDMasterPattern.get_patterns`  signals/ebsd_master_pattern.py:95-330
+* `EBSD.refine_orientation` / `refine_projection_center` /
+  `refine_orientation_projection_center`   signals/ebsd.py:1986-2700
 
 Like the reference's methods, each call hands back host data (`self.data` is
 replaced by the pre-processed array); callers that want the whole chain
@@ -111,6 +113,51 @@ class EBSD:
             return None
         return EBSD(out, self.static_background, self.xmap, self.step_sizes, self.scan_unit, self._device)
 
+    # ------------------------------------------------------------------ refinement
+    def _refine(self, mode, xmap, detector, master_pattern, energy, navigation_mask, signal_mask,
+                pseudo_symmetry_ops, method, method_kwargs, trust_region, initial_step, rtol, maxeval, compute,
+                verbose):
+        from kikuchipy_amd.indexing._refinement import refine
+
+        if not compute:
+            raise NotImplementedError("compute=False (a lazy Dask result) is not available: the whole "
+                                      "refinement is one GPU launch")
+        return refine(mode, np.asarray(self.data), _rotations_of(xmap), detector, master_pattern, energy,
+                      navigation_mask, signal_mask, pseudo_symmetry_ops, method, method_kwargs, trust_region,
+                      initial_step, rtol, maxeval, context=self.context, verbose=verbose)
+
+    def refine_orientation(self, xmap, detector, master_pattern, energy=None, navigation_mask=None,
+                           signal_mask=None, pseudo_symmetry_ops=None, method="minimize", method_kwargs=None,
+                           trust_region=None, initial_step=None, rtol=1e-4, maxeval=None, compute=True,
+                           rechunk=True, chunk_kwargs=None, *, verbose=True):
+        """signals/ebsd.py:1986-2185.  `xmap`: anything with `.rotations`
+        (e.g. the result of `dictionary_indexing`) or a quaternion array.
+        Returns a `RefinementResult` (`rotations`, `scores`, `num_evals`,
+        `pseudo_symmetry_index`)."""
+        return self._refine("ori", xmap, detector, master_pattern, energy, navigation_mask, signal_mask,
+                            pseudo_symmetry_ops, method, method_kwargs, trust_region, initial_step, rtol, maxeval,
+                            compute, verbose)[0]
+
+    def refine_projection_center(self, xmap, detector, master_pattern, energy=None, navigation_mask=None,
+                                 signal_mask=None, method="minimize", method_kwargs=None, trust_region=None,
+                                 initial_step=None, rtol=1e-4, maxeval=None, compute=True, rechunk=True,
+                                 chunk_kwargs=None, *, verbose=True):
+        """signals/ebsd.py:2187-2390.  Returns `(scores, new_detector, num_evals)`
+        like the reference."""
+        res, det = self._refine("pc", xmap, detector, master_pattern, energy, navigation_mask, signal_mask, None,
+                                method, method_kwargs, trust_region, initial_step, rtol, maxeval, compute, verbose)
+        return res.scores, det, res.num_evals
+
+    def refine_orientation_projection_center(self, xmap, detector, master_pattern, energy=None,
+                                             navigation_mask=None, signal_mask=None, pseudo_symmetry_ops=None,
+                                             method="minimize", method_kwargs=None, trust_region=None,
+                                             initial_step=None, rtol=1e-4, maxeval=None, compute=True,
+                                             rechunk=True, chunk_kwargs=None, *, verbose=True):
+        """signals/ebsd.py:2392-2700.  Returns `(RefinementResult, new_detector)`."""
+        return self._refine("ori_pc", xmap, detector, master_pattern, energy, navigation_mask, signal_mask,
+                            pseudo_symmetry_ops, method, method_kwargs, trust_region, initial_step, rtol, maxeval,
+                            compute, verbose)
+
     # ------------------------------------------------------------------ indexing
     def dictionary_indexing(self, dictionary, metric="ncc", keep_n=20, n_per_iteration=None,
                             navigation_mask=None, signal_mask=None, rechunk=False, dtype=None, *,
@@ -138,6 +185,12 @@ class EBSD:
             phase_name=dict_xmap.phase_name, scan_unit=self.scan_unit, device=self._device, comm=comm,
             verbose=verbose,
         )
+
+
+def _rotations_of(xmap):
+    """Quaternions of an indexing result / crystal-map-like object / plain array."""
+    rot = getattr(xmap, "rotations", xmap)
+    return np.asarray(getattr(rot, "data", rot), dtype=np.float64)
 
 
 class EBSDMasterPattern:
@@ -230,6 +283,11 @@ class EBSDMasterPattern:
         reference's `LazyEBSD`), with `xmap` holding the rotations.  `chunk_shape`
         in `kwargs` sets the number of patterns per lazy chunk."""
         self._is_suitable_for_projection(raise_if_not=True)
+        if detector.navigation_size != 1:
+            raise NotImplementedError(
+                "kikuchipy_amd projects a dictionary with ONE projection centre; the detector has "
+                f"{detector.navigation_size}"
+            )
         rot = np.asarray(getattr(rotations, "data", rotations), dtype=np.float64)
         if rot.shape[-1] != 4:
             raise ValueError("`rotations` must be an array of quaternions with a last axis of size 4")

@@ -235,3 +235,96 @@ def test_error_paths(g):
                            np.zeros((4, 1, 3)))
         with pytest.raises(_lib.KpdiError, match="out of range"):
             c.refine_objective(_lib.REFINE_ORI_PC, [7], np.zeros((1, 6)))
+
+
+# ------------------------------------------------------------------ Python interface
+@pytest.fixture(scope="module")
+def api_inputs(g):
+    import kikuchipy_amd as ka
+    from kikuchipy_amd.indexing._refinement import rotation_from_euler
+
+    p = load_golden("projection.npz")
+    mp = ka.EBSDMasterPattern(np.stack([p["mp_upper"], p["mp_lower"]]), phase_name="ni")
+    pats = g["patterns"].reshape(2, 2, 60, 60)
+    det = ka.EBSDDetector(shape=(60, 60), pc=g["pc0"].reshape(2, 2, 3), sample_tilt=70)
+    rot0 = rotation_from_euler(g["eu0"]).reshape(2, 2, 4)
+    return ka.EBSD(pats), det, mp, rot0
+
+
+def test_refine_orientation_api(api_inputs, g, g115, capsys):
+    """`s.refine_orientation(xmap, detector, master_pattern, energy)` as in the reference:
+    one PC per map point, uint8 master pattern (rescaled to float32 inside)."""
+    from kikuchipy_amd.indexing._refinement import euler_from_rotation
+
+    s, det, mp, rot0 = api_inputs
+    # the reference starts from orix's Euler angles of the indexed rotations: same values here
+    assert np.allclose(euler_from_rotation(rot0).reshape(-1, 3), g["eu0"], atol=1e-12)
+    res = s.refine_orientation(rot0, det, mp, energy=20)
+    out = capsys.readouterr().out
+    assert "Method: Nelder-Mead (local) from SciPy" in out and "Refining 4 orientation(s):" in out
+    assert "Refinement speed:" in out
+    want = g115["ori_nm"]
+    assert res.shape == (2, 2) and res.size == 4 and res.rotations.shape == (4, 4)
+    assert np.allclose(res.scores, want[:, 0], atol=1e-4)
+    assert np.allclose(res.euler, want[:, 2:5], atol=5e-4)
+    assert np.array_equal(res.num_evals, want[:, 1])
+    assert res.scores.mean() > 0.8 and res.pseudo_symmetry_index is None
+    # trust region + navigation mask + signal mask
+    nav = np.array([[False, True], [False, False]])
+    keep = ko.circular_window((60, 60)).astype(bool)
+    res2 = s.refine_orientation(rot0, det, mp, trust_region=[2, 2, 2], navigation_mask=nav, signal_mask=~keep,
+                                verbose=False)
+    assert res2.size == 3 and np.array_equal(res2.is_in_data, ~nav.ravel())
+    assert np.allclose(res2.euler, g115["ori_nm"][[0, 2, 3], 2:5], atol=2e-3)
+    # the k best rotations of dictionary indexing: only the best is refined
+    res3 = s.refine_orientation(np.stack([rot0, rot0[::-1]], axis=2), det, mp, verbose=False,
+                                method_kwargs=dict(method="Nelder-Mead", options=dict(maxfev=30)))
+    assert np.all(res3.num_evals == 30)
+
+
+def test_refine_pseudo_symmetry_api(api_inputs, g):
+    """A 'pseudo-symmetry' operator that is a real 20 degree rotation: the indexed
+    orientation (index 0) must win everywhere and the bookkeeping must hold."""
+    s, det, mp, rot0 = api_inputs
+    op = np.array([[np.cos(np.deg2rad(10)), 0, 0, np.sin(np.deg2rad(10))]])
+    res = s.refine_orientation(rot0, det, mp, pseudo_symmetry_ops=op, verbose=False)
+    assert np.array_equal(res.pseudo_symmetry_index, [0, 0, 0, 0])
+    base = s.refine_orientation(rot0, det, mp, verbose=False)
+    assert np.array_equal(res.scores, base.scores) and np.array_equal(res.num_evals, base.num_evals)
+    # start from the displaced orientations instead: the operator's inverse leads back
+    from kikuchipy_amd.indexing._refinement import quaternion_multiply
+
+    inv = op * [1, -1, -1, -1]
+    displaced = quaternion_multiply(inv[0], rot0)
+    res = s.refine_orientation(displaced, det, mp, pseudo_symmetry_ops=op, verbose=False)
+    assert np.array_equal(res.pseudo_symmetry_index, [1, 1, 1, 1])
+    assert np.allclose(res.scores, base.scores, atol=1e-3)
+
+
+def test_refine_pc_and_both_api(api_inputs, g, g115):
+    s, det, mp, rot0 = api_inputs
+    scores, new_det, num_evals = s.refine_projection_center(rot0, det, mp, verbose=False)
+    assert scores.shape == (4,) and new_det.pc.shape == (2, 2, 3) and num_evals.shape == (4,)
+    assert np.allclose(scores[:2], g115["pc_nm"][:, 0], atol=1e-4)
+    assert np.allclose(new_det.pc_flattened[:2], g115["pc_nm"][:, 2:5], atol=5e-4)
+    assert np.array_equal(num_evals[:2], g115["pc_nm"][:, 1])
+    assert not np.allclose(new_det.pc, det.pc)
+    res, new_det = s.refine_orientation_projection_center(rot0, det, mp, trust_region=[2, 2, 2, 0.02, 0.02, 0.02],
+                                                          verbose=False)
+    assert np.allclose(res.scores[:2], g115["ori_pc_nm_bounds"][:, 0], atol=5e-4)
+    assert new_det.pc.shape == (2, 2, 3) and res.rotations.shape == (4, 4)
+    # refining both can only do better than refining the orientation alone from the same start
+    only = s.refine_orientation(rot0, det, mp, trust_region=[2, 2, 2], verbose=False)
+    assert np.all(res.scores > only.scores - 1e-4)
+
+
+def test_float32_patterns_are_rescaled(api_inputs, g):
+    """Patterns given as float32 go through the [-1, 1] rescale (_refinement.py:956); NCC is
+    invariant to it up to rounding, so the refinement result is the same."""
+    import kikuchipy_amd as ka
+
+    s, det, mp, rot0 = api_inputs
+    sf = ka.EBSD(s.data.astype(np.float32) * 0.5 + 3)
+    a = s.refine_orientation(rot0, det, mp, verbose=False)
+    b = sf.refine_orientation(rot0, det, mp, verbose=False)
+    assert np.allclose(a.scores, b.scores, atol=1e-4) and np.allclose(a.euler, b.euler, atol=1e-3)

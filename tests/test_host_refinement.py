@@ -1,0 +1,138 @@
+"""Host logic of the refinement interface (no GPU): rotation conversions,
+bounds, optimiser options and messages (indexing/_refinement/_refinement.py of
+the reference)."""
+
+import numpy as np
+import pytest
+
+from oracle import kpdi_oracle as ko
+
+import kikuchipy_amd as ka
+from kikuchipy_amd.indexing import _refinement as rf
+
+
+def random_quaternions(n, seed=0):
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal((n, 4))
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    q[q[:, 0] < 0] *= -1
+    return q
+
+
+def test_rotation_from_euler_matches_oracle():
+    rng = np.random.default_rng(1)
+    eu = np.column_stack([rng.uniform(0, 2 * np.pi, 50), rng.uniform(0, np.pi, 50), rng.uniform(0, 2 * np.pi, 50)])
+    want = np.array([ko.rotation_from_euler(*e) for e in eu])
+    assert np.allclose(rf.rotation_from_euler(eu), want, rtol=0, atol=1e-15)
+    assert rf.rotation_from_euler(eu.reshape(5, 10, 3)).shape == (5, 10, 4)
+
+
+def test_euler_round_trip():
+    q = random_quaternions(500)
+    eu = rf.euler_from_rotation(q)
+    assert eu[:, 0].min() >= 0 and eu[:, 0].max() < 2 * np.pi
+    assert eu[:, 1].min() >= 0 and eu[:, 1].max() <= np.pi
+    assert eu[:, 2].min() >= 0 and eu[:, 2].max() < 2 * np.pi
+    assert np.allclose(rf.rotation_from_euler(eu), q, atol=1e-12)
+    # and the other way around
+    rng = np.random.default_rng(2)
+    eu = np.column_stack([rng.uniform(0, 2 * np.pi, 100), rng.uniform(0.01, np.pi - 0.01, 100),
+                          rng.uniform(0, 2 * np.pi, 100)])
+    assert np.allclose(rf.euler_from_rotation(rf.rotation_from_euler(eu)), eu, atol=1e-10)
+
+
+def test_euler_degenerate_cases():
+    # Phi = 0 and Phi = pi: phi2 = 0 by convention, the rotation is reproduced
+    for eu in ([1.2, 0.0, 0.0], [4.0, np.pi, 0.0], [0.0, 0.0, 0.0]):
+        q = rf.rotation_from_euler(np.array(eu))
+        back = rf.euler_from_rotation(q)
+        assert np.allclose(back, eu, atol=1e-12), (eu, back)
+    q = rf.rotation_from_euler(np.array([0.7, 0.0, 0.5]))  # phi1 + phi2 folded into phi1
+    assert np.allclose(rf.euler_from_rotation(q), [1.2, 0, 0], atol=1e-12)
+
+
+def test_quaternion_multiply_composes_rotations():
+    p, q = random_quaternions(20, 3), random_quaternions(20, 4)
+    v = np.random.default_rng(5).standard_normal((7, 3))
+    for a, b in zip(p, q):
+        # rotating by b then by a == rotating by a * b (ko.rotate_vector is the reference's rotate_vector)
+        want = ko.rotate_vector(a, ko.rotate_vector(b, v))
+        got = ko.rotate_vector(rf.quaternion_multiply(a, b), v)
+        assert np.allclose(got, want, atol=1e-12)
+    assert rf.quaternion_multiply(p[None, :3, :], q[:5, None, :]).shape == (5, 3, 4)
+
+
+def test_bounds_follow_the_reference():
+    """get_bound_constraints (indexing/_refinement/_refinement.py:1178-1242)."""
+    x0 = np.array([[[0.01, 3.1, 6.2]]])
+    lo, hi = rf._bounds("ori", x0, [2, 2, 2])
+    tr, lee = np.deg2rad(2), np.deg2rad(5)
+    assert np.allclose(lo, [[[0.01 - tr, 3.1 - tr, 6.2 - tr]]])
+    assert np.allclose(hi, [[[0.01 + tr, 3.1 + tr, min(6.2 + tr, 2 * np.pi + lee)]]])
+    lo, hi = rf._bounds("ori", np.array([[[0.0, 0.0, 6.36]]]), [10, 10, 10])
+    assert np.allclose(lo[0, 0, :2], -lee) and np.isclose(hi[0, 0, 2], 2 * np.pi + lee)
+    lo, hi = rf._bounds("pc", np.array([[[0.4, 0.5, 1.99]]]), [0.05, 0.05, 0.05])
+    assert np.allclose(lo, [[[0.35, 0.45, 1.94]]]) and np.allclose(hi, [[[0.45, 0.55, 2.0]]])
+    tr6 = [1, 1, 1, 0.02, 0.02, 0.02]
+    lo, hi = rf._bounds("ori_pc", np.array([[[1.0, 1.0, 1.0, 0.4, 0.5, 0.6]]]), tr6)
+    assert np.allclose(hi - lo, 2 * np.array([np.deg2rad(1)] * 3 + [0.02] * 3))
+    assert tr6 == [1, 1, 1, 0.02, 0.02, 0.02]  # caller's list untouched
+    assert rf._bounds("ori", x0, None) == (None, None)
+
+
+def test_optimiser_options():
+    nm, shown = rf._nelder_mead_options("minimize", None, None, None)
+    assert nm == dict(xatol=1e-4, fatol=1e-4, maxiter=None, maxfev=None) and shown == {"method": "Nelder-Mead"}
+    nm, shown = rf._nelder_mead_options("MINIMIZE", dict(method="Nelder-Mead", tol=1e-3, options=dict(maxfev=50)), None, None)
+    assert nm == dict(xatol=1e-3, fatol=1e-3, maxiter=None, maxfev=50)
+    with pytest.raises(ValueError, match="not in the list of supported methods"):
+        rf._nelder_mead_options("powell", None, None, None)
+    for method in ("ln_neldermead", "basinhopping", "differential_evolution", "dual_annealing", "shgo"):
+        with pytest.raises(NotImplementedError, match="not available on the GPU engine"):
+            rf._nelder_mead_options(method, None, None, None)
+    with pytest.raises(NotImplementedError, match="only 'Nelder-Mead'"):
+        rf._nelder_mead_options("minimize", dict(method="BFGS"), None, None)
+    with pytest.raises(NotImplementedError, match="option"):
+        rf._nelder_mead_options("minimize", dict(options=dict(adaptive=True)), None, None)
+
+
+def test_info_message():
+    msg = rf._info_message("ori", [1, 1, 1], {"method": "Nelder-Mead"}, 2)
+    assert msg == ("Refinement information:\n  Method: Nelder-Mead (local) from SciPy\n  Trust region (+/-): [1 1 1]\n"
+                   "  Keyword arguments passed to method: {'method': 'Nelder-Mead'}\n  No. pseudo-symmetry operators: 2")
+    assert "Trust region (+/-): None" in rf._info_message("pc", None, {}, 0)
+
+
+def test_master_pattern_data_is_float32():
+    up = np.arange(25, dtype=np.uint8).reshape(5, 5)
+    mp = ka.EBSDMasterPattern(up)
+    a, b = rf._master_pattern_data(mp, None)
+    want = ko.refinement_master_pattern(up, up)[0]
+    assert a.dtype == np.float32 and np.array_equal(a, want) and a.min() == -1 and a.max() == 1
+    f = np.linspace(0, 1, 25, dtype=np.float32).reshape(5, 5)
+    assert np.array_equal(rf._master_pattern_data(ka.EBSDMasterPattern(f), None)[0], f)
+
+
+def test_argument_validation():
+    det = ka.EBSDDetector(shape=(6, 6))
+    mp = ka.EBSDMasterPattern(np.zeros((11, 11), np.float32))
+    pats = np.zeros((2, 3, 6, 6), np.uint8)
+    rot = np.tile([1.0, 0, 0, 0], (2, 3, 1))
+    with pytest.raises(ValueError, match="Detector shape"):
+        rf.refine("ori", pats, rot, ka.EBSDDetector(shape=(5, 6)), mp)
+    with pytest.raises(ValueError, match="exactly one projection center"):
+        rf.refine("ori", pats, rot, ka.EBSDDetector(shape=(6, 6), pc=np.full((4, 3), 0.5)), mp)
+    with pytest.raises(ValueError, match="Signal mask shape"):
+        rf.refine("ori", pats, rot, det, mp, signal_mask=np.zeros((5, 5), bool))
+    with pytest.raises(ValueError, match="one rotation per pattern"):
+        rf.refine("ori", pats, rot[:1], det, mp)
+    with pytest.raises(ValueError, match="Navigation mask shape"):
+        rf.refine("ori", pats, rot, det, mp, navigation_mask=np.zeros((3, 2), bool))
+    with pytest.raises(ValueError, match="at least one pattern"):
+        rf.refine("ori", pats, rot, det, mp, navigation_mask=np.ones((2, 3), bool))
+    with pytest.raises(NotImplementedError, match="square Lambert"):
+        rf.refine("ori", pats, rot, det, ka.EBSDMasterPattern(np.zeros((11, 11)), projection="stereographic"))
+    with pytest.raises(ValueError, match="mode must be"):
+        rf.refine("both", pats, rot, det, mp)
+    with pytest.raises(NotImplementedError, match="compute=False"):
+        ka.EBSD(pats).refine_orientation(rot, det, mp, compute=False)

@@ -69,8 +69,23 @@ def test_pc_conventions(shape, pc, convention, desired):
 def test_pc_convention_raises():
     with pytest.raises(ValueError, match="Invalid projection/pattern center "):
         ka.EBSDDetector(pc=PC1, convention="nordif")
-    with pytest.raises(NotImplementedError, match="exactly one projection centre"):
-        ka.EBSDDetector(shape=(60, 60), pc=np.ones((4, 3)) * 0.5)
+    with pytest.raises(ValueError, match="must be \\(PCx, PCy, PCz\\)"):
+        ka.EBSDDetector(shape=(60, 60), pc=np.ones((4, 2)) * 0.5)
+
+
+def test_detector_with_one_pc_per_point():
+    pcs = np.array([[[0.4, 0.5, 0.4], [0.6, 0.5, 0.4]], [[0.4, 0.5, 0.6], [0.6, 0.5, 0.6]]])
+    det = ka.EBSDDetector(shape=(60, 60), pc=pcs)
+    assert det.navigation_shape == (2, 2) and det.navigation_size == 4
+    assert det.pc_flattened.shape == (4, 3) and det.gnomonic_bounds.shape == (2, 2, 4)
+    assert np.allclose(det.pc_average, [0.5, 0.5, 0.5])
+    one = ka.EBSDDetector(shape=(60, 60), pc=pcs[1, 0])
+    assert np.allclose(det.gnomonic_bounds[1, 0], one.gnomonic_bounds)
+    mp = ka.EBSDMasterPattern(np.zeros((11, 11)))
+    with pytest.raises(NotImplementedError, match="ONE projection centre"):
+        mp.get_patterns(np.array([[1.0, 0, 0, 0]]), det)
+    tsl = ka.EBSDDetector(shape=(60, 80), pc=[[0.35, 1, 0.65], [0.1, 0.2, 0.3]], convention="tsl")
+    assert np.allclose(tsl.pc, [[0.35, 0, 0.65], [0.1, 0.8, 0.3]])
 
 
 def test_sample_to_detector_golden(g):
