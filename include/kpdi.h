@@ -214,6 +214,20 @@ int kpdi_nelder_mead_selftest(kpdi_ctx *ctx, int kind, int nvar, const double *x
                               const double *lower, const double *upper, double xatol,
                               double fatol, int maxiter, int maxfev, double *result);
 
+/* ---- orientation similarity map ---------------------------------
+ * kikuchipy.indexing.orientation_similarity_map
+ * (indexing/_orientation_similarity_map.py:30-152).  simulation_indices: ny*nx x keep_n
+ * int64 in host memory, or NULL = the best-k lists still resident from the last sweep
+ * (kpdi_finalize; needs ny*nx == number of matched patterns).  footprint_offsets: n_fp
+ * (dy, dx) pairs, the non-zero footprint elements in row-major order relative to the
+ * footprint's centre (shape // 2); center_index as in the reference.  out: ny x nx x
+ * (n_best - from_n_best + 1) float32, layer 0 = n_best; NaN where a point has no
+ * neighbour. */
+int kpdi_orientation_similarity_map(kpdi_ctx *ctx, const int64_t *simulation_indices, int ny,
+                                    int nx, int keep_n, int n_best, int from_n_best,
+                                    const int32_t *footprint_offsets, int n_fp, int center_index,
+                                    int normalize, float *out);
+
 /* ---- multi-GPU: dictionary sharded over ranks, one process per GPU -------- */
 #define KPDI_UNIQUE_ID_BYTES 128
 int kpdi_comm_unique_id(uint8_t *id_out /* KPDI_UNIQUE_ID_BYTES */);

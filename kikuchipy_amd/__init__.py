@@ -16,6 +16,8 @@ from kikuchipy_amd.indexing import (  # noqa: E402,F401
     RefinementResult,
     SimilarityMetric,
     dictionary_indexing,
+    merge_crystal_maps,
+    orientation_similarity_map,
 )
 from kikuchipy_amd.pattern import remove_dynamic_background, remove_static_background  # noqa: E402,F401
 from kikuchipy_amd.detectors import EBSDDetector  # noqa: E402,F401
@@ -34,6 +36,8 @@ __all__ = [
     "NormalizedDotProductMetric",
     "SimilarityMetric",
     "dictionary_indexing",
+    "merge_crystal_maps",
+    "orientation_similarity_map",
     "remove_dynamic_background",
     "remove_static_background",
 ]

@@ -88,6 +88,7 @@ SIGNATURES = {
     "kpdi_refine_objective": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp]),
     "kpdi_refine_solve": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, C.c_double, C.c_double, _i, _i, _vp]),
     "kpdi_nelder_mead_selftest": (_i, [_vp, _i, _i, _vp, _vp, _vp, C.c_double, C.c_double, _i, _i, _vp]),
+    "kpdi_orientation_similarity_map": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "kpdi_reset_topk": (_i, [_vp]),
     "kpdi_finalize": (_i, [_vp, _vp, _vp]),
     "kpdi_comm_unique_id": (_i, [_vp]),
@@ -340,6 +341,22 @@ class Context:
                                                float(xatol), float(fatol), int(maxiter or 0), int(maxfev or 0),
                                                _ptr(res)))
         return res
+
+    # -- result consumers
+    def orientation_similarity_map(self, simulation_indices, shape, keep_n, n_best, from_n_best, offsets,
+                                   center_index, normalize):
+        """simulation_indices: (ny * nx, keep_n) integers, or None = the lists resident from
+        the last finalize().  offsets: (n_fp, 2) (dy, dx).  Returns (ny, nx, layers) float32."""
+        ny, nx = shape
+        idx = None
+        if simulation_indices is not None:
+            idx = np.ascontiguousarray(simulation_indices, dtype=np.int64).reshape(ny * nx, keep_n)
+        off = np.ascontiguousarray(offsets, dtype=np.int32).reshape(-1, 2)
+        out = np.empty((ny, nx, n_best - from_n_best + 1), dtype=np.float32)
+        check(load().kpdi_orientation_similarity_map(self._h, _ptr(idx), int(ny), int(nx), int(keep_n), int(n_best),
+                                                     int(from_n_best), _ptr(off), off.shape[0], int(center_index),
+                                                     int(bool(normalize)), _ptr(out)))
+        return out
 
     def reset_topk(self):
         check(load().kpdi_reset_topk(self._h))

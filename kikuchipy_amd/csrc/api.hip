@@ -134,6 +134,9 @@ struct kpdi_ctx {
   DevBuf run_s[2], run_i[2];   // running best-k ping-pong
   int run_cur = 0;
   bool run_valid = false;
+  bool final_valid = false;       // `final_idx` points at the lists kpdi_finalize handed out last
+  const int *final_idx = nullptr;
+  DevBuf osm_idx, osm_out;
   DevBuf gthr;                            // shared rejection bound of the match kernel
   int bound_key = -1;                     // plan the bound array was initialised for (-1: none)
   DevBuf tile_ctr;                        // dynamic tile counters of the match kernel
@@ -364,6 +367,7 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
   const int nsplit = choose_nsplit(c, row_blocks, n_tiles);
   const int k = c->keep_n;
   const int cur = c->run_cur, nxt = cur ^ 1;
+  c->final_valid = false;
 
   kpdi::MergeLaunch mg{};
   mg.m = c->m;
@@ -479,6 +483,7 @@ int set_experimental_common(kpdi_ctx *c, const void *src, bool src_on_device, in
   c->have_exp = true;
   c->exp_prepared = false;
   c->run_valid = false;
+  c->final_valid = false;
   return KPDI_OK;
 }
 
@@ -530,7 +535,7 @@ int kpdi_destroy(kpdi_ctx *c) {
                     &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps,
                     &c->mp_packed, &c->dcos, &c->rot, &c->proj_out,
                     &c->ref_raw, &c->ref_map, &c->ref_rowcol, &c->ref_pat, &c->ref_sqn, &c->ref_in, &c->ref_out,
-                    &c->ref_idx})
+                    &c->ref_idx, &c->osm_idx, &c->osm_out})
     b->release();
   for (auto *l : {&c->ev_match, &c->ev_prep, &c->ev_merge, &c->ev_proj})
     for (auto &pr : *l) {
@@ -582,6 +587,7 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   c->have_problem = true;
   c->exp_prepared = false;
   c->run_valid = false;
+  c->final_valid = false;
   c->cnt.kpad = c->kpad;
   c->cnt.k_kept = c->k_kept;
   return KPDI_OK;
@@ -593,6 +599,7 @@ int kpdi_set_keep_n(kpdi_ctx *c, int keep_n) {
   if (keep_n <= 0) return fail(KPDI_EINVAL, "keep_n must be >= 1");
   c->keep_n = keep_n;
   c->run_valid = false;
+  c->final_valid = false;
   return KPDI_OK;
 }
 
@@ -640,6 +647,7 @@ int kpdi_remove_static_background(kpdi_ctx *c, const float *static_bg, int opera
   HIPCHK(hipStreamSynchronize(c->stream));  // static_bg may be freed by the caller after return
   c->exp_prepared = false;
   c->run_valid = false;
+  c->final_valid = false;
   return KPDI_OK;
 }
 
@@ -704,6 +712,7 @@ int kpdi_remove_dynamic_background(kpdi_ctx *c, int operation, int filter_domain
   HIPCHK(hipStreamSynchronize(c->stream));  // `taps` dies at scope exit
   c->exp_prepared = false;
   c->run_valid = false;
+  c->final_valid = false;
   return KPDI_OK;
 }
 
@@ -1122,9 +1131,53 @@ int kpdi_nelder_mead_selftest(kpdi_ctx *c, int kind, int nvar, const double *x0,
   return KPDI_OK;
 }
 
+// ---- orientation similarity map ---------------------------------------------------
+int kpdi_orientation_similarity_map(kpdi_ctx *c, const int64_t *simulation_indices, int ny, int nx, int keep_n,
+                                    int n_best, int from_n_best, const int32_t *footprint_offsets, int n_fp,
+                                    int center_index, int normalize, float *out) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!footprint_offsets || !out) return fail(KPDI_EINVAL, "NULL argument");
+  if (ny <= 0 || nx <= 0 || (int64_t)ny * nx >= (int64_t)INT_MAX) return fail(KPDI_EINVAL, "bad map shape");
+  if (keep_n <= 0) return fail(KPDI_EINVAL, "keep_n must be positive");
+  if (n_best > keep_n) return fail(KPDI_EINVAL, "n_best %d cannot be greater than keep_n %d", n_best, keep_n);
+  if (from_n_best < 1 || from_n_best > n_best) return fail(KPDI_EINVAL, "from_n_best must be within 1..n_best");
+  if (n_fp < 1 || n_fp > 64) return fail(KPDI_EINVAL, "the footprint must have between 1 and 64 points");
+  if (center_index < 0 || center_index >= n_fp) return fail(KPDI_EINVAL, "center_index outside the footprint");
+  int rc = use_device(c);
+  if (rc) return rc;
+  const size_t n_points = (size_t)ny * nx, n = n_points * keep_n;
+  const int *d_idx = nullptr;
+  if (simulation_indices) {
+    std::vector<int> tmp(n);
+    for (size_t i = 0; i < n; ++i) {
+      if (simulation_indices[i] < INT_MIN || simulation_indices[i] > INT_MAX)
+        return fail(KPDI_EINVAL, "simulation index %lld does not fit 32 bits", (long long)simulation_indices[i]);
+      tmp[i] = (int)simulation_indices[i];
+    }
+    HIPCHK(c->osm_idx.reserve(n * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(c->osm_idx.p, tmp.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    d_idx = c->osm_idx.as<int>();
+  } else {
+    if (!c->final_valid) return fail(KPDI_EINVAL, "no resident result: call kpdi_finalize first");
+    if ((size_t)c->m != n_points || c->keep_n != keep_n)
+      return fail(KPDI_EINVAL, "the resident result is %d x %d but a %d x %d map with keep_n %d was asked for", c->m,
+                  c->keep_n, ny, nx, keep_n);
+    d_idx = c->final_idx;
+  }
+  const int n_layers = n_best - from_n_best + 1;
+  HIPCHK(c->osm_out.reserve(n_points * n_layers * sizeof(float)));
+  HIPCHK(kpdi::launch_osm(d_idx, ny, nx, keep_n, n_best, from_n_best, footprint_offsets, n_fp, center_index,
+                          normalize != 0, c->osm_out.as<float>(), c->stream));
+  HIPCHK(hipMemcpyAsync(out, c->osm_out.p, n_points * n_layers * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KPDI_OK;
+}
+
 int kpdi_reset_topk(kpdi_ctx *c) {
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
   c->run_valid = false;
+  c->final_valid = false;
   return KPDI_OK;
 }
 
@@ -1173,6 +1226,8 @@ int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
     d_i = c->run_i[nxt].as<int>();
     // the per-rank running list (run_cur) is left untouched: finalize is idempotent
   }
+  c->final_idx = d_i;
+  c->final_valid = true;
   std::vector<int> tmp(n);
   HIPCHK(hipMemcpyAsync(scores_out, d_s, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(tmp.data(), d_i, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -175,4 +175,9 @@ hipError_t launch_nelder_mead_selftest(int kind, int nvar, const double *x0, con
                                        double xatol, double fatol, int maxiter, int maxfun, double *result,
                                        hipStream_t s);
 
+// ---- orientation similarity map (osm.hip) -------------------------------------
+// idx: [ny * nx][keep_n] int32 on the device; offsets: n_fp x (dy, dx) on the HOST
+hipError_t launch_osm(const int *idx, int ny, int nx, int keep_n, int n_best, int from_n_best, const int *offsets,
+                      int n_fp, int center_index, int normalize, float *out, hipStream_t s);
+
 }  // namespace kpdi

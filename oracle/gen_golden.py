@@ -519,6 +519,121 @@ def gen_refinement():
     print(name, sorted(out))
 
 
+# ------------------------------------------------------------------ result consumers (8(f3))
+class FakeXmap:
+    """What `orientation_similarity_map` reads from a CrystalMap
+    (indexing/_orientation_similarity_map.py:118-121): `.prop[...]`, `.shape`."""
+
+    def __init__(self, prop, shape):
+        self.prop, self.shape = prop, shape
+
+
+def correlated_indices(rng, ny, nx, keep_n, n_dict=500):
+    """Top-k index lists that overlap between neighbours like a real map: every
+    point draws from a pool centred on a slowly varying grain label."""
+    grain = (np.add.outer(np.arange(ny) // 4, np.arange(nx) // 5) * 37) % n_dict
+    out = np.empty((ny * nx, keep_n), dtype=np.int64)
+    for p, g0 in enumerate(grain.ravel()):
+        pool = (g0 + np.arange(3 * keep_n)) % n_dict
+        out[p] = rng.choice(pool, keep_n, replace=False)
+    return out
+
+
+def gen_consumers():
+    import importlib
+
+    osm_mod = ref_shim._load("kikuchipy.indexing._orientation_similarity_map",
+                             "indexing/_orientation_similarity_map.py")
+    osm = osm_mod.orientation_similarity_map
+    rng = np.random.default_rng(31)
+    out = {}
+    idx = correlated_indices(rng, 9, 13, 20)
+    out["idx_9x13_k20"] = idx
+    x = FakeXmap({"simulation_indices": idx}, (9, 13))
+    out["osm_default"] = osm(x)
+    out["osm_normalized"] = osm(x, normalize=True)
+    out["osm_nbest7"] = osm(x, n_best=7)
+    out["osm_from5_to8"] = osm(x, n_best=8, from_n_best=5, normalize=True)
+    square = np.ones((3, 3), dtype=int)
+    out["osm_square_fp"] = osm(x, footprint=square, center_index=4)
+    wide = np.array([[1, 1, 1, 1, 1]])
+    out["osm_row_fp"] = osm(x, n_best=10, footprint=wide, center_index=2)
+    # duplicate indices inside a list (zero-filled rows of masked points): unique-set semantics
+    dup = idx.copy()
+    dup[::7] = 0
+    dup[3::11, 5:] = dup[3::11, :1]
+    out["idx_dup"] = dup
+    out["osm_dup"] = osm(FakeXmap({"simulation_indices": dup}, (9, 13)), n_best=12)
+    # the reference tests' cases (tests/test_indexing/test_orientation_similarity_map.py:27-64)
+    x = FakeXmap({"simulation_indices": np.tile(np.arange(5), (100, 1))}, (10, 10))
+    out["osm_reftest_tile"] = osm(x)
+    out["osm_reftest_tile_norm"] = osm(x, normalize=True)
+    out["osm_reftest_from2_shape"] = np.array(
+        osm(FakeXmap({"simulated_indices": np.ones((100, 5))}, (10, 10)), simulation_indices_prop="simulated_indices",
+            from_n_best=2).shape)
+    # ---- merge_crystal_maps with stand-in CrystalMaps (ref_shim.FakeCrystalMap)
+    _ns_ok = ref_shim._ns("kikuchipy.signals", os.path.join(ref_shim.SRC, "signals")) if "kikuchipy.signals" not in sys.modules else None
+    if "kikuchipy.signals.util" not in sys.modules:
+        ref_shim._ns("kikuchipy.signals.util", os.path.join(ref_shim.SRC, "signals", "util"))
+    ref_shim._load("kikuchipy.signals.util._crystal_map", "signals/util/_crystal_map.py")
+    merge = ref_shim._load("kikuchipy.indexing._merge_crystal_maps", "indexing/_merge_crystal_maps.py").merge_crystal_maps
+
+    def make_map(seed, shape, n, name, mask=None, lower_better=False, not_indexed=None):
+        r = np.random.default_rng(seed)
+        size = int(np.prod(shape))
+        m = size if mask is None else int((~mask).sum())
+        sc = np.sort(r.random((m, n)).astype(np.float32), axis=1)
+        sc = sc if lower_better else sc[:, ::-1].copy()
+        si = r.integers(0, 1000, (m, n)).astype(np.int64)
+        q = r.standard_normal((m, n, 4))
+        q /= np.linalg.norm(q, axis=-1, keepdims=True)
+        pid = np.zeros(m, dtype=int)
+        if not_indexed is not None:
+            pid[not_indexed] = -1
+        return dict(scores=sc, simulation_indices=si, rotations=q, phase_id=pid, mask=mask, name=name, shape=shape)
+
+    def to_fake(d):
+        return ref_shim.FakeCrystalMap(d["shape"], d["rotations"], {"scores": d["scores"],
+                                       "simulation_indices": d["simulation_indices"]}, d["name"],
+                                       None if d["mask"] is None else ~d["mask"].ravel(), d["phase_id"])
+
+    def record(tag, maps, **kw):
+        res = merge([to_fake(d) for d in maps], **kw)
+        k = res.kw
+        out[f"{tag}__phase_id"] = np.asarray(k["phase_id"])
+        out[f"{tag}__rotations"] = np.asarray(k["rotations"].args[0])
+        out[f"{tag}__phase_names"] = np.array(k["phase_list"].names)
+        for name, val in k["prop"].items():
+            out[f"{tag}__{name}"] = np.asarray(val)
+        for j, d in enumerate(maps):
+            for key in ("scores", "simulation_indices", "rotations", "phase_id"):
+                out[f"{tag}__in{j}_{key}"] = d[key]
+            if d["mask"] is not None:
+                out[f"{tag}__in{j}_mask"] = d["mask"]
+
+    shape = (4, 3)
+    two = [make_map(1, shape, 5, "a"), make_map(2, shape, 5, "b")]
+    record("merge2", two, simulation_indices_prop="simulation_indices")
+    record("merge2_mean3", two, mean_n_best=3, simulation_indices_prop="simulation_indices")
+    low = [make_map(3, shape, 5, "a", lower_better=True), make_map(4, shape, 5, "b", lower_better=True)]
+    record("merge2_lower", low, greater_is_better=False, simulation_indices_prop="simulation_indices")
+    record("merge2_negmean", low, mean_n_best=-2, simulation_indices_prop="simulation_indices")
+    m0 = np.zeros(shape, dtype=bool); m0[0, 0] = m0[2, 1] = True
+    m1 = np.zeros(shape, dtype=bool); m1[0, 0] = m1[3, 2] = m1[1, 1] = True
+    three = [make_map(5, shape, 4, "a", mask=m0, not_indexed=[1]), make_map(6, shape, 4, "b", mask=m1),
+             make_map(7, shape, 4, "c", not_indexed=[0, 1])]
+    three[2]["scores"][0] = 0  # all maps: point (0, 0) masked out or not indexed
+    record("merge3_masks", three, simulation_indices_prop="simulation_indices",
+           navigation_masks=[m0, m1, None])
+    same = [make_map(8, shape, 3, "a"), make_map(9, shape, 3, "a"), make_map(10, shape, 3, "b")]
+    record("merge3_same_name", same, simulation_indices_prop="simulation_indices")
+    record("merge2_no_indices", two)
+    ni = [make_map(11, shape, 4, "a", not_indexed=[3, 7]), make_map(12, shape, 4, "b", not_indexed=[3, 5])]
+    record("merge2_not_indexed", ni, simulation_indices_prop="simulation_indices")
+    np.savez_compressed(os.path.join(OUT, "consumers.npz"), **out)
+    print("consumers", sorted(out))
+
+
 # ------------------------------------------------------------------ the reference tests' own known answers
 def gen_refknown():
     """Extract the hard-coded known-answer ARRAYS (data, not code) that the
@@ -565,5 +680,6 @@ if __name__ == "__main__":
     gen_refknown()
     gen_projection()
     gen_refinement()
+    gen_consumers()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -660,6 +660,48 @@ def refine_solver(pattern, mode, x0, master_upper, master_lower, rescale, bounds
 
 
 # --------------------------------------------------------------------------
+# consumers of the indexing result
+# --------------------------------------------------------------------------
+def orientation_similarity_map(simulation_indices, shape, n_best=None, normalize=False, from_n_best=None,
+                               footprint=None, center_index=2):
+    """indexing/_orientation_similarity_map.py:30-152.  Per map point: the mean,
+    over its neighbours in `footprint` (scipy.ndimage.generic_filter: footprint
+    centred at shape // 2, values outside the map = -1, neighbours = footprint
+    points that are inside the map and are not the centre point), of the number
+    of dictionary indices shared by the n best matches of the point and of the
+    neighbour (`len(np.intersect1d(a, b))`: unique values).  One layer per n from
+    `n_best` down to `from_n_best`; float32; squeezed."""
+    simulation_indices = np.asarray(simulation_indices)
+    nav_size, keep_n = simulation_indices.shape
+    if n_best is None:
+        n_best = keep_n
+    elif n_best > keep_n:
+        raise ValueError(f"n_best {n_best} cannot be greater than keep_n {keep_n}")
+    if from_n_best is None:
+        from_n_best = n_best
+    ny, nx = shape
+    if footprint is None:
+        footprint = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+    footprint = np.asarray(footprint)
+    offsets = [(i - footprint.shape[0] // 2, j - footprint.shape[1] // 2)
+               for i in range(footprint.shape[0]) for j in range(footprint.shape[1]) if footprint[i, j]]
+    osm = np.zeros((ny, nx, n_best - from_n_best + 1), dtype=np.float32)
+    for layer, n in enumerate(range(n_best, from_n_best - 1, -1)):
+        sets = [set(row[:n].tolist()) for row in simulation_indices]
+        for y in range(ny):
+            for x in range(nx):
+                v = [(y + dy) * nx + (x + dx) if 0 <= y + dy < ny and 0 <= x + dx < nx else -1 for dy, dx in offsets]
+                centre = v[center_index]
+                counts = [len(sets[centre] & sets[p]) for p in v if p != -1 and p != centre]
+                with np.errstate(invalid="ignore"):
+                    value = np.float64(np.sum(counts)) / len(counts) if counts else np.float64(np.nan)
+                if normalize:
+                    value /= n
+                osm[y, x, layer] = value
+    return osm.squeeze()
+
+
+# --------------------------------------------------------------------------
 # comparison helper shared by the parity tests
 # --------------------------------------------------------------------------
 def assert_topk_parity(scores, indices, ref_scores, ref_indices, atol=1e-5, tie=2e-5):

@@ -93,11 +93,116 @@ class _Recorder:
         return self
 
 
+# ---- minimal stand-ins for the orix objects `merge_crystal_maps` manipulates
+# (indexing/_merge_crystal_maps.py): only what that function touches.
+class FakeStructure(list):
+    class _Lattice:
+        def abcABG(self):
+            return (1.0, 1.0, 1.0, 90.0, 90.0, 90.0)
+
+    lattice = _Lattice()
+
+
+class FakePhase:
+    def __init__(self, name):
+        self.name = name
+        self.space_group = None
+        self.point_group = None
+        self.structure = FakeStructure()
+
+    def deepcopy(self):
+        return FakePhase(self.name)
+
+
+class FakePhaseList:
+    """orix.crystal_map.PhaseList: IDs count up from 0 in the order of addition,
+    'not_indexed' has ID -1."""
+
+    def __init__(self, phases=None):
+        self._dict = {}
+        for p in phases or []:
+            self.add(p)
+
+    def add(self, phase):
+        ids = [i for i in self._dict if i >= 0]
+        self._dict[max(ids) + 1 if ids else 0] = phase
+
+    def add_not_indexed(self):
+        self._dict[-1] = FakePhase("not_indexed")
+
+    @property
+    def names(self):
+        return [p.name for p in self._dict.values()]
+
+    @property
+    def ids(self):
+        return list(self._dict)
+
+    def id_from_name(self, name):
+        return [i for i, p in self._dict.items() if p.name == name][0]
+
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return self._dict[self.id_from_name(key)]
+        return self._dict[key]
+
+
+class FakeRotations:
+    def __init__(self, data):
+        import numpy as np
+
+        self.data = np.asarray(data)
+
+    def __getitem__(self, key):
+        return FakeRotations(self.data[key])
+
+
+class FakeCrystalMap:
+    """A single-phase map: `prop` arrays hold the points that are in the data."""
+
+    def __init__(self, shape, rotations, prop, phase_name, is_in_data=None, phase_id=None, scan_unit="px"):
+        import numpy as np
+
+        self._original_shape = tuple(shape)
+        size = int(np.prod(shape))
+        self.is_in_data = np.ones(size, dtype=bool) if is_in_data is None else np.asarray(is_in_data)
+        n = int(self.is_in_data.sum())
+        self.rotations = FakeRotations(rotations)
+        self.prop = prop
+        self.phase_id = np.zeros(n, dtype=int) if phase_id is None else np.asarray(phase_id)
+        self._phase = FakePhase(phase_name)
+        self.scan_unit = scan_unit
+        self.dx = self.dy = 1.0
+
+    @property
+    def shape(self):
+        return self._original_shape
+
+    def _data_slices_from_coordinates(self):
+        return tuple(slice(None) for _ in self._original_shape)
+
+    @property
+    def rotations_per_point(self):
+        d = self.rotations.data
+        return 1 if d.ndim == 2 else d.shape[1]
+
+    @property
+    def phases_in_data(self):
+        pl = FakePhaseList()
+        if (self.phase_id == -1).any():
+            pl.add_not_indexed()
+        if (self.phase_id != -1).any():
+            pl.add(self._phase)
+        return pl
+
+
 def _stub_orix():
     orix = types.ModuleType("orix")
     cm = types.ModuleType("orix.crystal_map")
     qu = types.ModuleType("orix.quaternion")
     cm.CrystalMap = _Recorder
+    cm.Phase = FakePhase
+    cm.PhaseList = FakePhaseList
     cm.create_coordinate_arrays = lambda shape, step_sizes=None: ({}, None)
     qu.Rotation = _Recorder
     orix.crystal_map = cm
