@@ -228,6 +228,36 @@ int kpdi_orientation_similarity_map(kpdi_ctx *ctx, const int64_t *simulation_ind
                                     const int32_t *footprint_offsets, int n_fp, int center_index,
                                     int normalize, float *out);
 
+/* ---- kikuchipy h5ebsd files --------------------------------------
+ * What `kikuchipy.load("file.h5")` reads for this path
+ * (io/plugins/kikuchipy_h5ebsd/_api.py:64-160, io/plugins/_h5ebsd.py:303-390): the scan's
+ * header, `EBSD/Data/patterns` as (n_rows, n_columns, pattern_height, pattern_width) -
+ * zero padded when the file holds fewer patterns -, `EBSD/Header/static_background` and
+ * the projection centres.  The HDF5 C library is dlopen()ed (libhdf5.so from the
+ * loader path, /opt/conda/lib, or $KPDI_HDF5_LIB); without it these calls fail.
+ * `scan`: group name ("Scan 1"), NULL or "" = the first scan of the file. */
+typedef struct kpdi_h5ebsd_info {
+  char scan[64];                 /* the scan group that was read */
+  int32_t ny, nx, sy, sx;        /* n_rows, n_columns, pattern_height, pattern_width */
+  int32_t dtype;                 /* KPDI_* element type of the patterns */
+  int32_t has_static_background; /* EBSD/Header/static_background of shape sy x sx present */
+  int32_t static_background_dtype;
+  int32_t binning;
+  int64_t n_stored;              /* pattern values actually in the file (< ny*nx*sy*sx: padded) */
+  int64_t n_pc;                  /* projection centres in the header (1 or ny*nx), 0 = none */
+  double step_y, step_x, detector_pixel_size, sample_tilt, azimuth_angle, elevation_angle;
+} kpdi_h5ebsd_info;
+size_t kpdi_dtype_size(int dtype);
+int kpdi_h5ebsd_info_read(const char *path, const char *scan, kpdi_h5ebsd_info *info);
+int kpdi_h5ebsd_read_patterns(const char *path, const char *scan, void *out, size_t out_bytes);
+int kpdi_h5ebsd_read_static_background(const char *path, const char *scan, void *out, size_t out_bytes);
+/* out: n_pc x (PCx, PCy, PCz) float64 (Bruker convention, as stored) */
+int kpdi_h5ebsd_read_pc(const char *path, const char *scan, double *out, int64_t n_pc);
+/* read the scan's patterns through a pinned host buffer straight into the context's
+ * experimental set (= kpdi_set_experimental of the file's contents) */
+int kpdi_set_experimental_h5ebsd(kpdi_ctx *ctx, const char *path, const char *scan,
+                                 const uint8_t *nav_mask);
+
 /* ---- multi-GPU: dictionary sharded over ranks, one process per GPU -------- */
 #define KPDI_UNIQUE_ID_BYTES 128
 int kpdi_comm_unique_id(uint8_t *id_out /* KPDI_UNIQUE_ID_BYTES */);

@@ -23,6 +23,7 @@ from kikuchipy_amd.pattern import remove_dynamic_background, remove_static_backg
 from kikuchipy_amd.detectors import EBSDDetector  # noqa: E402,F401
 from kikuchipy_amd.signals import EBSD, DictionaryXmap, EBSDMasterPattern  # noqa: E402,F401
 from kikuchipy_amd.simulations import ProjectedDictionary  # noqa: E402,F401
+from kikuchipy_amd.io import load  # noqa: E402,F401
 
 __all__ = [
     "DictionaryIndexingResult",
@@ -36,6 +37,7 @@ __all__ = [
     "NormalizedDotProductMetric",
     "SimilarityMetric",
     "dictionary_indexing",
+    "load",
     "merge_crystal_maps",
     "orientation_similarity_map",
     "remove_dynamic_background",

@@ -58,6 +58,21 @@ class Counters(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class H5ebsdInfo(C.Structure):
+    _fields_ = [
+        ("scan", C.c_char * 64),
+        ("ny", C.c_int32), ("nx", C.c_int32), ("sy", C.c_int32), ("sx", C.c_int32),
+        ("dtype", C.c_int32),
+        ("has_static_background", C.c_int32),
+        ("static_background_dtype", C.c_int32),
+        ("binning", C.c_int32),
+        ("n_stored", C.c_int64),
+        ("n_pc", C.c_int64),
+        ("step_y", C.c_double), ("step_x", C.c_double), ("detector_pixel_size", C.c_double),
+        ("sample_tilt", C.c_double), ("azimuth_angle", C.c_double), ("elevation_angle", C.c_double),
+    ]
+
+
 # every symbol include/kpdi.h declares: (restype, argtypes)
 _vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 SIGNATURES = {
@@ -89,6 +104,12 @@ SIGNATURES = {
     "kpdi_refine_solve": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, C.c_double, C.c_double, _i, _i, _vp]),
     "kpdi_nelder_mead_selftest": (_i, [_vp, _i, _i, _vp, _vp, _vp, C.c_double, C.c_double, _i, _i, _vp]),
     "kpdi_orientation_similarity_map": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "kpdi_dtype_size": (_sz, [_i]),
+    "kpdi_h5ebsd_info_read": (_i, [C.c_char_p, C.c_char_p, C.POINTER(H5ebsdInfo)]),
+    "kpdi_h5ebsd_read_patterns": (_i, [C.c_char_p, C.c_char_p, _vp, _sz]),
+    "kpdi_h5ebsd_read_static_background": (_i, [C.c_char_p, C.c_char_p, _vp, _sz]),
+    "kpdi_h5ebsd_read_pc": (_i, [C.c_char_p, C.c_char_p, _vp, _i64]),
+    "kpdi_set_experimental_h5ebsd": (_i, [_vp, C.c_char_p, C.c_char_p, _vp]),
     "kpdi_reset_topk": (_i, [_vp]),
     "kpdi_finalize": (_i, [_vp, _vp, _vp]),
     "kpdi_comm_unique_id": (_i, [_vp]),
@@ -146,6 +167,36 @@ def dtype_code(dtype):
         return DTYPE_CODES[np.dtype(dtype)]
     except KeyError:
         raise KpdiError(f"pattern dtype {np.dtype(dtype)} is not supported by libkpdi") from None
+
+
+DTYPE_FROM_CODE = {code: dt for dt, code in DTYPE_CODES.items()}
+
+
+def _cstr(s):
+    return None if s is None else os.fsencode(s)
+
+
+def h5ebsd_info(path, scan=None):
+    info = H5ebsdInfo()
+    check(load().kpdi_h5ebsd_info_read(_cstr(path), _cstr(scan), C.byref(info)))
+    return info
+
+
+def h5ebsd_read(path, scan=None):
+    """(info, patterns (ny, nx, sy, sx), static background or None, PCs (n_pc, 3) or None)."""
+    info = h5ebsd_info(path, scan)
+    name = info.scan
+    pats = np.empty((info.ny, info.nx, info.sy, info.sx), dtype=DTYPE_FROM_CODE[info.dtype])
+    check(load().kpdi_h5ebsd_read_patterns(_cstr(path), name, _ptr(pats), pats.nbytes))
+    bg = None
+    if info.has_static_background:
+        bg = np.empty((info.sy, info.sx), dtype=DTYPE_FROM_CODE[info.static_background_dtype])
+        check(load().kpdi_h5ebsd_read_static_background(_cstr(path), name, _ptr(bg), bg.nbytes))
+    pc = None
+    if info.n_pc > 0:
+        pc = np.empty((info.n_pc, 3), dtype=np.float64)
+        check(load().kpdi_h5ebsd_read_pc(_cstr(path), name, _ptr(pc), info.n_pc))
+    return info, pats, bg, pc
 
 
 def _ptr(a):
@@ -209,6 +260,17 @@ class Context:
         check(load().kpdi_set_experimental(self._h, _ptr(p), dtype_code(p.dtype), m_all, _ptr(nm)))
         check(load().kpdi_synchronize(self._h))  # upload done: `p` may be a temporary
         self._exp_shape, self._exp_dtype = p.shape, p.dtype
+
+    def set_experimental_h5ebsd(self, path, scan=None, navigation_mask=None):
+        """Patterns of a kikuchipy h5ebsd scan: file -> pinned host buffer -> HBM."""
+        info = h5ebsd_info(path, scan)
+        nm = _mask_bytes(navigation_mask)
+        if nm is not None and nm.size != info.ny * info.nx:
+            raise KpdiError(f"navigation mask has {nm.size} elements, the scan has {info.ny * info.nx} patterns")
+        check(load().kpdi_set_experimental_h5ebsd(self._h, _cstr(path), info.scan, _ptr(nm)))
+        self._exp_shape = (info.ny * info.nx, info.sy, info.sx)
+        self._exp_dtype = DTYPE_FROM_CODE[info.dtype]
+        return info
 
     def set_experimental_dev(self, d_ptr, dtype, m_all, navigation_mask=None):
         nm = _mask_bytes(navigation_mask)

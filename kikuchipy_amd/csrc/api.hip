@@ -104,6 +104,18 @@ Rccl g_rccl;
 
 }  // namespace
 
+namespace kpdi {
+// for the other translation units with extern "C" entry points (h5ebsd.hip)
+int fail_msg(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  return fail(code, "%s", buf);
+}
+}  // namespace kpdi
+
 struct kpdi_ctx {
   int device = 0;
   int n_cu = 256;
@@ -1173,6 +1185,8 @@ int kpdi_orientation_similarity_map(kpdi_ctx *c, const int64_t *simulation_indic
   HIPCHK(hipStreamSynchronize(c->stream));
   return KPDI_OK;
 }
+
+size_t kpdi_dtype_size(int dtype) { return kpdi::dtype_size(dtype); }
 
 int kpdi_reset_topk(kpdi_ctx *c) {
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");

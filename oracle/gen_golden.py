@@ -634,6 +634,57 @@ def gen_consumers():
     print("consumers", sorted(out))
 
 
+# ------------------------------------------------------------------ h5ebsd fixture (8(f4))
+def gen_h5ebsd():
+    """tests/golden/h5ebsd_ni.h5: a kikuchipy-h5ebsd file (layout of
+    io/plugins/kikuchipy_h5ebsd/_api.py) written with h5py from the Ni patterns
+    the reference ships: Scan 1 contiguous uint8; Scan 2 chunked + gzip +
+    shuffle, one PC; Scan 3 float32, only 7 of the 9 patterns stored (the
+    reader zero pads, io/plugins/_h5ebsd.py:367-378), no static background.
+    Expected arrays go to h5ebsd_expected.npz."""
+    import h5py
+
+    pats, bg = load_ni()
+    src = os.path.join(ref_shim.SRC, "data", "kikuchipy_h5ebsd", "patterns.h5")
+    with h5py.File(src, "r") as f:
+        pcs = [f[f"Scan 1/EBSD/Header/pc{a}"][()] for a in "xyz"]
+    path = os.path.join(OUT, "h5ebsd_ni.h5")
+    flat = pats.reshape(9, 60, 60)
+    with h5py.File(path, "w") as f:
+        f.create_dataset("manufacturer", data=np.array([b"kikuchipy"]))
+        f.create_dataset("version", data=np.array([b"0.8.dev0"]))
+
+        def header(scan, **extra):
+            h = f.create_group(f"{scan}/EBSD/Header")
+            vals = dict(n_rows=3, n_columns=3, pattern_height=60, pattern_width=60, binning=8,
+                        detector_pixel_size=70.0, sample_tilt=70, azimuth_angle=0, elevation_angle=1.5,
+                        step_x=1.5, step_y=1.5)
+            vals.update(extra)
+            for k, v in vals.items():
+                h.create_dataset(k, data=np.atleast_1d(v))
+            f.create_group(f"{scan}/SEM/Header").create_dataset("beam_energy", data=np.array([20.0]))
+            return h
+
+        h = header("Scan 1")
+        h.create_dataset("static_background", data=bg)
+        for a, v in zip("xyz", pcs):
+            h.create_dataset(f"pc{a}", data=v)
+        f.create_dataset("Scan 1/EBSD/Data/patterns", data=flat)
+        h = header("Scan 2", step_x=0.5, step_y=0.25)
+        h.create_dataset("static_background", data=bg)
+        for a, v in zip("xyz", (0.42, 0.21, 0.5)):
+            h.create_dataset(f"pc{a}", data=np.array([v]))
+        f.create_dataset("Scan 2/EBSD/Data/patterns", data=flat[::-1], chunks=(2, 60, 60), compression="gzip",
+                         compression_opts=4, shuffle=True)
+        h = header("Scan 3", n_rows=1, n_columns=9)
+        f.create_dataset("Scan 3/EBSD/Data/patterns", data=flat[:7].astype(np.float32) / 3)
+    padded = np.zeros((9, 60, 60), dtype=np.float32)
+    padded[:7] = flat[:7].astype(np.float32) / 3
+    np.savez_compressed(os.path.join(OUT, "h5ebsd_expected.npz"), scan1=pats, scan2=flat[::-1].reshape(3, 3, 60, 60),
+                        scan3=padded, static_background=bg, pc1=np.stack([p.ravel() for p in pcs], axis=1))
+    print("h5ebsd", os.path.getsize(path))
+
+
 # ------------------------------------------------------------------ the reference tests' own known answers
 def gen_refknown():
     """Extract the hard-coded known-answer ARRAYS (data, not code) that the
@@ -681,5 +732,6 @@ if __name__ == "__main__":
     gen_projection()
     gen_refinement()
     gen_consumers()
+    gen_h5ebsd()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
