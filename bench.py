@@ -295,6 +295,54 @@ def main():
             "patterns_per_s_including_generation": round(w["m"] / dt, 1),
         }
 
+    if world == 1 and not a.no_generation:
+        # informational: orientation refinement of m patterns simulated from the same
+        # master pattern (1 degree off, noise added), SciPy-compatible Nelder-Mead on the device; beside
+        # it the oracle (NumPy objective + scipy.optimize.minimize, what the reference runs per pattern)
+        # on a few of the patterns.  Never `value`.
+        from kikuchipy_amd.indexing._refinement import rotation_from_euler
+
+        eu = np.column_stack([rng.uniform(0.3, 6, w["m"]), rng.uniform(0.3, 2.8, w["m"]), rng.uniform(0.3, 6, w["m"])])
+        mpu = np.fft.irfft2(np.fft.rfft2(rng.standard_normal((401, 401))) * np.exp(
+            -(np.add.outer(np.fft.fftfreq(401) ** 2, np.fft.rfftfreq(401) ** 2)) / (2 * 0.03**2)), s=(401, 401))
+        mpu = mpu.astype(np.float32)
+        ctx.set_master_pattern(mpu)
+        sim = ctx.project_patterns(rotation_from_euler(eu))
+        noisy = sim + 0.3 * sim.std() * rng.standard_normal(sim.shape).astype(np.float32)
+        pats = ((noisy - noisy.min()) / (noisy.max() - noisy.min()) * 255).astype(np.uint8).reshape(-1, w["sy"], w["sx"])
+        eu0 = eu + np.deg2rad(rng.uniform(-1, 1, eu.shape))
+        pcs = np.tile(pc, (w["m"], 1, 1))
+        ctx.refine_set_patterns(pats, mask, False, det_to_sample)
+        for r in range(3):
+            if r == 1:
+                ctx.reset_counters()
+                t0 = time.perf_counter()
+            res = ctx.refine_solve(_lib.REFINE_ORI, eu0[:, None, :], pcs)
+        dt = (time.perf_counter() - t0) / 2
+        kern = ctx.counters()["refine_ms"] / 2
+        evals = float(res[:, 0, 1].sum())
+        k_ref = int(w["sy"] * w["sx"] if mask is None else np.count_nonzero(~mask))
+        out["extra"]["refinement"] = {
+            "what": f"refine_orientation of {w['m']} patterns, Nelder-Mead on the device (kpdi::refine_solve_kernel)",
+            "patterns_per_s": round(w["m"] / dt, 1),
+            "kernel_ms": round(kern, 3),
+            "objective_evaluations_per_s": round(evals / (kern * 1e-3), 1),
+            "gpixel_per_s": round(evals * k_ref / (kern * 1e-3) / 1e9, 1),
+            "mean_evaluations": round(evals / w["m"], 1),
+            "mean_score": round(float(1 - res[:, 0, 0].mean()), 4),
+        }
+        if not a.no_cpu_baseline:
+            from oracle import kpdi_oracle as ko
+
+            keep = None if mask is None else ~mask.ravel()
+            dc = ko.direction_cosines_fixed_pc(np.asarray(bounds), pc[2], w["sy"], w["sx"], det_to_sample, keep)
+            n_cpu = 8
+            t0 = time.perf_counter()
+            for i in range(n_cpu):
+                p = pats[i].ravel() if keep is None else pats[i].ravel()[keep]
+                ko.refine_solver(p, "ori", eu0[i], mpu, mpu, False, direction_cosines=dc)
+            out["extra"]["refinement"]["cpu_port_patterns_per_s"] = round(n_cpu / (time.perf_counter() - t0), 2)
+
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, exp, dic, bg, mask, min(a.cpu_sample, w["n"]))
     ctx.close()

@@ -222,11 +222,10 @@ def refine(mode, patterns, rotations, detector, master_pattern, energy=None, nav
     rot = np.asarray(getattr(rotations, "data", rotations), dtype=np.float64)
     if rot.shape[-1] != 4:
         raise ValueError("`rotations` must be quaternions with a last axis of size 4")
-    if rot.ndim == len(nav_shape) + 2:  # several rotations per point: refine the best
-        rot = rot[..., 0, :]
-    if rot.size != nav_size * 4:
+    if rot.size % (nav_size * 4) != 0 or rot.size == 0:
         raise ValueError(f"need one rotation per pattern ({nav_size}), got an array of shape {rot.shape}")
-    rot = rot.reshape(nav_size, 4)
+    # several rotations per point (the k best of dictionary indexing): refine the best
+    rot = rot.reshape(nav_size, -1, 4)[:, 0]
     if navigation_mask is not None:
         if navigation_mask.shape != (nav_shape or (1,)):
             raise ValueError(
