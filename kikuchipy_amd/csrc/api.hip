@@ -242,14 +242,28 @@ int use_device(kpdi_ctx *c) {
   return KPDI_OK;
 }
 
-int choose_nsplit(const kpdi_ctx *c, int row_blocks, int n_tiles) {
-  // fill every CU with match_blocks_per_cu() workgroups; keep nsplit a multiple
-  // of 8 so that the workgroups of one XCD (block id % 8) share dictionary slabs
-  const int target = c->n_cu * kpdi::match_blocks_per_cu();
-  int ns = (target + row_blocks - 1) / row_blocks;
-  if (ns >= 8) ns = ((ns + 7) / 8) * 8;
-  ns = std::max(1, std::min(ns, n_tiles));
-  return ns;
+// How a sweep of `row_blocks` x `n_tiles` tile pairs is laid on the CUs (one persistent
+// workgroup per CU): `nsplit` workgroups share the dictionary tiles of a row block through
+// its dynamic tile counter, and a launch covers as many row blocks as fit the chip; larger
+// experimental sets take several launches.  The plan minimises the makespan counted in
+// tiles: launches * ceil(n_tiles / nsplit), plus a small per-launch cost.
+int choose_nsplit(const kpdi_ctx *c, int row_blocks, int n_tiles, int *rows_per_launch) {
+  const int cap = c->n_cu * kpdi::match_blocks_per_cu();
+  int best_ns = 1, best_rpl = std::max(1, std::min(row_blocks, cap));
+  double best_cost = 1e30;
+  for (int ns = 1; ns <= std::min(cap, n_tiles); ns = ns < 4 ? ns + 1 : ns + 4) {
+    const int rpl = std::max(1, std::min(row_blocks, cap / ns));
+    const int launches = (row_blocks + rpl - 1) / rpl;
+    // multiples of 8 keep the workgroups of one XCD (block id % 8) on the same row block
+    const double cost = launches * ((n_tiles + ns - 1) / ns + 0.5) * (ns % 8 == 0 ? 1.0 : 1.02);
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best_ns = ns;
+      best_rpl = rpl;
+    }
+  }
+  *rows_per_launch = best_rpl;
+  return best_ns;
 }
 
 int prepare_experimental(kpdi_ctx *c) {
@@ -292,8 +306,8 @@ int ensure_running(kpdi_ctx *c) {
 }
 
 // one match launch over the prepared chunk -> partial lists
-int run_match(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int list_len, int64_t global_start,
-              const float *bound_s, const int *bound_i) {
+int run_match(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int rows_per_launch, int list_len,
+              int64_t global_start, const float *bound_s, const int *bound_i) {
   const size_t part = (size_t)c->m_pad * 2 * nsplit * list_len;
   HIPCHK(c->part_s.reserve(part * sizeof(float)));
   HIPCHK(c->part_i.reserve(part * sizeof(int)));
@@ -329,13 +343,18 @@ int run_match(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int list_len, i
   HIPCHK(c->tile_ctr.reserve(ctr_bytes));
   HIPCHK(hipMemsetAsync(c->tile_ctr.p, 0, ctr_bytes, c->stream));
   ml.tile_ctr = c->tile_ctr.as<unsigned>();
+  const int row_blocks = c->m_pad / kpdi::TILE_EXP;
   {
-    ScopedTimer t(c, &c->ev_match);
-    HIPCHK(kpdi::launch_match(ml, c->stream));
+    ScopedTimer t(c, &c->ev_match);  // one timed region = the whole sweep of this chunk
+    for (int r0 = 0; r0 < row_blocks; r0 += rows_per_launch) {
+      ml.row_first = r0;
+      ml.rows = std::min(rows_per_launch, row_blocks - r0);
+      HIPCHK(kpdi::launch_match(ml, c->stream));
+    }
   }
   c->cnt.match_launches += 1;
   c->cnt.match_flops += 2.0 * (double)c->m * (double)n_chunk * (double)c->k_kept;
-  c->cnt.match_grid = (c->m_pad / kpdi::TILE_EXP) * nsplit;
+  c->cnt.match_grid = std::min(rows_per_launch, row_blocks) * nsplit;
   c->cnt.match_nsplit = nsplit;
   return KPDI_OK;
 }
@@ -376,7 +395,8 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
   }
 
   const int row_blocks = c->m_pad / kpdi::TILE_EXP;
-  const int nsplit = choose_nsplit(c, row_blocks, n_tiles);
+  int rows_per_launch = row_blocks;
+  const int nsplit = choose_nsplit(c, row_blocks, n_tiles, &rows_per_launch);
   const int k = c->keep_n;
   const int cur = c->run_cur, nxt = cur ^ 1;
   c->final_valid = false;
@@ -398,7 +418,7 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
 
   if (k <= kpdi::KMAX_LIMIT) {
     const int len = kpdi::match_list_len(k);
-    rc = run_match(c, (int)n_chunk, n_tiles, nsplit, len, global_start, nullptr, nullptr);
+    rc = run_match(c, (int)n_chunk, n_tiles, nsplit, rows_per_launch, len, global_start, nullptr, nullptr);
     if (rc) return rc;
     mg.src_scores[1] = c->part_s.as<float>();
     mg.src_idx[1] = c->part_i.as<int>();
@@ -422,7 +442,7 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
       const int kp = std::min(kpdi::KMAX_LIMIT, kk - done);
       const int len = kpdi::match_list_len(kp);
       c->bound_key = -1;  // each pass ranks a different slice: its shared bound starts from scratch
-      rc = run_match(c, (int)n_chunk, n_tiles, nsplit, len, global_start,
+      rc = run_match(c, (int)n_chunk, n_tiles, nsplit, rows_per_launch, len, global_start,
                      done ? c->bound_s.as<float>() : nullptr, done ? c->bound_i.as<int>() : nullptr);
       if (rc) return rc;
       kpdi::MergeLaunch pm{};

@@ -40,6 +40,8 @@ struct MatchLaunch {
   int n_valid;        // valid dictionary patterns in this chunk
   int m_pad;          // multiple of TILE_EXP
   int nsplit;         // dictionary splits (lists per pattern = 2 * nsplit)
+  int row_first;      // first 256-pattern row block of this launch
+  int rows;           // row blocks of this launch (grid = rows * nsplit)
   int idx_base;       // dictionary index of chunk row 0
   int list_len;       // KMAX of the instantiation
   float *part_scores; // [m_pad][2*nsplit][list_len]

@@ -59,7 +59,7 @@ __device__ __forceinline__ float key_score32(unsigned u);
 struct MatchArgs {
   const float *dict;
   const float *exp;
-  int kpad, n_tiles, n_valid, nsplit, idx_base;
+  int kpad, n_tiles, n_valid, nsplit, idx_base, row_first;
   float *part_scores;
   int *part_idx;
   const float *bound_score;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
   // block -> (block of 256 experimental patterns rb, list slot sp); block b sits on XCD
   // b%8 (speed only): consecutive blocks of one XCD share rb, i.e. the experimental slabs
   const int sp = blockIdx.x % a.nsplit;
-  const int rb = blockIdx.x / a.nsplit;
+  const int rb = a.row_first + blockIdx.x / a.nsplit;
   // kernel arguments into locals (nothing below takes the address of `a`)
   const float *a_dict = a.dict;
   const int n_tiles = a.n_tiles, n_valid = a.n_valid, idx_base = a.idx_base;
@@ -482,6 +482,7 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   g.n_valid = a.n_valid;
   g.nsplit = a.nsplit;
   g.idx_base = a.idx_base;
+  g.row_first = a.row_first;
   g.part_scores = a.part_scores;
   g.part_idx = a.part_idx;
   g.bound_score = a.bound_score;
@@ -490,7 +491,7 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   g.bound_rank = a.bound_rank;
   g.bound_grouped = a.bound_grouped;
   g.tile_ctr = a.tile_ctr;
-  const int grid = (a.m_pad / TILE_EXP) * a.nsplit;
+  const int grid = a.rows * a.nsplit;
   const bool bounded = a.bound_score != nullptr;
 #define KPDI_CASE(K)                                           \
   case K:                                                      \
