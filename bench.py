@@ -254,12 +254,13 @@ def main():
     if world == 1 and not a.no_pcie:
         # informational: the same sweep with the dictionary handed over as a HOST
         # buffer (pageable memory -> PCIe inside the step).  Never `value`.
-        ctx.set_experimental_dev(d_exp, exp.dtype, w["m"])
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        ctx.push_dictionary_chunk(dic, 0)
-        ctx.finalize(w["keep_n"])
-        out["extra"]["pcie_inclusive_patterns_per_s"] = round(w["m"] / (time.perf_counter() - t0), 1)
+        for r in range(2):  # the first pass allocates the staging buffers
+            ctx.set_experimental_dev(d_exp, exp.dtype, w["m"])
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            ctx.push_dictionary_chunk(dic, 0)
+            ctx.finalize(w["keep_n"])
+            out["extra"]["pcie_inclusive_patterns_per_s"] = round(w["m"] / (time.perf_counter() - t0), 1)
 
     if world == 1 and not a.no_generation:
         # informational: the dictionary is SIMULATED on the device inside the step

@@ -124,7 +124,11 @@ int kpdi_get_experimental(kpdi_ctx *ctx, void *patterns_out);
  * match + top-k of the chunk + merge into the running best-k, all on the GPU.
  * `global_start` is the dictionary index of the chunk's first pattern
  * (`simulation_indices_i += start`, :118).  Chunks may arrive in any order and,
- * with several ranks, each rank pushes only its own shard. */
+ * with several ranks, each rank pushes only its own shard.
+ * The host-pointer form returns as soon as the upload has consumed `patterns` (the sweep
+ * of the chunk is still running; it is ordered before every later call on the context);
+ * uploads go through two staging buffers on a copy stream and overlap the sweep of the
+ * previous piece / chunk. */
 int kpdi_push_dictionary_chunk(kpdi_ctx *ctx, const void *patterns, int dtype,
                                int64_t n_chunk, int64_t global_start);
 int kpdi_push_dictionary_chunk_dev(kpdi_ctx *ctx, const void *d_patterns, int dtype,

@@ -299,9 +299,9 @@ class Context:
     # -- sweep
     def push_dictionary_chunk(self, patterns, global_start):
         p = np.ascontiguousarray(patterns)
+        # returns when the upload has consumed `p`; the sweep of the chunk runs on
         check(load().kpdi_push_dictionary_chunk(self._h, _ptr(p), dtype_code(p.dtype), p.shape[0],
                                                 int(global_start)))
-        check(load().kpdi_synchronize(self._h))  # the H2D copy has consumed `p`
 
     def push_dictionary_chunk_dev(self, d_ptr, dtype, n_chunk, global_start):
         check(load().kpdi_push_dictionary_chunk_dev(self._h, C.c_void_p(d_ptr), dtype_code(dtype),

@@ -140,6 +140,12 @@ struct kpdi_ctx {
 
   // dictionary chunk
   DevBuf dict_raw, dict_y;
+  // host-pointer pushes are cut into pieces whose upload (copy stream) overlaps the sweep of
+  // the previous piece (compute stream): two staging buffers, events for hand-over
+  DevBuf stage[2];
+  hipStream_t copy_stream = nullptr;
+  int stage_next = 0;
+  hipEvent_t stage_filled[2] = {nullptr, nullptr}, stage_free[2] = {nullptr, nullptr};
 
   // top-k state
   DevBuf part_s, part_i;       // partial lists of one match launch
@@ -567,7 +573,7 @@ int kpdi_destroy(kpdi_ctx *c) {
                     &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps,
                     &c->mp_packed, &c->dcos, &c->rot, &c->proj_out,
                     &c->ref_raw, &c->ref_map, &c->ref_rowcol, &c->ref_pat, &c->ref_sqn, &c->ref_in, &c->ref_out,
-                    &c->ref_idx, &c->osm_idx, &c->osm_out})
+                    &c->ref_idx, &c->osm_idx, &c->osm_out, &c->stage[0], &c->stage[1]})
     b->release();
   for (auto *l : {&c->ev_match, &c->ev_prep, &c->ev_merge, &c->ev_proj})
     for (auto &pr : *l) {
@@ -575,6 +581,14 @@ int kpdi_destroy(kpdi_ctx *c) {
       (void)hipEventDestroy(pr.second);
     }
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  for (int b = 0; b < 2; ++b) {
+    if (c->stage_filled[b]) (void)hipEventDestroy(c->stage_filled[b]);
+    if (c->stage_free[b]) (void)hipEventDestroy(c->stage_free[b]);
+  }
+  if (c->copy_stream) {
+    (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamDestroy(c->copy_stream);
+  }
   (void)hipStreamDestroy(c->stream);
   delete c;
   return KPDI_OK;
@@ -768,11 +782,46 @@ int kpdi_push_dictionary_chunk(kpdi_ctx *c, const void *patterns, int dtype, int
   if (n_chunk <= 0) return fail(KPDI_EINVAL, "dictionary chunk must hold at least one pattern");
   int rc = use_device(c);
   if (rc) return rc;
-  const size_t bytes = (size_t)n_chunk * c->npix * es;
-  HIPCHK(c->dict_raw.reserve(bytes));
-  HIPCHK(hipMemcpyAsync(c->dict_raw.p, patterns, bytes, hipMemcpyHostToDevice, c->stream));
-  c->cnt.h2d_bytes += (double)bytes;
-  return push_chunk_dev(c, c->dict_raw.p, dtype, n_chunk, global_start);
+  // The upload always goes through two staging buffers on a copy stream, so that it overlaps
+  // the sweep of the previous piece - of this call (large chunks are cut into pieces of >= 192
+  // dictionary tiles, which keeps the match kernel's tile counts per workgroup healthy) or of
+  // the previous call (a caller streaming chunk after chunk, like the reference's loop).
+  // On return the host buffer has been consumed; the sweep itself may still be running.
+  const int64_t piece = 192 * kpdi::TILE_DICT;
+  const int64_t n_pieces = std::max<int64_t>(1, n_chunk / piece);
+  const size_t row_bytes = (size_t)c->npix * es;
+  if (!c->copy_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+      HIPCHK(hipEventCreateWithFlags(&c->stage_filled[b], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&c->stage_free[b], hipEventDisableTiming));
+      HIPCHK(hipEventRecord(c->stage_free[b], c->stream));
+    }
+  }
+  const int64_t per = (n_chunk + n_pieces - 1) / n_pieces;
+  for (int b = 0; b < 2; ++b)
+    if (c->stage[b].cap < (size_t)per * row_bytes) {
+      // growing a buffer frees it: everything queued on it must have finished
+      HIPCHK(hipStreamSynchronize(c->copy_stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(c->stage[b].reserve((size_t)per * row_bytes));
+    }
+  for (int64_t start = 0; start < n_chunk; start += per) {
+    const int b = c->stage_next;
+    c->stage_next ^= 1;
+    const int64_t n = std::min(per, n_chunk - start);
+    HIPCHK(hipStreamWaitEvent(c->copy_stream, c->stage_free[b], 0));
+    HIPCHK(hipMemcpyAsync(c->stage[b].p, (const char *)patterns + (size_t)start * row_bytes, (size_t)n * row_bytes,
+                          hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(hipEventRecord(c->stage_filled[b], c->copy_stream));
+    c->cnt.h2d_bytes += (double)n * row_bytes;
+    HIPCHK(hipStreamWaitEvent(c->stream, c->stage_filled[b], 0));
+    rc = push_chunk_dev(c, c->stage[b].p, dtype, n, global_start + start);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->stage_free[b], c->stream));  // the prep kernel has consumed the piece
+  }
+  HIPCHK(hipStreamSynchronize(c->copy_stream));  // the caller's buffer is free again
+  return KPDI_OK;
 }
 
 int kpdi_push_dictionary_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk,
