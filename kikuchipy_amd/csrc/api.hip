@@ -143,6 +143,8 @@ struct kpdi_ctx {
   // host-pointer pushes are cut into pieces whose upload (copy stream) overlaps the sweep of
   // the previous piece (compute stream): two staging buffers, events for hand-over
   DevBuf stage[2];
+  hipStream_t stream2 = nullptr;  // second compute stream of multi-launch sweeps
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t copy_stream = nullptr;
   int stage_next = 0;
   hipEvent_t stage_filled[2] = {nullptr, nullptr}, stage_free[2] = {nullptr, nullptr};
@@ -352,10 +354,27 @@ int run_match(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int rows_per_la
   const int row_blocks = c->m_pad / kpdi::TILE_EXP;
   {
     ScopedTimer t(c, &c->ev_match);  // one timed region = the whole sweep of this chunk
-    for (int r0 = 0; r0 < row_blocks; r0 += rows_per_launch) {
+    // several launches (large experimental sets) alternate between two streams: the workgroups
+    // of launch j+1 start on the CUs that launch j's tail leaves idle
+    const bool two = row_blocks > rows_per_launch;
+    if (two) {
+      if (!c->stream2) {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+      }
+      HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+      HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    }
+    int j = 0;
+    for (int r0 = 0; r0 < row_blocks; r0 += rows_per_launch, ++j) {
       ml.row_first = r0;
       ml.rows = std::min(rows_per_launch, row_blocks - r0);
-      HIPCHK(kpdi::launch_match(ml, c->stream));
+      HIPCHK(kpdi::launch_match(ml, (two && (j & 1)) ? c->stream2 : c->stream));
+    }
+    if (two) {
+      HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+      HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     }
   }
   c->cnt.match_launches += 1;
@@ -588,6 +607,12 @@ int kpdi_destroy(kpdi_ctx *c) {
   if (c->copy_stream) {
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipStreamDestroy(c->copy_stream);
+  }
+  if (c->stream2) {
+    (void)hipStreamSynchronize(c->stream2);
+    (void)hipStreamDestroy(c->stream2);
+    (void)hipEventDestroy(c->ev_fork);
+    (void)hipEventDestroy(c->ev_join);
   }
   (void)hipStreamDestroy(c->stream);
   delete c;
