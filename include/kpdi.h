@@ -170,6 +170,14 @@ int kpdi_get_direction_cosines(kpdi_ctx *ctx, double *out);
  * every pattern is min-max rescaled to [out_min, out_max] (pattern/_pattern.py:97-111). */
 int kpdi_project_patterns(kpdi_ctx *ctx, const double *rotations, int64_t n, int rescale,
                           double out_min, double out_max, int dtype_out, void *out);
+/* `_project_patterns_from_master_pattern_with_varying_pc` (:374-445) with
+ * `_get_direction_cosines_for_varying_pc` (:216-295): pattern i is projected with its own
+ * PC pcs[i] = (PCx, PCy, PCz), Bruker convention; the direction cosines are formed on the
+ * device.  Needs only kpdi_set_master_pattern. */
+int kpdi_project_patterns_varying_pc(kpdi_ctx *ctx, const double *rotations, const double *pcs,
+                                     int64_t n, int nrows, int ncols,
+                                     const double *om_detector_to_sample, int rescale,
+                                     double out_min, double out_max, int dtype_out, void *out);
 /* generate + match in one call: the chunk of the dictionary belonging to
  * `rotations` is projected as float32 straight into device memory and swept like
  * kpdi_push_dictionary_chunk(..., KPDI_F32, n, global_start); the detector must have

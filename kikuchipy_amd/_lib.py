@@ -97,6 +97,7 @@ SIGNATURES = {
     "kpdi_set_direction_cosines": (_i, [_vp, _vp, _i64]),
     "kpdi_get_direction_cosines": (_i, [_vp, _vp]),
     "kpdi_project_patterns": (_i, [_vp, _vp, _i64, _i, C.c_double, C.c_double, _i, _vp]),
+    "kpdi_project_patterns_varying_pc": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, C.c_double, C.c_double, _i, _vp]),
     "kpdi_push_rotations_chunk": (_i, [_vp, _vp, _i64, _i64, _i, C.c_double, C.c_double]),
     "kpdi_refine_set_patterns": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _i, _vp]),
     "kpdi_refine_get_prepared": (_i, [_vp, _vp, _vp]),
@@ -340,6 +341,19 @@ class Context:
         out = np.empty((rot.shape[0], self._dc_npix), dtype=dtype_out)
         check(load().kpdi_project_patterns(self._h, _ptr(rot), rot.shape[0], int(bool(rescale)),
                                            float(out_min), float(out_max), dtype_code(out.dtype), _ptr(out)))
+        return out
+
+    def project_patterns_varying_pc(self, rotations, pcs, shape, om_detector_to_sample, rescale=False, out_min=-1.0,
+                                    out_max=1.0, dtype_out=np.float32):
+        rot = np.ascontiguousarray(rotations, dtype=np.float64).reshape(-1, 4)
+        pc = np.ascontiguousarray(pcs, dtype=np.float64).reshape(-1, 3)
+        if pc.shape[0] != rot.shape[0]:
+            raise KpdiError(f"{rot.shape[0]} rotations but {pc.shape[0]} projection centres")
+        om = np.ascontiguousarray(om_detector_to_sample, dtype=np.float64).ravel()
+        out = np.empty((rot.shape[0], shape[0] * shape[1]), dtype=dtype_out)
+        check(load().kpdi_project_patterns_varying_pc(self._h, _ptr(rot), _ptr(pc), rot.shape[0], int(shape[0]),
+                                                      int(shape[1]), _ptr(om), int(bool(rescale)), float(out_min),
+                                                      float(out_max), dtype_code(out.dtype), _ptr(out)))
         return out
 
     def push_rotations_chunk(self, rotations, global_start, rescale=False, out_min=-1.0, out_max=1.0):

@@ -947,22 +947,39 @@ int kpdi_get_direction_cosines(kpdi_ctx *c, double *out) {
 }
 
 namespace {
-// rotations (host) -> device, then one pattern per rotation into `d_out`
+// rotations (host) -> device, then one pattern per rotation into `d_out`; `pcs` != NULL: one
+// PC per pattern with the detector shape / orientation of `geom`
+struct VarPc {
+  const double *pcs;
+  int nrows, ncols;
+  const double *om;
+};
 int project_to_device(kpdi_ctx *c, const double *rotations, int64_t n, int rescale, double out_min, double out_max,
-                      int dtype_out, void *d_out) {
+                      int dtype_out, void *d_out, const VarPc *var = nullptr) {
   if (!c->have_master) return fail(KPDI_EINVAL, "kpdi_set_master_pattern has not been called");
-  if (!c->have_dc) return fail(KPDI_EINVAL, "kpdi_set_detector has not been called");
+  if (!var && !c->have_dc) return fail(KPDI_EINVAL, "kpdi_set_detector has not been called");
   if (!rotations) return fail(KPDI_EINVAL, "rotations pointer is NULL");
   if (n <= 0 || n >= (int64_t)INT_MAX) return fail(KPDI_EINVAL, "need between 1 and 2^31-1 rotations per call");
   if (rescale && !(out_max > out_min)) return fail(KPDI_EINVAL, "rescale needs out_max > out_min");
-  HIPCHK(c->rot.reserve((size_t)n * 4 * sizeof(double)));
+  HIPCHK(c->rot.reserve((size_t)n * 7 * sizeof(double)));
   HIPCHK(hipMemcpyAsync(c->rot.p, rotations, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   c->cnt.h2d_bytes += (double)n * 4 * sizeof(double);
-  kpdi::ProjectLaunch p;
+  kpdi::ProjectLaunch p{};
   p.rotations = c->rot.as<double>();
   p.n = n;
-  p.direction_cosines = c->dcos.as<double>();
-  p.npix = (int)c->dc_npix;
+  if (var) {
+    double *d_pcs = c->rot.as<double>() + (size_t)n * 4;
+    HIPCHK(hipMemcpyAsync(d_pcs, var->pcs, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    p.pcs = d_pcs;
+    p.nrows = var->nrows;
+    p.ncols = var->ncols;
+    for (int i = 0; i < 9; ++i) p.om[i] = var->om[i];
+    p.direction_cosines = nullptr;
+    p.npix = var->nrows * var->ncols;
+  } else {
+    p.direction_cosines = c->dcos.as<double>();
+    p.npix = (int)c->dc_npix;
+  }
   p.master_packed = c->mp_packed.as<float>();
   p.npx = c->mp_npx;
   p.npy = c->mp_npy;
@@ -994,6 +1011,26 @@ int kpdi_project_patterns(kpdi_ctx *c, const double *rotations, int64_t n, int r
   const size_t bytes = (size_t)n * c->dc_npix * kpdi::dtype_size(dtype_out);
   if (n > 0) HIPCHK(c->proj_out.reserve(bytes));
   rc = project_to_device(c, rotations, n, rescale, out_min, out_max, dtype_out, c->proj_out.p);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->proj_out.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KPDI_OK;
+}
+
+int kpdi_project_patterns_varying_pc(kpdi_ctx *c, const double *rotations, const double *pcs, int64_t n, int nrows,
+                                     int ncols, const double *om, int rescale, double out_min, double out_max,
+                                     int dtype_out, void *out) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!out || !pcs || !om) return fail(KPDI_EINVAL, "NULL argument");
+  if (nrows <= 0 || ncols <= 0) return fail(KPDI_EINVAL, "detector must have at least one pixel");
+  if (dtype_out != KPDI_F32 && dtype_out != KPDI_F64 && dtype_out != KPDI_U8 && dtype_out != KPDI_U16)
+    return fail(KPDI_EINVAL, "dtype_out must be float32, float64, uint8 or uint16");
+  int rc = use_device(c);
+  if (rc) return rc;
+  const size_t bytes = (size_t)n * nrows * ncols * kpdi::dtype_size(dtype_out);
+  if (n > 0) HIPCHK(c->proj_out.reserve(bytes));
+  const VarPc var{pcs, nrows, ncols, om};
+  rc = project_to_device(c, rotations, n, rescale, out_min, out_max, dtype_out, c->proj_out.p, &var);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(out, c->proj_out.p, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));

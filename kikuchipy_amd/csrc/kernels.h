@@ -136,8 +136,11 @@ size_t dtype_size(int dtype);
 struct ProjectLaunch {
   const double *rotations;          // [n][4] unit quaternions
   int64_t n;
-  const double *direction_cosines;  // [npix][3]
+  const double *direction_cosines;  // [npix][3] (one PC for all patterns), unused with `pcs`
   int npix;
+  const double *pcs;                // [n][3] one PC per pattern, or nullptr
+  int nrows, ncols;                 // with `pcs`: detector shape (npix = nrows * ncols)
+  double om[9];                     // with `pcs`: detector -> sample matrix
   const float *master_packed;       // pack_master_pattern() layout
   int npx, npy;
   int rescale;

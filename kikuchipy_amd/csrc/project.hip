@@ -66,13 +66,65 @@ __device__ __forceinline__ void block_minmax(double &lo, double &hi, double *red
   }
 }
 
-template <typename T, bool IN_REGS>
+// One PC per pattern (_get_direction_cosines_for_varying_pc, signals/util/_master_pattern.py:216-295):
+// the direction cosine of a pixel is formed on the fly from the pattern's PC instead of being read
+struct DetectorGeom {
+  const double *pcs;  // [n][3] (PCx, PCy, PCz) Bruker convention, or nullptr: read `dc`
+  int nrows, ncols;
+  double om[9];       // detector -> sample, row-major
+};
+
+struct PixelRay {
+  double x_min, y_max, x_scale, y_scale, x_half, y_half, pcz;
+  int ncols;
+  const double *om;
+  __device__ __forceinline__ void init(const DetectorGeom &g, const double *pc) {
+    const double aspect = (double)g.ncols / (double)g.nrows;
+    pcz = pc[2];
+    x_min = -aspect * (pc[0] / pcz);
+    const double x_max = aspect * (1.0 - pc[0]) / pcz, y_min = -(1.0 - pc[1]) / pcz;
+    y_max = pc[1] / pcz;
+    x_scale = (x_max - x_min) / (double)g.ncols;
+    y_scale = (y_max - y_min) / (double)g.nrows;
+    x_half = x_scale / 2.0;
+    y_half = y_scale / 2.0;
+    ncols = g.ncols;
+    om = g.om;
+  }
+  __device__ __forceinline__ void at(int c, double &x, double &y, double &z) const {
+    const int row = c / ncols, col = c - row * ncols;
+    const double v0 = (x_min + (double)col * x_scale + x_half) * pcz;
+    const double v1 = (y_max + (double)row * (-y_scale) - y_half) * pcz;
+    const double w0 = v0 * om[0] + v1 * om[1] + pcz * om[2];
+    const double w1 = v0 * om[3] + v1 * om[4] + pcz * om[5];
+    const double w2 = v0 * om[6] + v1 * om[7] + pcz * om[8];
+    const double rn = rsq_fast(w0 * w0 + w1 * w1 + w2 * w2);
+    x = w0 * rn;
+    y = w1 * rn;
+    z = w2 * rn;
+  }
+};
+
+template <typename T, bool IN_REGS, bool VARPC>
 __global__ __launch_bounds__(PROJ_THREADS, PROJ_MIN_BLOCKS) void project_kernel(const double *rotations, const double *dc, int npix,
-                                                               MasterView mp, int rescale, double omin,
+                                                               MasterView mp, DetectorGeom geom, int rescale, double omin,
                                                                double omax, T *out) {
   __shared__ double red[2 * PROJ_THREADS / 64];
   const int64_t n = blockIdx.x;
   const RotCoeff r = rot_coeff(rotations + 4 * n);
+  PixelRay ray;
+  if (VARPC) ray.init(geom, geom.pcs + 3 * n);
+  auto pixel = [&](int c) {
+    double x, y, z;
+    if (VARPC) {
+      ray.at(c, x, y, z);
+    } else {
+      x = dc[3 * c];
+      y = dc[3 * c + 1];
+      z = dc[3 * c + 2];
+    }
+    return project_pixel(r, x, y, z, mp);
+  };
   T *o = out + n * (int64_t)npix;
   const int tid = threadIdx.x;
   if (IN_REGS) {
@@ -85,7 +137,7 @@ __global__ __launch_bounds__(PROJ_THREADS, PROJ_MIN_BLOCKS) void project_kernel(
     for (int i = 0; i < PROJ_VALUES; ++i) {
       const int c = tid + PROJ_THREADS * i;
       const int cc = min(c, last);
-      v[i] = project_pixel(r, dc[3 * cc], dc[3 * cc + 1], dc[3 * cc + 2], mp);
+      v[i] = pixel(cc);
       lo = fmin(lo, v[i]);  // a clamped slot repeats the last pixel: min/max unchanged
       hi = fmax(hi, v[i]);
       // two pixels in flight per thread; without the fence the scheduler interleaves all 16
@@ -109,7 +161,7 @@ __global__ __launch_bounds__(PROJ_THREADS, PROJ_MIN_BLOCKS) void project_kernel(
     double lo = INFINITY, hi = -INFINITY;
     if (rescale) {
       for (int c = tid; c < npix; c += PROJ_THREADS) {
-        const double v = project_pixel(r, dc[3 * c], dc[3 * c + 1], dc[3 * c + 2], mp);
+        const double v = pixel(c);
         lo = fmin(lo, v);
         hi = fmax(hi, v);
       }
@@ -117,7 +169,7 @@ __global__ __launch_bounds__(PROJ_THREADS, PROJ_MIN_BLOCKS) void project_kernel(
     }
     const double gain = (omax - omin) / (hi - lo);
     for (int c = tid; c < npix; c += PROJ_THREADS) {
-      double v = project_pixel(r, dc[3 * c], dc[3 * c + 1], dc[3 * c + 2], mp);
+      double v = pixel(c);
       if (rescale) v = (v - lo) * gain + omin;
       o[c] = cast_out<T>(v);
     }
@@ -150,14 +202,21 @@ hipError_t launch_project(const ProjectLaunch &a, hipStream_t s) {
   mp.scale = (double)(a.npx - 1) / 2.0;
   mp.lam2px = mp.scale / 1.2533141373155002512;  // sqrt(pi / 2)
   const bool regs = a.npix <= PROJ_THREADS * PROJ_VALUES;
+  DetectorGeom geom;
+  geom.pcs = a.pcs;
+  geom.nrows = a.nrows;
+  geom.ncols = a.ncols;
+  for (int i = 0; i < 9; ++i) geom.om[i] = a.pcs ? a.om[i] : 0.0;
   dim3 grid((unsigned)a.n), block(PROJ_THREADS);
+#define KPDI_PROJECT_V(T, R, V)                                                                           \
+  hipLaunchKernelGGL((project_kernel<T, R, V>), grid, block, 0, s, a.rotations, a.direction_cosines,     \
+                     a.npix, mp, geom, a.rescale, a.out_min, a.out_max, (T *)a.out)
 #define KPDI_PROJECT(T)                                                                                   \
-  if (regs)                                                                                               \
-    hipLaunchKernelGGL((project_kernel<T, true>), grid, block, 0, s, a.rotations, a.direction_cosines,   \
-                       a.npix, mp, a.rescale, a.out_min, a.out_max, (T *)a.out);                          \
-  else                                                                                                    \
-    hipLaunchKernelGGL((project_kernel<T, false>), grid, block, 0, s, a.rotations, a.direction_cosines,  \
-                       a.npix, mp, a.rescale, a.out_min, a.out_max, (T *)a.out);                          \
+  if (a.pcs) {                                                                                            \
+    if (regs) KPDI_PROJECT_V(T, true, true); else KPDI_PROJECT_V(T, false, true);                         \
+  } else {                                                                                                \
+    if (regs) KPDI_PROJECT_V(T, true, false); else KPDI_PROJECT_V(T, false, false);                       \
+  }                                                                                                       \
   break;
   switch (a.dtype_out) {
     case KPDI_F32: KPDI_PROJECT(float)
@@ -167,6 +226,7 @@ hipError_t launch_project(const ProjectLaunch &a, hipStream_t s) {
     default: return hipErrorInvalidValue;
   }
 #undef KPDI_PROJECT
+#undef KPDI_PROJECT_V
   return hipGetLastError();
 }
 

@@ -374,6 +374,24 @@ def gen_projection():
                                          np.float32)
     out["det48x60_f32__patterns"] = project(rot[:4], dcs["det48x60"], upf, lof, False, 1, 2, np.float32)
 
+    # ---- one PC per pattern (_get_direction_cosines_for_varying_pc + ..._with_varying_pc)
+    pcs = np.array([[0.40, 0.50, 0.40], [0.60, 0.50, 0.40], [0.40, 0.50, 0.60], [0.4210, 0.7794, 0.5049]])
+    gb = np.stack([-(pcs[:, 0] / pcs[:, 2]), (1 - pcs[:, 0]) / pcs[:, 2], -(1 - pcs[:, 1]) / pcs[:, 2],
+                   pcs[:, 1] / pcs[:, 2]], axis=1)
+    om60 = np.ascontiguousarray(out["det60__s2d"].T)
+    dcv = mpm._get_direction_cosines_for_varying_pc(
+        gnomonic_bounds=gb, pcz=np.ascontiguousarray(pcs[:, 2]), nrows=60, ncols=60, om_detector_to_sample=om60,
+        signal_mask=np.ones(3600, bool))
+    out["varpc__pcs"] = pcs
+    out["varpc__dc_sample"] = dcv[:, ::97]
+    kw = dict(rotations=rot[:4], direction_cosines=dcv, master_upper=upf, master_lower=lof, npx=401, npy=401,
+              scale=200.0)
+    out["varpc_f32__patterns"] = mpm._project_patterns_from_master_pattern_with_varying_pc(
+        rescale=False, out_min=1, out_max=2, dtype_out=np.float32, **kw)
+    kw.update(master_upper=up, master_lower=lo)
+    out["varpc_u8mp_f32__patterns"] = mpm._project_patterns_from_master_pattern_with_varying_pc(
+        rescale=True, out_min=-1, out_max=1, dtype_out=np.float32, **kw)
+
     # ---- end to end: dictionary of 1200 projected patterns -> reference DI
     n_dict = 1200
     rot_d = random_quaternions(rng, n_dict)

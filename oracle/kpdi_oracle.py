@@ -478,6 +478,19 @@ def detector_direction_cosines(shape, pc, sample_tilt=70.0, tilt=0.0, azimuthal=
                                       m.T, signal_mask)
 
 
+def project_patterns_varying_pc(rotations, pcs, shape, om_detector_to_sample, master_upper, master_lower,
+                                rescale=False, out_min=-1, out_max=1, dtype_out=np.float32):
+    """signals/util/_master_pattern.py:216-295 + :374-445: pattern i is projected
+    with its own projection centre pcs[i] (Bruker convention): direction cosines
+    per PC, then the single-pattern projection."""
+    rotations = np.asarray(rotations, dtype=np.float64).reshape(-1, 4)
+    out = np.empty((rotations.shape[0], shape[0] * shape[1]), dtype=dtype_out)
+    for i, (rot, pc) in enumerate(zip(rotations, np.asarray(pcs, dtype=np.float64).reshape(-1, 3))):
+        dc = direction_cosines_fixed_pc(gnomonic_bounds(shape, pc), pc[2], shape[0], shape[1], om_detector_to_sample)
+        out[i] = project_patterns(rot, dc, master_upper, master_lower, rescale, out_min, out_max, dtype_out)[0]
+    return out
+
+
 def rotate_vector(rotation, vector):
     """_utils/numba.py:59-81: passive rotation of (n, 3) vectors by the unit
     quaternion (a, b, c, d)."""

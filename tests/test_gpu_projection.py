@@ -84,6 +84,38 @@ def test_patterns_other_detector(ctx, g):
     assert np.allclose(got, g["det48x60_f32__patterns"], rtol=3e-7, atol=1e-4)
 
 
+def test_one_pc_per_pattern(ctx, g):
+    """`_project_patterns_from_master_pattern_with_varying_pc`: direction cosines formed on the device."""
+    om = g["det60__s2d"].T
+    ctx.set_master_pattern(*master_arrays(g, np.float32, "lower"))
+    got = ctx.project_patterns_varying_pc(g["rot8"][:4], g["varpc__pcs"], (60, 60), om)
+    assert np.allclose(got, g["varpc_f32__patterns"], rtol=3e-7, atol=1e-4)
+    ctx.set_master_pattern(g["mp_upper"], g["mp_lower"])
+    got = ctx.project_patterns_varying_pc(g["rot8"][:4], g["varpc__pcs"], (60, 60), om, True, -1, 1)
+    assert np.allclose(got, g["varpc_u8mp_f32__patterns"], rtol=3e-7, atol=3e-7)
+    # a detector above 4096 pixels (the recompute path) against the oracle
+    rng = np.random.default_rng(9)
+    up = rng.random((101, 101)).astype(np.float32)
+    pcs = np.array([0.45, 0.6, 0.55]) + rng.uniform(-0.05, 0.05, (3, 3))
+    q = rng.standard_normal((3, 4))
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    m = ko.sample_to_detector_matrix(70.0, 10.0, 2.0, 1.0)
+    ctx.set_master_pattern(up)
+    got = ctx.project_patterns_varying_pc(q, pcs, (70, 90), m.T, True, 0, 1)
+    want = ko.project_patterns_varying_pc(q, pcs, (70, 90), m.T, up, up, True, 0, 1)
+    assert np.allclose(got, want, rtol=3e-7, atol=3e-7)
+
+
+def test_get_patterns_with_one_pc_per_rotation(g):
+    import kikuchipy_amd as ka
+
+    mp = ka.EBSDMasterPattern(np.stack([g["mp_upper"], g["mp_lower"]]))
+    det = ka.EBSDDetector(shape=(60, 60), pc=g["varpc__pcs"].reshape(2, 2, 3))
+    sim = mp.get_patterns(g["rot8"][:4].reshape(2, 2, 4), det, compute=True)
+    assert sim.data.shape == (2, 2, 60, 60)
+    assert np.allclose(sim.data.reshape(4, -1), g["varpc_u8mp_f32__patterns"], rtol=3e-7, atol=3e-7)
+
+
 def test_single_hemisphere_and_f64_output(ctx, g):
     up = g["mp_upper"].astype(np.float32)
     ctx.set_master_pattern(up)  # lower = upper

@@ -82,8 +82,10 @@ def test_detector_with_one_pc_per_point():
     one = ka.EBSDDetector(shape=(60, 60), pc=pcs[1, 0])
     assert np.allclose(det.gnomonic_bounds[1, 0], one.gnomonic_bounds)
     mp = ka.EBSDMasterPattern(np.zeros((11, 11)))
-    with pytest.raises(NotImplementedError, match="ONE projection centre"):
+    with pytest.raises(ValueError, match="must be equal to `rotations.shape`"):
         mp.get_patterns(np.array([[1.0, 0, 0, 0]]), det)
+    with pytest.raises(NotImplementedError, match="needs compute=True"):
+        mp.get_patterns(np.tile([1.0, 0, 0, 0], (2, 2, 1)), det)
     tsl = ka.EBSDDetector(shape=(60, 80), pc=[[0.35, 1, 0.65], [0.1, 0.2, 0.3]], convention="tsl")
     assert np.allclose(tsl.pc, [[0.35, 0, 0.65], [0.1, 0.8, 0.3]])
 

@@ -127,6 +127,21 @@ def test_project_patterns_uint8(g, name, mp_dtype, rescale):
     assert diff.max() <= 1 and np.mean(diff != 0) < 1e-3
 
 
+def test_project_patterns_one_pc_per_pattern(g):
+    om = g["det60__s2d"].T
+    pcs = g["varpc__pcs"]
+    for i, pc in enumerate(pcs):
+        dc = ko.direction_cosines_fixed_pc(ko.gnomonic_bounds((60, 60), pc), pc[2], 60, 60, om)
+        assert np.allclose(dc[::97], g["varpc__dc_sample"][i], rtol=0, atol=1e-14)
+    up, lo = master_arrays(g, np.float32, "lower")
+    got = ko.project_patterns_varying_pc(g["rot8"][:4], pcs, (60, 60), om, up, lo)
+    assert np.allclose(got, g["varpc_f32__patterns"], rtol=3e-7, atol=1e-4)
+    got = ko.project_patterns_varying_pc(g["rot8"][:4], pcs, (60, 60), om, g["mp_upper"], g["mp_lower"], True, -1, 1)
+    assert np.allclose(got, g["varpc_u8mp_f32__patterns"], rtol=3e-7, atol=3e-7)
+    # the last PC is the fixed one of the other fixtures
+    assert np.allclose(got[3], g["u8mp_f32__patterns"][3], rtol=3e-7, atol=3e-7)
+
+
 def test_hemisphere_selection_matters(g):
     a, b = g["f32mp_f32__patterns"], g["hemis_f32__patterns"]
     assert np.any(a != b)  # some pixels of the 8 patterns look into the lower hemisphere
