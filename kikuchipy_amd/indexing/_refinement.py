@@ -185,7 +185,7 @@ def _master_pattern_data(master_pattern, energy):
 
 def refine(mode, patterns, rotations, detector, master_pattern, energy=None, navigation_mask=None,
            signal_mask=None, pseudo_symmetry_ops=None, method="minimize", method_kwargs=None, trust_region=None,
-           initial_step=None, rtol=1e-4, maxeval=None, context=None, device=0, verbose=True):
+           initial_step=None, rtol=1e-4, maxeval=None, context=None, device=0, verbose=True, comm=None):
     """Shared driver of the three refinements.
 
     patterns
@@ -196,6 +196,10 @@ def refine(mode, patterns, rotations, detector, master_pattern, energy=None, nav
         returns them; only the best is refined, _refinement.py:963-966).
     detector
         `EBSDDetector` with one PC or one PC per navigation point.
+    comm
+        `kikuchipy_amd.parallel.Communicator`: every rank (one process per GPU)
+        passes the same arguments, refines its contiguous block of the points and
+        all ranks return the complete result.
     Returns `(RefinementResult, new_detector)`; `new_detector` is None in
     mode "ori".
     """
@@ -264,14 +268,26 @@ def refine(mode, patterns, rotations, detector, master_pattern, energy=None, nav
         what = {"ori": "orientation(s)", "pc": "projection center(s)", "ori_pc": "orientation(s) and projection center(s)"}
         print(f"Refining {n} {what[mode]}:")
 
+    lo_i, hi_i = 0, n
+    if comm is not None and comm.world_size > 1:
+        from kikuchipy_amd.parallel import shard_range
+
+        lo_i, hi_i = shard_range(n, comm.rank, comm.world_size)
+    part = slice(lo_i, hi_i)
     ctx = context if context is not None else _lib.Context(device)
     try:
-        ctx.set_master_pattern(*_master_pattern_data(master_pattern, energy))
-        # rescale exactly when the patterns are float32 (_refinement.py:956)
-        ctx.refine_set_patterns(pats, signal_mask, pats.dtype == np.float32, detector.detector_to_sample)
         t0 = time.time()
-        res = ctx.refine_solve(MODES[mode], x0, fixed, lower, upper, nm["xatol"], nm["fatol"], nm["maxiter"] or 0,
-                               nm["maxfev"] or 0)
+        if hi_i > lo_i:
+            ctx.set_master_pattern(*_master_pattern_data(master_pattern, energy))
+            # rescale exactly when the patterns are float32 (_refinement.py:956)
+            ctx.refine_set_patterns(pats[part], signal_mask, pats.dtype == np.float32, detector.detector_to_sample)
+            res = ctx.refine_solve(MODES[mode], x0[part], None if fixed is None else fixed[part],
+                                   None if lower is None else lower[part], None if upper is None else upper[part],
+                                   nm["xatol"], nm["fatol"], nm["maxiter"] or 0, nm["maxfev"] or 0)
+        else:
+            res = np.empty((0, starts, 3 + x0.shape[2]))
+        if comm is not None and comm.world_size > 1:
+            res = comm.all_gather_rows(res)
         total = time.time() - t0
     finally:
         if context is None:

@@ -11,6 +11,10 @@ per rank over xGMI inside `kpdi_finalize`, followed by the same (score desc,
 index asc) merge kernel used between chunks, so every rank ends with the
 bit-identical global result.
 
+Refinement shards the other way: every rank refines a contiguous block of the
+map's patterns (they are independent), and the per-pattern results (9 doubles)
+are concatenated over the control plane (`Communicator.all_gather_rows`).
+
 Control plane (rank discovery, the 128-byte RCCL unique id, barriers) goes
 through `torch.distributed` (gloo), which is what `torchrun` sets up; the data
 path never touches torch.
@@ -33,11 +37,12 @@ class Communicator:
     libkpdi context.  `broadcast_bytes(payload_or_None, src) -> bytes` moves the
     unique id from rank 0 to everybody (default: torch.distributed)."""
 
-    def __init__(self, rank, world_size, broadcast_bytes=None, barrier=None):
+    def __init__(self, rank, world_size, broadcast_bytes=None, barrier=None, all_gather=None):
         self.rank = int(rank)
         self.world_size = int(world_size)
         self._broadcast = broadcast_bytes or _torch_broadcast_bytes
         self._barrier = barrier or _torch_barrier
+        self._all_gather = all_gather or _torch_all_gather
         self._attached = set()
 
     @classmethod
@@ -55,6 +60,13 @@ class Communicator:
         if self.world_size == 1:
             return payload
         return self._broadcast(payload, 0)
+
+    def all_gather_rows(self, array):
+        """Concatenate the ranks' row blocks (rank order) on every rank - for small
+        per-pattern results (refinement: a few doubles per pattern) over the control plane."""
+        if self.world_size == 1:
+            return array
+        return _concat(self._all_gather(array))
 
     def attach(self, ctx):
         """Create the RCCL communicator of `ctx` once (collective call)."""
@@ -86,3 +98,17 @@ def _torch_barrier():
     import torch.distributed as dist
 
     dist.barrier()
+
+
+def _torch_all_gather(obj):
+    import torch.distributed as dist
+
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, obj)
+    return box
+
+
+def _concat(blocks):
+    import numpy as np
+
+    return np.concatenate([np.asarray(b) for b in blocks], axis=0)

@@ -116,7 +116,7 @@ class EBSD:
     # ------------------------------------------------------------------ refinement
     def _refine(self, mode, xmap, detector, master_pattern, energy, navigation_mask, signal_mask,
                 pseudo_symmetry_ops, method, method_kwargs, trust_region, initial_step, rtol, maxeval, compute,
-                verbose):
+                verbose, comm=None):
         from kikuchipy_amd.indexing._refinement import refine
 
         if not compute:
@@ -124,39 +124,40 @@ class EBSD:
                                       "refinement is one GPU launch")
         return refine(mode, np.asarray(self.data), _rotations_of(xmap), detector, master_pattern, energy,
                       navigation_mask, signal_mask, pseudo_symmetry_ops, method, method_kwargs, trust_region,
-                      initial_step, rtol, maxeval, context=self.context, verbose=verbose)
+                      initial_step, rtol, maxeval, context=self.context, verbose=verbose, comm=comm)
 
     def refine_orientation(self, xmap, detector, master_pattern, energy=None, navigation_mask=None,
                            signal_mask=None, pseudo_symmetry_ops=None, method="minimize", method_kwargs=None,
                            trust_region=None, initial_step=None, rtol=1e-4, maxeval=None, compute=True,
-                           rechunk=True, chunk_kwargs=None, *, verbose=True):
+                           rechunk=True, chunk_kwargs=None, *, verbose=True, comm=None):
         """signals/ebsd.py:1986-2185.  `xmap`: anything with `.rotations`
         (e.g. the result of `dictionary_indexing`) or a quaternion array.
         Returns a `RefinementResult` (`rotations`, `scores`, `num_evals`,
         `pseudo_symmetry_index`)."""
         return self._refine("ori", xmap, detector, master_pattern, energy, navigation_mask, signal_mask,
                             pseudo_symmetry_ops, method, method_kwargs, trust_region, initial_step, rtol, maxeval,
-                            compute, verbose)[0]
+                            compute, verbose, comm)[0]
 
     def refine_projection_center(self, xmap, detector, master_pattern, energy=None, navigation_mask=None,
                                  signal_mask=None, method="minimize", method_kwargs=None, trust_region=None,
                                  initial_step=None, rtol=1e-4, maxeval=None, compute=True, rechunk=True,
-                                 chunk_kwargs=None, *, verbose=True):
+                                 chunk_kwargs=None, *, verbose=True, comm=None):
         """signals/ebsd.py:2187-2390.  Returns `(scores, new_detector, num_evals)`
         like the reference."""
         res, det = self._refine("pc", xmap, detector, master_pattern, energy, navigation_mask, signal_mask, None,
-                                method, method_kwargs, trust_region, initial_step, rtol, maxeval, compute, verbose)
+                                method, method_kwargs, trust_region, initial_step, rtol, maxeval, compute, verbose,
+                                comm)
         return res.scores, det, res.num_evals
 
     def refine_orientation_projection_center(self, xmap, detector, master_pattern, energy=None,
                                              navigation_mask=None, signal_mask=None, pseudo_symmetry_ops=None,
                                              method="minimize", method_kwargs=None, trust_region=None,
                                              initial_step=None, rtol=1e-4, maxeval=None, compute=True,
-                                             rechunk=True, chunk_kwargs=None, *, verbose=True):
+                                             rechunk=True, chunk_kwargs=None, *, verbose=True, comm=None):
         """signals/ebsd.py:2392-2700.  Returns `(RefinementResult, new_detector)`."""
         return self._refine("ori_pc", xmap, detector, master_pattern, energy, navigation_mask, signal_mask,
                             pseudo_symmetry_ops, method, method_kwargs, trust_region, initial_step, rtol, maxeval,
-                            compute, verbose)
+                            compute, verbose, comm)
 
     # ------------------------------------------------------------------ indexing
     def dictionary_indexing(self, dictionary, metric="ncc", keep_n=20, n_per_iteration=None,
