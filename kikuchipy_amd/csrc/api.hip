@@ -347,7 +347,13 @@ int run_match(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int rows_per_la
     ml.bound_grouped = grouped;
   }
   ml.gthr = c->gthr.as<unsigned>();
-  const size_t ctr_bytes = (size_t)(c->m_pad / kpdi::TILE_EXP) * sizeof(unsigned);
+  // XCD-affine tile groups (KPDI_TILE_GROUPS=8) are an experiment kept for measurement: they
+  // make the workgroups of one XCD take the same dictionary tiles in every row block, but the
+  // workgroups drift apart by more than the 4 MB L2 holds, so the fabric traffic only drops
+  // from 26.4 to 25.0 GB per config-2 launch and the time not at all (profiles/r01_summary.md).
+  const char *tg_env = getenv("KPDI_TILE_GROUPS");
+  ml.tile_groups = (tg_env && atoi(tg_env) == 8 && nsplit % 8 == 0) ? 8 : 1;
+  const size_t ctr_bytes = (size_t)(c->m_pad / kpdi::TILE_EXP) * ml.tile_groups * sizeof(unsigned);
   HIPCHK(c->tile_ctr.reserve(ctr_bytes));
   HIPCHK(hipMemsetAsync(c->tile_ctr.p, 0, ctr_bytes, c->stream));
   ml.tile_ctr = c->tile_ctr.as<unsigned>();

@@ -54,7 +54,8 @@ struct MatchLaunch {
   // launch_init_bound at the start of a sweep (and of every bounded pass)
   unsigned *gthr;
   int bound_rank, bound_grouped;  // from bound_plan()
-  unsigned *tile_ctr;  // [m_pad / TILE_EXP] dynamic tile counters, zeroed before every launch
+  unsigned *tile_ctr;  // [m_pad / TILE_EXP][tile_groups] dynamic tile counters, zeroed before every launch
+  int tile_groups;     // 8 = XCD-affine hand-out (nsplit % 8 == 0), 1 = one counter per row block
 };
 constexpr unsigned THRESHOLD_NONE = 0x007fffffu;  // key of -inf
 constexpr int BOUND_SLOTS = 32;

@@ -64,7 +64,8 @@ struct MatchArgs {
   int *part_idx;
   const float *bound_score;
   const int *bound_idx;
-  unsigned *tile_ctr;  // [row blocks] next dictionary tile to hand out, zero at launch
+  unsigned *tile_ctr;  // [row blocks][tile_groups] next dictionary tile to hand out, zero at launch
+  int tile_groups;
   unsigned *gthr;      // [m_pad][BOUND_SLOTS] published list ranks (monotone keys), see shared_bound()
   int bound_rank;      // which entry (1-based) of its list a workgroup lane publishes
   int bound_grouped;   // 1: all 32 slots are in use and bound_rank == 1 (grouped form)
@@ -229,7 +230,12 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
   unsigned *gthr_arr = a.gthr;
   const int kpad = a.kpad;
   const int nslab = kpad / TILE_K;
-  unsigned *tile_ctr = a.tile_ctr + rb;
+  // Tiles are handed out per (row block, tile group): with `tile_groups` = 8 the workgroups of
+  // XCD x (block id % 8 == split % 8 == x, nsplit being a multiple of 8) take the tiles
+  // t % 8 == x of EVERY row block, so a dictionary tile crosses the fabric once per XCD-resident
+  // L2 instead of once per row block; within a group the hand-out stays dynamic.
+  const int tgroups = a.tile_groups, tg = sp % tgroups;
+  unsigned *tile_ctr = a.tile_ctr + rb * tgroups + tg;
   volatile int *ctrl = (volatile int *)(smem + LDS_BYTES);  // control words behind the ring
 
   const unsigned goff = (unsigned)lane * 16u;
@@ -280,9 +286,9 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
   // next two (the loads run two slabs ahead, which can reach two tiles ahead)
   int t0, t1, t2;
   if (tid == 0) {
-    ctrl[0] = (int)atomicAdd(tile_ctr, 1u);
-    ctrl[1] = (int)atomicAdd(tile_ctr, 1u);
-    ctrl[2] = (int)atomicAdd(tile_ctr, 1u);
+    ctrl[0] = (int)atomicAdd(tile_ctr, 1u) * tgroups + tg;
+    ctrl[1] = (int)atomicAdd(tile_ctr, 1u) * tgroups + tg;
+    ctrl[2] = (int)atomicAdd(tile_ctr, 1u) * tgroups + tg;
   }
   __syncthreads();
   t0 = __builtin_amdgcn_readfirstlane(ctrl[0]);
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
       const char *ls = smem + stage * STAGE_BYTES;
       const int nstage = stage == NSTAGE - 1 ? 0 : stage + 1;
       const char *ls_next = smem + nstage * STAGE_BYTES;
-      if (slab == 0 && tid == 0) fetched = (int)atomicAdd(tile_ctr, 1u);
+      if (slab == 0 && tid == 0) fetched = (int)atomicAdd(tile_ctr, 1u) * tgroups + tg;
       if (slab == nslab - 1) {  // landed by the mid-step wait, used in the epilogue
         g0 = shared_bound<KMAX>(line0, bound_grouped);
         g1 = shared_bound<KMAX>(line1, bound_grouped);
@@ -491,6 +497,7 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   g.bound_rank = a.bound_rank;
   g.bound_grouped = a.bound_grouped;
   g.tile_ctr = a.tile_ctr;
+  g.tile_groups = a.tile_groups;
   const int grid = a.rows * a.nsplit;
   const bool bounded = a.bound_score != nullptr;
 #define KPDI_CASE(K)                                           \
