@@ -111,3 +111,71 @@ def test_config5_large_detector():
         s, i = sweep(ctx, exp, dic, "ncc", 20, chunks=2)
     assert i[7, 0] == 4321 and abs(s[7, 0] - 1) < ATOL
     spot_check(exp, dic, np.array([0, 7, 150, 299]), "ncc", 20, s, i)
+
+
+def smooth_master_pattern(rng, n=401):
+    """Low-pass filtered noise: a master pattern with Kikuchi-like smooth structure."""
+    f = np.fft.rfft2(rng.standard_normal((n, n)))
+    ky, kx = np.meshgrid(np.fft.fftfreq(n), np.fft.rfftfreq(n), indexing="ij")
+    return np.fft.irfft2(f * np.exp(-(kx**2 + ky**2) / (2 * 0.03**2)), s=(n, n)).astype(np.float32)
+
+
+def test_config2_generated_dictionary_round_trip():
+    """configs[1] sizes with the dictionary SIMULATED on the device: the
+    experimental patterns are noisy projections at 4096 of the 100 000 dictionary rotations,
+    so the best match of each must be its own rotation (round trip), whatever the chunking."""
+    import kikuchipy_amd as ka
+
+    rng = np.random.default_rng(12)
+    mp = ka.EBSDMasterPattern(np.stack([smooth_master_pattern(rng), smooth_master_pattern(rng)]))
+    det = ka.EBSDDetector(shape=(60, 60), pc=(0.42, 0.78, 0.5))
+    q = rng.standard_normal((100000, 4))
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    planted = rng.choice(100000, 4096, replace=False)
+    sim = mp.get_patterns(q[planted], det, compute=True).data
+    noisy = sim + 0.2 * sim.std() * rng.standard_normal(sim.shape).astype(np.float32)
+    exp = ((noisy - noisy.min()) / (noisy.max() - noisy.min()) * 255).astype(np.uint8)
+    dictionary = mp.get_patterns(q, det, chunk_shape=30000)
+    s = ka.EBSD(exp)
+    res = s.dictionary_indexing(dictionary, keep_n=20, verbose=False)
+    assert np.array_equal(res.simulation_indices[:, 0], planted)
+    assert res.scores[:, 0].min() > 0.9 and np.all(np.diff(res.scores, axis=1) <= 0)
+    res2 = s.dictionary_indexing(dictionary, keep_n=20, n_per_iteration=100000, verbose=False)
+    assert np.array_equal(res.simulation_indices, res2.simulation_indices)
+    assert np.array_equal(res.scores, res2.scores)
+    # oracle spot check of three rows against a materialised slice of the dictionary
+    rows = np.array([0, 2000, 4095])
+    lo = int(planted[rows].min()) // 1000 * 1000
+    block = dictionary.data[lo:lo + 1000].compute()
+    for r in rows:
+        if lo <= planted[r] < lo + 1000:
+            rs, ri = ko.dictionary_indexing(exp[r:r + 1], block, keep_n=1)
+            assert ri[0, 0] + lo == planted[r] and abs(rs[0, 0] - res.scores[r, 0]) < ATOL
+
+
+def test_refinement_of_a_whole_map():
+    """4096 patterns refined in one launch: starts 1 degree off the truth
+    come back to it, every score rises, and a second run is bit-identical."""
+    import kikuchipy_amd as ka
+    from kikuchipy_amd import _lib
+    from kikuchipy_amd.indexing._refinement import rotation_from_euler
+
+    rng = np.random.default_rng(13)
+    mp = ka.EBSDMasterPattern(smooth_master_pattern(rng))
+    det = ka.EBSDDetector(shape=(60, 60), pc=(0.42, 0.78, 0.5))
+    eu = np.column_stack([rng.uniform(0.3, 6, 4096), rng.uniform(0.3, 2.8, 4096), rng.uniform(0.3, 6, 4096)])
+    sim = mp.get_patterns(rotation_from_euler(eu), det, compute=True).data
+    noisy = sim + 0.3 * sim.std() * rng.standard_normal(sim.shape).astype(np.float32)
+    exp = ((noisy - noisy.min()) / (noisy.max() - noisy.min()) * 255).astype(np.uint8)
+    eu0 = eu + np.deg2rad(rng.uniform(-1, 1, eu.shape))
+    s = ka.EBSD(exp.reshape(64, 64, 60, 60))
+    res = s.refine_orientation(rotation_from_euler(eu0).reshape(64, 64, 4), det, mp, verbose=False)
+    err0 = np.rad2deg(np.abs(eu0 - eu)).max(axis=1)
+    err = np.rad2deg(np.abs(res.euler - eu)).max(axis=1)
+    assert np.median(err) < 0.05 and np.median(err) < np.median(err0) / 5
+    ctx = s.context
+    start = 1 - ctx.refine_objective(_lib.REFINE_ORI, np.arange(4096), eu0, np.tile(det.pc_flattened, (4096, 1)))
+    assert np.all(res.scores >= start - 1e-6) and res.scores.mean() > 0.9
+    assert res.num_evals.min() >= 4 and res.num_evals.max() <= 600
+    again = s.refine_orientation(rotation_from_euler(eu0).reshape(64, 64, 4), det, mp, verbose=False)
+    assert np.array_equal(again.scores, res.scores) and np.array_equal(again.euler, res.euler)
