@@ -19,8 +19,8 @@
 // and the master pattern (2 x npx x npy f32, L2/MALL resident) are shared by every
 // pattern; per pixel the kernel reads 24 B of direction cosines, gathers 4 x 4 B and
 // writes one output value.  Detectors up to 64 x 64 keep the f64 intensities of the
-// pattern in registers between the min/max reduction and the rescale; larger ones
-// recompute them.
+// pattern in registers (8 per thread, 512 threads: 116 VGPRs, four waves per SIMD) between
+// the min/max reduction and the rescale; larger ones recompute them.
 #include "kernels.h"
 #include "../../include/kpdi.h"
 
@@ -34,10 +34,13 @@ namespace kpdi {
 #define PROJ_MIN_BLOCKS 2
 #endif
 #ifndef PROJ_FENCE
-#define PROJ_FENCE 4
+#define PROJ_FENCE 2
 #endif
-constexpr int PROJ_THREADS = 256;
-constexpr int PROJ_VALUES = 16;  // register-resident pixels per thread (<= 4096 per pattern)
+#ifndef PROJ_THREADS_N
+#define PROJ_THREADS_N 512
+#endif
+constexpr int PROJ_THREADS = PROJ_THREADS_N;
+constexpr int PROJ_VALUES = 4096 / PROJ_THREADS;  // register-resident pixels per thread (<= 4096 per pattern)
 
 template <typename T>
 __device__ __forceinline__ T cast_out(double v);
@@ -140,8 +143,8 @@ __global__ __launch_bounds__(PROJ_THREADS, PROJ_MIN_BLOCKS) void project_kernel(
       v[i] = pixel(cc);
       lo = fmin(lo, v[i]);  // a clamped slot repeats the last pixel: min/max unchanged
       hi = fmax(hi, v[i]);
-      // two pixels in flight per thread; without the fence the scheduler interleaves all 16
-      // and the kernel needs > 400 VGPRs (one wave per SIMD)
+      // two pixels in flight per thread; without the fence the scheduler interleaves all the
+      // slots and the kernel needs > 400 VGPRs (one wave per SIMD)
       if ((i % PROJ_FENCE) == PROJ_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
     }
     double gain = 1.0, offs = 0.0, base = 0.0;

@@ -53,12 +53,15 @@ __device__ __forceinline__ double rsq_fast(double x) {
   return fma(y, e * fma(0.375, e, 0.5), y);
 }
 
-// coefficients of atan(u)/u in u^2 (uniform loads: they live in SGPRs, which an f64 FMA
-// can take as an operand; 64-bit literals would each cost a VGPR pair and a move)
-static __constant__ double ATAN_C[11] = {
-    0x1.ffffffffffff8p-1,  -0x1.555555555329bp-2, 0x1.999999973269cp-3,  -0x1.24924889af9fep-3,
-    0x1.c71c469a22141p-4,  -0x1.745968dbb8c55p-4, 0x1.3adfd52a966cfp-4,  -0x1.0f2d87b7f5b5cp-4,
-    0x1.ca7e184710557p-5,  -0x1.50b33e5fd9dc6p-5, 0x1.2edf629854fb0p-6};
+// d = a * b + c with the uniform constant c read from a scalar register pair.  Written as
+// asm because the compiler otherwise evaluates Horner's scheme with v_fmac_f64 (D = A*B + D),
+// which needs every coefficient moved into a fresh VGPR pair first: two extra VALU moves per
+// term, 22 per pixel.  Scalar moves issue beside the vector pipe.
+__device__ __forceinline__ double fma_sconst(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+  return d;
+}
 
 // atan(a / b) for 0 <= a <= b, b > 0, with ONE division: below tan(pi/8) the quotient is
 // the argument, above it atan(t) = pi/4 + atan((t - 1) / (t + 1)) = pi/4 + atan((a - b) / (a + b)).
@@ -71,10 +74,19 @@ __device__ __forceinline__ double atan_ratio(double a, double b) {
   const double r = rcp_fast(den);
   double u = num * r;
   u = fma(fma(-den, u, num), r, u);  // one residual step: u = num / den to rounding level
+  // atan(u)/u in s = u^2 (Chebyshev fit, see above), Horner with scalar-register coefficients
   const double s = u * u;
-  double p = ATAN_C[10];
-#pragma unroll
-  for (int i = 9; i >= 0; --i) p = fma(p, s, ATAN_C[i]);
+  double p = 0x1.2edf629854fb0p-6;
+  p = fma_sconst(p, s, -0x1.50b33e5fd9dc6p-5);
+  p = fma_sconst(p, s, 0x1.ca7e184710557p-5);
+  p = fma_sconst(p, s, -0x1.0f2d87b7f5b5cp-4);
+  p = fma_sconst(p, s, 0x1.3adfd52a966cfp-4);
+  p = fma_sconst(p, s, -0x1.745968dbb8c55p-4);
+  p = fma_sconst(p, s, 0x1.c71c469a22141p-4);
+  p = fma_sconst(p, s, -0x1.24924889af9fep-3);
+  p = fma_sconst(p, s, 0x1.999999973269cp-3);
+  p = fma_sconst(p, s, -0x1.555555555329bp-2);
+  p = fma_sconst(p, s, 0x1.ffffffffffff8p-1);
   return fma(u, p, low ? 0.0 : 0.78539816339744831);
 }
 
