@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkpdi.so")
 
 METRIC_NCC, METRIC_NDP = 0, 1
-COMPUTE_F32 = 0
+COMPUTE_F32, COMPUTE_F16X2 = 0, 1
 OP_SUBTRACT, OP_DIVIDE = 0, 1
 DOMAIN_FREQUENCY, DOMAIN_SPATIAL = 0, 1
 UNIQUE_ID_BYTES = 128
@@ -241,11 +241,11 @@ class Context:
         check(load().kpdi_synchronize(self._h))
 
     # -- set-up
-    def set_problem(self, sy, sx, signal_mask=None, metric=METRIC_NCC, keep_n=20):
+    def set_problem(self, sy, sx, signal_mask=None, metric=METRIC_NCC, keep_n=20, compute=COMPUTE_F32):
         sm = _mask_bytes(signal_mask)
         if sm is not None and sm.size != sy * sx:
             raise KpdiError(f"signal mask has {sm.size} elements, detector has {sy * sx}")
-        check(load().kpdi_set_problem(self._h, int(sy), int(sx), _ptr(sm), int(metric), COMPUTE_F32,
+        check(load().kpdi_set_problem(self._h, int(sy), int(sx), _ptr(sm), int(metric), int(compute),
                                       int(keep_n)))
 
     def set_keep_n(self, keep_n):

@@ -128,6 +128,7 @@ struct kpdi_ctx {
   bool have_sig_mask = false;
   DevBuf pix_map;  // int[k_kept]
   int metric = KPDI_METRIC_NCC;
+  int compute = KPDI_COMPUTE_F32;
   int keep_n = 0;
 
   // experimental
@@ -294,6 +295,8 @@ int prepare_experimental(kpdi_ctx *c) {
   {
     ScopedTimer t(c, &c->ev_prep);
     HIPCHK(kpdi::launch_prep(p, c->stream));
+    if (c->compute == KPDI_COMPUTE_F16X2)
+      HIPCHK(kpdi::launch_split_f16(c->exp_x.as<float>(), c->m_pad, c->kpad, c->stream));
   }
   c->exp_prepared = true;
   return KPDI_OK;
@@ -333,6 +336,7 @@ int run_match(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int rows_per_la
   ml.part_idx = c->part_i.as<int>();
   ml.bound_score = bound_s;
   ml.bound_idx = bound_i;
+  ml.split_f16 = c->compute == KPDI_COMPUTE_F16X2;
   {
     // the published ranks are only comparable under one plan: (re)initialise when it changes
     int rank, grouped, used;
@@ -423,6 +427,8 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
   {
     ScopedTimer t(c, &c->ev_prep);
     HIPCHK(kpdi::launch_prep(p, c->stream));
+    if (c->compute == KPDI_COMPUTE_F16X2)
+      HIPCHK(kpdi::launch_split_f16(c->dict_y.as<float>(), n_pad, c->kpad, c->stream));
   }
 
   const int row_blocks = c->m_pad / kpdi::TILE_EXP;
@@ -638,7 +644,8 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
   if (sy <= 0 || sx <= 0) return fail(KPDI_EINVAL, "detector shape (%d, %d) must be positive", sy, sx);
   if (metric != KPDI_METRIC_NCC && metric != KPDI_METRIC_NDP) return fail(KPDI_EINVAL, "unknown metric %d", metric);
-  if (compute_dtype != KPDI_COMPUTE_F32) return fail(KPDI_EINVAL, "unknown compute dtype %d", compute_dtype);
+  if (compute_dtype != KPDI_COMPUTE_F32 && compute_dtype != KPDI_COMPUTE_F16X2)
+    return fail(KPDI_EINVAL, "unknown compute dtype %d", compute_dtype);
   if (keep_n <= 0) return fail(KPDI_EINVAL, "keep_n must be >= 1");
   int rc = use_device(c);
   if (rc) return rc;
@@ -660,6 +667,7 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   c->k_kept = signal_mask ? (int)keep.size() : npix;
   c->kpad = kpdi::round_up(c->k_kept, kpdi::TILE_K);
   c->metric = metric;
+  c->compute = compute_dtype;
   c->keep_n = keep_n;
   c->have_problem = true;
   c->exp_prepared = false;

@@ -56,6 +56,7 @@ struct MatchLaunch {
   int bound_rank, bound_grouped;  // from bound_plan()
   unsigned *tile_ctr;  // [m_pad / TILE_EXP][tile_groups] dynamic tile counters, zeroed before every launch
   int tile_groups;     // 8 = XCD-affine hand-out (nsplit % 8 == 0), 1 = one counter per row block
+  int split_f16;       // operands are in the split-f16 form (launch_split_f16), see match.hip
 };
 constexpr unsigned THRESHOLD_NONE = 0x007fffffu;  // key of -inf
 constexpr int BOUND_SLOTS = 32;
@@ -90,6 +91,10 @@ struct PrepLaunch {
   float *out;          // (>= n_out, kpad)
 };
 hipError_t launch_prep(const PrepLaunch &a, hipStream_t s);
+// in place: prepared f32 rows [0, n_rows_pad) x kpad -> split-f16 form (KPDI_COMPUTE_F16X2): every
+// 128-byte row-slab (32 pixels) becomes 4 slots of high halves + 4 slots of low halves of
+// 2^12 * value, eight f16 pixels per 16-byte slot; n_rows_pad multiple of 128
+hipError_t launch_split_f16(float *prepared, int n_rows_pad, int kpad, hipStream_t s);
 
 // ---- top-k merge (merge.hip) -------------------------------------------------
 struct MergeLaunch {

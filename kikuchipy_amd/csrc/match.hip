@@ -165,17 +165,19 @@ __device__ __forceinline__ float next_up(float f) {
 // last entry), and only a register in which some lane does takes the exact path (valid
 // row, multi-pass bound, insertion).  The register index r is a scalar loop counter
 // (relative VGPR addressing), so there is one copy of the insertion code per accumulator.
-template <int KMAX, bool BOUNDED>
+template <int KMAX, bool BOUNDED, bool SPLIT>
 __device__ __forceinline__ void scan_tile(f32x16 (&acc)[4], float (&best)[KMAX], int (&best_idx)[KMAX],
                                           float gthr, float ub, int ub_idx, int row0, int n_valid,
                                           int idx_base) {
+  // split-f16 operands are stored scaled by 2^12 each: the accumulators hold 2^24 * score
+  constexpr float unscale = SPLIT ? 0x1p-24f : 1.f;
   // v > best[KMAX-1]  <=>  v >= nextafter(best[KMAX-1], +inf)   (scores are finite)
   float thr = fmaxf(gthr, next_up(best[KMAX - 1]));
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
 #pragma unroll 1
     for (int r = 0; r < 16; ++r) {
-      const float v = acc[rt][r] + 0.f;  // -0 -> +0 so that ties compare as the merge does
+      const float v = acc[rt][r] * unscale + 0.f;  // -0 -> +0 so that ties compare as the merge does
       if (__builtin_amdgcn_ballot_w64(v >= thr) != 0) {
         const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
         const int idx = idx_base + lrow;
@@ -202,6 +204,11 @@ __device__ __forceinline__ void mfma_acc(f32x16 &c, float a, float b) {
   asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
+// split-f16 form: acc += A x B for 16 pixels, A and B = 8 f16 per lane (one 16-byte LDS slot)
+__device__ __forceinline__ void mfma_acc_h(f32x16 &c, const f32x4 &a, const f32x4 &b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
 // One of a wave's twelve 1 KB LDS-DMA pieces of a stage: 0-3 dictionary slab, 4-7 / 8-11
 // the two experimental slabs.  `gd`/`ge` already include the lane's 16-byte offset.
 __device__ __forceinline__ void issue_piece(const char *gd, const char *ge, size_t tile_bytes, char *stage_base,
@@ -214,7 +221,7 @@ __device__ __forceinline__ void issue_piece(const char *gd, const char *ge, size
                                    16, 0, 0);
 }
 
-template <int KMAX, bool BOUNDED>
+template <int KMAX, bool BOUNDED, bool SPLIT>
 __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -334,11 +341,19 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
     __syncthreads();
 
     // A (dictionary) and B (experimental) fragments, double buffered by pixel group
-    f32x4 fa[2][4], fb[2][2];
+    // (split-f16: by 16-pixel step; [.][0..3] = the high halves of the 4 row tiles / 2 column
+    // groups, [.][4..7] / [.][2..3] the low halves)
+    f32x4 fa[2][SPLIT ? 8 : 4], fb[2][SPLIT ? 4 : 2];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) fa[0][rt] = *(const f32x4 *)(smem + rt * 4096 + frag[0]);
 #pragma unroll
     for (int c = 0; c < 2; ++c) fb[0][c] = *(const f32x4 *)(smem + exp_frag + c * 4096 + frag[0]);
+    if (SPLIT) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) fa[0][4 + rt] = *(const f32x4 *)(smem + rt * 4096 + frag[2]);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) fb[0][2 + c] = *(const f32x4 *)(smem + exp_frag + c * 4096 + frag[2]);
+    }
 
     int stage = 0;
 #pragma clang loop unroll(disable)
@@ -364,6 +379,42 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
       KPDI_CURSOR_SET();
       char *ld_base = smem + ld_stage * STAGE_BYTES;
 
+      if (SPLIT) {
+        // ---- split-f16 slab: 2 steps of 16 pixels; per step and accumulator three MFMAs
+        // hi.hi + hi.lo + lo.hi (the lo.lo term is below 2^-22 of the product).  The 16-byte
+        // LDS slots hold 8 f16: slots 0-3 of a row = high halves of pixels 8q..8q+7, slots
+        // 4-7 the low halves, so the fragment addresses are the f32 kernel's frag[0..3].
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const int cur = st;
+          if (st == 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (slab == 0 && tid == 0) ctrl[4 + tp] = fetched;
+            __syncthreads();
+          }
+          // fragments of the next step: step 1 of this slab, or step 0 of the next slab
+          const char *src_hi = st == 0 ? ls + frag[1] : ls_next + frag[0];
+          const char *src_lo = st == 0 ? ls + frag[3] : ls_next + frag[2];
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+              const f32x4 &av = fa[cur][g == 2 ? 4 + rt : rt];
+              mfma_acc_h(acc0[rt], av, fb[cur][g == 1 ? 2 : 0]);
+              mfma_acc_h(acc1[rt], av, fb[cur][g == 1 ? 3 : 1]);
+              // in the shadow of these MFMAs: one fragment load and (second half of the slab,
+              // after the barrier) one LDS-DMA piece of the slab two steps ahead
+              const int slot = g * 4 + rt;  // 0..11
+              if (slot < 4) fa[cur ^ 1][slot] = *(const f32x4 *)(src_hi + slot * 4096);
+              else if (slot < 8) fa[cur ^ 1][slot] = *(const f32x4 *)(src_lo + (slot - 4) * 4096);
+              else if (slot < 10) fb[cur ^ 1][slot - 8] = *(const f32x4 *)(src_hi + exp_frag + (slot - 8) * 4096);
+              else fb[cur ^ 1][slot - 8] = *(const f32x4 *)(src_lo + exp_frag + (slot - 10) * 4096);
+              if (st == 1) issue_piece(gd, ge, tile_bytes, ld_base, wv, slot);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg) {
         const int cur = kg & 1;
@@ -400,6 +451,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      }
       KPDI_CURSOR_ADVANCE();
       stage = nstage;
       }  // slabs
@@ -416,8 +468,8 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
           pub0 = j == bound_rank - 1 ? best0[j] : pub0;
           pub1 = j == bound_rank - 1 ? best1[j] : pub1;
         }
-        scan_tile<KMAX, BOUNDED>(acc0, best0, bidx0, g0, ub0, ubi0, row0, n_valid, idx_base);
-        scan_tile<KMAX, BOUNDED>(acc1, best1, bidx1, g1, ub1, ubi1, row0, n_valid, idx_base);
+        scan_tile<KMAX, BOUNDED, SPLIT>(acc0, best0, bidx0, g0, ub0, ubi0, row0, n_valid, idx_base);
+        scan_tile<KMAX, BOUNDED, SPLIT>(acc1, best1, bidx1, g1, ub1, ubi1, row0, n_valid, idx_base);
         // publish the list entry the bound is built from, if it rose
         float now0 = best0[0], now1 = best1[0];
 #pragma unroll
@@ -466,16 +518,17 @@ int match_list_len(int k) {
 
 int match_blocks_per_cu() { return 1; }
 
-template <int KMAX, bool BOUNDED>
+template <int KMAX, bool BOUNDED, bool SPLIT>
 static hipError_t launch_t(const MatchArgs &args, int grid, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)match_topk_kernel<KMAX, BOUNDED>,
+    hipError_t e = hipFuncSetAttribute((const void *)match_topk_kernel<KMAX, BOUNDED, SPLIT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 32);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((match_topk_kernel<KMAX, BOUNDED>), dim3(grid), dim3(MATCH_THREADS), LDS_BYTES + 32, s, args);
+  hipLaunchKernelGGL((match_topk_kernel<KMAX, BOUNDED, SPLIT>), dim3(grid), dim3(MATCH_THREADS), LDS_BYTES + 32, s,
+                     args);
   return hipGetLastError();
 }
 
@@ -500,9 +553,10 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   g.tile_groups = a.tile_groups;
   const int grid = a.rows * a.nsplit;
   const bool bounded = a.bound_score != nullptr;
-#define KPDI_CASE(K)                                           \
-  case K:                                                      \
-    return bounded ? launch_t<K, true>(g, grid, s) : launch_t<K, false>(g, grid, s);
+#define KPDI_CASE(K)                                                                             \
+  case K:                                                                                        \
+    if (a.split_f16) return bounded ? launch_t<K, true, true>(g, grid, s) : launch_t<K, false, true>(g, grid, s); \
+    return bounded ? launch_t<K, true, false>(g, grid, s) : launch_t<K, false, false>(g, grid, s);
   switch (a.list_len) {
     KPDI_CASE(1)
     KPDI_CASE(8)

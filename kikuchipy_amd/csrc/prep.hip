@@ -248,6 +248,52 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_masked_kernel(const T 
   }
 }
 
+// ---- split-f16 form of a prepared matrix (KPDI_COMPUTE_F16X2), in place -------------------
+// One thread per (pattern row, 32-pixel slab): its eight 16-byte slots hold 32 floats
+// (slot q = pixels 4q..4q+3); they are rewritten as v * 2^12 = hi + lo with hi = f16(v * 2^12),
+// lo = f16(v * 2^12 - hi): slots 0-3 = hi of pixels 8q..8q+7, slots 4-7 = lo of the same.
+// A thread reads all of its slots before it writes any, and no two threads share a slot.
+__global__ __launch_bounds__(256) void split_f16_kernel(float *prepared, int nslab, int64_t n_items) {
+  const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (item >= n_items) return;
+  const int row = (int)(item & 127);
+  const int64_t block = item >> 7;  // tile * nslab + slab
+  float4 *base = (float4 *)(prepared + block * 4096);
+  const int rp = row >> 1, hb = (row & 1) << 3, sw = rp & 7;
+  float v[32];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float4 f = base[rp * 16 + ((hb | q) ^ sw)];
+    v[4 * q] = f.x;
+    v[4 * q + 1] = f.y;
+    v[4 * q + 2] = f.z;
+    v[4 * q + 3] = f.w;
+  }
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = v[8 * q + e] * 4096.f;
+      const _Float16 h = (_Float16)x;
+      hi[e] = h;
+      lo[e] = (_Float16)(x - (float)h);
+    }
+    *(h8 *)&base[rp * 16 + ((hb | q) ^ sw)] = hi;
+    *(h8 *)&base[rp * 16 + ((hb | (4 + q)) ^ sw)] = lo;
+  }
+}
+
+hipError_t launch_split_f16(float *prepared, int n_rows_pad, int kpad, hipStream_t s) {
+  const int nslab = kpad / TILE_K;
+  const int64_t n_items = (int64_t)n_rows_pad * nslab;
+  if (n_items <= 0) return hipSuccess;
+  hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, prepared, nslab,
+                     n_items);
+  return hipGetLastError();
+}
+
 hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   if (a.n_out <= 0) return hipSuccess;
   const bool wave_path = a.k <= 64 * WAVE_VALUES;

@@ -83,10 +83,10 @@ def _is_lazy(a):
 
 
 def prepare_metric(metric, navigation_mask, signal_mask, dtype, rechunk, n_experimental,
-                   n_dictionary_patterns, device=0):
+                   n_dictionary_patterns, device=0, compute="f32"):
     """EBSD._prepare_metric (signals/ebsd.py:3049-3088)."""
     if isinstance(metric, str) and metric in METRICS:
-        metric = METRICS[metric](device=device)
+        metric = METRICS[metric](device=device, compute=compute)
         metric.rechunk = rechunk
     if not isinstance(metric, SimilarityMetric):
         raise ValueError(
@@ -132,6 +132,7 @@ def dictionary_indexing(
     device=0,
     comm=None,
     verbose=True,
+    compute="f32",
 ):
     """Index experimental patterns against a dictionary of simulated patterns.
 
@@ -154,6 +155,9 @@ def dictionary_indexing(
     step_sizes, dictionary_rotations, phase_name, scan_unit
         What the reference takes from the signals' axes managers and from
         `dictionary.xmap` (rotations as an (N, 4) quaternion array).
+    compute
+        "f32" (default) or the opt-in "f16x2" arithmetic of the match kernel, see
+        `NormalizedCrossCorrelationMetric`; ignored when `metric` is an instance.
     comm
         `kikuchipy_amd.parallel.Communicator` to shard the dictionary over
         ranks (one process per GPU).  Every rank must pass the same arrays; each
@@ -208,7 +212,7 @@ def dictionary_indexing(
 
     n_experimental_all = int(np.prod(nav_shape_exp)) if nav_shape_exp else 1
     metric = prepare_metric(metric, navigation_mask, signal_mask, dtype, rechunk, n_experimental_all,
-                            dict_size, device=device)
+                            dict_size, device=device, compute=compute)
     if not isinstance(metric, _HipMetric):
         raise ValueError("the stand-alone driver runs the GPU metrics of kikuchipy_amd only")
 

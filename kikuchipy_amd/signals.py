@@ -162,7 +162,7 @@ class EBSD:
     # ------------------------------------------------------------------ indexing
     def dictionary_indexing(self, dictionary, metric="ncc", keep_n=20, n_per_iteration=None,
                             navigation_mask=None, signal_mask=None, rechunk=False, dtype=None, *,
-                            comm=None, verbose=True):
+                            comm=None, verbose=True, compute="f32"):
         """See `kikuchipy_amd.dictionary_indexing`; `dictionary` is an `EBSD`
         with a 1-D navigation axis and an `xmap` of equal size."""
         dict_data = dictionary.data
@@ -184,6 +184,7 @@ class EBSD:
             self.data, dict_data, metric, keep_n, n_per_iteration, navigation_mask, signal_mask,
             rechunk, dtype, step_sizes=self.step_sizes, dictionary_rotations=dict_xmap.rotations,
             phase_name=dict_xmap.phase_name, scan_unit=self.scan_unit, device=self._device, comm=comm,
+            compute=compute,
             verbose=verbose,
         )
 
