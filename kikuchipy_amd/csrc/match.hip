@@ -227,8 +227,6 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // block -> (block of 256 experimental patterns rb, list slot sp); block b sits on XCD
-  // b%8 (speed only): consecutive blocks of one XCD share rb, i.e. the experimental slabs
   const int sp = blockIdx.x % a.nsplit;
   const int rb = a.row_first + blockIdx.x / a.nsplit;
   // kernel arguments into locals (nothing below takes the address of `a`)
