@@ -221,3 +221,27 @@ def test_sharded_sweep_equals_full_sweep(synth_inputs):
     order = np.lexsort((i, -s), axis=1)[:, :k]
     assert np.array_equal(np.take_along_axis(i, order, 1), ref_i)
     assert np.array_equal(np.take_along_axis(s, order, 1), ref_s)
+
+
+@pytest.mark.parametrize("k,metric", [(20, "ncc"), (40, "ndp")])
+def test_large_experimental_set_takes_several_launches(k, metric):
+    """More than 256 / nsplit row blocks: the sweep is cut into launches over two streams
+    (api.hip: choose_nsplit); with keep_n > 32 every pass is."""
+    from kikuchipy_amd import _lib
+
+    rng = np.random.default_rng(77)
+    exp = rng.integers(0, 256, (17000, 12, 12), dtype=np.uint8)
+    dic = rng.random((1500, 12, 12)).astype(np.float32)
+    nav = rng.random(17000) < 0.1
+    with _lib.Context(0) as c:
+        c.set_problem(12, 12, None, {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[metric], k)
+        c.set_experimental(exp, nav)
+        for a in range(0, 1500, 700):
+            c.push_dictionary_chunk(dic[a:a + 700], a)
+        s, i = c.finalize(k)
+        grid = c.counters()["match_grid"]
+    assert s.shape == (int((~nav).sum()), k) and grid <= 256
+    rows = np.flatnonzero(~nav)[::97]
+    rs, ri = ko.dictionary_indexing(exp[rows], dic, metric=metric, keep_n=k)
+    pos = np.searchsorted(np.flatnonzero(~nav), rows)
+    ko.assert_topk_parity(s[pos], i[pos], rs, ri, atol=ATOL)
