@@ -1,15 +1,15 @@
 """`kikuchipy.indexing.merge_crystal_maps` for the engine's result objects
 (indexing/_merge_crystal_maps.py:28-354 of the reference).
 
-Host-side NumPy: this is bookkeeping over (M, N, K) score arrays (which phase
-wins each map point, the merged ranking over all phases), a few MB even for a
-200 x 200 map - there is nothing for the GPU to win.  The orix `CrystalMap` /
-`PhaseList` handling of the reference is replaced by plain arrays and phase
-names; the arithmetic is the reference's.
+Host-side NumPy: this is bookkeeping over an (M points, N scores, K maps) array -
+which phase wins each map point, and the ranking of all phases' matches per
+point - a few MB even for a 200 x 200 map, so there is nothing for the GPU to
+win.  The orix `CrystalMap` / `PhaseList` handling of the reference is replaced by
+plain arrays and phase names; inputs, outputs, error messages and arithmetic are
+the reference's (pinned by tests/golden/consumers.npz).
 """
 
 from math import copysign
-import warnings
 
 import numpy as np
 
@@ -55,14 +55,84 @@ class MergedIndexingResult:
         return out
 
 
-def _prop(xmap, name):
-    return np.asarray(xmap.prop[name])
+class _Layout:
+    """Which map points each input map covers.  `where[i]` is None for a map that
+    covers every point, else the flat indices of its points (its property arrays
+    have one row per covered point, in that order)."""
+
+    def __init__(self, maps, masks):
+        n_in_data = [int(np.sum(x.is_in_data)) for x in maps]
+        if masks is None and not all(n == np.size(x.is_in_data) for n, x in zip(n_in_data, maps)):
+            # derived from the maps themselves (the reference slices `is_in_data` to the map shape)
+            masks = [~np.asarray(x.is_in_data).reshape(x.shape) for x in maps]
+        shapes = [tuple(x.shape) for x in maps]
+        if masks is not None:
+            if len(masks) != len(maps):
+                raise ValueError("Number of crystal maps and navigation masks must be equal")
+            for i, mask in enumerate(masks):
+                if mask is None:
+                    continue
+                if not isinstance(mask, np.ndarray):
+                    raise ValueError(f"{i}. navigation mask must be a NumPy array or 'None'")
+                kept = int(np.sum(~mask))
+                if kept != n_in_data[i]:
+                    raise ValueError(
+                        f"{i}. navigation mask does not have as many 'False', {kept}, as there are points in the "
+                        f"crystal map, {n_in_data[i]}"
+                    )
+                shapes[i] = mask.shape
+        if len(set(shapes)) != 1:
+            raise ValueError("Crystal maps (and/or navigation masks) must have the same navigation shape")
+        self.shape = shapes[0]
+        self.size = int(np.prod(self.shape))
+        self.masked = masks is not None
+        if masks is None:
+            self.where = [None] * len(maps)
+        else:
+            self.where = [np.arange(self.size) if m is None else np.flatnonzero(~m.ravel()) for m in masks]
+        self._in_data = [np.asarray(x.is_in_data, dtype=bool) for x in maps]
+
+    def rows(self, i, array):
+        """The rows of map i's property `array` that belong to its covered points: results of
+        this package carry full-size arrays with empty rows at masked-out points."""
+        array = np.asarray(array)
+        isin = self._in_data[i]
+        if array.shape[0] == isin.size and not isin.all():
+            return array[isin]
+        return array
+
+    def scatter(self, per_map, fill, dtype):
+        """(M, ..., K): map i's rows placed at its points, `fill` elsewhere."""
+        inner = per_map[0].shape[1:]
+        out = np.full((self.size,) + inner + (len(per_map),), fill, dtype=dtype)
+        for i, (where, values) in enumerate(zip(self.where, per_map)):
+            if where is None:
+                out[..., i] = values
+            else:
+                out[where, ..., i] = values
+        return out
+
+    def local_rows(self, i, points):
+        """Row numbers inside map i's arrays of the (covered) map points `points`."""
+        if self.where[i] is None:
+            return points
+        lookup = np.full(self.size, -1)
+        lookup[self.where[i]] = np.arange(self.where[i].size)
+        return lookup[points]
 
 
-def _phase_ids(xmap, n_points):
-    """-1 where a point of the map is marked not indexed."""
-    pid = getattr(xmap, "phase_id", None)
-    return np.zeros(n_points, dtype=int) if pid is None else np.asarray(pid)
+def _not_indexed_everywhere(layout, maps, n_rows):
+    """Points whose phase ID is -1 in every map.  The reference records the -1 points of a
+    map only when the merge runs without navigation masks: with masks it assigns into a
+    temporary (`not_indexed[i, mask][xmap.phase_id == -1] = True`, :167), which leaves the
+    table untouched - reproduced here, results must equal the reference's."""
+    table = np.zeros((len(maps), layout.size), dtype=bool)
+    if not layout.masked:
+        for i, xmap in enumerate(maps):
+            pid = getattr(xmap, "phase_id", None)
+            if pid is not None:
+                table[i, np.asarray(pid)[: n_rows[i]] == -1] = True
+    return table.all(axis=0)
 
 
 def merge_crystal_maps(crystal_maps, mean_n_best=1, greater_is_better=None, scores_prop="scores",
@@ -73,143 +143,78 @@ def merge_crystal_maps(crystal_maps, mean_n_best=1, greater_is_better=None, scor
 
     crystal_maps
         `DictionaryIndexingResult`s / `RefinementResult`s (anything with
-        `.prop[...]`, `.rotations`, `.shape`, `.is_in_data`, `.phase_name`);
-        their property arrays hold the points that are in the data.
+        `.prop[...]`, `.rotations`, `.shape`, `.is_in_data`, `.phase_name`).
     mean_n_best, greater_is_better, scores_prop, simulation_indices_prop, navigation_masks
-        As in the reference (masks: True = point NOT in that map).
+        As in the reference (masks: True = point NOT in that map; a negative
+        `mean_n_best` means lower scores are better when `greater_is_better` is
+        not given).
     """
-    n_maps = len(crystal_maps)
-    if navigation_masks is None:
-        all_in = [np.all(x.is_in_data) for x in crystal_maps]
-        if not all(all_in):
-            navigation_masks = [~np.asarray(x.is_in_data).reshape(x.shape) for x in crystal_maps]
-    if navigation_masks is not None:
-        if len(navigation_masks) != n_maps:
-            raise ValueError("Number of crystal maps and navigation masks must be equal")
-        map_shapes = []
-        for i, (mask, xmap) in enumerate(zip(navigation_masks, crystal_maps)):
-            if isinstance(mask, np.ndarray):
-                mask_is_in_data = np.sum(~mask)
-                map_is_in_data = int(np.sum(xmap.is_in_data))
-                if mask_is_in_data != map_is_in_data:
-                    raise ValueError(
-                        f"{i}. navigation mask does not have as many 'False', {mask_is_in_data}, as there are "
-                        f"points in the crystal map, {map_is_in_data}"
-                    )
-                map_shapes.append(mask.shape)
-            elif mask is None:
-                map_shapes.append(tuple(xmap.shape))
-            else:
-                raise ValueError(f"{i}. navigation mask must be a NumPy array or 'None'")
-    else:
-        map_shapes = [tuple(x.shape) for x in crystal_maps]
-    if len({len(s) for s in map_shapes}) != 1 or not np.sum(abs(np.diff(map_shapes, axis=0))) == 0:
-        raise ValueError("Crystal maps (and/or navigation masks) must have the same navigation shape")
-    map_shape = map_shapes[0]
-    map_size = int(np.prod(map_shape))
-    if navigation_masks is not None:
-        masks1d = [np.ones(map_size, dtype=bool) if m is None else ~m.ravel() for m in navigation_masks]
-    else:
-        masks1d = [None] * n_maps
-
-    def in_data(xmap, arr):
-        """Property rows of the points that are in the data (results of this package carry
-        full-size arrays with zero rows for masked points)."""
-        arr = np.asarray(arr)
-        isin = np.asarray(xmap.is_in_data)
-        return arr[isin] if arr.shape[0] == isin.size and not isin.all() else arr
-
-    scores_all = [in_data(x, _prop(x, scores_prop)) for x in crystal_maps]
-    per_point = [1 if s.ndim == 1 else s.shape[1] for s in scores_all]
-    if not all(np.diff(per_point) == 0):
+    maps = list(crystal_maps)
+    layout = _Layout(maps, navigation_masks)
+    scores = [layout.rows(i, x.prop[scores_prop]) for i, x in enumerate(maps)]
+    per_point = {1 if s.ndim == 1 else s.shape[1] for s in scores}
+    if len(per_point) != 1:
         raise ValueError("Crystal maps must have the same number of rotations and scores per point")
-    n_scores_per_point = per_point[0]
-    sim_all = None
+    n_scores = per_point.pop()
+    indices = None
     if simulation_indices_prop is not None:
-        sim_all = [in_data(x, _prop(x, simulation_indices_prop)) for x in crystal_maps]
-        n_sim_idx = sim_all[0].shape
-        if len(n_sim_idx) > 1 and n_sim_idx[1] > n_scores_per_point:
+        indices = [layout.rows(i, x.prop[simulation_indices_prop]) for i, x in enumerate(maps)]
+        if indices[0].ndim > 1 and indices[0].shape[1] > n_scores:
             raise ValueError("Cannot merge maps with more simulation indices than scores per point")
     if greater_is_better is None:
-        sign = copysign(1, mean_n_best)
-        mean_n_best = abs(mean_n_best)
+        direction, n_mean = copysign(1, mean_n_best), abs(mean_n_best)
     else:
-        sign = 1 if greater_is_better else -1
+        direction, n_mean = (1 if greater_is_better else -1), mean_n_best
 
-    comb_shape = (map_size,) + ((n_scores_per_point,) if n_scores_per_point > 1 else ()) + (n_maps,)
-    scores_dtype = scores_all[0].dtype
-    combined_scores = np.full(comb_shape, np.nan, dtype=np.dtype(f"f{scores_dtype.itemsize}"))
-    for i, (mask, sc) in enumerate(zip(masks1d, scores_all)):
-        if mask is not None:
-            combined_scores[mask, ..., i] = sc
-        else:
-            combined_scores[..., i] = sc
-    if n_scores_per_point > 1:
-        best_scores = combined_scores[:, :mean_n_best].squeeze()
-        if len(best_scores.shape) > 2:
-            best_scores = np.nanmean(best_scores, axis=1)
+    # ---- which map wins each point
+    score_dtype = scores[0].dtype
+    stack = layout.scatter(scores, np.nan, np.dtype(f"f{score_dtype.itemsize}"))  # (M, N, K) or (M, K)
+    if n_scores > 1:
+        criterion = stack[:, :n_mean].squeeze()
+        if criterion.ndim > 2:
+            criterion = np.nanmean(criterion, axis=1)
     else:
-        best_scores = combined_scores
-    phase_id = np.nanargmax(sign * best_scores, axis=1)
+        criterion = stack
+    winner = np.nanargmax(direction * criterion, axis=1)
+    winner[_not_indexed_everywhere(layout, maps, [s.shape[0] for s in scores])] = -1
 
-    not_indexed = np.zeros((n_maps, map_size), dtype=bool)
-    for i, (mask, xmap) in enumerate(zip(masks1d, crystal_maps)):
-        pid = _phase_ids(xmap, scores_all[i].shape[0])
-        if mask is not None:
-            # the reference writes `not_indexed[i, mask][xmap.phase_id == -1] = True` (:167), i.e.
-            # into a temporary copy: not-indexed points of a map that comes with a navigation
-            # mask are NOT recorded.  Kept as is: results must equal the reference's.
-            pass
-        else:
-            not_indexed[i, pid == -1] = True
-    not_indexed = np.logical_and.reduce(not_indexed)
-    phase_id[not_indexed] = -1
-
-    new_rotations = np.zeros(comb_shape[:-1] + (4,), dtype="float")
-    new_scores = np.zeros(comb_shape[:-1], dtype=scores_dtype)
-    new_indices = np.zeros(comb_shape[:-1], dtype="int32") if sim_all is not None else None
+    # ---- the winner's own rotations, scores and indices; phase IDs count up in the order in
+    # which phases first win a point, maps of an already listed phase share its ID (:225-243)
+    point_shape = stack.shape[:-1]
+    rotations = np.zeros(point_shape + (4,), dtype=np.float64)
+    best_scores = np.zeros(point_shape, dtype=score_dtype)
+    best_indices = np.zeros(point_shape, dtype=np.int32) if indices is not None else None
     phase_names = []
-    for i, (mask, xmap) in enumerate(zip(masks1d, crystal_maps)):
-        phase_mask = phase_id == i
-        if not phase_mask.any():
+    phase_id = winner.copy()
+    for i, xmap in enumerate(maps):
+        points = np.flatnonzero(winner == i)
+        if points.size == 0:
             continue
         name = getattr(xmap, "phase_name", "") or ""
         if name in phase_names:
-            # same name = same phase here (names are all these result objects know of a phase):
-            # not duplicated in the phase list, the points get the first map's ID (:231-237)
-            phase_id[phase_mask] = phase_names.index(name)
+            phase_id[points] = phase_names.index(name)
         else:
-            phase_names.append(name)  # PhaseList.add: IDs count up in the order of addition
-        rot = in_data(xmap, np.asarray(getattr(xmap.rotations, "data", xmap.rotations)))
-        rows = phase_mask[mask] if mask is not None else phase_mask
-        new_rotations[phase_mask] = rot[rows]
-        new_scores[phase_mask] = scores_all[i][rows]
-        if sim_all is not None:
-            new_indices[phase_mask] = sim_all[i][rows]
+            phase_names.append(name)
+        local = layout.local_rows(i, points)
+        rot = layout.rows(i, np.asarray(getattr(xmap.rotations, "data", xmap.rotations)))
+        rotations[points] = rot[local]
+        best_scores[points] = scores[i][local]
+        if indices is not None:
+            best_indices[points] = indices[i][local]
 
-    mergesort_shape = (comb_shape[0], int(np.prod(comb_shape[1:])))
-    comb_scores_reshaped = combined_scores.reshape(mergesort_shape)
-    best_sorted_idx = np.argsort(sign * -comb_scores_reshaped, kind="mergesort", axis=1)
-    merged_best_scores = np.take_along_axis(comb_scores_reshaped, best_sorted_idx, axis=-1)
-    merged_sim = None
-    if sim_all is not None:
-        comb = []
-        for mask, si in zip(masks1d, sim_all):
-            if mask is not None:
-                full = np.full(comb_shape[:-1], np.nan)
-                full[mask] = si
-                comb.append(full)
-            else:
-                comb.append(si)
-        comb_sim_idx = np.dstack(comb)
-        # make the indices unique across the maps so that an orientation similarity map can
-        # be computed from the merged lists
-        for i in range(1, comb_sim_idx.shape[-1]):
-            increment = abs(np.nanmax(comb_sim_idx[..., i - 1]) - np.nanmin(comb_sim_idx[..., i])) + 1
-            comb_sim_idx[..., i] += increment
-        comb_sim_idx = comb_sim_idx.reshape(mergesort_shape)
-        merged_sim = np.take_along_axis(comb_sim_idx, best_sorted_idx, axis=-1)
-    first = crystal_maps[0]
-    return MergedIndexingResult(map_shape, phase_id, phase_names, new_rotations, new_scores, merged_best_scores,
-                                new_indices, merged_sim, scores_prop, simulation_indices_prop,
+    # ---- all phases' matches of a point ranked together (stable, like the reference's mergesort)
+    flat = stack.reshape(layout.size, -1)
+    order = np.argsort(direction * -flat, kind="stable", axis=1)
+    merged_scores = np.take_along_axis(flat, order, axis=1)
+    merged_indices = None
+    if indices is not None:
+        index_stack = layout.scatter([np.asarray(ix, dtype=np.float64) for ix in indices], np.nan, np.float64)
+        # shifted per map so that no two maps share an index value: an orientation similarity
+        # map can then be computed from the merged lists (:313-322)
+        for i in range(1, index_stack.shape[-1]):
+            index_stack[..., i] += abs(np.nanmax(index_stack[..., i - 1]) - np.nanmin(index_stack[..., i])) + 1
+        merged_indices = np.take_along_axis(index_stack.reshape(layout.size, -1), order, axis=1)
+    first = maps[0]
+    return MergedIndexingResult(layout.shape, phase_id, phase_names, rotations, best_scores, merged_scores,
+                                best_indices, merged_indices, scores_prop, simulation_indices_prop,
                                 getattr(first, "step_sizes", None), getattr(first, "scan_unit", None))
