@@ -291,12 +291,11 @@ int prepare_experimental(kpdi_ctx *c) {
   p.kpad = c->kpad;
   p.n_out = c->m;
   p.metric = c->metric;
+  p.split_f16 = c->compute == KPDI_COMPUTE_F16X2;
   p.out = c->exp_x.as<float>();
   {
     ScopedTimer t(c, &c->ev_prep);
     HIPCHK(kpdi::launch_prep(p, c->stream));
-    if (c->compute == KPDI_COMPUTE_F16X2)
-      HIPCHK(kpdi::launch_split_f16(c->exp_x.as<float>(), c->m_pad, c->kpad, c->stream));
   }
   c->exp_prepared = true;
   return KPDI_OK;
@@ -423,12 +422,11 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
   p.kpad = c->kpad;
   p.n_out = (int)n_chunk;
   p.metric = c->metric;
+  p.split_f16 = c->compute == KPDI_COMPUTE_F16X2;
   p.out = c->dict_y.as<float>();
   {
     ScopedTimer t(c, &c->ev_prep);
     HIPCHK(kpdi::launch_prep(p, c->stream));
-    if (c->compute == KPDI_COMPUTE_F16X2)
-      HIPCHK(kpdi::launch_split_f16(c->dict_y.as<float>(), n_pad, c->kpad, c->stream));
   }
 
   const int row_blocks = c->m_pad / kpdi::TILE_EXP;

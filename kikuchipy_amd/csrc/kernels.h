@@ -89,6 +89,7 @@ struct PrepLaunch {
   int n_out;           // rows to produce
   int metric;          // KPDI_METRIC_*
   float *out;          // (>= n_out, kpad)
+  int split_f16;       // write the split-f16 form (KPDI_COMPUTE_F16X2) instead of f32
 };
 hipError_t launch_prep(const PrepLaunch &a, hipStream_t s);
 // in place: prepared f32 rows [0, n_rows_pad) x kpad -> split-f16 form (KPDI_COMPUTE_F16X2): every

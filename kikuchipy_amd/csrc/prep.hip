@@ -120,8 +120,10 @@ __device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], flo
 }
 
 // same, v[4*i + e] holds kept pixel 4*(lane + 64*i) + e: float4 stores (full 16-byte slots)
+// `split`: store the split-f16 form directly (see split_f16_kernel below): the lane's four
+// pixels are half of an 8-pixel slot, i.e. 8 bytes of the high-half slot and 8 of the low-half slot
 __device__ __forceinline__ void normalise_and_store_quads(float (&v)[WAVE_VALUES], float s, int lane, int r, int k,
-                                                          int kpad, int metric, float *out) {
+                                                          int kpad, int metric, float *out, int split) {
   const int nslab = kpad / TILE_K;
   float mean = 0.f;
   if (metric == KPDI_METRIC_NCC) mean = wave_sum(s) / (float)k;
@@ -147,7 +149,24 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[WAVE_VALUES
       w.y = v[4 * i + 1] * inv;
       w.z = v[4 * i + 2] * inv;
       w.w = v[4 * i + 3] * inv;
-      *reinterpret_cast<float4 *>(out + prepared_offset(r, c, nslab)) = w;
+      if (!split) {
+        *reinterpret_cast<float4 *>(out + prepared_offset(r, c, nslab)) = w;
+      } else {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const float x[4] = {w.x * 4096.f, w.y * 4096.f, w.z * 4096.f, w.w * 4096.f};
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hi[e] = (_Float16)x[e];
+          lo[e] = (_Float16)(x[e] - (float)hi[e]);
+        }
+        const int g8 = (c & 31) >> 3, half = (c & 7) >> 2;  // 8-pixel group of the slab; first / second 4 pixels
+        const int slab_first = c & ~31;                      // any pixel of slot q lies at slab_first + 4 q
+        char *hi_slot = (char *)(out + prepared_offset(r, slab_first + 4 * g8, nslab));
+        char *lo_slot = (char *)(out + prepared_offset(r, slab_first + 4 * (4 + g8), nslab));
+        *reinterpret_cast<h4 *>(hi_slot + 8 * half) = hi;
+        *reinterpret_cast<h4 *>(lo_slot + 8 * half) = lo;
+      }
     }
   }
 }
@@ -158,7 +177,7 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[WAVE_VALUES
 template <typename T, int VEC>
 __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, int npix, const int *row_map,
                                                                  const int *pix_map, int k, int kpad,
-                                                                 int metric, int n_out, float *out) {
+                                                                 int metric, int n_out, float *out, int split) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * (PREP_THREADS / 64) + (threadIdx.x >> 6);
   if (r >= n_out) return;
@@ -179,7 +198,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, i
         s += v[4 * i + e];
       }
     }
-    normalise_and_store_quads(v, s, lane, r, k, kpad, metric, out);
+    normalise_and_store_quads(v, s, lane, r, k, kpad, metric, out, split);
   } else {
 #pragma unroll
     for (int i = 0; i < WAVE_VALUES; ++i) {
@@ -198,7 +217,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, i
 template <typename T>
 __global__ __launch_bounds__(PREP_THREADS) void prep_wave_masked_kernel(const T *raw, int npix, const int *row_map,
                                                                         const int *pix_map, int k, int kpad,
-                                                                        int metric, int n_out, float *out) {
+                                                                        int metric, int n_out, float *out, int split) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int *map = (int *)smem_raw;
   const int map_words = (k + 3) & ~3;
@@ -242,7 +261,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_masked_kernel(const T 
         v[4 * i + 3] = c + 3 < k ? row[px.w] : 0.f;
         s += (v[4 * i] + v[4 * i + 1]) + (v[4 * i + 2] + v[4 * i + 3]);
       }
-      normalise_and_store_quads(v, s, lane, r, k, kpad, metric, out);
+      normalise_and_store_quads(v, s, lane, r, k, kpad, metric, out, split);
     }
     __syncthreads();  // rows are overwritten by the next group
   }
@@ -307,7 +326,7 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
 #define KPDI_PREP(T)                                                                                     \
   if (vec4)                                                                                              \
     hipLaunchKernelGGL((prep_wave_kernel<T, 4>), grid, block, 0, s, (const T *)a.raw, a.npix,           \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out);                     \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, a.split_f16);        \
   else if (staged) {                                                                                     \
     if (staged_lds > 64 * 1024) {                                                                        \
       hipError_t e = hipFuncSetAttribute((const void *)prep_wave_masked_kernel<T>,                       \
@@ -315,10 +334,10 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
       if (e != hipSuccess) return e;                                                                     \
     }                                                                                                    \
     hipLaunchKernelGGL((prep_wave_masked_kernel<T>), grid, block, staged_lds, s, (const T *)a.raw,      \
-                       a.npix, a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out);             \
+                       a.npix, a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, a.split_f16); \
   } else if (wave_path)                                                                                  \
     hipLaunchKernelGGL((prep_wave_kernel<T, 1>), grid, block, 0, s, (const T *)a.raw, a.npix,           \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out);                     \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, 0);                  \
   else                                                                                                   \
     hipLaunchKernelGGL((prep_kernel<T>), grid, block, 0, s, (const T *)a.raw, a.npix, a.row_map,        \
                        a.pix_map, a.k, a.kpad, a.metric, a.out);                                         \
@@ -335,7 +354,13 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
     default: return hipErrorInvalidValue;
   }
 #undef KPDI_PREP
-  return hipGetLastError();
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  // paths that store whole float4 slots write the split-f16 form themselves; the others are
+  // converted in place afterwards (rows beyond n_out are zero in either form)
+  if (a.split_f16 && !(vec4 || staged))
+    return launch_split_f16(a.out, round_up(a.n_out, TILE_DICT), a.kpad, s);
+  return hipSuccess;
 }
 
 }  // namespace kpdi
