@@ -123,6 +123,10 @@ def main():
         a.gpus = world
     dist = None
     if world > 1:
+        # one node: RCCL's bootstrap can always use the loopback interface (the container's
+        # hostname may not resolve), and the host driver only supports dmabuf IPC
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         from kikuchipy_amd.parallel import init_process_group
 
         dist = init_process_group("gloo")
