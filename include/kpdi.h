@@ -183,7 +183,9 @@ int kpdi_project_patterns_varying_pc(kpdi_ctx *ctx, const double *rotations, con
                                      int64_t n, int nrows, int ncols,
                                      const double *om_detector_to_sample, int rescale,
                                      double out_min, double out_max, int dtype_out, void *out);
-/* generate + match in one call: the chunk of the dictionary belonging to
+/* generate + match in one call - what the reference does when the dictionary is a lazy
+ * `get_patterns(..., compute=False)` signal: the chunk is computed inside the indexing loop
+ * (indexing/_dictionary_indexing.py:106-108).  The chunk of the dictionary belonging to
  * `rotations` is projected as float32 straight into device memory and swept like
  * kpdi_push_dictionary_chunk(..., KPDI_F32, n, global_start); the detector must have
  * sy*sx pixels (kpdi_set_problem). */
