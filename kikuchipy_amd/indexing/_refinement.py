@@ -103,6 +103,27 @@ class RefinementResult:
             out["pseudo_symmetry_index"] = self.pseudo_symmetry_index
         return out
 
+    def to_crystal_map(self, phase_list=None, step_sizes=None):
+        """The refined `orix.crystal_map.CrystalMap` as the reference assembles it
+        (indexing/_refinement/_refinement.py:104-131; needs orix, which is not a
+        dependency of this package)."""
+        from orix.crystal_map import CrystalMap, create_coordinate_arrays
+        from orix.quaternion import Rotation
+
+        if self.rotations is None:
+            raise ValueError("a projection-centre refinement has no rotations")
+        kw, _ = create_coordinate_arrays(self.shape, step_sizes)
+        n_all = self.is_in_data.size
+        rot = np.zeros((n_all, 4))
+        rot[:, 0] = 1
+        rot[self.is_in_data] = self.rotations
+        prop = {}
+        for name, values in self.prop.items():
+            full = np.zeros(n_all, dtype=np.asarray(values).dtype)
+            full[self.is_in_data] = values
+            prop[name] = full
+        return CrystalMap(rotations=Rotation(rot), phase_list=phase_list, prop=prop, is_in_data=self.is_in_data, **kw)
+
 
 # --------------------------------------------------------------------------- set-up
 def _nelder_mead_options(method, method_kwargs, initial_step, maxeval):
