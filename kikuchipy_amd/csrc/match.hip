@@ -36,7 +36,11 @@
 //    current step and no wave ever waits on LDS or memory at a step boundary.
 //  * ds_read_b128 hands a lane 4 consecutive pixels of its row; MFMA j of a group
 //    takes element j for both operands (lanes 0-31 pixel j, lanes 32-63 pixel 4+j):
-//    a permutation of the summation order only.  16 LDS reads per 128 MFMAs.
+//    a permutation of the summation order only.  24 LDS reads (16 A + 8 B) per 128 MFMAs.
+//  * SPLIT = true is the opt-in split-f16 form (KPDI_COMPUTE_F16X2) of the same skeleton:
+//    the 16-byte slots hold 8 float16 (high halves in slots 0-3 of a row-slab, low halves
+//    in 4-7), a slab is 2 steps of 16 pixels with three v_mfma_f32_32x32x16_f16 per
+//    accumulator (hi.hi + hi.lo + lo.hi), and the epilogue rescales by 2^-24.
 //
 // Algorithmic work per launch: 2 * M * n_chunk * K flops (K = kept pixels).
 #include "kernels.h"
