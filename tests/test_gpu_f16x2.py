@@ -169,3 +169,17 @@ def test_config2_planted_matches():
     spot = np.array([0, 1777, 4095, rows[0]])
     rs, ri = ko.dictionary_indexing(exp[spot], dic, keep_n=20, n_per_iteration=25000)
     ko.assert_topk_parity(s[spot], i[spot], rs, ri, atol=ATOL)
+
+
+def test_config5_geometry(ctx):
+    """configs[4] (120x120 detector, K = 14 400: the fp16-input / fp32-accumulate configuration
+    of BASELINE.md) in the split-f16 form, held to the fp32 parity bar."""
+    rng = np.random.default_rng(5)
+    exp = rng.integers(0, 256, (300, 120, 120), dtype=np.uint8)
+    dic = rng.random((5000, 120, 120), dtype=np.float32)
+    dic[4321] = exp[7].astype(np.float32) + 3.0
+    s, i = run_engine(ctx, exp, dic, keep_n=20, chunk=2600)
+    assert i[7, 0] == 4321 and abs(s[7, 0] - 1) < ATOL
+    rows = np.array([0, 7, 150, 299])
+    rs, ri = ko.dictionary_indexing(exp[rows], dic, keep_n=20)
+    ko.assert_topk_parity(s[rows], i[rows], rs, ri, atol=ATOL)
