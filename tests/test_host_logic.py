@@ -152,3 +152,23 @@ def test_communicator_single_rank_needs_no_torch():
     c = Communicator(0, 1)
     assert c.exchange_unique_id(lambda: b"x" * 128) == b"x" * 128
     c.barrier()
+
+
+def test_filters_window():
+    """`~Window("circular", shape).astype(bool)`: the signal mask of the canonical pipeline
+    (filters/window.py:163-187, :249-269), against the mask the reference made."""
+    from conftest import load_golden
+
+    import kikuchipy_amd as ka
+    from oracle import kpdi_oracle as ko
+
+    g = load_golden("di_synth.npz")
+    w = ka.filters.Window("circular", (60, 60))
+    assert np.array_equal(~w.astype(bool), g["circular_mask"]) and int(w.sum()) == 2819
+    assert w.circular and w.name == "rectangular" and w.origin == (30, 30) and tuple(w.n_neighbours) == (29, 29)
+    for shape in [(61, 47), (3, 3), (120, 120), (5, 8)]:
+        assert np.array_equal(np.asarray(ka.filters.Window("circular", shape)), ko.circular_window(shape))
+    gw = ka.filters.Window("gaussian", (30, 30), std=7.5)
+    assert np.allclose(gw, np.outer(ko.gaussian_window_1d(30, 7.5), ko.gaussian_window_1d(30, 7.5)))
+    with pytest.raises(NotImplementedError, match="supports 'circular'"):
+        ka.filters.Window("modified_hann", (5, 5))
