@@ -256,132 +256,148 @@ def main():
             out["roofline"]["algorithmic_operand_bytes"] = float(w["n"] * k_kept * 4 + w["m"] * k_kept * 4)
 
     if world == 1 and not a.no_pcie:
-        # informational: the same sweep with the dictionary handed over as a HOST
-        # buffer (pageable memory -> PCIe inside the step).  Never `value`.
-        for r in range(2):  # the first pass allocates the staging buffers
-            ctx.set_experimental_dev(d_exp, exp.dtype, w["m"])
-            ctx.synchronize()
-            t0 = time.perf_counter()
-            ctx.push_dictionary_chunk(dic, 0)
-            ctx.finalize(w["keep_n"])
-            out["extra"]["pcie_inclusive_patterns_per_s"] = round(w["m"] / (time.perf_counter() - t0), 1)
-
-    if world == 1 and not a.no_generation:
-        # informational: the same sweep with the OPT-IN split-f16 arithmetic of the match kernel
-        # (KPDI_COMPUTE_F16X2: value = hi + lo in float16, three f16 MFMAs per term, f32 accumulate).
-        # Never `value`: the headline stays the exact-f32 GEMM north_star names.
-        c16 = _lib.Context(local_rank)
-        c16.set_problem(w["sy"], w["sx"], mask, metric, w["keep_n"], _lib.COMPUTE_F16X2)
-        c16.set_profiling(True)
-        for r in range(4):
-            if r == 1:
-                c16.reset_counters()
-                c16.synchronize()
-                t0 = time.perf_counter()
-            c16.set_experimental_dev(d_exp, exp.dtype, w["m"])
-            if w["preprocess"]:
-                c16.remove_static_background(bg_f32, _lib.OP_SUBTRACT, False)
-                c16.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
-            c16.push_dictionary_chunk_dev(d_dic, shard.dtype, n_local, lo)
-            s16, i16 = c16.finalize(w["keep_n"])
-        dt16 = (time.perf_counter() - t0) / 3
-        cnt16 = c16.counters()
-        c16.close()
-        out["extra"]["split_f16_mode"] = {
-            "what": "opt-in KPDI_COMPUTE_F16X2: same sweep, operands as two float16 terms, 3 f16 MFMAs per product term",
-            "patterns_per_s": round(w["m"] / dt16, 1),
-            "match_ms": round(cnt16["match_ms"] / 3, 3),
-            "prep_ms": round(cnt16["prep_ms"] / 3, 3),
-            "f16_mfma_tflops": round(3 * cnt16["match_flops"] / (cnt16["match_ms"] * 1e-3) / 1e12, 1),
-            "f16_mfma_frac_of_2500": round(3 * cnt16["match_flops"] / (cnt16["match_ms"] * 1e-3) / 1e12 / 2500.0, 3),
-            "max_abs_score_diff_vs_f32": float(np.abs(s16 - scores).max()),
-            "index_mismatch_fraction_vs_f32": float(np.mean(i16 != indices)),
-        }
-
-    if world == 1 and not a.no_generation:
-        # informational: the dictionary is SIMULATED on the device inside the step
-        # from n rotations (32 B each over PCIe) and a 401 x 401 x 2 synthetic master pattern, then
-        # swept as above.  Never `value`.
-        rng = np.random.default_rng(7)
-        quat = rng.standard_normal((w["n"], 4))
-        quat /= np.linalg.norm(quat, axis=1)[:, None]
-        ctx.set_master_pattern(rng.random((401, 401), dtype=np.float32), rng.random((401, 401), dtype=np.float32))
-        pc = (0.421, 0.7794, 0.5049)
-        aspect = w["sx"] / w["sy"]
-        bounds = [-aspect * pc[0] / pc[2], aspect * (1 - pc[0]) / pc[2], -(1 - pc[1]) / pc[2], pc[1] / pc[2]]
-        ct, st = np.cos(np.deg2rad(70.0)), np.sin(np.deg2rad(70.0))
-        det_to_sample = np.array([[0, 1, 0], [-st, 0, ct], [ct, 0, st]], dtype=np.float64).T
-        ctx.set_detector(bounds, pc[2], w["sy"], w["sx"], det_to_sample)
-        ctx.set_profiling(True)
-        reps = 3
-        for r in range(reps + 1):
-            if r == 1:
-                ctx.reset_counters()
+        try:
+            # informational: the same sweep with the dictionary handed over as a HOST
+            # buffer (pageable memory -> PCIe inside the step).  Never `value`.
+            for r in range(2):  # the first pass allocates the staging buffers
+                ctx.set_experimental_dev(d_exp, exp.dtype, w["m"])
                 ctx.synchronize()
                 t0 = time.perf_counter()
-            ctx.set_experimental_dev(d_exp, exp.dtype, w["m"])
-            ctx.push_rotations_chunk(quat, 0, True, -1.0, 1.0)
-            ctx.finalize(w["keep_n"])
-        dt = (time.perf_counter() - t0) / reps
-        pj = ctx.counters()["project_ms"] / reps
-        ctx.set_profiling(False)
-        out["extra"]["dictionary_generation"] = {
-            "what": "100k patterns projected from a 2x401x401 master pattern inside the step (kpdi::project_kernel)",
-            "project_ms_per_step": round(pj, 3),
-            "gpixel_per_s": round(w["n"] * w["sy"] * w["sx"] / (pj * 1e-3) / 1e9, 1),
-            "patterns_per_s_including_generation": round(w["m"] / dt, 1),
-        }
+                ctx.push_dictionary_chunk(dic, 0)
+                ctx.finalize(w["keep_n"])
+                out["extra"]["pcie_inclusive_patterns_per_s"] = round(w["m"] / (time.perf_counter() - t0), 1)
+        except Exception as err:  # an informational leg must not cost the bench line
+            out["extra"]["pcie_inclusive_error"] = f"{type(err).__name__}: {err}"
 
     if world == 1 and not a.no_generation:
-        # informational: orientation refinement of m patterns simulated from the same
-        # master pattern (1 degree off, noise added), SciPy-compatible Nelder-Mead on the device; beside
-        # it the oracle (NumPy objective + scipy.optimize.minimize, what the reference runs per pattern)
-        # on a few of the patterns.  Never `value`.
-        from kikuchipy_amd.indexing._refinement import rotation_from_euler
+        try:
+            # informational: the same sweep with the OPT-IN split-f16 arithmetic of the match kernel
+            # (KPDI_COMPUTE_F16X2: value = hi + lo in float16, three f16 MFMAs per term, f32 accumulate).
+            # Never `value`: the headline stays the exact-f32 GEMM north_star names.
+            c16 = _lib.Context(local_rank)
+            c16.set_problem(w["sy"], w["sx"], mask, metric, w["keep_n"], _lib.COMPUTE_F16X2)
+            c16.set_profiling(True)
+            for r in range(4):
+                if r == 1:
+                    c16.reset_counters()
+                    c16.synchronize()
+                    t0 = time.perf_counter()
+                c16.set_experimental_dev(d_exp, exp.dtype, w["m"])
+                if w["preprocess"]:
+                    c16.remove_static_background(bg_f32, _lib.OP_SUBTRACT, False)
+                    c16.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
+                c16.push_dictionary_chunk_dev(d_dic, shard.dtype, n_local, lo)
+                s16, i16 = c16.finalize(w["keep_n"])
+            dt16 = (time.perf_counter() - t0) / 3
+            cnt16 = c16.counters()
+            c16.close()
+            out["extra"]["split_f16_mode"] = {
+                "what": "opt-in KPDI_COMPUTE_F16X2: same sweep, operands as two float16 terms, 3 f16 MFMAs per product term",
+                "patterns_per_s": round(w["m"] / dt16, 1),
+                "match_ms": round(cnt16["match_ms"] / 3, 3),
+                "prep_ms": round(cnt16["prep_ms"] / 3, 3),
+                "f16_mfma_tflops": round(3 * cnt16["match_flops"] / (cnt16["match_ms"] * 1e-3) / 1e12, 1),
+                "f16_mfma_frac_of_2500": round(3 * cnt16["match_flops"] / (cnt16["match_ms"] * 1e-3) / 1e12 / 2500.0, 3),
+                "max_abs_score_diff_vs_f32": float(np.abs(s16 - scores).max()),
+                "index_mismatch_fraction_vs_f32": float(np.mean(i16 != indices)),
+            }
+        except Exception as err:  # an informational leg must not cost the bench line
+            out["extra"]["split_f16_mode_error"] = f"{type(err).__name__}: {err}"
 
-        eu = np.column_stack([rng.uniform(0.3, 6, w["m"]), rng.uniform(0.3, 2.8, w["m"]), rng.uniform(0.3, 6, w["m"])])
-        mpu = np.fft.irfft2(np.fft.rfft2(rng.standard_normal((401, 401))) * np.exp(
-            -(np.add.outer(np.fft.fftfreq(401) ** 2, np.fft.rfftfreq(401) ** 2)) / (2 * 0.03**2)), s=(401, 401))
-        mpu = mpu.astype(np.float32)
-        ctx.set_master_pattern(mpu)
-        sim = ctx.project_patterns(rotation_from_euler(eu))
-        noisy = sim + 0.3 * sim.std() * rng.standard_normal(sim.shape).astype(np.float32)
-        pats = ((noisy - noisy.min()) / (noisy.max() - noisy.min()) * 255).astype(np.uint8).reshape(-1, w["sy"], w["sx"])
-        eu0 = eu + np.deg2rad(rng.uniform(-1, 1, eu.shape))
-        pcs = np.tile(pc, (w["m"], 1, 1))
-        ctx.refine_set_patterns(pats, mask, False, det_to_sample)
-        for r in range(3):
-            if r == 1:
-                ctx.reset_counters()
+    if world == 1 and not a.no_generation:
+        try:
+            # informational: the dictionary is SIMULATED on the device inside the step
+            # from n rotations (32 B each over PCIe) and a 401 x 401 x 2 synthetic master pattern, then
+            # swept as above.  Never `value`.
+            rng = np.random.default_rng(7)
+            quat = rng.standard_normal((w["n"], 4))
+            quat /= np.linalg.norm(quat, axis=1)[:, None]
+            ctx.set_master_pattern(rng.random((401, 401), dtype=np.float32), rng.random((401, 401), dtype=np.float32))
+            pc = (0.421, 0.7794, 0.5049)
+            aspect = w["sx"] / w["sy"]
+            bounds = [-aspect * pc[0] / pc[2], aspect * (1 - pc[0]) / pc[2], -(1 - pc[1]) / pc[2], pc[1] / pc[2]]
+            ct, st = np.cos(np.deg2rad(70.0)), np.sin(np.deg2rad(70.0))
+            det_to_sample = np.array([[0, 1, 0], [-st, 0, ct], [ct, 0, st]], dtype=np.float64).T
+            ctx.set_detector(bounds, pc[2], w["sy"], w["sx"], det_to_sample)
+            ctx.set_profiling(True)
+            reps = 3
+            for r in range(reps + 1):
+                if r == 1:
+                    ctx.reset_counters()
+                    ctx.synchronize()
+                    t0 = time.perf_counter()
+                ctx.set_experimental_dev(d_exp, exp.dtype, w["m"])
+                ctx.push_rotations_chunk(quat, 0, True, -1.0, 1.0)
+                ctx.finalize(w["keep_n"])
+            dt = (time.perf_counter() - t0) / reps
+            pj = ctx.counters()["project_ms"] / reps
+            ctx.set_profiling(False)
+            out["extra"]["dictionary_generation"] = {
+                "what": "100k patterns projected from a 2x401x401 master pattern inside the step (kpdi::project_kernel)",
+                "project_ms_per_step": round(pj, 3),
+                "gpixel_per_s": round(w["n"] * w["sy"] * w["sx"] / (pj * 1e-3) / 1e9, 1),
+                "patterns_per_s_including_generation": round(w["m"] / dt, 1),
+            }
+        except Exception as err:  # an informational leg must not cost the bench line
+            out["extra"]["dictionary_generation_error"] = f"{type(err).__name__}: {err}"
+
+    if world == 1 and not a.no_generation:
+        try:
+            # informational: orientation refinement of m patterns simulated from the same
+            # master pattern (1 degree off, noise added), SciPy-compatible Nelder-Mead on the device; beside
+            # it the oracle (NumPy objective + scipy.optimize.minimize, what the reference runs per pattern)
+            # on a few of the patterns.  Never `value`.
+            from kikuchipy_amd.indexing._refinement import rotation_from_euler
+
+            eu = np.column_stack([rng.uniform(0.3, 6, w["m"]), rng.uniform(0.3, 2.8, w["m"]), rng.uniform(0.3, 6, w["m"])])
+            mpu = np.fft.irfft2(np.fft.rfft2(rng.standard_normal((401, 401))) * np.exp(
+                -(np.add.outer(np.fft.fftfreq(401) ** 2, np.fft.rfftfreq(401) ** 2)) / (2 * 0.03**2)), s=(401, 401))
+            mpu = mpu.astype(np.float32)
+            ctx.set_master_pattern(mpu)
+            sim = ctx.project_patterns(rotation_from_euler(eu))
+            noisy = sim + 0.3 * sim.std() * rng.standard_normal(sim.shape).astype(np.float32)
+            pats = ((noisy - noisy.min()) / (noisy.max() - noisy.min()) * 255).astype(np.uint8).reshape(-1, w["sy"], w["sx"])
+            eu0 = eu + np.deg2rad(rng.uniform(-1, 1, eu.shape))
+            pcs = np.tile(pc, (w["m"], 1, 1))
+            ctx.refine_set_patterns(pats, mask, False, det_to_sample)
+            for r in range(3):
+                if r == 1:
+                    ctx.reset_counters()
+                    t0 = time.perf_counter()
+                res = ctx.refine_solve(_lib.REFINE_ORI, eu0[:, None, :], pcs)
+            dt = (time.perf_counter() - t0) / 2
+            kern = ctx.counters()["refine_ms"] / 2
+            evals = float(res[:, 0, 1].sum())
+            k_ref = int(w["sy"] * w["sx"] if mask is None else np.count_nonzero(~mask))
+            out["extra"]["refinement"] = {
+                "what": f"refine_orientation of {w['m']} patterns, Nelder-Mead on the device (kpdi::refine_solve_kernel)",
+                "patterns_per_s": round(w["m"] / dt, 1),
+                "kernel_ms": round(kern, 3),
+                "objective_evaluations_per_s": round(evals / (kern * 1e-3), 1),
+                "gpixel_per_s": round(evals * k_ref / (kern * 1e-3) / 1e9, 1),
+                "mean_evaluations": round(evals / w["m"], 1),
+                "mean_score": round(float(1 - res[:, 0, 0].mean()), 4),
+            }
+            if not a.no_cpu_baseline:
+                from oracle import kpdi_oracle as ko
+
+                keep = None if mask is None else ~mask.ravel()
+                dc = ko.direction_cosines_fixed_pc(np.asarray(bounds), pc[2], w["sy"], w["sx"], det_to_sample, keep)
+                n_cpu = 8
                 t0 = time.perf_counter()
-            res = ctx.refine_solve(_lib.REFINE_ORI, eu0[:, None, :], pcs)
-        dt = (time.perf_counter() - t0) / 2
-        kern = ctx.counters()["refine_ms"] / 2
-        evals = float(res[:, 0, 1].sum())
-        k_ref = int(w["sy"] * w["sx"] if mask is None else np.count_nonzero(~mask))
-        out["extra"]["refinement"] = {
-            "what": f"refine_orientation of {w['m']} patterns, Nelder-Mead on the device (kpdi::refine_solve_kernel)",
-            "patterns_per_s": round(w["m"] / dt, 1),
-            "kernel_ms": round(kern, 3),
-            "objective_evaluations_per_s": round(evals / (kern * 1e-3), 1),
-            "gpixel_per_s": round(evals * k_ref / (kern * 1e-3) / 1e9, 1),
-            "mean_evaluations": round(evals / w["m"], 1),
-            "mean_score": round(float(1 - res[:, 0, 0].mean()), 4),
-        }
-        if not a.no_cpu_baseline:
-            from oracle import kpdi_oracle as ko
-
-            keep = None if mask is None else ~mask.ravel()
-            dc = ko.direction_cosines_fixed_pc(np.asarray(bounds), pc[2], w["sy"], w["sx"], det_to_sample, keep)
-            n_cpu = 8
-            t0 = time.perf_counter()
-            for i in range(n_cpu):
-                p = pats[i].ravel() if keep is None else pats[i].ravel()[keep]
-                ko.refine_solver(p, "ori", eu0[i], mpu, mpu, False, direction_cosines=dc)
-            out["extra"]["refinement"]["cpu_port_patterns_per_s"] = round(n_cpu / (time.perf_counter() - t0), 2)
+                for i in range(n_cpu):
+                    p = pats[i].ravel() if keep is None else pats[i].ravel()[keep]
+                    ko.refine_solver(p, "ori", eu0[i], mpu, mpu, False, direction_cosines=dc)
+                out["extra"]["refinement"]["cpu_port_patterns_per_s"] = round(n_cpu / (time.perf_counter() - t0), 2)
+        except Exception as err:  # an informational leg must not cost the bench line
+            out["extra"]["refinement_error"] = f"{type(err).__name__}: {err}"
 
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(w, exp, dic, bg, mask, min(a.cpu_sample, w["n"]))
+        try:
+            out["cpu_baseline"] = cpu_baseline(w, exp, dic, bg, mask, min(a.cpu_sample, w["n"]))
+        except Exception as err:
+            out["cpu_baseline"] = {"value": None, "unit": "patterns/s", "cores": 0, "kind": "port", "sample": "",
+                                   "error": f"{type(err).__name__}: {err}"}
     ctx.close()
     print(json.dumps(out))
 
