@@ -269,6 +269,35 @@ def main():
         except Exception as err:  # an informational leg must not cost the bench line
             out["extra"]["pcie_inclusive_error"] = f"{type(err).__name__}: {err}"
 
+    if world == 1 and not a.no_pcie:
+        try:
+            # informational: a SERIES of maps against one dictionary that was handed over as a host
+            # buffer once and stays prepared in HBM (kpdi_hold_dictionary_chunk / kpdi_sweep_held):
+            # per map only the experimental set moves.  Never `value` (it skips prepare_dictionary).
+            ctx.hold_dictionary_chunk(dic, 0)
+            ctx.synchronize()
+            reps = 3
+            for r in range(reps + 1):
+                if r == 1:
+                    ctx.synchronize()
+                    t0 = time.perf_counter()
+                ctx.set_experimental(exp, None)  # host buffer, PCIe inside the step
+                if w["preprocess"]:
+                    ctx.remove_static_background(bg_f32, _lib.OP_SUBTRACT, False)
+                    ctx.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
+                ctx.sweep_held()
+                s_held, i_held = ctx.finalize(w["keep_n"])
+            dt = (time.perf_counter() - t0) / reps
+            out["extra"]["resident_dictionary"] = {
+                "what": "maps 2..n of a series: dictionary prepared once and held in HBM, experimental set from host",
+                "patterns_per_s": round(w["m"] / dt, 1),
+                "held_bytes": ctx.held_size()[1],
+                "identical_to_value_run": bool(np.array_equal(s_held, scores) and np.array_equal(i_held, indices)),
+            }
+            ctx.release_held()
+        except Exception as err:  # an informational leg must not cost the bench line
+            out["extra"]["resident_dictionary_error"] = f"{type(err).__name__}: {err}"
+
     if world == 1 and not a.no_generation:
         try:
             # informational: the same sweep with the OPT-IN split-f16 arithmetic of the match kernel

@@ -192,6 +192,30 @@ int kpdi_project_patterns_varying_pc(kpdi_ctx *ctx, const double *rotations, con
 int kpdi_push_rotations_chunk(kpdi_ctx *ctx, const double *rotations, int64_t n,
                               int64_t global_start, int rescale, double out_min, double out_max);
 
+/* ---- resident dictionary: one dictionary, many maps -------------------------------
+ * The reference prepares the dictionary again for every `dictionary_indexing()` call
+ * (`metric.prepare_dictionary` inside the loop, indexing/_dictionary_indexing.py:106-110),
+ * because host memory rarely holds it twice.  A prepared 60 x 60 dictionary of 100 000
+ * patterns is 1.45 GB of the 288 GB of HBM, so a series of maps of the same phase and
+ * detector (one `kpdi_set_problem`) can be indexed against chunks that are uploaded /
+ * simulated and prepared ONCE: `hold` = prepare_dictionary into a buffer that stays,
+ * `kpdi_sweep_held` = the match + top-k + merge of every held chunk against the current
+ * experimental set (like pushing all of them again, results identical), then
+ * kpdi_finalize.  kpdi_set_problem releases the held chunks (their layout depends on
+ * shape, mask, metric and arithmetic); set_experimental / reset_topk / set_keep_n do not.
+ * With several ranks each rank holds its own shard. */
+int kpdi_hold_dictionary_chunk(kpdi_ctx *ctx, const void *patterns, int dtype, int64_t n_chunk,
+                               int64_t global_start);
+int kpdi_hold_dictionary_chunk_dev(kpdi_ctx *ctx, const void *d_patterns, int dtype,
+                                   int64_t n_chunk, int64_t global_start);
+/* simulated on the device like kpdi_push_rotations_chunk, then held */
+int kpdi_hold_rotations_chunk(kpdi_ctx *ctx, const double *rotations, int64_t n,
+                              int64_t global_start, int rescale, double out_min, double out_max);
+int kpdi_sweep_held(kpdi_ctx *ctx);
+int kpdi_release_held(kpdi_ctx *ctx);
+/* patterns held and the device memory they occupy; either pointer may be NULL */
+int kpdi_held_size(kpdi_ctx *ctx, int64_t *n_patterns, int64_t *n_bytes);
+
 /* ---- refinement of orientations / projection centres ---------
  * EBSD.refine_orientation / refine_projection_center / refine_orientation_projection_center
  * with the default optimiser (scipy.optimize.minimize, Nelder-Mead): the chunk functions

@@ -14,6 +14,7 @@ from kikuchipy_amd.indexing import (  # noqa: E402,F401
     NormalizedCrossCorrelationMetric,
     NormalizedDotProductMetric,
     RefinementResult,
+    ResidentDictionary,
     SimilarityMetric,
     dictionary_indexing,
     merge_crystal_maps,
@@ -34,6 +35,7 @@ __all__ = [
     "EBSDMasterPattern",
     "ProjectedDictionary",
     "RefinementResult",
+    "ResidentDictionary",
     "NormalizedCrossCorrelationMetric",
     "NormalizedDotProductMetric",
     "SimilarityMetric",

@@ -99,6 +99,12 @@ SIGNATURES = {
     "kpdi_project_patterns": (_i, [_vp, _vp, _i64, _i, C.c_double, C.c_double, _i, _vp]),
     "kpdi_project_patterns_varying_pc": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, C.c_double, C.c_double, _i, _vp]),
     "kpdi_push_rotations_chunk": (_i, [_vp, _vp, _i64, _i64, _i, C.c_double, C.c_double]),
+    "kpdi_hold_dictionary_chunk": (_i, [_vp, _vp, _i, _i64, _i64]),
+    "kpdi_hold_dictionary_chunk_dev": (_i, [_vp, _vp, _i, _i64, _i64]),
+    "kpdi_hold_rotations_chunk": (_i, [_vp, _vp, _i64, _i64, _i, C.c_double, C.c_double]),
+    "kpdi_sweep_held": (_i, [_vp]),
+    "kpdi_release_held": (_i, [_vp]),
+    "kpdi_held_size": (_i, [_vp, _vp, _vp]),
     "kpdi_refine_set_patterns": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _i, _vp]),
     "kpdi_refine_get_prepared": (_i, [_vp, _vp, _vp]),
     "kpdi_refine_objective": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp]),
@@ -307,6 +313,33 @@ class Context:
     def push_dictionary_chunk_dev(self, d_ptr, dtype, n_chunk, global_start):
         check(load().kpdi_push_dictionary_chunk_dev(self._h, C.c_void_p(d_ptr), dtype_code(dtype),
                                                     int(n_chunk), int(global_start)))
+
+    # -- resident dictionary: prepared once, swept against several experimental sets
+    def hold_dictionary_chunk(self, patterns, global_start):
+        p = np.ascontiguousarray(patterns)
+        check(load().kpdi_hold_dictionary_chunk(self._h, _ptr(p), dtype_code(p.dtype), p.shape[0],
+                                                int(global_start)))
+
+    def hold_dictionary_chunk_dev(self, d_ptr, dtype, n_chunk, global_start):
+        check(load().kpdi_hold_dictionary_chunk_dev(self._h, C.c_void_p(d_ptr), dtype_code(dtype),
+                                                    int(n_chunk), int(global_start)))
+
+    def hold_rotations_chunk(self, rotations, global_start, rescale=False, out_min=-1.0, out_max=1.0):
+        rot = np.ascontiguousarray(rotations, dtype=np.float64).reshape(-1, 4)
+        check(load().kpdi_hold_rotations_chunk(self._h, _ptr(rot), rot.shape[0], int(global_start),
+                                               int(bool(rescale)), float(out_min), float(out_max)))
+
+    def sweep_held(self):
+        check(load().kpdi_sweep_held(self._h))
+
+    def release_held(self):
+        check(load().kpdi_release_held(self._h))
+
+    def held_size(self):
+        """(patterns held, bytes of device memory they occupy)."""
+        n, b = C.c_int64(0), C.c_int64(0)
+        check(load().kpdi_held_size(self._h, C.byref(n), C.byref(b)))
+        return n.value, b.value
 
     # -- dictionary generation on the device
     def set_master_pattern(self, upper, lower=None):

@@ -141,6 +141,13 @@ struct kpdi_ctx {
 
   // dictionary chunk
   DevBuf dict_raw, dict_y;
+  // prepared chunks kept resident for sweeps against several experimental sets
+  struct HeldChunk {
+    DevBuf y;
+    int64_t n = 0, start = 0;
+  };
+  std::vector<HeldChunk> held;
+  std::vector<int> kept_pixels;  // host copy of pix_map: tells whether a new problem keeps the layout
   // host-pointer pushes are cut into pieces whose upload (copy stream) overlaps the sweep of
   // the previous piece (compute stream): two staging buffers, events for hand-over
   DevBuf stage[2];
@@ -316,13 +323,13 @@ int ensure_running(kpdi_ctx *c) {
 }
 
 // one match launch over the prepared chunk -> partial lists
-int run_match(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int rows_per_launch, int list_len,
-              int64_t global_start, const float *bound_s, const int *bound_i) {
+int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int nsplit, int rows_per_launch,
+              int list_len, int64_t global_start, const float *bound_s, const int *bound_i) {
   const size_t part = (size_t)c->m_pad * 2 * nsplit * list_len;
   HIPCHK(c->part_s.reserve(part * sizeof(float)));
   HIPCHK(c->part_i.reserve(part * sizeof(int)));
   kpdi::MatchLaunch ml;
-  ml.dict = c->dict_y.as<float>();
+  ml.dict = dict_y;
   ml.exp = c->exp_x.as<float>();
   ml.kpad = c->kpad;
   ml.n_tiles = n_tiles;
@@ -393,24 +400,13 @@ int run_match(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int rows_per_la
   return KPDI_OK;
 }
 
-int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start) {
-  if (!c->have_problem) return fail(KPDI_EINVAL, "kpdi_set_problem has not been called");
-  if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
-  if (n_chunk <= 0) return fail(KPDI_EINVAL, "dictionary chunk must hold at least one pattern");
-  if (kpdi::dtype_size(dtype) == 0) return fail(KPDI_EINVAL, "unknown dtype %d", dtype);
-  if (global_start < 0 || global_start + n_chunk >= (int64_t)INT_MAX)
-    return fail(KPDI_EINVAL, "dictionary indices must fit in int32");
-  if (c->m == 0) return KPDI_OK;
-  int rc = prepare_experimental(c);
-  if (rc) return rc;
-  rc = ensure_running(c);
-  if (rc) return rc;
-
+// raw chunk (device) -> prepared layout at `out` (n_pad rows of kpad floats, tiles of 128 patterns);
+// `out` may point into a larger buffer at a tile boundary
+int prepare_chunk(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, float *out) {
   const int n_pad = kpdi::round_up(n_chunk, kpdi::TILE_DICT);
   const int n_tiles = n_pad / kpdi::TILE_DICT;
-  HIPCHK(c->dict_y.reserve((size_t)n_pad * c->kpad * sizeof(float)));
   if (n_pad > n_chunk)  // rows of the last 128-pattern tile are interleaved: clear the whole tile
-    HIPCHK(hipMemsetAsync(c->dict_y.as<float>() + (size_t)(n_tiles - 1) * kpdi::TILE_DICT * c->kpad, 0,
+    HIPCHK(hipMemsetAsync(out + (size_t)(n_tiles - 1) * kpdi::TILE_DICT * c->kpad, 0,
                           (size_t)kpdi::TILE_DICT * c->kpad * sizeof(float), c->stream));
   kpdi::PrepLaunch p;
   p.raw = d_patterns;
@@ -423,11 +419,44 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
   p.n_out = (int)n_chunk;
   p.metric = c->metric;
   p.split_f16 = c->compute == KPDI_COMPUTE_F16X2;
-  p.out = c->dict_y.as<float>();
+  p.out = out;
   {
     ScopedTimer t(c, &c->ev_prep);
     HIPCHK(kpdi::launch_prep(p, c->stream));
   }
+  return KPDI_OK;
+}
+
+int check_chunk_args(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_start) {
+  if (!c->have_problem) return fail(KPDI_EINVAL, "kpdi_set_problem has not been called");
+  if (n_chunk <= 0) return fail(KPDI_EINVAL, "dictionary chunk must hold at least one pattern");
+  if (kpdi::dtype_size(dtype) == 0) return fail(KPDI_EINVAL, "unknown dtype %d", dtype);
+  if (global_start < 0 || global_start + n_chunk >= (int64_t)INT_MAX)
+    return fail(KPDI_EINVAL, "dictionary indices must fit in int32");
+  return KPDI_OK;
+}
+
+int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_start);
+void release_held(kpdi_ctx *c);
+
+int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start) {
+  int rc = check_chunk_args(c, dtype, n_chunk, global_start);
+  if (rc) return rc;
+  if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
+  if (c->m == 0) return KPDI_OK;
+  HIPCHK(c->dict_y.reserve((size_t)kpdi::round_up(n_chunk, kpdi::TILE_DICT) * c->kpad * sizeof(float)));
+  rc = prepare_chunk(c, d_patterns, dtype, n_chunk, c->dict_y.as<float>());
+  if (rc) return rc;
+  return sweep_prepared(c, c->dict_y.as<float>(), n_chunk, global_start);
+}
+
+// every experimental pattern against one prepared chunk, merged into the running best-k
+int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_start) {
+  int rc = prepare_experimental(c);
+  if (rc) return rc;
+  rc = ensure_running(c);
+  if (rc) return rc;
+  const int n_tiles = kpdi::round_up(n_chunk, kpdi::TILE_DICT) / kpdi::TILE_DICT;
 
   const int row_blocks = c->m_pad / kpdi::TILE_EXP;
   int rows_per_launch = row_blocks;
@@ -453,7 +482,7 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
 
   if (k <= kpdi::KMAX_LIMIT) {
     const int len = kpdi::match_list_len(k);
-    rc = run_match(c, (int)n_chunk, n_tiles, nsplit, rows_per_launch, len, global_start, nullptr, nullptr);
+    rc = run_match(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, len, global_start, nullptr, nullptr);
     if (rc) return rc;
     mg.src_scores[1] = c->part_s.as<float>();
     mg.src_idx[1] = c->part_i.as<int>();
@@ -477,7 +506,7 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
       const int kp = std::min(kpdi::KMAX_LIMIT, kk - done);
       const int len = kpdi::match_list_len(kp);
       c->bound_key = -1;  // each pass ranks a different slice: its shared bound starts from scratch
-      rc = run_match(c, (int)n_chunk, n_tiles, nsplit, rows_per_launch, len, global_start,
+      rc = run_match(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, len, global_start,
                      done ? c->bound_s.as<float>() : nullptr, done ? c->bound_i.as<int>() : nullptr);
       if (rc) return rc;
       kpdi::MergeLaunch pm{};
@@ -556,6 +585,74 @@ int set_experimental_common(kpdi_ctx *c, const void *src, bool src_on_device, in
 
 }  // namespace
 
+namespace {
+
+// Host chunk -> device in pieces of `per` patterns through two staging buffers on the copy
+// stream; `consume(d_piece, n, offset)` queues the work that reads a piece on the compute
+// stream.  The upload of piece j+1 overlaps whatever `consume` queued for piece j - pieces
+// of this call or of the previous call (a caller streaming chunk after chunk, like the
+// reference's loop).  On return the host buffer has been consumed.
+template <typename F>
+int staged_upload(kpdi_ctx *c, const void *patterns, size_t row_bytes, int64_t n_chunk, int64_t per, F consume) {
+  if (!c->copy_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+      HIPCHK(hipEventCreateWithFlags(&c->stage_filled[b], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&c->stage_free[b], hipEventDisableTiming));
+      HIPCHK(hipEventRecord(c->stage_free[b], c->stream));
+    }
+  }
+  for (int b = 0; b < 2; ++b)
+    if (c->stage[b].cap < (size_t)per * row_bytes) {
+      // growing a buffer frees it: everything queued on it must have finished
+      HIPCHK(hipStreamSynchronize(c->copy_stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(c->stage[b].reserve((size_t)per * row_bytes));
+    }
+  for (int64_t start = 0; start < n_chunk; start += per) {
+    const int b = c->stage_next;
+    c->stage_next ^= 1;
+    const int64_t n = std::min(per, n_chunk - start);
+    HIPCHK(hipStreamWaitEvent(c->copy_stream, c->stage_free[b], 0));
+    HIPCHK(hipMemcpyAsync(c->stage[b].p, (const char *)patterns + (size_t)start * row_bytes, (size_t)n * row_bytes,
+                          hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(hipEventRecord(c->stage_filled[b], c->copy_stream));
+    c->cnt.h2d_bytes += (double)n * row_bytes;
+    HIPCHK(hipStreamWaitEvent(c->stream, c->stage_filled[b], 0));
+    int rc = consume(c->stage[b].p, n, start);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->stage_free[b], c->stream));  // the prep kernel has consumed the piece
+  }
+  HIPCHK(hipStreamSynchronize(c->copy_stream));  // the caller's buffer is free again
+  return KPDI_OK;
+}
+
+// a new resident chunk: its prepared buffer, sized for n patterns
+int new_held_chunk(kpdi_ctx *c, int64_t n_chunk, int64_t global_start, float **out) {
+  c->held.emplace_back();
+  kpdi_ctx::HeldChunk &h = c->held.back();
+  const hipError_t e = h.y.reserve((size_t)kpdi::round_up(n_chunk, kpdi::TILE_DICT) * c->kpad * sizeof(float));
+  if (e != hipSuccess) {
+    c->held.pop_back();
+    return fail(KPDI_ENOMEM, "no device memory for a resident chunk of %lld patterns: %s", (long long)n_chunk,
+                hipGetErrorString(e));
+  }
+  h.n = n_chunk;
+  h.start = global_start;
+  *out = h.y.as<float>();
+  return KPDI_OK;
+}
+
+void release_held(kpdi_ctx *c) {
+  if (c->held.empty()) return;
+  (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  for (auto &h : c->held) h.y.release();
+  c->held.clear();
+}
+
+}  // namespace
+
 extern "C" {
 
 const char *kpdi_version(void) { return "kpdi 0.1.0 (gfx950)"; }
@@ -597,6 +694,7 @@ int kpdi_destroy(kpdi_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  release_held(c);
   for (DevBuf *b : {&c->pix_map, &c->exp_raw, &c->row_map, &c->exp_x, &c->dict_raw, &c->dict_y, &c->part_s,
                     &c->part_i, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
                     &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps,
@@ -658,6 +756,11 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   if (npix != c->npix) c->have_exp = false;  // resident patterns belong to another detector shape
+  // the prepared layout of held chunks depends on shape, mask, metric and arithmetic
+  if (!c->have_problem || sy != c->sy || sx != c->sx || metric != c->metric || compute_dtype != c->compute ||
+      (signal_mask != nullptr) != c->have_sig_mask || keep != c->kept_pixels)
+    release_held(c);
+  c->kept_pixels = keep;
   c->sy = sy;
   c->sx = sx;
   c->npix = npix;
@@ -819,46 +922,16 @@ int kpdi_push_dictionary_chunk(kpdi_ctx *c, const void *patterns, int dtype, int
   if (n_chunk <= 0) return fail(KPDI_EINVAL, "dictionary chunk must hold at least one pattern");
   int rc = use_device(c);
   if (rc) return rc;
-  // The upload always goes through two staging buffers on a copy stream, so that it overlaps
-  // the sweep of the previous piece - of this call (large chunks are cut into pieces of >= 192
-  // dictionary tiles, which keeps the match kernel's tile counts per workgroup healthy) or of
-  // the previous call (a caller streaming chunk after chunk, like the reference's loop).
-  // On return the host buffer has been consumed; the sweep itself may still be running.
+  // large chunks are cut into pieces of >= 192 dictionary tiles, which keeps the match
+  // kernel's tile counts per workgroup healthy; the sweep of the last piece may still be
+  // running on return
   const int64_t piece = 192 * kpdi::TILE_DICT;
   const int64_t n_pieces = std::max<int64_t>(1, n_chunk / piece);
-  const size_t row_bytes = (size_t)c->npix * es;
-  if (!c->copy_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    for (int b = 0; b < 2; ++b) {
-      HIPCHK(hipEventCreateWithFlags(&c->stage_filled[b], hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&c->stage_free[b], hipEventDisableTiming));
-      HIPCHK(hipEventRecord(c->stage_free[b], c->stream));
-    }
-  }
   const int64_t per = (n_chunk + n_pieces - 1) / n_pieces;
-  for (int b = 0; b < 2; ++b)
-    if (c->stage[b].cap < (size_t)per * row_bytes) {
-      // growing a buffer frees it: everything queued on it must have finished
-      HIPCHK(hipStreamSynchronize(c->copy_stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
-      HIPCHK(c->stage[b].reserve((size_t)per * row_bytes));
-    }
-  for (int64_t start = 0; start < n_chunk; start += per) {
-    const int b = c->stage_next;
-    c->stage_next ^= 1;
-    const int64_t n = std::min(per, n_chunk - start);
-    HIPCHK(hipStreamWaitEvent(c->copy_stream, c->stage_free[b], 0));
-    HIPCHK(hipMemcpyAsync(c->stage[b].p, (const char *)patterns + (size_t)start * row_bytes, (size_t)n * row_bytes,
-                          hipMemcpyHostToDevice, c->copy_stream));
-    HIPCHK(hipEventRecord(c->stage_filled[b], c->copy_stream));
-    c->cnt.h2d_bytes += (double)n * row_bytes;
-    HIPCHK(hipStreamWaitEvent(c->stream, c->stage_filled[b], 0));
-    rc = push_chunk_dev(c, c->stage[b].p, dtype, n, global_start + start);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(c->stage_free[b], c->stream));  // the prep kernel has consumed the piece
-  }
-  HIPCHK(hipStreamSynchronize(c->copy_stream));  // the caller's buffer is free again
-  return KPDI_OK;
+  return staged_upload(c, patterns, (size_t)c->npix * es, n_chunk, per,
+                       [&](const void *d_piece, int64_t n, int64_t offset) {
+                         return push_chunk_dev(c, d_piece, dtype, n, global_start + offset);
+                       });
 }
 
 int kpdi_push_dictionary_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk,
@@ -871,6 +944,80 @@ int kpdi_push_dictionary_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtyp
 }
 
 // ---- dictionary generation --------------------------------------------------
+int kpdi_hold_dictionary_chunk(kpdi_ctx *c, const void *patterns, int dtype, int64_t n_chunk, int64_t global_start) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!patterns) return fail(KPDI_EINVAL, "patterns pointer is NULL");
+  int rc = check_chunk_args(c, dtype, n_chunk, global_start);
+  if (rc) return rc;
+  rc = use_device(c);
+  if (rc) return rc;
+  float *y = nullptr;
+  rc = new_held_chunk(c, n_chunk, global_start, &y);
+  if (rc) return rc;
+  // pieces of whole tiles, so that every piece is prepared straight into its place
+  const int64_t per = 192 * kpdi::TILE_DICT;
+  const size_t kpad = c->kpad;
+  rc = staged_upload(c, patterns, (size_t)c->npix * kpdi::dtype_size(dtype), n_chunk, per,
+                     [&](const void *d_piece, int64_t n, int64_t offset) {
+                       return prepare_chunk(c, d_piece, dtype, n, y + (size_t)offset * kpad);
+                     });
+  if (rc) {
+    (void)hipStreamSynchronize(c->stream);
+    c->held.back().y.release();
+    c->held.pop_back();
+  }
+  return rc;
+}
+
+int kpdi_hold_dictionary_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk,
+                                   int64_t global_start) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!d_patterns) return fail(KPDI_EINVAL, "patterns pointer is NULL");
+  int rc = check_chunk_args(c, dtype, n_chunk, global_start);
+  if (rc) return rc;
+  rc = use_device(c);
+  if (rc) return rc;
+  float *y = nullptr;
+  rc = new_held_chunk(c, n_chunk, global_start, &y);
+  if (rc) return rc;
+  return prepare_chunk(c, d_patterns, dtype, n_chunk, y);
+}
+
+int kpdi_sweep_held(kpdi_ctx *c) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!c->have_problem) return fail(KPDI_EINVAL, "kpdi_set_problem has not been called");
+  if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
+  if (c->held.empty()) return fail(KPDI_EINVAL, "no resident dictionary: kpdi_hold_dictionary_chunk has not been called");
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (c->m == 0) return KPDI_OK;
+  for (auto &h : c->held) {
+    rc = sweep_prepared(c, h.y.as<float>(), h.n, h.start);
+    if (rc) return rc;
+  }
+  return KPDI_OK;
+}
+
+int kpdi_release_held(kpdi_ctx *c) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  int rc = use_device(c);
+  if (rc) return rc;
+  release_held(c);
+  return KPDI_OK;
+}
+
+int kpdi_held_size(kpdi_ctx *c, int64_t *n_patterns, int64_t *n_bytes) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  int64_t n = 0, bytes = 0;
+  for (auto &h : c->held) {
+    n += h.n;
+    bytes += (int64_t)h.y.cap;
+  }
+  if (n_patterns) *n_patterns = n;
+  if (n_bytes) *n_bytes = bytes;
+  return KPDI_OK;
+}
+
 int kpdi_set_master_pattern(kpdi_ctx *c, const void *upper, const void *lower, int dtype, int npx, int npy) {
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
   if (!upper) return fail(KPDI_EINVAL, "upper hemisphere pointer is NULL");
@@ -1062,6 +1209,25 @@ int kpdi_push_rotations_chunk(kpdi_ctx *c, const double *rotations, int64_t n, i
   rc = project_to_device(c, rotations, n, rescale, out_min, out_max, KPDI_F32, c->dict_raw.p);
   if (rc) return rc;
   return push_chunk_dev(c, c->dict_raw.p, KPDI_F32, n, global_start);
+}
+
+int kpdi_hold_rotations_chunk(kpdi_ctx *c, const double *rotations, int64_t n, int64_t global_start, int rescale,
+                              double out_min, double out_max) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  int rc = check_chunk_args(c, KPDI_F32, n, global_start);
+  if (rc) return rc;
+  rc = use_device(c);
+  if (rc) return rc;
+  if (c->have_dc && c->dc_npix != c->npix)
+    return fail(KPDI_EINVAL, "detector has %lld pixels but the problem's signal shape has %d", (long long)c->dc_npix,
+                c->npix);
+  HIPCHK(c->dict_raw.reserve((size_t)n * c->npix * sizeof(float)));
+  rc = project_to_device(c, rotations, n, rescale, out_min, out_max, KPDI_F32, c->dict_raw.p);
+  if (rc) return rc;
+  float *y = nullptr;
+  rc = new_held_chunk(c, n, global_start, &y);
+  if (rc) return rc;
+  return prepare_chunk(c, c->dict_raw.p, KPDI_F32, n, y);
 }
 
 // ---- refinement ---------------------------------------------------------------

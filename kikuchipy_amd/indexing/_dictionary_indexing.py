@@ -146,7 +146,8 @@ def dictionary_indexing(
         `.compute()`), in which case chunks are computed one at a time inside
         the loop as in the reference (:106-108), or the `ProjectedDictionary`
         of `EBSDMasterPattern.get_patterns()`, whose chunks are simulated
-        directly in device memory.
+        directly in device memory, or a `ResidentDictionary` (prepared once and
+        kept in HBM for a series of maps; it brings its own metric and signal mask).
     metric
         "ncc", "ndp" or an instance of this package's metrics.
     keep_n, n_per_iteration, navigation_mask, signal_mask, rechunk, dtype
@@ -163,6 +164,16 @@ def dictionary_indexing(
         ranks (one process per GPU).  Every rank must pass the same arrays; each
         matches its own contiguous block and all ranks return the global result.
     """
+    from kikuchipy_amd.indexing._resident_dictionary import ResidentDictionary
+
+    resident = dictionary if isinstance(dictionary, ResidentDictionary) else None
+    if resident is not None:
+        resident.check_call(metric, signal_mask, comm)
+        metric, signal_mask = resident.metric, resident.signal_mask
+        metric.navigation_mask = None  # of an earlier map
+        if dictionary_rotations is None:
+            dictionary_rotations = resident.rotations
+        phase_name = phase_name or resident.phase_name
     experimental = experimental if _is_lazy(experimental) else np.asarray(experimental)
     if experimental.ndim < 2 or experimental.ndim > 4:
         raise ValueError("experimental patterns must have 0, 1 or 2 navigation axes and 2 signal axes")
@@ -232,7 +243,9 @@ def dictionary_indexing(
 
     lo, hi = shard_range(dict_size, rank, world)
     time_start = time.time()
-    for start, end in chunk_bounds(dict_size, n_per_iteration):
+    if resident is not None:
+        ctx.sweep_held()
+    for start, end in ([] if resident is not None else chunk_bounds(dict_size, n_per_iteration)):
         start, end = max(start, lo), min(end, hi)  # this rank's part of the chunk
         if start >= end:
             continue

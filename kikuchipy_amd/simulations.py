@@ -99,6 +99,15 @@ class ProjectedDictionary:
         self.configure(ctx)
         ctx.push_rotations_chunk(self.rotations, global_start, self.rescale, self.out_min, self.out_max)
 
+    def hold_in_engine(self, ctx, global_start):
+        """Generate this (slice of the) dictionary in device memory and keep it prepared there
+        (`kikuchipy_amd.ResidentDictionary`)."""
+        if self.dtype != np.float32:
+            ctx.hold_dictionary_chunk(self.compute(ctx), global_start)
+            return
+        self.configure(ctx)
+        ctx.hold_rotations_chunk(self.rotations, global_start, self.rescale, self.out_min, self.out_max)
+
     def compute(self, ctx=None):
         """The patterns as a NumPy array (projected on the GPU)."""
         if ctx is None:
