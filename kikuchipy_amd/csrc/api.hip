@@ -267,7 +267,7 @@ int choose_nsplit(const kpdi_ctx *c, int row_blocks, int n_tiles, int *rows_per_
   const int cap = c->n_cu * kpdi::match_blocks_per_cu();
   int best_ns = 1, best_rpl = std::max(1, std::min(row_blocks, cap));
   double best_cost = 1e30;
-  for (int ns = 1; ns <= std::min(cap, n_tiles); ns = ns < 4 ? ns + 1 : ns + 4) {
+  for (int ns = 1; ns <= std::min(cap, n_tiles); ++ns) {
     const int rpl = std::max(1, std::min(row_blocks, cap / ns));
     const int launches = (row_blocks + rpl - 1) / rpl;
     // multiples of 8 keep the workgroups of one XCD (block id % 8) on the same row block
@@ -593,7 +593,8 @@ namespace {
 // of this call or of the previous call (a caller streaming chunk after chunk, like the
 // reference's loop).  On return the host buffer has been consumed.
 template <typename F>
-int staged_upload(kpdi_ctx *c, const void *patterns, size_t row_bytes, int64_t n_chunk, int64_t per, F consume) {
+int staged_upload(kpdi_ctx *c, const void *patterns, size_t row_bytes, const std::vector<int64_t> &pieces, F consume) {
+  const int64_t per = *std::max_element(pieces.begin(), pieces.end());
   if (!c->copy_stream) {
     HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (int b = 0; b < 2; ++b) {
@@ -609,10 +610,10 @@ int staged_upload(kpdi_ctx *c, const void *patterns, size_t row_bytes, int64_t n
       HIPCHK(hipStreamSynchronize(c->stream));
       HIPCHK(c->stage[b].reserve((size_t)per * row_bytes));
     }
-  for (int64_t start = 0; start < n_chunk; start += per) {
+  int64_t start = 0;
+  for (const int64_t n : pieces) {
     const int b = c->stage_next;
     c->stage_next ^= 1;
-    const int64_t n = std::min(per, n_chunk - start);
     HIPCHK(hipStreamWaitEvent(c->copy_stream, c->stage_free[b], 0));
     HIPCHK(hipMemcpyAsync(c->stage[b].p, (const char *)patterns + (size_t)start * row_bytes, (size_t)n * row_bytes,
                           hipMemcpyHostToDevice, c->copy_stream));
@@ -622,9 +623,54 @@ int staged_upload(kpdi_ctx *c, const void *patterns, size_t row_bytes, int64_t n
     int rc = consume(c->stage[b].p, n, start);
     if (rc) return rc;
     HIPCHK(hipEventRecord(c->stage_free[b], c->stream));  // the prep kernel has consumed the piece
+    start += n;
   }
   HIPCHK(hipStreamSynchronize(c->copy_stream));  // the caller's buffer is free again
   return KPDI_OK;
+}
+
+// How a host chunk is cut for the upload/sweep pipeline: uniform pieces (the remainder last),
+// each one match launch set.  Short pieces bound the two ends that do not overlap (the upload
+// of the first piece, the sweep of the last); long pieces waste less on whole tiles per
+// workgroup and on the per-piece prep/merge.  Which wins depends on whether the job is
+// upload-bound (few experimental patterns) or sweep-bound (many), so the size is picked by
+// playing the two-stage pipeline through for every candidate with the launch plan's own cost
+// model: upload at ~56 GB/s (pageable memory over PCIe 5, measured), one workgroup-tile
+// (256 x 128 x kpad MACs) at 88 % of a CU's f32 MFMA rate, 0.45 ms per piece of fixed work
+// (launch ramp, top-k epilogue, prep, merge; fitted).  The model lands within ~1 ms of the
+// measurements (tools/pcie_probe.py): config 2 (upload alone 25.5 ms) 32-tile pieces 37.4 ms,
+// 80 tiles 28.1 ms (the model's pick), 192 tiles 32.1 ms; 10 000 experimental patterns
+// 128 tiles 63.5 ms (the pick), 256 tiles 66.7 ms.  KPDI_UPLOAD_TILES=<tiles per piece> overrides.
+std::vector<int64_t> upload_pieces(const kpdi_ctx *c, int64_t n_chunk, size_t row_bytes) {
+  const int64_t tiles = (n_chunk + kpdi::TILE_DICT - 1) / kpdi::TILE_DICT;
+  int64_t piece = tiles;
+  if (const char *env = getenv("KPDI_UPLOAD_TILES"); env && atol(env) > 0) {
+    piece = atol(env);
+  } else if (c->have_exp && c->m_pad > 0) {
+    const int row_blocks = c->m_pad / kpdi::TILE_EXP;
+    const double t_tile = 2.0 * kpdi::TILE_EXP * kpdi::TILE_DICT * c->kpad / (157.3e12 / 256 * 0.88);
+    const double t_row = row_bytes / 56e9, t_fixed = 0.45e-3;
+    auto sweep_time = [&](int64_t t) {
+      int rpl = 0;
+      const int ns = choose_nsplit(c, row_blocks, (int)t, &rpl);
+      return ((row_blocks + rpl - 1) / rpl) * (double)((t + ns - 1) / ns) * t_tile + t_fixed;
+    };
+    double best = 1e30;
+    for (int64_t cand = 32; cand <= 512 + 8; cand += 8) {
+      const int64_t p = cand > 512 ? tiles : std::min(cand, tiles);  // last candidate: one piece
+      const double s_full = sweep_time(p), s_rest = tiles % p ? sweep_time(tiles % p) : 0.0;
+      double copied = 0, swept = 0;
+      for (int64_t left = tiles; left > 0; left -= p) {
+        const int64_t t = std::min(p, left);
+        copied += t * kpdi::TILE_DICT * t_row;
+        swept = std::max(swept, copied) + (t == p ? s_full : s_rest);
+      }
+      if (swept < best - 1e-9) best = swept, piece = p;
+    }
+  }
+  std::vector<int64_t> out;
+  for (int64_t left = n_chunk, per = piece * kpdi::TILE_DICT; left > 0; left -= per) out.push_back(std::min(per, left));
+  return out;
 }
 
 // a new resident chunk: its prepared buffer, sized for n patterns
@@ -922,13 +968,8 @@ int kpdi_push_dictionary_chunk(kpdi_ctx *c, const void *patterns, int dtype, int
   if (n_chunk <= 0) return fail(KPDI_EINVAL, "dictionary chunk must hold at least one pattern");
   int rc = use_device(c);
   if (rc) return rc;
-  // large chunks are cut into pieces of >= 192 dictionary tiles, which keeps the match
-  // kernel's tile counts per workgroup healthy; the sweep of the last piece may still be
-  // running on return
-  const int64_t piece = 192 * kpdi::TILE_DICT;
-  const int64_t n_pieces = std::max<int64_t>(1, n_chunk / piece);
-  const int64_t per = (n_chunk + n_pieces - 1) / n_pieces;
-  return staged_upload(c, patterns, (size_t)c->npix * es, n_chunk, per,
+  // the sweep of the last piece may still be running on return
+  return staged_upload(c, patterns, (size_t)c->npix * es, upload_pieces(c, n_chunk, (size_t)c->npix * es),
                        [&](const void *d_piece, int64_t n, int64_t offset) {
                          return push_chunk_dev(c, d_piece, dtype, n, global_start + offset);
                        });
@@ -955,9 +996,10 @@ int kpdi_hold_dictionary_chunk(kpdi_ctx *c, const void *patterns, int dtype, int
   rc = new_held_chunk(c, n_chunk, global_start, &y);
   if (rc) return rc;
   // pieces of whole tiles, so that every piece is prepared straight into its place
-  const int64_t per = 192 * kpdi::TILE_DICT;
+  std::vector<int64_t> pieces;
+  for (int64_t left = n_chunk, per = 192 * kpdi::TILE_DICT; left > 0; left -= per) pieces.push_back(std::min(per, left));
   const size_t kpad = c->kpad;
-  rc = staged_upload(c, patterns, (size_t)c->npix * kpdi::dtype_size(dtype), n_chunk, per,
+  rc = staged_upload(c, patterns, (size_t)c->npix * kpdi::dtype_size(dtype), pieces,
                      [&](const void *d_piece, int64_t n, int64_t offset) {
                        return prepare_chunk(c, d_piece, dtype, n, y + (size_t)offset * kpad);
                      });

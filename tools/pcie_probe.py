@@ -38,3 +38,32 @@ for n in (25000, 50000):
     ctx.synchronize()
     dt = time.perf_counter() - t0
     print(f"push in chunks of {n}: {dt*1e3:.1f} ms = {4096/dt:.0f} patterns/s", flush=True)
+# piece size of the upload/sweep pipeline (KPDI_UPLOAD_TILES=<dictionary tiles per piece>)
+for sched in ("", "32", "48", "64", "80", "96", "128", "192"):
+    if sched:
+        os.environ["KPDI_UPLOAD_TILES"] = sched
+    best = 1e9
+    for rep in range(4):
+        ctx.reset_topk()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        ctx.push_dictionary_chunk(dic, 0)
+        ctx.finalize(20)
+        best = min(best, time.perf_counter() - t0)
+    print(f"pieces of {sched or 'default'} tiles: {best*1e3:.1f} ms = {4096/best:.0f} patterns/s", flush=True)
+os.environ.pop("KPDI_UPLOAD_TILES")
+for m in (1024, 10000):
+    ctx.set_experimental(rng.integers(0, 256, (m, 60, 60), dtype=np.uint8))
+    for sched in ("", "64", "128", "192", "256"):
+        os.environ.pop("KPDI_UPLOAD_TILES", None)
+        if sched:
+            os.environ["KPDI_UPLOAD_TILES"] = sched
+        best = 1e9
+        for rep in range(3):
+            ctx.reset_topk()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            ctx.push_dictionary_chunk(dic, 0)
+            ctx.finalize(20)
+            best = min(best, time.perf_counter() - t0)
+        print(f"m={m} pieces of {sched or 'default'} tiles: {best*1e3:.1f} ms = {m/best:.0f} patterns/s", flush=True)
