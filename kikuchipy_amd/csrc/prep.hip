@@ -18,7 +18,9 @@
 //                gathered from LDS through the LDS copy of the pixel map
 //                                                                   (prep_wave_masked_kernel)
 //     otherwise: scalar gather from global memory                   (prep_wave_kernel<T,1>)
-//   larger detectors: one workgroup per pattern re-reading the pattern from L2 (prep_kernel).
+//   K <= 16384 (up to 128x128): ONE WORKGROUP per pattern, the same scheme with 256 threads
+//                                                                   (prep_block_kernel)
+//   larger still: one workgroup per pattern re-reading the pattern from L2 (prep_kernel).
 //
 // A pattern with zero norm (constant pattern; 0/0 = NaN in the reference, out of
 // contract per SURVEY.md 8(a)) becomes an all-zero row: it scores exactly 0
@@ -122,15 +124,25 @@ __device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], flo
 // same, v[4*i + e] holds kept pixel 4*(lane + 64*i) + e: float4 stores (full 16-byte slots)
 // `split`: store the split-f16 form directly (see split_f16_kernel below): the lane's four
 // pixels are half of an 8-pixel slot, i.e. 8 bytes of the high-half slot and 8 of the low-half slot
+// NT threads share the pattern: 64 = one wave (`lane` = lane id), PREP_THREADS = the whole
+// workgroup (`lane` = thread id, sums through `red` in LDS)
+template <int NT>
+__device__ __forceinline__ float group_sum(float v, float *red) {
+  if (NT == 64) return wave_sum(v);
+  return block_sum(v, red);
+}
+
+template <int NT = 64>
 __device__ __forceinline__ void normalise_and_store_quads(float (&v)[WAVE_VALUES], float s, int lane, int r, int k,
-                                                          int kpad, int metric, float *out, int split) {
+                                                          int kpad, int metric, float *out, int split,
+                                                          float *red = nullptr) {
   const int nslab = kpad / TILE_K;
   float mean = 0.f;
-  if (metric == KPDI_METRIC_NCC) mean = wave_sum(s) / (float)k;
+  if (metric == KPDI_METRIC_NCC) mean = group_sum<NT>(s, red) / (float)k;
   float q2 = 0.f;
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES; ++i) {
-    const int c = 4 * (lane + 64 * (i / 4)) + (i & 3);
+    const int c = 4 * (lane + NT * (i / 4)) + (i & 3);
     if (c < k) {
       v[i] -= mean;
       q2 += v[i] * v[i];
@@ -138,11 +150,11 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[WAVE_VALUES
       v[i] = 0.f;
     }
   }
-  const float norm = sqrtf(wave_sum(q2));
+  const float norm = sqrtf(group_sum<NT>(q2, red));
   const float inv = norm > 0.f ? 1.f / norm : 0.f;
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES / 4; ++i) {
-    const int c = 4 * (lane + 64 * i);
+    const int c = 4 * (lane + NT * i);
     if (c < kpad) {
       float4 w;
       w.x = v[4 * i] * inv;
@@ -209,6 +221,39 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, i
     }
     normalise_and_store(v, s, lane, r, k, kpad, metric, out);
   }
+}
+
+// ---- 4096 < K <= 16384 kept pixels (up to 128x128 detectors): one workgroup per pattern ----
+// The same register-resident scheme with 256 threads x 64 values: every pixel is read once
+// (vector loads when there is no signal mask, else a gather through the pixel map - the row
+// is then served by L2 after its first touch) and stored once as whole 16-byte slots.
+template <typename T, bool MASKED>
+__global__ __launch_bounds__(PREP_THREADS) void prep_block_kernel(const T *raw, int npix, const int *row_map,
+                                                                  const int *pix_map, int k, int kpad,
+                                                                  int metric, float *out, int split) {
+  __shared__ float red[PREP_THREADS / 64];
+  const int tid = threadIdx.x;
+  const int r = blockIdx.x;
+  const int64_t src = row_map ? row_map[r] : r;
+  const T *p = raw + src * (int64_t)npix;
+  float v[WAVE_VALUES];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < WAVE_VALUES / 4; ++i) {
+    const int c = 4 * (tid + PREP_THREADS * i);
+    if (!MASKED) {
+      Quad<T> q;
+      q.v[0] = q.v[1] = q.v[2] = q.v[3] = (T)0;
+      if (c < k) q = *reinterpret_cast<const Quad<T> *>(p + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * i + e] = (float)q.v[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * i + e] = c + e < k ? (float)p[pix_map[c + e]] : 0.f;
+    }
+    s += (v[4 * i] + v[4 * i + 1]) + (v[4 * i + 2] + v[4 * i + 3]);
+  }
+  normalise_and_store_quads<PREP_THREADS>(v, s, tid, r, k, kpad, metric, out, split, red);
 }
 
 // ---- one wave per pattern, signal mask, row staged in LDS -------------------------------
@@ -319,6 +364,10 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   const bool vec_ok = (a.npix % 4) == 0 && ((uintptr_t)a.raw % (4 * dtype_size(a.dtype))) == 0;
   const bool vec4 = wave_path && a.pix_map == nullptr && (a.k % 4) == 0 && vec_ok;
   const bool staged = wave_path && a.pix_map != nullptr && vec_ok && a.npix <= 64 * WAVE_VALUES;
+  // larger detectors, still register-resident: one workgroup per pattern
+  const bool block_path = !wave_path && a.k <= PREP_THREADS * WAVE_VALUES;
+  const bool block_vec = block_path && a.pix_map == nullptr && (a.k % 4) == 0 && vec_ok;
+  const bool block_masked = block_path && a.pix_map != nullptr;
   const size_t staged_lds = (size_t)(((a.k + 3) & ~3) + 4 * a.npix) * 4;
   dim3 block(PREP_THREADS);
   dim3 grid(wave_path ? (a.n_out + 3) / 4 : a.n_out);
@@ -338,6 +387,12 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   } else if (wave_path)                                                                                  \
     hipLaunchKernelGGL((prep_wave_kernel<T, 1>), grid, block, 0, s, (const T *)a.raw, a.npix,           \
                        a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, 0);                  \
+  else if (block_vec)                                                                                    \
+    hipLaunchKernelGGL((prep_block_kernel<T, false>), grid, block, 0, s, (const T *)a.raw, a.npix,      \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, a.split_f16);                 \
+  else if (block_masked)                                                                                 \
+    hipLaunchKernelGGL((prep_block_kernel<T, true>), grid, block, 0, s, (const T *)a.raw, a.npix,       \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, a.split_f16);                 \
   else                                                                                                   \
     hipLaunchKernelGGL((prep_kernel<T>), grid, block, 0, s, (const T *)a.raw, a.npix, a.row_map,        \
                        a.pix_map, a.k, a.kpad, a.metric, a.out);                                         \
@@ -358,7 +413,7 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   if (e != hipSuccess) return e;
   // paths that store whole float4 slots write the split-f16 form themselves; the others are
   // converted in place afterwards (rows beyond n_out are zero in either form)
-  if (a.split_f16 && !(vec4 || staged))
+  if (a.split_f16 && !(vec4 || staged || block_vec || block_masked))
     return launch_split_f16(a.out, round_up(a.n_out, TILE_DICT), a.kpad, s);
   return hipSuccess;
 }

@@ -120,6 +120,43 @@ def test_vs_oracle_shapes(ctx, m, n, sy, sx, k, chunk, metric):
     ko.assert_topk_parity(s, i, rs, ri, atol=ATOL)
 
 
+@pytest.mark.parametrize("sy,sx,masked,dtype,metric", [
+    (70, 72, False, np.float32, "ncc"),    # K = 5040: one workgroup per pattern, vector loads
+    (120, 120, False, np.uint8, "ndp"),    # configs[4] detector
+    (128, 128, False, np.uint16, "ncc"),   # K = 16384, the largest register-resident pattern
+    (96, 80, True, np.float32, "ncc"),     # signal mask: gather through the pixel map
+    (120, 120, True, np.uint8, "ncc"),
+    (75, 75, False, np.float32, "ncc"),    # K % 4 != 0: generic kernel
+    (130, 130, False, np.uint8, "ncc"),    # K > 16384: generic kernel
+    (130, 130, True, np.float32, "ndp"),
+])
+def test_large_detectors(ctx, sy, sx, masked, dtype, metric):
+    """Pattern preparation switches kernels with the number of kept pixels (csrc/prep.hip)."""
+    from kikuchipy_amd import _lib
+
+    rng = np.random.default_rng(sy * sx)
+    exp = (rng.random((21, sy, sx)) * 250).astype(dtype)
+    dic = (rng.random((300, sy, sx)) * 250).astype(dtype)
+    signal_mask = None
+    if masked:
+        yy, xx = np.mgrid[:sy, :sx]
+        signal_mask = (yy - sy / 2) ** 2 + (xx - sx / 2) ** 2 > (min(sy, sx) / 2) ** 2
+    nav_mask = np.zeros(21, dtype=bool)
+    nav_mask[[3, 20]] = True
+    s, i = run_engine(ctx, exp, dic, metric=metric, keep_n=7, chunk=170, signal_mask=signal_mask,
+                      navigation_mask=nav_mask)
+    rs, ri = ko.dictionary_indexing(exp, dic, metric=metric, keep_n=7, signal_mask=signal_mask,
+                                    navigation_mask=nav_mask)
+    ko.assert_topk_parity(s, i, rs, ri, atol=ATOL)
+    # the opt-in split-f16 arithmetic goes through the same preparation kernels
+    ctx.set_problem(sy, sx, signal_mask, {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[metric], 7,
+                    _lib.COMPUTE_F16X2)
+    ctx.set_experimental(exp, nav_mask)
+    ctx.push_dictionary_chunk(dic, 0)
+    s16, i16 = ctx.finalize(7)
+    ko.assert_topk_parity(s16, i16, rs, ri, atol=ATOL)
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32, np.float64])
 def test_input_dtypes(ctx, dtype):
     rng = np.random.default_rng(5)
