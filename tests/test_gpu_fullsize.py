@@ -179,3 +179,62 @@ def test_refinement_of_a_whole_map():
     assert res.num_evals.min() >= 4 and res.num_evals.max() <= 600
     again = s.refine_orientation(rotation_from_euler(eu0).reshape(64, 64, 4), det, mp, verbose=False)
     assert np.array_equal(again.scores, res.scores) and np.array_equal(again.euler, res.euler)
+
+
+def test_experimental_set_beyond_2_31_prepared_elements():
+    """A 700 000-pattern map (a large modern scan): 2.52e9 prepared floats on the experimental side."""
+    from kikuchipy_amd import _lib
+
+    rng = np.random.default_rng(0)
+    ctx = _lib.Context(0)
+
+    m = 700_000
+    exp = rng.integers(0, 256, (m, 60, 60), dtype=np.uint8)
+    dic = rng.random((3000, 60, 60), dtype=np.float32)
+    ctx.set_problem(60, 60, None, _lib.METRIC_NCC, 20)
+    ctx.set_experimental(exp)
+    ctx.push_dictionary_chunk(dic[:1700], 0)
+    ctx.push_dictionary_chunk(dic[1700:], 1700)
+    s, i = ctx.finalize(20)
+    rows = np.array([0, 1, 255, 256, 596_523, 596_524, 600_000, 699_999])
+    rs, ri = ko.dictionary_indexing(exp[rows], dic, keep_n=20)
+    ko.assert_topk_parity(s[rows], i[rows], rs, ri, atol=1e-5)
+    # every row: descending, valid indices
+    assert np.all(np.diff(s, axis=1) <= 0) and i.min() >= 0 and i.max() < 3000
+    ctx.close()
+
+
+def test_dictionary_chunk_beyond_2_31_prepared_elements():
+    """One chunk of 620 000 patterns, simulated on the device (8.9 GB raw + 8.9 GB prepared), pushed and held."""
+    from kikuchipy_amd import _lib
+
+    rng = np.random.default_rng(1)
+    ctx = _lib.Context(0)
+    ctx.set_problem(60, 60, None, _lib.METRIC_NCC, 20)
+    n = 620_000
+    quat = rng.standard_normal((n, 4))
+    quat /= np.linalg.norm(quat, axis=1)[:, None]
+    f = np.fft.rfft2(rng.standard_normal((2, 401, 401)))
+    ky, kx = np.meshgrid(np.fft.fftfreq(401), np.fft.rfftfreq(401), indexing="ij")
+    mp = np.fft.irfft2(f * np.exp(-(kx**2 + ky**2) / (2 * 0.03**2)), s=(401, 401)).astype(np.float32)
+    ctx.set_master_pattern(mp[0], mp[1])
+    pc = (0.421, 0.7794, 0.5049)
+    bounds = [-pc[0] / pc[2], (1 - pc[0]) / pc[2], -(1 - pc[1]) / pc[2], pc[1] / pc[2]]
+    ct, st = np.cos(np.deg2rad(70.0)), np.sin(np.deg2rad(70.0))
+    det_to_sample = np.array([[0, 1, 0], [-st, 0, ct], [ct, 0, st]], dtype=np.float64).T
+    ctx.set_detector(bounds, pc[2], 60, 60, det_to_sample)
+    picks = np.array([0, 127, 300_000, 596_523, 596_524, 600_001, 619_999])
+    planted = ctx.project_patterns(quat[picks], True, -1.0, 1.0, np.float32).reshape(-1, 60, 60)
+    noise = planted + 0.05 * rng.standard_normal(planted.shape).astype(np.float32)
+    ctx.set_experimental(np.concatenate([planted, noise]))
+    ctx.push_rotations_chunk(quat, 5, True, -1.0, 1.0)
+    s, i = ctx.finalize(20)
+    assert np.array_equal(i[:7, 0], picks + 5) and np.allclose(s[:7, 0], 1, atol=1e-5), (i[:, 0], s[:, 0])
+    assert np.array_equal(i[7:, 0], picks + 5), i[7:, 0]
+    # the same as a held chunk
+    ctx.hold_rotations_chunk(quat, 5, True, -1.0, 1.0)
+    ctx.reset_topk()
+    ctx.sweep_held()
+    s2, i2 = ctx.finalize(20)
+    assert np.array_equal(s, s2) and np.array_equal(i, i2)
+    ctx.close()
