@@ -14,6 +14,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 ctx = _lib.Context(0)
 for case in range(n_cases):
     sy, sx = int(rng.integers(2, 70)), int(rng.integers(2, 70))
+    if rng.random() < 0.08:  # larger detectors: the other preparation kernels
+        sy, sx = int(rng.integers(64, 133)), int(rng.integers(64, 133))
     m = int(rng.choice([1, 3, 40, 257, 600, 1500]))
     n = int(rng.choice([1, 5, 127, 128, 129, 900, 4000]))
     k = int(min(n, rng.choice([1, 2, 8, 20, 21, 33, 64])))
@@ -34,8 +36,14 @@ for case in range(n_cases):
     chunk = int(rng.choice([n, max(1, n // 3), 100]))
     ctx.set_problem(sy, sx, sig, {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[metric], k, mode)
     ctx.set_experimental(exp, nav)
-    for a in range(0, n, chunk):
-        ctx.push_dictionary_chunk(dic[a:a + chunk], a)
+    if rng.random() < 0.3:  # resident dictionary: prepared chunks held, then swept
+        for a in range(0, n, chunk):
+            ctx.hold_dictionary_chunk(dic[a:a + chunk], a)
+        ctx.sweep_held()
+        ctx.release_held()
+    else:
+        for a in range(0, n, chunk):
+            ctx.push_dictionary_chunk(dic[a:a + chunk], a)
     s, i = ctx.finalize(k)
     e = exp if nav is None else exp[~nav]
     rs, ri = ko.dictionary_indexing(e, dic, metric=metric, keep_n=k, n_per_iteration=chunk, signal_mask=sig)
