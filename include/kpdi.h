@@ -60,6 +60,7 @@ typedef struct kpdi_ctx kpdi_ctx;
 #define KPDI_I16 5
 #define KPDI_I32 6
 #define KPDI_U32 7
+#define KPDI_F16 8 /* IEEE half: dictionaries stored at half the bytes; not for background removal */
 
 /* arithmetic of the match kernel */
 #define KPDI_COMPUTE_F32 0 /* exact f32 MFMA (v_mfma_f32_32x32x2_f32), f32 accumulate: the default */

@@ -31,6 +31,7 @@ DTYPE_CODES = {
     np.dtype(np.int16): 5,
     np.dtype(np.int32): 6,
     np.dtype(np.uint32): 7,
+    np.dtype(np.float16): 8,
 }
 
 

@@ -856,6 +856,8 @@ int kpdi_remove_static_background(kpdi_ctx *c, const float *static_bg, int opera
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
   if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
   if (!static_bg) return fail(KPDI_EINVAL, "static_bg is NULL");
+  if (c->exp_dtype == KPDI_F16 || c->exp_dtype == KPDI_I32 || c->exp_dtype == KPDI_U32)
+    return fail(KPDI_EINVAL, "background removal takes uint8/int8/uint16/int16/float32/float64 patterns");
   if (operation != KPDI_OP_SUBTRACT && operation != KPDI_OP_DIVIDE) return fail(KPDI_EINVAL, "unknown operation");
   int rc = use_device(c);
   if (rc) return rc;
@@ -887,6 +889,8 @@ int kpdi_remove_dynamic_background(kpdi_ctx *c, int operation, int filter_domain
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
   if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
   if (operation != KPDI_OP_SUBTRACT && operation != KPDI_OP_DIVIDE) return fail(KPDI_EINVAL, "unknown operation");
+  if (c->exp_dtype == KPDI_F16 || c->exp_dtype == KPDI_I32 || c->exp_dtype == KPDI_U32)
+    return fail(KPDI_EINVAL, "background removal takes uint8/int8/uint16/int16/float32/float64 patterns");
   int rc = use_device(c);
   if (rc) return rc;
   if (std <= 0) std = c->sx / 8.0;  // signals/ebsd.py:648-649

@@ -35,7 +35,7 @@ namespace kpdi {
 size_t dtype_size(int dtype) {
   switch (dtype) {
     case KPDI_U8: case KPDI_I8: return 1;
-    case KPDI_U16: case KPDI_I16: return 2;
+    case KPDI_U16: case KPDI_I16: case KPDI_F16: return 2;
     case KPDI_F32: case KPDI_I32: case KPDI_U32: return 4;
     case KPDI_F64: return 8;
   }
@@ -406,6 +406,7 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
     case KPDI_U32: KPDI_PREP(uint32_t)
     case KPDI_F32: KPDI_PREP(float)
     case KPDI_F64: KPDI_PREP(double)
+    case KPDI_F16: KPDI_PREP(_Float16)
     default: return hipErrorInvalidValue;
   }
 #undef KPDI_PREP

@@ -489,6 +489,7 @@ hipError_t launch_refine_prep(const void *raw, int dtype, int64_t n, int npix, c
     case KPDI_U32: KPDI_RPREP(uint32_t)
     case KPDI_F32: KPDI_RPREP(float)
     case KPDI_F64: KPDI_RPREP(double)
+    case KPDI_F16: KPDI_RPREP(_Float16)
     default: return hipErrorInvalidValue;
   }
 #undef KPDI_RPREP

@@ -157,7 +157,7 @@ def test_large_detectors(ctx, sy, sx, masked, dtype, metric):
     ko.assert_topk_parity(s16, i16, rs, ri, atol=ATOL)
 
 
-@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32, np.float64])
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float16, np.float32, np.float64])
 def test_input_dtypes(ctx, dtype):
     rng = np.random.default_rng(5)
     exp = (rng.random((40, 24, 24)) * 200).astype(dtype)

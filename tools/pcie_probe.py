@@ -67,3 +67,15 @@ for m in (1024, 10000):
             ctx.finalize(20)
             best = min(best, time.perf_counter() - t0)
         print(f"m={m} pieces of {sched or 'default'} tiles: {best*1e3:.1f} ms = {m/best:.0f} patterns/s", flush=True)
+# a float16 dictionary (half the bytes over PCIe; exact cast to float32 on the device)
+os.environ.pop("KPDI_UPLOAD_TILES", None)
+ctx.set_experimental(exp)
+dic16 = dic.astype(np.float16)
+for rep in range(3):
+    ctx.reset_topk()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.push_dictionary_chunk(dic16, 0)
+    ctx.finalize(20)
+    dt = time.perf_counter() - t0
+    print(f"push float16 dictionary: {dt*1e3:.1f} ms = {4096/dt:.0f} patterns/s", flush=True)
