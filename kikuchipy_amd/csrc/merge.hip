@@ -9,8 +9,10 @@
 // how candidates were split over lanes, workgroups, chunks or ranks.
 //
 // One wave per experimental pattern; k rounds of "largest key below the previous
-// winner" over all candidates (they sit in L2).  Latency-bound and tiny next to
-// the match kernel (M*k*(lists*len) key compares).
+// winner" over all candidates.  Up to 48 * 64 candidates per pattern are read ONCE into
+// registers as 64-bit keys (merge_cached_kernel; config 2: 32 lists x 20 + the running 20 =
+// 660 candidates, 11 per lane); more are re-read from L2 every round (merge_kernel).
+// Latency-bound and tiny next to the match kernel.
 #include "kernels.h"
 #include <limits.h>
 #include <math.h>
@@ -87,6 +89,66 @@ __global__ __launch_bounds__(256) void merge_kernel(MergeArgs a) {
   }
 }
 
+// candidates in registers: lane holds candidates lane, lane + 64, ... of the sources laid end to end
+template <int NK>
+__global__ __launch_bounds__(256) void merge_cached_kernel(MergeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= a.m) return;
+  const int end0 = a.lists[0] * a.len[0];
+  const int end1 = end0 + (a.n_src > 1 ? a.lists[1] * a.len[1] : 0);
+  const int end2 = end1 + (a.n_src > 2 ? a.lists[2] * a.len[2] : 0);
+  unsigned long long keys[NK];
+#pragma unroll
+  for (int i = 0; i < NK; ++i) {
+    // branch-free (a divergent branch around the loads makes the compiler copy the whole key
+    // array at every join): slots past the last candidate read candidate 0 and are zeroed
+    const int c0 = lane + 64 * i;
+    const bool live = c0 < end2;
+    const int c = live ? c0 : 0;
+    // the source of candidate c, picked with constant indices into the argument arrays
+    const bool in0 = c < end0, in1 = c < end1;
+    const float *ps = in0 ? a.s[0] : (in1 ? a.s[1] : a.s[2]);
+    const int *pi = in0 ? a.i[0] : (in1 ? a.i[1] : a.i[2]);
+    const int len = in0 ? a.len[0] : (in1 ? a.len[1] : a.len[2]);
+    const int stride = in0 ? a.stride[0] : (in1 ? a.stride[1] : a.stride[2]);
+    const int list_stride = in0 ? a.list_stride[0] : (in1 ? a.list_stride[1] : a.list_stride[2]);
+    const int local = c - (in0 ? 0 : (in1 ? end0 : end1));
+    // local / len without an integer division: local < 3072, len <= 32, so the float quotient of
+    // local + 0.5 is at least 1/64 away from an integer
+    const int l = (int)(((float)local + 0.5f) / (float)len);
+    const size_t e = (size_t)m * stride + (size_t)l * list_stride + (local - l * len);
+    const int idx = pi[e];
+    const unsigned long long key = topk_key(ps[e], idx);
+    keys[i] = (live && idx != INT_MAX) ? key : 0ull;
+  }
+  unsigned long long prev = ~0ull;
+  for (int r = 0; r < a.k; ++r) {
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int i = 0; i < NK; ++i)
+      if (keys[i] < prev && keys[i] > best) best = keys[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffu), o, 64);
+      const unsigned hi = __shfl_xor((unsigned)(best >> 32), o, 64);
+      const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+      best = other > best ? other : best;
+    }
+    if (lane == 0) {
+      const size_t o = (size_t)m * a.out_stride + a.out_offset + r;
+      if (best == 0ull) {
+        a.out_s[o] = -INFINITY;
+        a.out_i[o] = INT_MAX;
+      } else {
+        a.out_s[o] = key_score(best);
+        a.out_i[o] = key_idx(best);
+      }
+    }
+    prev = best;  // 0 once the candidates are exhausted: nothing is below it
+  }
+}
+
 hipError_t launch_merge(const MergeLaunch &l, hipStream_t s) {
   if (l.m <= 0 || l.k <= 0) return hipSuccess;
   MergeArgs a;
@@ -105,7 +167,19 @@ hipError_t launch_merge(const MergeLaunch &l, hipStream_t s) {
   a.out_i = l.out_idx;
   a.out_stride = l.out_stride;
   a.out_offset = l.out_offset;
-  hipLaunchKernelGGL(merge_kernel, dim3((l.m + 3) / 4), dim3(256), 0, s, a);
+  int candidates = 0;
+  for (int j = 0; j < l.n_src; ++j) candidates += l.src_lists[j] * l.src_len[j];
+  const dim3 grid((l.m + 3) / 4), block(256);
+  if (candidates <= 4 * 64)
+    hipLaunchKernelGGL(merge_cached_kernel<4>, grid, block, 0, s, a);
+  else if (candidates <= 12 * 64)
+    hipLaunchKernelGGL(merge_cached_kernel<12>, grid, block, 0, s, a);
+  else if (candidates <= 24 * 64)
+    hipLaunchKernelGGL(merge_cached_kernel<24>, grid, block, 0, s, a);
+  else if (candidates <= 48 * 64)
+    hipLaunchKernelGGL(merge_cached_kernel<48>, grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL(merge_kernel, grid, block, 0, s, a);
   return hipGetLastError();
 }
 

@@ -63,7 +63,7 @@ for case in range(n_cases):
         eng = np.abs(s - np.take_along_axis(exact, i, 1)).max()
         orc = np.abs(rs - np.take_along_axis(exact, ri, 1)).max()
         print(f"  engine vs exact: max {eng:.2e};  oracle vs exact: max {orc:.2e}")
-        if eng < 5e-6 and orc > eng:
+        if eng < 1e-5 and orc > eng:
             # the float32 oracle (like the reference's sgemm) carries the larger error; the
             # engine is the one closer to exact arithmetic
             print(f"ok {case} (oracle float32 noise): {sy}x{sx} m={m} n={n} k={k} {metric} mode={mode}", flush=True)
