@@ -72,7 +72,7 @@ if match:
     summary["match_traffic_bytes_per_launch"] = mk.get("fetch_bytes_per_launch", 0) + mk.get("write_bytes_per_launch", 0)
 json.dump(summary, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
 
-lines = [f"# rocprofv3 summary {tag}: `python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pcie`", "",
+lines = [f"# rocprofv3 summary {tag}: `python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pcie --no-generation` (tools/collect_profiles.sh)", "",
          "| kernel | calls | avg ms | % | fetch GB/launch | write GB/launch | MFMA busy | clock GHz |",
          "|---|---|---|---|---|---|---|---|"]
 for name, k in summary["kernels"].items():
