@@ -365,7 +365,9 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   ml.tile_groups = (tg_env && atoi(tg_env) == 8 && nsplit % 8 == 0) ? 8 : 1;
   const size_t ctr_bytes = (size_t)(c->m_pad / kpdi::TILE_EXP) * ml.tile_groups * sizeof(unsigned);
   HIPCHK(c->tile_ctr.reserve(ctr_bytes));
-  HIPCHK(hipMemsetAsync(c->tile_ctr.p, 0, ctr_bytes, c->stream));
+  // every workgroup's first three draws are fixed (match.hip), the counters start behind them
+  HIPCHK(kpdi::launch_fill_u32(c->tile_ctr.as<unsigned>(), 3u * (unsigned)(nsplit / ml.tile_groups),
+                               (int64_t)(ctr_bytes / sizeof(unsigned)), c->stream));
   ml.tile_ctr = c->tile_ctr.as<unsigned>();
   const int row_blocks = c->m_pad / kpdi::TILE_EXP;
   {

@@ -68,7 +68,7 @@ struct MatchArgs {
   int *part_idx;
   const float *bound_score;
   const int *bound_idx;
-  unsigned *tile_ctr;  // [row blocks][tile_groups] next dictionary tile to hand out, zero at launch
+  unsigned *tile_ctr;  // [row blocks][tile_groups] next draw to hand out; 3 * nsplit / tile_groups at launch
   int tile_groups;
   unsigned *gthr;      // [m_pad][BOUND_SLOTS] published list ranks (monotone keys), see shared_bound()
   int bound_rank;      // which entry (1-based) of its list a workgroup lane publishes
@@ -294,16 +294,18 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
   // ---- dictionary tiles are handed out dynamically; t0 = tile being computed, t1/t2 the
   // next two (the loads run two slabs ahead, which can reach two tiles ahead)
   int t0, t1, t2;
-  if (tid == 0) {
-    ctrl[0] = (int)atomicAdd(tile_ctr, 1u) * tgroups + tg;
-    ctrl[1] = (int)atomicAdd(tile_ctr, 1u) * tgroups + tg;
-    ctrl[2] = (int)atomicAdd(tile_ctr, 1u) * tgroups + tg;
+  // The first three tiles of a workgroup are fixed (draws r, r + G, r + 2G for the r-th of the G
+  // workgroups sharing the counter, which starts at 3G): workgroups do not start at the same
+  // time, and when the early ones drew their look-ahead tiles from the counter a launch with
+  // <= 3 tiles per workgroup took about one tile-time more than its share (4096 x 2048 / 4096 /
+  // 6144 patterns: 1.00 / 1.48 / 1.96 ms before, 0.57 / 1.06 / 1.59 ms now).  Everything after
+  // is drawn while the previous tile is computed.
+  {
+    const int group = a.nsplit / tgroups, r = sp / tgroups;
+    t0 = r * tgroups + tg;
+    t1 = (r + group) * tgroups + tg;
+    t2 = (r + 2 * group) * tgroups + tg;
   }
-  __syncthreads();
-  t0 = __builtin_amdgcn_readfirstlane(ctrl[0]);
-  t1 = __builtin_amdgcn_readfirstlane(ctrl[1]);
-  t2 = __builtin_amdgcn_readfirstlane(ctrl[2]);
-  __syncthreads();
   if (t0 >= n_tiles) goto write_out;
 
   {
