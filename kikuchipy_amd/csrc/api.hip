@@ -638,11 +638,12 @@ int staged_upload(kpdi_ctx *c, const void *patterns, size_t row_bytes, const std
 // upload-bound (few experimental patterns) or sweep-bound (many), so the size is picked by
 // playing the two-stage pipeline through for every candidate with the launch plan's own cost
 // model: upload at ~56 GB/s (pageable memory over PCIe 5, measured), one workgroup-tile
-// (256 x 128 x kpad MACs) at 88 % of a CU's f32 MFMA rate, 0.45 ms per piece of fixed work
-// (launch ramp, top-k epilogue, prep, merge; fitted).  The model lands within ~1 ms of the
-// measurements (tools/pcie_probe.py): config 2 (upload alone 25.5 ms) 32-tile pieces 37.4 ms,
-// 80 tiles 28.1 ms (the model's pick), 192 tiles 32.1 ms; 10 000 experimental patterns
-// 128 tiles 63.5 ms (the pick), 256 tiles 66.7 ms.  KPDI_UPLOAD_TILES=<tiles per piece> overrides.
+// (256 x 128 x kpad MACs) at 88 % of a CU's f32 MFMA rate, 0.18 ms per piece of fixed work
+// (launch ramp, prep, merge; fitted).  The model lands within ~0.3 ms of the measurements at
+// config 2 (tools/pcie_probe.py; upload alone 25.5 ms): 32-tile pieces 27.2 ms, 48 tiles 27.5 ms
+// (about the model's pick), 96 tiles 28.7 ms, 192 tiles 31.3 ms; with 10 000 experimental
+// patterns it picks 128 tiles (60.7 ms; 64 tiles 63.1 ms, 256 tiles 65.5 ms).
+// KPDI_UPLOAD_TILES=<tiles per piece> overrides.
 std::vector<int64_t> upload_pieces(const kpdi_ctx *c, int64_t n_chunk, size_t row_bytes) {
   const int64_t tiles = (n_chunk + kpdi::TILE_DICT - 1) / kpdi::TILE_DICT;
   int64_t piece = tiles;
@@ -651,7 +652,7 @@ std::vector<int64_t> upload_pieces(const kpdi_ctx *c, int64_t n_chunk, size_t ro
   } else if (c->have_exp && c->m_pad > 0) {
     const int row_blocks = c->m_pad / kpdi::TILE_EXP;
     const double t_tile = 2.0 * kpdi::TILE_EXP * kpdi::TILE_DICT * c->kpad / (157.3e12 / 256 * 0.88);
-    const double t_row = row_bytes / 56e9, t_fixed = 0.45e-3;
+    const double t_row = row_bytes / 56e9, t_fixed = 0.18e-3;
     auto sweep_time = [&](int64_t t) {
       int rpl = 0;
       const int ns = choose_nsplit(c, row_blocks, (int)t, &rpl);
