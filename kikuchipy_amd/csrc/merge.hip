@@ -11,7 +11,9 @@
 // One wave per experimental pattern; k rounds of "largest key below the previous
 // winner" over all candidates.  Up to 48 * 64 candidates per pattern are read ONCE into
 // registers as 64-bit keys (merge_cached_kernel; config 2: 32 lists x 20 + the running 20 =
-// 660 candidates, 11 per lane); more are re-read from L2 every round (merge_kernel).
+// 660 candidates, 11 per lane); up to 64 * 256 with one workgroup per pattern
+// (merge_block_kernel: few experimental patterns -> many lists each); more are re-read from
+// L2 every round (merge_kernel).
 // Latency-bound and tiny next to the match kernel.
 #include "kernels.h"
 #include <limits.h>
@@ -89,7 +91,53 @@ __global__ __launch_bounds__(256) void merge_kernel(MergeArgs a) {
   }
 }
 
-// candidates in registers: lane holds candidates lane, lane + 64, ... of the sources laid end to end
+// candidate c (sources laid end to end) of pattern m as a key; 0 = none.  Branch-free: a divergent
+// branch around the loads makes the compiler copy the whole key array at every join (312 VGPRs);
+// slots past the last candidate read candidate 0 and are zeroed.
+__device__ __forceinline__ unsigned long long candidate_key(const MergeArgs &a, int m, int c0, int end0, int end1,
+                                                            int end2) {
+  const bool live = c0 < end2;
+  const int c = live ? c0 : 0;
+  // the source of candidate c, picked with constant indices into the argument arrays
+  const bool in0 = c < end0, in1 = c < end1;
+  const float *ps = in0 ? a.s[0] : (in1 ? a.s[1] : a.s[2]);
+  const int *pi = in0 ? a.i[0] : (in1 ? a.i[1] : a.i[2]);
+  const int len = in0 ? a.len[0] : (in1 ? a.len[1] : a.len[2]);
+  const int stride = in0 ? a.stride[0] : (in1 ? a.stride[1] : a.stride[2]);
+  const int list_stride = in0 ? a.list_stride[0] : (in1 ? a.list_stride[1] : a.list_stride[2]);
+  const int local = c - (in0 ? 0 : (in1 ? end0 : end1));
+  // local / len without an integer division: local < 16384, len <= 32, so the float quotient of
+  // local + 0.5 is at least 1/64 away from an integer (and float holds it to 2^-9)
+  const int l = (int)(((float)local + 0.5f) / (float)len);
+  const size_t e = (size_t)m * stride + (size_t)l * list_stride + (local - l * len);
+  const int idx = pi[e];
+  const unsigned long long key = topk_key(ps[e], idx);
+  return (live && idx != INT_MAX) ? key : 0ull;
+}
+
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long best) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffu), o, 64);
+    const unsigned hi = __shfl_xor((unsigned)(best >> 32), o, 64);
+    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+    best = other > best ? other : best;
+  }
+  return best;
+}
+
+__device__ __forceinline__ void store_rank(const MergeArgs &a, int m, int r, unsigned long long best) {
+  const size_t o = (size_t)m * a.out_stride + a.out_offset + r;
+  if (best == 0ull) {
+    a.out_s[o] = -INFINITY;
+    a.out_i[o] = INT_MAX;
+  } else {
+    a.out_s[o] = key_score(best);
+    a.out_i[o] = key_idx(best);
+  }
+}
+
+// candidates in registers, one WAVE per pattern: lane holds candidates lane, lane + 64, ...
 template <int NK>
 __global__ __launch_bounds__(256) void merge_cached_kernel(MergeArgs a) {
   const int lane = threadIdx.x & 63;
@@ -100,52 +148,48 @@ __global__ __launch_bounds__(256) void merge_cached_kernel(MergeArgs a) {
   const int end2 = end1 + (a.n_src > 2 ? a.lists[2] * a.len[2] : 0);
   unsigned long long keys[NK];
 #pragma unroll
-  for (int i = 0; i < NK; ++i) {
-    // branch-free (a divergent branch around the loads makes the compiler copy the whole key
-    // array at every join): slots past the last candidate read candidate 0 and are zeroed
-    const int c0 = lane + 64 * i;
-    const bool live = c0 < end2;
-    const int c = live ? c0 : 0;
-    // the source of candidate c, picked with constant indices into the argument arrays
-    const bool in0 = c < end0, in1 = c < end1;
-    const float *ps = in0 ? a.s[0] : (in1 ? a.s[1] : a.s[2]);
-    const int *pi = in0 ? a.i[0] : (in1 ? a.i[1] : a.i[2]);
-    const int len = in0 ? a.len[0] : (in1 ? a.len[1] : a.len[2]);
-    const int stride = in0 ? a.stride[0] : (in1 ? a.stride[1] : a.stride[2]);
-    const int list_stride = in0 ? a.list_stride[0] : (in1 ? a.list_stride[1] : a.list_stride[2]);
-    const int local = c - (in0 ? 0 : (in1 ? end0 : end1));
-    // local / len without an integer division: local < 3072, len <= 32, so the float quotient of
-    // local + 0.5 is at least 1/64 away from an integer
-    const int l = (int)(((float)local + 0.5f) / (float)len);
-    const size_t e = (size_t)m * stride + (size_t)l * list_stride + (local - l * len);
-    const int idx = pi[e];
-    const unsigned long long key = topk_key(ps[e], idx);
-    keys[i] = (live && idx != INT_MAX) ? key : 0ull;
-  }
+  for (int i = 0; i < NK; ++i) keys[i] = candidate_key(a, m, lane + 64 * i, end0, end1, end2);
   unsigned long long prev = ~0ull;
   for (int r = 0; r < a.k; ++r) {
     unsigned long long best = 0ull;
 #pragma unroll
     for (int i = 0; i < NK; ++i)
       if (keys[i] < prev && keys[i] > best) best = keys[i];
+    best = wave_max_key(best);
+    if (lane == 0) store_rank(a, m, r, best);
+    prev = best;  // 0 once the candidates are exhausted: nothing is below it
+  }
+}
+
+// candidates in registers, one WORKGROUP per pattern: few experimental patterns make the launch
+// plan split the dictionary tiles over up to 256 workgroups, i.e. up to 2 * 256 lists per pattern
+template <int NK>
+__global__ __launch_bounds__(256) void merge_block_kernel(MergeArgs a) {
+  __shared__ unsigned long long wave_best[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int m = blockIdx.x;
+  const int end0 = a.lists[0] * a.len[0];
+  const int end1 = end0 + (a.n_src > 1 ? a.lists[1] * a.len[1] : 0);
+  const int end2 = end1 + (a.n_src > 2 ? a.lists[2] * a.len[2] : 0);
+  unsigned long long keys[NK];
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      const unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffu), o, 64);
-      const unsigned hi = __shfl_xor((unsigned)(best >> 32), o, 64);
-      const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+  for (int i = 0; i < NK; ++i) keys[i] = candidate_key(a, m, tid + 256 * i, end0, end1, end2);
+  unsigned long long prev = ~0ull;
+  for (int r = 0; r < a.k; ++r) {
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int i = 0; i < NK; ++i)
+      if (keys[i] < prev && keys[i] > best) best = keys[i];
+    best = wave_max_key(best);
+    if (lane == 0) wave_best[r & 1][wv] = best;  // two buffers: one barrier per round
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const unsigned long long other = wave_best[r & 1][w];
       best = other > best ? other : best;
     }
-    if (lane == 0) {
-      const size_t o = (size_t)m * a.out_stride + a.out_offset + r;
-      if (best == 0ull) {
-        a.out_s[o] = -INFINITY;
-        a.out_i[o] = INT_MAX;
-      } else {
-        a.out_s[o] = key_score(best);
-        a.out_i[o] = key_idx(best);
-      }
-    }
-    prev = best;  // 0 once the candidates are exhausted: nothing is below it
+    if (tid == 0) store_rank(a, m, r, best);
+    prev = best;
   }
 }
 
@@ -178,6 +222,10 @@ hipError_t launch_merge(const MergeLaunch &l, hipStream_t s) {
     hipLaunchKernelGGL(merge_cached_kernel<24>, grid, block, 0, s, a);
   else if (candidates <= 48 * 64)
     hipLaunchKernelGGL(merge_cached_kernel<48>, grid, block, 0, s, a);
+  else if (candidates <= 24 * 256)
+    hipLaunchKernelGGL(merge_block_kernel<24>, dim3(l.m), block, 0, s, a);
+  else if (candidates <= 64 * 256)
+    hipLaunchKernelGGL(merge_block_kernel<64>, dim3(l.m), block, 0, s, a);
   else
     hipLaunchKernelGGL(merge_kernel, grid, block, 0, s, a);
   return hipGetLastError();
