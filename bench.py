@@ -39,7 +39,13 @@ WORKLOADS = {
                     name="configs[1]: 4096 exp (60x60 u8) x 100k dict (f32), ncc, keep_n=20"),
     "config3": dict(m=4096, n=100000, sy=60, sx=60, metric="ncc", keep_n=20, mask=True, preprocess=True,
                     name="configs[2]: configs[1] + circular signal mask + static/dynamic background pre-kernels"),
+    # the two 8-GPU configurations also fit ONE MI355X (288 GB): not bench lines, measured for DESIGN.md
+    "config4": dict(m=40000, n=300000, sy=60, sx=60, metric="ndp", keep_n=20, mask=False, preprocess=False,
+                    name="configs[3]: 200x200 map (40 000 exp, 60x60 u8) x 300k dict (f32), ndp, keep_n=20"),
+    "config5": dict(m=4096, n=500000, sy=120, sx=120, metric="ncc", keep_n=20, mask=False, preprocess=False,
+                    name="configs[4]: 4096 exp (120x120 u8) x 500k dict (f32), ncc, keep_n=20"),
 }
+BLOCK = 25000  # dictionary patterns per generated block of the large workloads
 
 
 def synth(w, seed=2024):
@@ -49,6 +55,24 @@ def synth(w, seed=2024):
     dic = rng.random((w["n"], w["sy"], w["sx"]), dtype=np.float32)
     bg = rng.integers(1, 256, (w["sy"], w["sx"]), dtype=np.uint8)
     return exp, dic, bg
+
+
+def dictionary_block(w, b):
+    """Block b (patterns [b * BLOCK, (b + 1) * BLOCK)) of a large workload's dictionary: seeded per
+    block, so that every rank can generate exactly its own shard."""
+    n = min(BLOCK, w["n"] - b * BLOCK)
+    return np.random.default_rng([2024, b]).random((n, w["sy"], w["sx"]), dtype=np.float32)
+
+
+def upload_generated_shard(ctx, w, lo, hi):
+    """Device buffer with dictionary patterns [lo, hi) of a large workload (never whole on the host)."""
+    row = w["sy"] * w["sx"] * 4
+    d = ctx.dev_alloc((hi - lo) * row)
+    for b in range(lo // BLOCK, (hi - 1) // BLOCK + 1):
+        blk = dictionary_block(w, b)
+        a0, a1 = max(lo, b * BLOCK), min(hi, b * BLOCK + len(blk))
+        ctx.h2d(d + (a0 - lo) * row, blk[a0 - b * BLOCK:a1 - b * BLOCK])
+    return d
 
 
 def circular_mask(sy, sx):
@@ -112,6 +136,8 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-pointer sweep")
     ap.add_argument("--no-generation", action="store_true",
                     help="skip the informational sweep with the dictionary simulated on the device")
+    ap.add_argument("--compute", default="f32", choices=["f32", "f16x2"],
+                    help="arithmetic of the match kernel; f16x2 is the opt-in split-float16 mode (never the default)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,7 +161,14 @@ def main():
     from kikuchipy_amd.parallel import Communicator, shard_range
 
     w = WORKLOADS[a.workload]
-    exp, dic, bg = synth(w)
+    large = a.workload in ("config4", "config5")
+    if large:
+        rng = np.random.default_rng(2024)
+        exp = rng.integers(0, 256, (w["m"], w["sy"], w["sx"]), dtype=np.uint8)
+        dic, bg = None, np.ones((w["sy"], w["sx"]), dtype=np.uint8)
+        a.no_pcie = a.no_generation = True  # the informational legs belong to configs[1]
+    else:
+        exp, dic, bg = synth(w)
     mask = circular_mask(w["sy"], w["sx"]) if w["mask"] else None
     lo, hi = shard_range(w["n"], rank, world)
     n_local = hi - lo
@@ -144,13 +177,17 @@ def main():
     comm = Communicator(rank, world)
     comm.attach(ctx)
     metric = {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[w["metric"]]
-    ctx.set_problem(w["sy"], w["sx"], mask, metric, w["keep_n"])
+    compute = {"f32": _lib.COMPUTE_F32, "f16x2": _lib.COMPUTE_F16X2}[a.compute]
+    ctx.set_problem(w["sy"], w["sx"], mask, metric, w["keep_n"], compute)
     # raw inputs resident in HBM before the timed region
     d_exp = ctx.dev_alloc(exp.nbytes)
     ctx.h2d(d_exp, exp)
-    shard = np.ascontiguousarray(dic[lo:hi])
-    d_dic = ctx.dev_alloc(shard.nbytes)
-    ctx.h2d(d_dic, shard)
+    if large:
+        d_dic = upload_generated_shard(ctx, w, lo, hi)
+    else:
+        shard = np.ascontiguousarray(dic[lo:hi])
+        d_dic = ctx.dev_alloc(shard.nbytes)
+        ctx.h2d(d_dic, shard)
     bg_f32 = bg.astype(np.float32)
 
     def step():
@@ -158,7 +195,7 @@ def main():
         if w["preprocess"]:
             ctx.remove_static_background(bg_f32, _lib.OP_SUBTRACT, False)
             ctx.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
-        ctx.push_dictionary_chunk_dev(d_dic, shard.dtype, n_local, lo)
+        ctx.push_dictionary_chunk_dev(d_dic, np.float32, n_local, lo)
         return ctx.finalize(w["keep_n"])
 
     def barrier():
@@ -198,7 +235,8 @@ def main():
     avg_ms = cnt["match_ms"] / launches
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     out = {
-        "metric": "experimental patterns indexed/sec (whole node), 60x60 px x 100k dict",
+        "metric": ("experimental patterns indexed/sec (whole node), 60x60 px x 100k dict" if not large else
+                   f"experimental patterns indexed/sec (whole node), {w['sy']}x{w['sx']} px x {w['n'] // 1000}k dict"),
         "value": round(value, 1),
         "unit": "patterns/s",
         "n_gpus": world,
@@ -208,7 +246,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if a.compute == "f32" else "f16x2 (opt-in: values as two float16, f32 accumulate)",
         "data": "synthetic (default_rng(2024): uint8 patterns, uniform float32 dictionary), raw inputs resident in HBM",
         "config": {
             "workload": w["name"],
@@ -221,7 +259,8 @@ def main():
             "parallelism": f"dictionary sharded over {world} GPU(s)" + (", RCCL all-gather merge" if world > 1 else ""),
         },
         "roofline": {
-            "kernel": "kpdi::match_topk_kernel<20,false> (f32 MFMA GEMM + fused top-k), rank 0",
+            "kernel": "kpdi::match_topk_kernel<20,false> (f32 MFMA GEMM + fused top-k), rank 0" if a.compute == "f32"
+            else "kpdi::match_topk_kernel<20,false,split> (3 f16 MFMAs per term; flops counted once, peak = f32 MFMA)",
             "bound": "mfma",
             "achieved": round(achieved, 2),
             "peak": F32_MFMA_PEAK_TFLOPS,
@@ -244,7 +283,7 @@ def main():
     # HBM-side traffic of the match kernel cannot be read from inside the process; it comes from
     # the committed rocprofv3 PMC passes of this same command (tools/summarize_pmc.py:
     # FETCH_SIZE*1024*2 + WRITE_SIZE*1024 per launch, the gfx950 corrections of the microarch guide)
-    if a.workload == "config2" and world == 1:
+    if a.workload == "config2" and world == 1 and a.compute == "f32":
         import glob
 
         pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
@@ -298,7 +337,7 @@ def main():
         except Exception as err:  # an informational leg must not cost the bench line
             out["extra"]["resident_dictionary_error"] = f"{type(err).__name__}: {err}"
 
-    if world == 1 and not a.no_generation:
+    if world == 1 and not a.no_generation and a.compute == "f32":
         try:
             # informational: the same sweep with the OPT-IN split-f16 arithmetic of the match kernel
             # (KPDI_COMPUTE_F16X2: value = hi + lo in float16, three f16 MFMAs per term, f32 accumulate).
@@ -315,7 +354,7 @@ def main():
                 if w["preprocess"]:
                     c16.remove_static_background(bg_f32, _lib.OP_SUBTRACT, False)
                     c16.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
-                c16.push_dictionary_chunk_dev(d_dic, shard.dtype, n_local, lo)
+                c16.push_dictionary_chunk_dev(d_dic, np.float32, n_local, lo)
                 s16, i16 = c16.finalize(w["keep_n"])
             dt16 = (time.perf_counter() - t0) / 3
             cnt16 = c16.counters()
@@ -423,7 +462,12 @@ def main():
 
     if world == 1 and not a.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(w, exp, dic, bg, mask, min(a.cpu_sample, w["n"]))
+            # bounded: ~the flops of configs[1]'s sample whatever the workload
+            n_sample = min(a.cpu_sample, w["n"])
+            if large:
+                n_sample = max(500, min(BLOCK, int(a.cpu_sample * (4096 * 3600) / (w["m"] * w["sy"] * w["sx"]))))
+                dic = dictionary_block(w, 0)
+            out["cpu_baseline"] = cpu_baseline(w, exp, dic, bg, mask, n_sample)
         except Exception as err:
             out["cpu_baseline"] = {"value": None, "unit": "patterns/s", "cores": 0, "kind": "port", "sample": "",
                                    "error": f"{type(err).__name__}: {err}"}

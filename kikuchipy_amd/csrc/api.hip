@@ -69,6 +69,26 @@ struct DevBuf {
   T *as() const { return (T *)p; }
 };
 
+// page-locked host staging (results come back through it: a device-to-host copy into pageable
+// memory goes through the runtime's pin-on-the-fly path, measured at several ms per call and a
+// slower following sweep for a 40 000 x 20 result)
+struct PinBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    release();
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
 struct Rccl {
   void *lib = nullptr;
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
@@ -170,6 +190,7 @@ struct kpdi_ctx {
   DevBuf tile_ctr;                        // dynamic tile counters of the match kernel
   DevBuf loc_s, loc_i, bound_s, bound_i;  // multi-pass (keep_n > 32)
   DevBuf gather_s, gather_i;              // RCCL all-gather target
+  PinBuf pin_out;                         // kpdi_finalize: scores + indices on their way to the caller
 
   // pre-processing scratch
   DevBuf bg, taps;
@@ -374,7 +395,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
     ScopedTimer t(c, &c->ev_match);  // one timed region = the whole sweep of this chunk
     // several launches (large experimental sets) alternate between two streams: the workgroups
     // of launch j+1 start on the CUs that launch j's tail leaves idle
-    const bool two = row_blocks > rows_per_launch;
+    const bool two = row_blocks > rows_per_launch && !getenv("KPDI_ONE_STREAM");
     if (two) {
       if (!c->stream2) {
         HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
@@ -744,6 +765,7 @@ int kpdi_destroy(kpdi_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   release_held(c);
+  c->pin_out.release();
   for (DevBuf *b : {&c->pix_map, &c->exp_raw, &c->row_map, &c->exp_x, &c->dict_raw, &c->dict_y, &c->part_s,
                     &c->part_i, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
                     &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps,
@@ -1600,11 +1622,14 @@ int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
   }
   c->final_idx = d_i;
   c->final_valid = true;
-  std::vector<int> tmp(n);
-  HIPCHK(hipMemcpyAsync(scores_out, d_s, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(tmp.data(), d_i, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c->pin_out.reserve(n * (sizeof(float) + sizeof(int))));
+  float *h_s = (float *)c->pin_out.p;
+  int *h_i = (int *)(h_s + n);
+  HIPCHK(hipMemcpyAsync(h_s, d_s, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(h_i, d_i, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (size_t i = 0; i < n; ++i) indices_out[i] = (int64_t)tmp[i];
+  memcpy(scores_out, h_s, n * sizeof(float));
+  for (size_t i = 0; i < n; ++i) indices_out[i] = (int64_t)h_i[i];
   return KPDI_OK;
 }
 
