@@ -723,6 +723,23 @@ void release_held(kpdi_ctx *c) {
 
 }  // namespace
 
+namespace {
+
+// device -> caller's (pageable) buffer through the page-locked staging buffer, then synchronise
+int results_to_host(kpdi_ctx *c, void *dst, const void *d_src, size_t bytes) {
+  if (bytes == 0) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KPDI_OK;
+  }
+  HIPCHK(c->pin_out.reserve(bytes));
+  HIPCHK(hipMemcpyAsync(c->pin_out.p, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  memcpy(dst, c->pin_out.p, bytes);
+  return KPDI_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 const char *kpdi_version(void) { return "kpdi 0.1.0 (gfx950)"; }
@@ -1414,9 +1431,7 @@ int kpdi_refine_objective(kpdi_ctx *c, int mode, int64_t n_eval, const int32_t *
   a.x0 = d_x;
   a.fixed = d_f;
   HIPCHK(kpdi::launch_refine_objective(a, c->ref_idx.as<int>(), c->ref_out.as<double>(), c->stream));
-  HIPCHK(hipMemcpyAsync(out, c->ref_out.p, (size_t)n_eval * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  return KPDI_OK;
+  return results_to_host(c, out, c->ref_out.p, (size_t)n_eval * sizeof(double));
 }
 
 namespace {
@@ -1487,9 +1502,8 @@ int kpdi_refine_solve(kpdi_ctx *c, int mode, int64_t n_patterns, int n_starts, c
   HIPCHK(hipEventRecord(e0, c->stream));
   HIPCHK(kpdi::launch_refine_solve(a, c->stream));
   HIPCHK(hipEventRecord(e1, c->stream));
-  HIPCHK(hipMemcpyAsync(results, c->ref_out.p, (size_t)jobs * kpdi::REFINE_RESULT_STRIDE * sizeof(double),
-                        hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  rc = results_to_host(c, results, c->ref_out.p, (size_t)jobs * kpdi::REFINE_RESULT_STRIDE * sizeof(double));
+  if (rc) return rc;
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
   c->cnt.refine_ms += ms;
@@ -1561,9 +1575,7 @@ int kpdi_orientation_similarity_map(kpdi_ctx *c, const int64_t *simulation_indic
   HIPCHK(c->osm_out.reserve(n_points * n_layers * sizeof(float)));
   HIPCHK(kpdi::launch_osm(d_idx, ny, nx, keep_n, n_best, from_n_best, footprint_offsets, n_fp, center_index,
                           normalize != 0, c->osm_out.as<float>(), c->stream));
-  HIPCHK(hipMemcpyAsync(out, c->osm_out.p, n_points * n_layers * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  return KPDI_OK;
+  return results_to_host(c, out, c->osm_out.p, n_points * n_layers * sizeof(float));
 }
 
 size_t kpdi_dtype_size(int dtype) { return kpdi::dtype_size(dtype); }
