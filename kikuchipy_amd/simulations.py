@@ -56,8 +56,9 @@ class ProjectedDictionary:
     def chunksize(self):
         n = self.rotations.shape[0]
         if self._chunk is None:
-            # ~1 GiB of float32 patterns per iteration (8-byte safety like get_chunking's default)
-            per = max(1, (1 << 30) // (4 * self.detector.size))
+            # 8 GiB of float32 patterns per iteration: a chunk only ever exists in device memory
+            # (raw + prepared = 16 of the 288 GiB), and fewer, larger sweeps waste less on launch tails
+            per = max(1, (8 << 30) // (4 * self.detector.size))
             return (min(n, per),) + self.detector.shape
         return (min(n, self._chunk),) + self.detector.shape
 

@@ -162,7 +162,7 @@ def test_get_patterns_lazy_protocol_and_rescale_rule(g):
     mpf = ka.EBSDMasterPattern(g["mp_upper"].astype(np.float32))
     assert not mpf.get_patterns(rot, det).data.rescale
     assert mpf.get_patterns(rot, det, dtype_out=np.uint16).data.out_max == 65535.0
-    # default chunk: about 1 GiB of float32 patterns
+    # default chunk: 8 GiB of float32 patterns (it only exists in device memory)
     assert mpf.get_patterns(rot, det).data.chunksize == (1200, 60, 60)
-    big = ka.ProjectedDictionary(None, None, np.zeros((200000, 4)), det, False, 1, 2)
-    assert big.chunksize[0] == (1 << 30) // (4 * 3600)
+    big = ka.ProjectedDictionary(None, None, np.zeros((800000, 4)), det, False, 1, 2)
+    assert big.chunksize[0] == (8 << 30) // (4 * 3600)
