@@ -731,7 +731,12 @@ int results_to_host(kpdi_ctx *c, void *dst, const void *d_src, size_t bytes) {
     HIPCHK(hipStreamSynchronize(c->stream));
     return KPDI_OK;
   }
-  HIPCHK(c->pin_out.reserve(bytes));
+  if (c->pin_out.reserve(bytes) != hipSuccess) {  // no page-locked memory to be had: copy directly
+    (void)hipGetLastError();
+    HIPCHK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KPDI_OK;
+  }
   HIPCHK(hipMemcpyAsync(c->pin_out.p, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   memcpy(dst, c->pin_out.p, bytes);
@@ -1634,13 +1639,21 @@ int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
   }
   c->final_idx = d_i;
   c->final_valid = true;
-  HIPCHK(c->pin_out.reserve(n * (sizeof(float) + sizeof(int))));
-  float *h_s = (float *)c->pin_out.p;
-  int *h_i = (int *)(h_s + n);
+  std::vector<int> pageable;
+  float *h_s = scores_out;
+  int *h_i = nullptr;
+  if (c->pin_out.reserve(n * (sizeof(float) + sizeof(int))) == hipSuccess) {
+    h_s = (float *)c->pin_out.p;
+    h_i = (int *)(h_s + n);
+  } else {  // no page-locked memory to be had: copy directly
+    (void)hipGetLastError();
+    pageable.resize(n);
+    h_i = pageable.data();
+  }
   HIPCHK(hipMemcpyAsync(h_s, d_s, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(h_i, d_i, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  memcpy(scores_out, h_s, n * sizeof(float));
+  if (h_s != scores_out) memcpy(scores_out, h_s, n * sizeof(float));
   for (size_t i = 0; i < n; ++i) indices_out[i] = (int64_t)h_i[i];
   return KPDI_OK;
 }
