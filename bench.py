@@ -136,8 +136,9 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-pointer sweep")
     ap.add_argument("--no-generation", action="store_true",
                     help="skip the informational sweep with the dictionary simulated on the device")
-    ap.add_argument("--compute", default="f32", choices=["f32", "f16x2"],
-                    help="arithmetic of the match kernel; f16x2 is the opt-in split-float16 mode (never the default)")
+    ap.add_argument("--compute", default="f32", choices=["f32", "f16x2", "f16"],
+                    help="arithmetic of the match kernel; f16x2 / f16 are the opt-in float16 modes (never the default; "
+                         "f16 is reduced precision)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -177,7 +178,7 @@ def main():
     comm = Communicator(rank, world)
     comm.attach(ctx)
     metric = {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[w["metric"]]
-    compute = {"f32": _lib.COMPUTE_F32, "f16x2": _lib.COMPUTE_F16X2}[a.compute]
+    compute = {"f32": _lib.COMPUTE_F32, "f16x2": _lib.COMPUTE_F16X2, "f16": _lib.COMPUTE_F16}[a.compute]
     ctx.set_problem(w["sy"], w["sx"], mask, metric, w["keep_n"], compute)
     # raw inputs resident in HBM before the timed region
     d_exp = ctx.dev_alloc(exp.nbytes)
@@ -246,7 +247,8 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32" if a.compute == "f32" else "f16x2 (opt-in: values as two float16, f32 accumulate)",
+        "dtype": {"f32": "f32", "f16x2": "f16x2 (opt-in: values as two float16, f32 accumulate)",
+                  "f16": "f16 (opt-in, REDUCED PRECISION: values as one float16, f32 accumulate)"}[a.compute],
         "data": "synthetic (default_rng(2024): uint8 patterns, uniform float32 dictionary), raw inputs resident in HBM",
         "config": {
             "workload": w["name"],
@@ -260,7 +262,7 @@ def main():
         },
         "roofline": {
             "kernel": "kpdi::match_topk_kernel<20,false> (f32 MFMA GEMM + fused top-k), rank 0" if a.compute == "f32"
-            else "kpdi::match_topk_kernel<20,false,split> (3 f16 MFMAs per term; flops counted once, peak = f32 MFMA)",
+            else f"kpdi::match_topk_kernel<20,false,{a.compute}> (f16 MFMAs; flops counted once, peak = f32 MFMA)",
             "bound": "mfma",
             "achieved": round(achieved, 2),
             "peak": F32_MFMA_PEAK_TFLOPS,
@@ -337,13 +339,19 @@ def main():
         except Exception as err:  # an informational leg must not cost the bench line
             out["extra"]["resident_dictionary_error"] = f"{type(err).__name__}: {err}"
 
-    if world == 1 and not a.no_generation and a.compute == "f32":
+    for key, mode, mfmas, what in (
+            ("split_f16_mode", "COMPUTE_F16X2", 3,
+             "opt-in KPDI_COMPUTE_F16X2: same sweep, operands as two float16 terms, 3 f16 MFMAs per product term"),
+            ("f16_mode", "COMPUTE_F16", 1,
+             "opt-in KPDI_COMPUTE_F16, REDUCED PRECISION: same sweep, operands rounded to one float16, 1 f16 MFMA "
+             "per 16 product terms")):
+        if not (world == 1 and not a.no_generation and a.compute == "f32"):
+            break
         try:
-            # informational: the same sweep with the OPT-IN split-f16 arithmetic of the match kernel
-            # (KPDI_COMPUTE_F16X2: value = hi + lo in float16, three f16 MFMAs per term, f32 accumulate).
+            # informational: the same sweep with the OPT-IN float16 arithmetics of the match kernel.
             # Never `value`: the headline stays the exact-f32 GEMM north_star names.
             c16 = _lib.Context(local_rank)
-            c16.set_problem(w["sy"], w["sx"], mask, metric, w["keep_n"], _lib.COMPUTE_F16X2)
+            c16.set_problem(w["sy"], w["sx"], mask, metric, w["keep_n"], getattr(_lib, mode))
             c16.set_profiling(True)
             for r in range(4):
                 if r == 1:
@@ -359,18 +367,21 @@ def main():
             dt16 = (time.perf_counter() - t0) / 3
             cnt16 = c16.counters()
             c16.close()
-            out["extra"]["split_f16_mode"] = {
-                "what": "opt-in KPDI_COMPUTE_F16X2: same sweep, operands as two float16 terms, 3 f16 MFMAs per product term",
+            tf = mfmas * cnt16["match_flops"] / (cnt16["match_ms"] * 1e-3) / 1e12
+            out["extra"][key] = {
+                "what": what,
                 "patterns_per_s": round(w["m"] / dt16, 1),
                 "match_ms": round(cnt16["match_ms"] / 3, 3),
                 "prep_ms": round(cnt16["prep_ms"] / 3, 3),
-                "f16_mfma_tflops": round(3 * cnt16["match_flops"] / (cnt16["match_ms"] * 1e-3) / 1e12, 1),
-                "f16_mfma_frac_of_2500": round(3 * cnt16["match_flops"] / (cnt16["match_ms"] * 1e-3) / 1e12 / 2500.0, 3),
+                "f16_mfma_tflops": round(tf, 1),
+                "f16_mfma_frac_of_2500": round(tf / 2500.0, 3),
                 "max_abs_score_diff_vs_f32": float(np.abs(s16 - scores).max()),
+                "mean_abs_score_diff_vs_f32": float(np.abs(s16 - scores).mean()),
                 "index_mismatch_fraction_vs_f32": float(np.mean(i16 != indices)),
+                "best_match_mismatch_fraction_vs_f32": float(np.mean(i16[:, 0] != indices[:, 0])),
             }
         except Exception as err:  # an informational leg must not cost the bench line
-            out["extra"]["split_f16_mode_error"] = f"{type(err).__name__}: {err}"
+            out["extra"][key + "_error"] = f"{type(err).__name__}: {err}"
 
     if world == 1 and not a.no_generation:
         try:

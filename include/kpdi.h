@@ -69,6 +69,13 @@ typedef struct kpdi_ctx kpdi_ctx;
  * Scores differ from the f32 path by a few 1e-7 (the reference's own sgemm differs from exact
  * arithmetic by as much); inside the 1e-5 contract, not bit-identical to KPDI_COMPUTE_F32. */
 #define KPDI_COMPUTE_F16X2 1
+/* OPT-IN, REDUCED PRECISION (the "fp16 MFMA, fp32 accumulate" variant BASELINE.json configs[4]
+ * names): every prepared value is ONE f16 (2^12 v rounded to 11 significant bits), one
+ * v_mfma_f32_32x32x16_f16 per 16 pixels, f32 accumulation.  The rounding errors of the 2 K
+ * operands of a score average out: measured against the f32 path at K = 3600, max 2e-5 / mean
+ * 4e-6 - OUTSIDE the 1e-5 contract, and near-ties rank differently (1.3 % of the best-20 entries
+ * of a random dictionary); a few 1e-4 for small K. */
+#define KPDI_COMPUTE_F16 2
 
 /* background operations (`operation=` of remove_*_background) */
 #define KPDI_OP_SUBTRACT 0

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkpdi.so")
 
 METRIC_NCC, METRIC_NDP = 0, 1
-COMPUTE_F32, COMPUTE_F16X2 = 0, 1
+COMPUTE_F32, COMPUTE_F16X2, COMPUTE_F16 = 0, 1, 2
 OP_SUBTRACT, OP_DIVIDE = 0, 1
 DOMAIN_FREQUENCY, DOMAIN_SPATIAL = 0, 1
 UNIQUE_ID_BYTES = 128

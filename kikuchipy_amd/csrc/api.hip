@@ -319,7 +319,7 @@ int prepare_experimental(kpdi_ctx *c) {
   p.kpad = c->kpad;
   p.n_out = c->m;
   p.metric = c->metric;
-  p.split_f16 = c->compute == KPDI_COMPUTE_F16X2;
+  p.operand_form = c->compute;
   p.out = c->exp_x.as<float>();
   {
     ScopedTimer t(c, &c->ev_prep);
@@ -363,7 +363,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   ml.part_idx = c->part_i.as<int>();
   ml.bound_score = bound_s;
   ml.bound_idx = bound_i;
-  ml.split_f16 = c->compute == KPDI_COMPUTE_F16X2;
+  ml.operand_form = c->compute;
   {
     // the published ranks are only comparable under one plan: (re)initialise when it changes
     int rank, grouped, used;
@@ -441,7 +441,7 @@ int prepare_chunk(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chun
   p.kpad = c->kpad;
   p.n_out = (int)n_chunk;
   p.metric = c->metric;
-  p.split_f16 = c->compute == KPDI_COMPUTE_F16X2;
+  p.operand_form = c->compute;
   p.out = out;
   {
     ScopedTimer t(c, &c->ev_prep);
@@ -833,7 +833,7 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
   if (sy <= 0 || sx <= 0) return fail(KPDI_EINVAL, "detector shape (%d, %d) must be positive", sy, sx);
   if (metric != KPDI_METRIC_NCC && metric != KPDI_METRIC_NDP) return fail(KPDI_EINVAL, "unknown metric %d", metric);
-  if (compute_dtype != KPDI_COMPUTE_F32 && compute_dtype != KPDI_COMPUTE_F16X2)
+  if (compute_dtype != KPDI_COMPUTE_F32 && compute_dtype != KPDI_COMPUTE_F16X2 && compute_dtype != KPDI_COMPUTE_F16)
     return fail(KPDI_EINVAL, "unknown compute dtype %d", compute_dtype);
   if (keep_n <= 0) return fail(KPDI_EINVAL, "keep_n must be >= 1");
   int rc = use_device(c);
@@ -859,7 +859,9 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   c->npix = npix;
   c->have_sig_mask = signal_mask != nullptr;
   c->k_kept = signal_mask ? (int)keep.size() : npix;
-  c->kpad = kpdi::round_up(c->k_kept, kpdi::TILE_K);
+  // floats per prepared row; the float16 form packs two pixels into one: 64-pixel slabs
+  c->kpad = compute_dtype == KPDI_COMPUTE_F16 ? kpdi::round_up(c->k_kept, 2 * kpdi::TILE_K) / 2
+                                              : kpdi::round_up(c->k_kept, kpdi::TILE_K);
   c->metric = metric;
   c->compute = compute_dtype;
   c->keep_n = keep_n;

@@ -56,7 +56,7 @@ struct MatchLaunch {
   int bound_rank, bound_grouped;  // from bound_plan()
   unsigned *tile_ctr;  // [m_pad / TILE_EXP][tile_groups] dynamic tile counters, zeroed before every launch
   int tile_groups;     // 8 = XCD-affine hand-out (nsplit % 8 == 0), 1 = one counter per row block
-  int split_f16;       // operands are in the split-f16 form (launch_split_f16), see match.hip
+  int operand_form;    // 0 = f32, 1 = split-f16 (KPDI_COMPUTE_F16X2), 2 = f16 (KPDI_COMPUTE_F16), see match.hip
 };
 constexpr unsigned THRESHOLD_NONE = 0x007fffffu;  // key of -inf
 constexpr int BOUND_SLOTS = 32;
@@ -89,7 +89,8 @@ struct PrepLaunch {
   int n_out;           // rows to produce
   int metric;          // KPDI_METRIC_*
   float *out;          // (>= n_out, kpad)
-  int split_f16;       // write the split-f16 form (KPDI_COMPUTE_F16X2) instead of f32
+  int operand_form;    // 0 = f32; 1 = split-f16 (KPDI_COMPUTE_F16X2); 2 = f16 (KPDI_COMPUTE_F16): `kpad` then
+                       // counts pairs of pixels (the row holds 2 * kpad float16)
 };
 hipError_t launch_prep(const PrepLaunch &a, hipStream_t s);
 // in place: prepared f32 rows [0, n_rows_pad) x kpad -> split-f16 form (KPDI_COMPUTE_F16X2): every

@@ -37,10 +37,12 @@
 //  * ds_read_b128 hands a lane 4 consecutive pixels of its row; MFMA j of a group
 //    takes element j for both operands (lanes 0-31 pixel j, lanes 32-63 pixel 4+j):
 //    a permutation of the summation order only.  24 LDS reads (16 A + 8 B) per 128 MFMAs.
-//  * SPLIT = true is the opt-in split-f16 form (KPDI_COMPUTE_F16X2) of the same skeleton:
+//  * FORM = 1 is the opt-in split-f16 form (KPDI_COMPUTE_F16X2) of the same skeleton:
 //    the 16-byte slots hold 8 float16 (high halves in slots 0-3 of a row-slab, low halves
 //    in 4-7), a slab is 2 steps of 16 pixels with three v_mfma_f32_32x32x16_f16 per
 //    accumulator (hi.hi + hi.lo + lo.hi), and the epilogue rescales by 2^-24.
+//  * FORM = 2 is the opt-in plain float16 form (KPDI_COMPUTE_F16, reduced precision): every
+//    value one f16 (times 2^12), a slab = 64 pixels = 4 steps of one MFMA per accumulator.
 //
 // Algorithmic work per launch: 2 * M * n_chunk * K flops (K = kept pixels).
 #include "kernels.h"
@@ -169,12 +171,12 @@ __device__ __forceinline__ float next_up(float f) {
 // last entry), and only a register in which some lane does takes the exact path (valid
 // row, multi-pass bound, insertion).  The register index r is a scalar loop counter
 // (relative VGPR addressing), so there is one copy of the insertion code per accumulator.
-template <int KMAX, bool BOUNDED, bool SPLIT>
+template <int KMAX, bool BOUNDED, int FORM>
 __device__ __forceinline__ void scan_tile(f32x16 (&acc)[4], float (&best)[KMAX], int (&best_idx)[KMAX],
                                           float gthr, float ub, int ub_idx, int row0, int n_valid,
                                           int idx_base) {
-  // split-f16 operands are stored scaled by 2^12 each: the accumulators hold 2^24 * score
-  constexpr float unscale = SPLIT ? 0x1p-24f : 1.f;
+  // float16 operands (split or not) are stored scaled by 2^12 each: the accumulators hold 2^24 * score
+  constexpr float unscale = FORM != 0 ? 0x1p-24f : 1.f;
   // v > best[KMAX-1]  <=>  v >= nextafter(best[KMAX-1], +inf)   (scores are finite)
   float thr = fmaxf(gthr, next_up(best[KMAX - 1]));
 #pragma unroll
@@ -225,7 +227,7 @@ __device__ __forceinline__ void issue_piece(const char *gd, const char *ge, size
                                    16, 0, 0);
 }
 
-template <int KMAX, bool BOUNDED, bool SPLIT>
+template <int KMAX, bool BOUNDED, int FORM>
 __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
     // A (dictionary) and B (experimental) fragments, double buffered by pixel group
     // (split-f16: by 16-pixel step; [.][0..3] = the high halves of the 4 row tiles / 2 column
     // groups, [.][4..7] / [.][2..3] the low halves)
+    constexpr bool SPLIT = FORM == 1;
     f32x4 fa[2][SPLIT ? 8 : 4], fb[2][SPLIT ? 4 : 2];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) fa[0][rt] = *(const f32x4 *)(smem + rt * 4096 + frag[0]);
@@ -418,6 +421,36 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
             }
           }
         }
+      } else if (FORM == 2) {
+        // ---- float16 slab: 64 pixels, one 16-byte slot = 8 f16 of a row; 4 steps of 16 pixels,
+        // one v_mfma_f32_32x32x16_f16 per accumulator and step.  Same stage / barrier / piece
+        // schedule as the f32 slab below.
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+          const int cur = kg & 1;
+          if (kg == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (slab == 0 && tid == 0) ctrl[4 + tp] = fetched;
+            __syncthreads();
+          }
+          const char *src = kg < 3 ? ls + frag[kg + 1] : ls_next + frag[0];
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) {
+            mfma_acc_h(acc0[rt], fa[cur][rt], fb[cur][0]);
+            mfma_acc_h(acc1[rt], fa[cur][rt], fb[cur][1]);
+            // in the shadow of these MFMAs: the fragments of the next step and, after the barrier,
+            // this wave's 12 LDS-DMA pieces of the slab two steps ahead
+            fa[cur ^ 1][rt] = *(const f32x4 *)(src + rt * 4096);
+            if (rt == 1) fb[cur ^ 1][0] = *(const f32x4 *)(src + exp_frag);
+            if (rt == 3) fb[cur ^ 1][1] = *(const f32x4 *)(src + exp_frag + 4096);
+            if (kg == 2) {
+              issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * rt);
+              issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * rt + 1);
+            }
+            if (kg == 3) issue_piece(gd, ge, tile_bytes, ld_base, wv, 8 + rt);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       } else {
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg) {
@@ -472,8 +505,8 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
           pub0 = j == bound_rank - 1 ? best0[j] : pub0;
           pub1 = j == bound_rank - 1 ? best1[j] : pub1;
         }
-        scan_tile<KMAX, BOUNDED, SPLIT>(acc0, best0, bidx0, g0, ub0, ubi0, row0, n_valid, idx_base);
-        scan_tile<KMAX, BOUNDED, SPLIT>(acc1, best1, bidx1, g1, ub1, ubi1, row0, n_valid, idx_base);
+        scan_tile<KMAX, BOUNDED, FORM>(acc0, best0, bidx0, g0, ub0, ubi0, row0, n_valid, idx_base);
+        scan_tile<KMAX, BOUNDED, FORM>(acc1, best1, bidx1, g1, ub1, ubi1, row0, n_valid, idx_base);
         // publish the list entry the bound is built from, if it rose
         float now0 = best0[0], now1 = best1[0];
 #pragma unroll
@@ -522,16 +555,16 @@ int match_list_len(int k) {
 
 int match_blocks_per_cu() { return 1; }
 
-template <int KMAX, bool BOUNDED, bool SPLIT>
+template <int KMAX, bool BOUNDED, int FORM>
 static hipError_t launch_t(const MatchArgs &args, int grid, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)match_topk_kernel<KMAX, BOUNDED, SPLIT>,
+    hipError_t e = hipFuncSetAttribute((const void *)match_topk_kernel<KMAX, BOUNDED, FORM>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 32);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((match_topk_kernel<KMAX, BOUNDED, SPLIT>), dim3(grid), dim3(MATCH_THREADS), LDS_BYTES + 32, s,
+  hipLaunchKernelGGL((match_topk_kernel<KMAX, BOUNDED, FORM>), dim3(grid), dim3(MATCH_THREADS), LDS_BYTES + 32, s,
                      args);
   return hipGetLastError();
 }
@@ -559,8 +592,9 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   const bool bounded = a.bound_score != nullptr;
 #define KPDI_CASE(K)                                                                             \
   case K:                                                                                        \
-    if (a.split_f16) return bounded ? launch_t<K, true, true>(g, grid, s) : launch_t<K, false, true>(g, grid, s); \
-    return bounded ? launch_t<K, true, false>(g, grid, s) : launch_t<K, false, false>(g, grid, s);
+    if (a.operand_form == 2) return bounded ? launch_t<K, true, 2>(g, grid, s) : launch_t<K, false, 2>(g, grid, s); \
+    if (a.operand_form == 1) return bounded ? launch_t<K, true, 1>(g, grid, s) : launch_t<K, false, 1>(g, grid, s); \
+    return bounded ? launch_t<K, true, 0>(g, grid, s) : launch_t<K, false, 0>(g, grid, s);
   switch (a.list_len) {
     KPDI_CASE(1)
     KPDI_CASE(8)

@@ -68,11 +68,18 @@ struct alignas(sizeof(T) * 4) Quad {
   T v[4];
 };
 
+// ---- float16 form (KPDI_COMPUTE_F16): a row holds 2 * kpad f16, value * 2^12; the 16 KB block of
+// (tile, slab) covers 64 pixels, slot q of a row = pixels 8q..8q+7 of the slab, placed like the f32
+// slot q (prepared_offset of float column 32 * slab + 4 * q)
+__device__ __forceinline__ char *half_slot(float *out, int r, int c, int nslab) {
+  return (char *)(out + prepared_offset(r, ((c >> 6) << 5) + (((c >> 3) & 7) << 2), nslab)) + 2 * (c & 7);
+}
+
 // ---- large detectors: one workgroup per pattern ----------------------------------------
 template <typename T>
 __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const T *raw, int npix, const int *row_map,
                                                             const int *pix_map, int k, int kpad,
-                                                            int metric, float *out) {
+                                                            int metric, float *out, int form) {
   __shared__ float red[PREP_THREADS / 64];
   const int r = blockIdx.x;
   const int64_t src = row_map ? row_map[r] : r;
@@ -91,13 +98,19 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const T *raw, int np
   }
   const float norm = sqrtf(block_sum(q, red));
   const float inv = norm > 0.f ? 1.f / norm : 0.f;
+  if (form == 2) {
+    for (int c = tid; c < 2 * kpad; c += PREP_THREADS)
+      *(_Float16 *)half_slot(out, r, c, nslab) =
+          (_Float16)((c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv * 4096.f : 0.f);
+    return;
+  }
   for (int c = tid; c < kpad; c += PREP_THREADS)
     out[prepared_offset(r, c, nslab)] = (c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv : 0.f;
 }
 
 // ---- shared tail of the wave-per-pattern kernels: v[i] holds kept pixel lane + 64*i -----
 __device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], float s, int lane, int r, int k,
-                                                    int kpad, int metric, float *out) {
+                                                    int kpad, int metric, float *out, int form) {
   const int nslab = kpad / TILE_K;
   float mean = 0.f;
   if (metric == KPDI_METRIC_NCC) mean = wave_sum(s) / (float)k;
@@ -117,13 +130,18 @@ __device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], flo
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES; ++i) {
     const int c = lane + 64 * i;
-    if (c < kpad) out[prepared_offset(r, c, nslab)] = v[i] * inv;
+    if (form == 2) {
+      if (c < 2 * kpad) *(_Float16 *)half_slot(out, r, c, nslab) = (_Float16)(v[i] * inv * 4096.f);
+    } else if (c < kpad) {
+      out[prepared_offset(r, c, nslab)] = v[i] * inv;
+    }
   }
 }
 
 // same, v[4*i + e] holds kept pixel 4*(lane + 64*i) + e: float4 stores (full 16-byte slots)
-// `split`: store the split-f16 form directly (see split_f16_kernel below): the lane's four
-// pixels are half of an 8-pixel slot, i.e. 8 bytes of the high-half slot and 8 of the low-half slot
+// `split` = the operand form: 1 stores the split-f16 form directly (see split_f16_kernel below): the
+// lane's four pixels are half of an 8-pixel slot, i.e. 8 bytes of the high-half slot and 8 of the
+// low-half slot; 2 stores the float16 form (half_slot above)
 // NT threads share the pattern: 64 = one wave (`lane` = lane id), PREP_THREADS = the whole
 // workgroup (`lane` = thread id, sums through `red` in LDS)
 template <int NT>
@@ -155,7 +173,7 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[WAVE_VALUES
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES / 4; ++i) {
     const int c = 4 * (lane + NT * i);
-    if (c < kpad) {
+    if (c < (split == 2 ? 2 * kpad : kpad)) {
       float4 w;
       w.x = v[4 * i] * inv;
       w.y = v[4 * i + 1] * inv;
@@ -163,6 +181,14 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[WAVE_VALUES
       w.w = v[4 * i + 3] * inv;
       if (!split) {
         *reinterpret_cast<float4 *>(out + prepared_offset(r, c, nslab)) = w;
+      } else if (split == 2) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 h;
+        h[0] = (_Float16)(w.x * 4096.f);
+        h[1] = (_Float16)(w.y * 4096.f);
+        h[2] = (_Float16)(w.z * 4096.f);
+        h[3] = (_Float16)(w.w * 4096.f);
+        *reinterpret_cast<h4 *>(half_slot(out, r, c, nslab)) = h;  // half of a slot: 8 bytes
       } else {
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         const float x[4] = {w.x * 4096.f, w.y * 4096.f, w.z * 4096.f, w.w * 4096.f};
@@ -219,7 +245,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, i
       if (c < k) v[i] = (float)p[pix_map ? pix_map[c] : c];
       s += v[i];
     }
-    normalise_and_store(v, s, lane, r, k, kpad, metric, out);
+    normalise_and_store(v, s, lane, r, k, kpad, metric, out, split);
   }
 }
 
@@ -375,7 +401,7 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
 #define KPDI_PREP(T)                                                                                     \
   if (vec4)                                                                                              \
     hipLaunchKernelGGL((prep_wave_kernel<T, 4>), grid, block, 0, s, (const T *)a.raw, a.npix,           \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, a.split_f16);        \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, a.operand_form);        \
   else if (staged) {                                                                                     \
     if (staged_lds > 64 * 1024) {                                                                        \
       hipError_t e = hipFuncSetAttribute((const void *)prep_wave_masked_kernel<T>,                       \
@@ -383,19 +409,19 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
       if (e != hipSuccess) return e;                                                                     \
     }                                                                                                    \
     hipLaunchKernelGGL((prep_wave_masked_kernel<T>), grid, block, staged_lds, s, (const T *)a.raw,      \
-                       a.npix, a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, a.split_f16); \
+                       a.npix, a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, a.operand_form); \
   } else if (wave_path)                                                                                  \
     hipLaunchKernelGGL((prep_wave_kernel<T, 1>), grid, block, 0, s, (const T *)a.raw, a.npix,           \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, 0);                  \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, a.operand_form == 2 ? 2 : 0); \
   else if (block_vec)                                                                                    \
     hipLaunchKernelGGL((prep_block_kernel<T, false>), grid, block, 0, s, (const T *)a.raw, a.npix,      \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, a.split_f16);                 \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, a.operand_form);                 \
   else if (block_masked)                                                                                 \
     hipLaunchKernelGGL((prep_block_kernel<T, true>), grid, block, 0, s, (const T *)a.raw, a.npix,       \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, a.split_f16);                 \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, a.operand_form);                 \
   else                                                                                                   \
     hipLaunchKernelGGL((prep_kernel<T>), grid, block, 0, s, (const T *)a.raw, a.npix, a.row_map,        \
-                       a.pix_map, a.k, a.kpad, a.metric, a.out);                                         \
+                       a.pix_map, a.k, a.kpad, a.metric, a.out, a.operand_form == 2 ? 2 : 0);            \
   break;
   switch (a.dtype) {
     case KPDI_U8: KPDI_PREP(uint8_t)
@@ -413,8 +439,9 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   // paths that store whole float4 slots write the split-f16 form themselves; the others are
-  // converted in place afterwards (rows beyond n_out are zero in either form)
-  if (a.split_f16 && !(vec4 || staged || block_vec || block_masked))
+  // converted in place afterwards (rows beyond n_out are zero in either form).  The float16
+  // form is written directly by every path.
+  if (a.operand_form == 1 && !(vec4 || staged || block_vec || block_masked))
     return launch_split_f16(a.out, round_up(a.n_out, TILE_DICT), a.kpad, s);
   return hipSuccess;
 }

@@ -147,7 +147,7 @@ class _HipMetric(SimilarityMetric):
     _sign = 1
     _metric_code = None
 
-    COMPUTE_MODES = {"f32": _lib.COMPUTE_F32, "f16x2": _lib.COMPUTE_F16X2}
+    COMPUTE_MODES = {"f32": _lib.COMPUTE_F32, "f16x2": _lib.COMPUTE_F16X2, "f16": _lib.COMPUTE_F16}
 
     def __init__(self, *args, device=0, context=None, compute="f32", **kwargs):
         """compute
@@ -155,7 +155,9 @@ class _HipMetric(SimilarityMetric):
             "f32" (default) = exact float32 products on the f32 matrix cores; "f16x2" = every
             prepared value split into two float16 (22 significant bits), three float16
             matrix-core products per term, float32 accumulation: ~2.5x the throughput, scores
-            within ~1e-6 of the float32 path."""
+            within ~1e-6 of the float32 path; "f16" = every prepared value rounded to ONE float16
+            (reduced precision: scores within ~1e-3, near-ties may rank differently), one float16
+            matrix-core product per term."""
         super().__init__(*args, **kwargs)
         if compute not in self.COMPUTE_MODES:
             raise ValueError(f"compute must be one of {sorted(self.COMPUTE_MODES)}, not {compute!r}")

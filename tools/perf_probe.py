@@ -17,6 +17,7 @@ ap.add_argument("--k", type=int, default=20)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--mask", action="store_true")
 ap.add_argument("--f16", action="store_true", help="opt-in split-f16 compute mode")
+ap.add_argument("--half", action="store_true", help="opt-in plain float16 compute mode (reduced precision)")
 a = ap.parse_args()
 
 rng = np.random.default_rng(2024)
@@ -29,7 +30,7 @@ mask = None
 if a.mask:
     yy, xx = np.ogrid[:a.s, :a.s]
     mask = np.sqrt((yy - a.s // 2) ** 2 + (xx - a.s // 2) ** 2) > a.s // 2
-ctx.set_problem(a.s, a.s, mask, _lib.METRIC_NCC, a.k, _lib.COMPUTE_F16X2 if a.f16 else _lib.COMPUTE_F32)
+ctx.set_problem(a.s, a.s, mask, _lib.METRIC_NCC, a.k, _lib.COMPUTE_F16 if a.half else (_lib.COMPUTE_F16X2 if a.f16 else _lib.COMPUTE_F32))
 d_dic = ctx.dev_alloc(dic.nbytes)
 ctx.h2d(d_dic, dic)
 ctx.set_experimental(exp)
