@@ -274,6 +274,12 @@ void dtype_range(int dtype, float *omin, float *omax) {
   }
 }
 
+// what the prep kernels are told: `ndp` is evaluated in its centred form (prep.hip) except in the
+// float16 form
+int prep_metric(const kpdi_ctx *c) {
+  return c->metric == KPDI_METRIC_NDP && c->compute != KPDI_COMPUTE_F16 ? 2 : c->metric;
+}
+
 int use_device(kpdi_ctx *c) {
   HIPCHK(hipSetDevice(c->device));
   return KPDI_OK;
@@ -318,7 +324,7 @@ int prepare_experimental(kpdi_ctx *c) {
   p.k = c->k_kept;
   p.kpad = c->kpad;
   p.n_out = c->m;
-  p.metric = c->metric;
+  p.metric = prep_metric(c);
   p.operand_form = c->compute;
   p.out = c->exp_x.as<float>();
   {
@@ -440,7 +446,7 @@ int prepare_chunk(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chun
   p.k = c->k_kept;
   p.kpad = c->kpad;
   p.n_out = (int)n_chunk;
-  p.metric = c->metric;
+  p.metric = prep_metric(c);
   p.operand_form = c->compute;
   p.out = out;
   {
@@ -859,9 +865,11 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   c->npix = npix;
   c->have_sig_mask = signal_mask != nullptr;
   c->k_kept = signal_mask ? (int)keep.size() : npix;
-  // floats per prepared row; the float16 form packs two pixels into one: 64-pixel slabs
-  c->kpad = compute_dtype == KPDI_COMPUTE_F16 ? kpdi::round_up(c->k_kept, 2 * kpdi::TILE_K) / 2
-                                              : kpdi::round_up(c->k_kept, kpdi::TILE_K);
+  // floats per prepared row; the float16 form packs two pixels into one: 64-pixel slabs.  `ndp`
+  // rows carry one extra column (prep.hip: centred evaluation), except in the float16 form
+  c->kpad = compute_dtype == KPDI_COMPUTE_F16
+                ? kpdi::round_up(c->k_kept, 2 * kpdi::TILE_K) / 2
+                : kpdi::round_up(c->k_kept + (metric == KPDI_METRIC_NDP ? 1 : 0), kpdi::TILE_K);
   c->metric = metric;
   c->compute = compute_dtype;
   c->keep_n = keep_n;

@@ -22,6 +22,15 @@
 //                                                                   (prep_block_kernel)
 //   larger still: one workgroup per pattern re-reading the pattern from L2 (prep_kernel).
 //
+// NDP is evaluated in a centred form (`metric` = NORM_NDP_CENTRED inside this file): with the
+// row mean mu and d = x - mu,  sum x y = sum d_x d_y + K mu_x mu_y,  so the prepared row holds
+// d / ||x|| in its K columns and sqrt(K) mu / ||x|| in column K (the product of two such entries is
+// the second term).  The match kernel then accumulates small numbers of both signs and adds the one
+// large term last, instead of ~K/2 roundings at the magnitude of the score: against exact float64
+// scores `ndp` drops from ~3e-6 (1e-5 on integer x integer pattern pairs, whose equal increments
+// round with a systematic bias) to the 1e-7 of `ncc`.  Not in the float16 form, whose 11 bits
+// cannot carry the constant.
+//
 // A pattern with zero norm (constant pattern; 0/0 = NaN in the reference, out of
 // contract per SURVEY.md 8(a)) becomes an all-zero row: it scores exactly 0
 // against everything.
@@ -42,6 +51,7 @@ size_t dtype_size(int dtype) {
   return 0;
 }
 
+constexpr int NORM_NDP_CENTRED = 2;  // internal value of the `metric` argument, see above
 constexpr int PREP_THREADS = 256;
 constexpr int WAVE_VALUES = 64;  // values per lane of the wave-per-pattern kernels (K <= 4096)
 
@@ -90,14 +100,17 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const T *raw, int np
   float s = 0.f;
   for (int c = tid; c < k; c += PREP_THREADS) s += (float)p[pix_map ? pix_map[c] : c];
   float mean = 0.f;
-  if (metric == KPDI_METRIC_NCC) mean = block_sum(s, red) / (float)k;
+  if (metric != KPDI_METRIC_NDP) mean = block_sum(s, red) / (float)k;
   float q = 0.f;
   for (int c = tid; c < k; c += PREP_THREADS) {
     const float d = (float)p[pix_map ? pix_map[c] : c] - mean;
     q += d * d;
   }
-  const float norm = sqrtf(block_sum(q, red));
+  q = block_sum(q, red);
+  const bool centred = metric == NORM_NDP_CENTRED;
+  const float norm = sqrtf(centred ? q + (float)k * mean * mean : q);
   const float inv = norm > 0.f ? 1.f / norm : 0.f;
+  const float cval = sqrtf((float)k) * mean * inv;
   if (form == 2) {
     for (int c = tid; c < 2 * kpad; c += PREP_THREADS)
       *(_Float16 *)half_slot(out, r, c, nslab) =
@@ -105,7 +118,8 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const T *raw, int np
     return;
   }
   for (int c = tid; c < kpad; c += PREP_THREADS)
-    out[prepared_offset(r, c, nslab)] = (c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv : 0.f;
+    out[prepared_offset(r, c, nslab)] =
+        (c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv : ((centred && c == k) ? cval : 0.f);
 }
 
 // ---- shared tail of the wave-per-pattern kernels: v[i] holds kept pixel lane + 64*i -----
@@ -113,7 +127,7 @@ __device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], flo
                                                     int kpad, int metric, float *out, int form) {
   const int nslab = kpad / TILE_K;
   float mean = 0.f;
-  if (metric == KPDI_METRIC_NCC) mean = wave_sum(s) / (float)k;
+  if (metric != KPDI_METRIC_NDP) mean = wave_sum(s) / (float)k;
   float q2 = 0.f;
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES; ++i) {
@@ -125,15 +139,18 @@ __device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], flo
       v[i] = 0.f;
     }
   }
-  const float norm = sqrtf(wave_sum(q2));
+  q2 = wave_sum(q2);
+  const bool centred = metric == NORM_NDP_CENTRED;
+  const float norm = sqrtf(centred ? q2 + (float)k * mean * mean : q2);
   const float inv = norm > 0.f ? 1.f / norm : 0.f;
+  const float cval = sqrtf((float)k) * mean * inv;
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES; ++i) {
     const int c = lane + 64 * i;
     if (form == 2) {
       if (c < 2 * kpad) *(_Float16 *)half_slot(out, r, c, nslab) = (_Float16)(v[i] * inv * 4096.f);
     } else if (c < kpad) {
-      out[prepared_offset(r, c, nslab)] = v[i] * inv;
+      out[prepared_offset(r, c, nslab)] = (centred && c == k) ? cval : v[i] * inv;
     }
   }
 }
@@ -156,7 +173,7 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[WAVE_VALUES
                                                           float *red = nullptr) {
   const int nslab = kpad / TILE_K;
   float mean = 0.f;
-  if (metric == KPDI_METRIC_NCC) mean = group_sum<NT>(s, red) / (float)k;
+  if (metric != KPDI_METRIC_NDP) mean = group_sum<NT>(s, red) / (float)k;
   float q2 = 0.f;
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES; ++i) {
@@ -168,17 +185,20 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[WAVE_VALUES
       v[i] = 0.f;
     }
   }
-  const float norm = sqrtf(group_sum<NT>(q2, red));
+  q2 = group_sum<NT>(q2, red);
+  const bool centred = metric == NORM_NDP_CENTRED;
+  const float norm = sqrtf(centred ? q2 + (float)k * mean * mean : q2);
   const float inv = norm > 0.f ? 1.f / norm : 0.f;
+  const float cval = sqrtf((float)k) * mean * inv;
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES / 4; ++i) {
     const int c = 4 * (lane + NT * i);
     if (c < (split == 2 ? 2 * kpad : kpad)) {
       float4 w;
-      w.x = v[4 * i] * inv;
-      w.y = v[4 * i + 1] * inv;
-      w.z = v[4 * i + 2] * inv;
-      w.w = v[4 * i + 3] * inv;
+      w.x = (centred && c == k) ? cval : v[4 * i] * inv;
+      w.y = (centred && c + 1 == k) ? cval : v[4 * i + 1] * inv;
+      w.z = (centred && c + 2 == k) ? cval : v[4 * i + 2] * inv;
+      w.w = (centred && c + 3 == k) ? cval : v[4 * i + 3] * inv;
       if (!split) {
         *reinterpret_cast<float4 *>(out + prepared_offset(r, c, nslab)) = w;
       } else if (split == 2) {
@@ -386,12 +406,13 @@ hipError_t launch_split_f16(float *prepared, int n_rows_pad, int kpad, hipStream
 
 hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   if (a.n_out <= 0) return hipSuccess;
-  const bool wave_path = a.k <= 64 * WAVE_VALUES;
+  const int cols = a.k + (a.metric == NORM_NDP_CENTRED ? 1 : 0);  // columns of a row that are not padding
+  const bool wave_path = cols <= 64 * WAVE_VALUES;
   const bool vec_ok = (a.npix % 4) == 0 && ((uintptr_t)a.raw % (4 * dtype_size(a.dtype))) == 0;
   const bool vec4 = wave_path && a.pix_map == nullptr && (a.k % 4) == 0 && vec_ok;
   const bool staged = wave_path && a.pix_map != nullptr && vec_ok && a.npix <= 64 * WAVE_VALUES;
   // larger detectors, still register-resident: one workgroup per pattern
-  const bool block_path = !wave_path && a.k <= PREP_THREADS * WAVE_VALUES;
+  const bool block_path = !wave_path && cols <= PREP_THREADS * WAVE_VALUES;
   const bool block_vec = block_path && a.pix_map == nullptr && (a.k % 4) == 0 && vec_ok;
   const bool block_masked = block_path && a.pix_map != nullptr;
   const size_t staged_lds = (size_t)(((a.k + 3) & ~3) + 4 * a.npix) * 4;
