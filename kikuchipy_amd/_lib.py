@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libkpdi.so")
+# KPDI_LIB_PATH: another build of the library (kernel experiments, tools/README.md)
+LIB_PATH = os.environ.get("KPDI_LIB_PATH") or os.path.join(_HERE, "csrc", "libkpdi.so")
 
 METRIC_NCC, METRIC_NDP = 0, 1
 COMPUTE_F32, COMPUTE_F16X2, COMPUTE_F16 = 0, 1, 2

@@ -216,7 +216,34 @@ __device__ __forceinline__ void mfma_acc_h(f32x16 &c, const f32x4 &a, const f32x
 }
 
 // One of a wave's twelve 1 KB LDS-DMA pieces of a stage: 0-3 dictionary slab, 4-7 / 8-11
-// the two experimental slabs.  `gd`/`ge` already include the lane's 16-byte offset.
+// the two experimental slabs.
+// KPDI_DMA_BUFFER = 1 (default): `buffer_load_dwordx4 ... offen lds` - `gd` / `ge` are wave-uniform
+// slab addresses (scalar registers, one buffer descriptor each), the lane's 16-byte offset is the
+// ONE VGPR operand of every piece, and piece / slab / tile offsets travel in the scalar offset.
+// KPDI_DMA_BUFFER = 0 keeps the `global_load_lds_dwordx4` form (a 64-bit per-lane address per
+// piece) for comparison: with one wave per SIMD the issue of a piece blocks the wave's only
+// instruction stream, and the global form did so for ~40 cycles - config 2 measured 21.58 ms
+// (86.9 % of the f32 MFMA peak) against 20.90 ms (89.7 %) in the buffer form, which is what the
+// timing-only ablation without any pieces had given (89.4 %).
+#ifndef KPDI_DMA_BUFFER
+#define KPDI_DMA_BUFFER 1
+#endif
+#if KPDI_DMA_BUFFER
+__device__ __forceinline__ void issue_piece(const char *gd, const char *ge, size_t tile_bytes, char *stage_base,
+                                            int wv, int p, unsigned goff) {
+  const int c = p & 3, part = p >> 2;
+  const int kb = (wv + 4 * c) * 1024;
+  __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(part == 0 ? gd : ge), 0, 0x7fffffff, 0x00020000);
+  const int soffset = part == 0 ? kb : (int)((size_t)(part - 1) * tile_bytes) + kb;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(
+      rsrc, (__attribute__((address_space(3))) void *)(stage_base + part * SLAB_BYTES + kb), 16, (int)goff, soffset,
+      0, 0);
+}
+#define KPDI_GOFF_ARG , goff
+#define KPDI_LANE_BASE 0u
+#else
+// `gd`/`ge` already include the lane's 16-byte offset.
 __device__ __forceinline__ void issue_piece(const char *gd, const char *ge, size_t tile_bytes, char *stage_base,
                                             int wv, int p) {
   const int c = p & 3, part = p >> 2;
@@ -226,6 +253,9 @@ __device__ __forceinline__ void issue_piece(const char *gd, const char *ge, size
                                                                               (wv + 4 * c) * 1024),
                                    16, 0, 0);
 }
+#define KPDI_GOFF_ARG
+#define KPDI_LANE_BASE goff
+#endif
 
 template <int KMAX, bool BOUNDED, int FORM>
 __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs a) {
@@ -252,7 +282,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
   const unsigned goff = (unsigned)lane * 16u;
   const size_t tile_bytes = (size_t)nslab * SLAB_BYTES;  // one 128-pattern dictionary tile, all slabs
   // the workgroup's 256 experimental patterns = prepared tiles 2*rb and 2*rb+1
-  const char *exp_base = (const char *)a.exp + (size_t)rb * 2 * tile_bytes + goff;
+  const char *exp_base = (const char *)a.exp + (size_t)rb * 2 * tile_bytes + KPDI_LANE_BASE;
   // wave wv's two column groups inside a stage: rows wv*64 + c*32 + (lane&31) of the 256
   const unsigned exp_frag = SLAB_BYTES + (wv >> 1) * SLAB_BYTES + ((wv & 1) * 2) * 4096;
 
@@ -317,7 +347,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
     int fetched = 0;  // thread 0: tile number drawn during the current tile
     int tp = 0;       // tile parity: the drawn number is handed over through ctrl[4 + tp]
     const char *gd = nullptr, *ge = nullptr;
-    const char *dict_base = (const char *)a_dict + goff;
+    const char *dict_base = (const char *)a_dict + KPDI_LANE_BASE;
     // (plain macros instead of lambdas: by-reference captures put the whole state in scratch)
 #define KPDI_CURSOR_SET()                                                                        \
   {                                                                                              \
@@ -337,11 +367,11 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
     // ---- prologue: slabs 0 and 1 in flight, then everything landed and visible
     KPDI_CURSOR_SET();
 #pragma unroll
-    for (int p = 0; p < 12; ++p) issue_piece(gd, ge, tile_bytes, smem + ld_stage * STAGE_BYTES, wv, p);
+    for (int p = 0; p < 12; ++p) issue_piece(gd, ge, tile_bytes, smem + ld_stage * STAGE_BYTES, wv, p KPDI_GOFF_ARG);
     KPDI_CURSOR_ADVANCE();
     KPDI_CURSOR_SET();
 #pragma unroll
-    for (int p = 0; p < 12; ++p) issue_piece(gd, ge, tile_bytes, smem + ld_stage * STAGE_BYTES, wv, p);
+    for (int p = 0; p < 12; ++p) issue_piece(gd, ge, tile_bytes, smem + ld_stage * STAGE_BYTES, wv, p KPDI_GOFF_ARG);
     KPDI_CURSOR_ADVANCE();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -416,7 +446,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
               else if (slot < 8) fa[cur ^ 1][slot] = *(const f32x4 *)(src_lo + (slot - 4) * 4096);
               else if (slot < 10) fb[cur ^ 1][slot - 8] = *(const f32x4 *)(src_hi + exp_frag + (slot - 8) * 4096);
               else fb[cur ^ 1][slot - 8] = *(const f32x4 *)(src_lo + exp_frag + (slot - 10) * 4096);
-              if (st == 1) issue_piece(gd, ge, tile_bytes, ld_base, wv, slot);
+              if (st == 1) issue_piece(gd, ge, tile_bytes, ld_base, wv, slot KPDI_GOFF_ARG);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -444,10 +474,10 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
             if (rt == 1) fb[cur ^ 1][0] = *(const f32x4 *)(src + exp_frag);
             if (rt == 3) fb[cur ^ 1][1] = *(const f32x4 *)(src + exp_frag + 4096);
             if (kg == 2) {
-              issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * rt);
-              issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * rt + 1);
+              issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * rt KPDI_GOFF_ARG);
+              issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * rt + 1 KPDI_GOFF_ARG);
             }
-            if (kg == 3) issue_piece(gd, ge, tile_bytes, ld_base, wv, 8 + rt);
+            if (kg == 3) issue_piece(gd, ge, tile_bytes, ld_base, wv, 8 + rt KPDI_GOFF_ARG);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -481,10 +511,10 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
           }
           // ... and the slab two steps ahead: this wave's 12 LDS-DMA pieces
           if (kg == 2) {
-            issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * j);
-            issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * j + 1);
+            issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * j KPDI_GOFF_ARG);
+            issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * j + 1 KPDI_GOFF_ARG);
           }
-          if (kg == 3) issue_piece(gd, ge, tile_bytes, ld_base, wv, 8 + j);
+          if (kg == 3) issue_piece(gd, ge, tile_bytes, ld_base, wv, 8 + j KPDI_GOFF_ARG);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
