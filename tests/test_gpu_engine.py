@@ -129,6 +129,7 @@ def test_vs_oracle_shapes(ctx, m, n, sy, sx, k, chunk, metric):
     (75, 75, False, np.float32, "ncc"),    # K % 4 != 0: generic kernel
     (130, 130, False, np.uint8, "ncc"),    # K > 16384: generic kernel
     (130, 130, True, np.float32, "ndp"),
+    (256, 250, False, np.uint8, "ncc"),    # K = 64 000: 32 MB per dictionary tile (scalar offsets of the LDS-DMA pieces)
 ])
 def test_large_detectors(ctx, sy, sx, masked, dtype, metric):
     """Pattern preparation switches kernels with the number of kept pixels (csrc/prep.hip)."""
