@@ -261,7 +261,7 @@ def main():
             "parallelism": f"dictionary sharded over {world} GPU(s)" + (", RCCL all-gather merge" if world > 1 else ""),
         },
         "roofline": {
-            "kernel": "kpdi::match_topk_kernel<20,false> (f32 MFMA GEMM + fused top-k), rank 0" if a.compute == "f32"
+            "kernel": "kpdi::match_topk_kernel<20,false,0> (f32 MFMA GEMM + fused top-k), rank 0" if a.compute == "f32"
             else f"kpdi::match_topk_kernel<20,false,{a.compute}> (f16 MFMAs; flops counted once, peak = f32 MFMA)",
             "bound": "mfma",
             "achieved": round(achieved, 2),
