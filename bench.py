@@ -141,6 +141,13 @@ def main():
                          "f16 is reduced precision)")
     a = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line
+    # version banner through C stdio when a communicator is created, flushed at exit): keep the real
+    # stdout aside for the JSON line and point file descriptor 1 - Python's and C's - at stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -483,7 +490,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "patterns/s", "cores": 0, "kind": "port", "sample": "",
                                    "error": f"{type(err).__name__}: {err}"}
     ctx.close()
-    print(json.dumps(out))
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
