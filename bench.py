@@ -57,19 +57,34 @@ def synth(w, seed=2024):
     return exp, dic, bg
 
 
-def dictionary_block(w, b):
+def plant_table(w, n_plant=16):
+    """(experimental rows, dictionary indices): the dictionary entries that are replaced by exact
+    (rescaled) copies of experimental patterns, so that a run can be checked without an oracle sweep:
+    row r must come out with dictionary index d first and score 1 (`ncc`) / 1 (`ndp`)."""
+    rng = np.random.default_rng(99)
+    return rng.choice(w["m"], n_plant, replace=False), np.sort(rng.choice(w["n"], n_plant, replace=False))
+
+
+def dictionary_block(w, b, exp=None):
     """Block b (patterns [b * BLOCK, (b + 1) * BLOCK)) of a large workload's dictionary: seeded per
-    block, so that every rank can generate exactly its own shard."""
+    block, so that every rank can generate exactly its own shard.  With `exp`, the planted copies
+    of `plant_table` that fall into the block are written in."""
     n = min(BLOCK, w["n"] - b * BLOCK)
-    return np.random.default_rng([2024, b]).random((n, w["sy"], w["sx"]), dtype=np.float32)
+    blk = np.random.default_rng([2024, b]).random((n, w["sy"], w["sx"]), dtype=np.float32)
+    if exp is not None:
+        rows, at = plant_table(w)
+        for r, d in zip(rows, at):
+            if b * BLOCK <= d < b * BLOCK + n:
+                blk[d - b * BLOCK] = exp[r].astype(np.float32) / 255.0
+    return blk
 
 
-def upload_generated_shard(ctx, w, lo, hi):
+def upload_generated_shard(ctx, w, lo, hi, exp):
     """Device buffer with dictionary patterns [lo, hi) of a large workload (never whole on the host)."""
     row = w["sy"] * w["sx"] * 4
     d = ctx.dev_alloc((hi - lo) * row)
     for b in range(lo // BLOCK, (hi - 1) // BLOCK + 1):
-        blk = dictionary_block(w, b)
+        blk = dictionary_block(w, b, exp)
         a0, a1 = max(lo, b * BLOCK), min(hi, b * BLOCK + len(blk))
         ctx.h2d(d + (a0 - lo) * row, blk[a0 - b * BLOCK:a1 - b * BLOCK])
     return d
@@ -79,6 +94,43 @@ def circular_mask(sy, sx):
     """`~Window("circular", (sy, sx)).astype(bool)` (filters/window.py:249-269)."""
     yy, xx = np.ogrid[:sy, :sx]
     return np.sqrt((yy - sy // 2) ** 2 + (xx - sx // 2) ** 2) > max(sy // 2, sx // 2)
+
+
+def check_result(w, exp, dic, bg, mask, scores, indices, n_rows, large):
+    """The result of the timed run against the C oracle (oracle/kpdi_oracle_c.c, float64-accumulated
+    dot products, OpenMP over the host cores) on a sample of experimental rows over the WHOLE
+    dictionary, plus the planted copies of the large workloads.  The oracle is the checker here,
+    never the thing measured.  Raises on a mismatch: a bench line is only printed for a correct run."""
+    from oracle import c_oracle
+    from oracle import kpdi_oracle as ko
+
+    t0 = time.perf_counter()
+    rows = np.sort(np.random.default_rng(5).choice(w["m"], n_rows, replace=False))
+    e = exp[rows]
+    if w["preprocess"]:
+        e = ko.remove_dynamic_background(ko.remove_static_background(e, bg))
+    if large:
+        chunks = ((b * BLOCK, dictionary_block(w, b, exp)) for b in range((w["n"] + BLOCK - 1) // BLOCK))
+    else:
+        chunks = [(0, dic)]
+    rs, ri = c_oracle.rows_topk_f64(e, chunks, np.arange(n_rows), w["metric"], w["keep_n"], mask)
+    out = {"rows": int(n_rows), "oracle": "oracle/kpdi_oracle_c.c rows_topk_f64 (float64 accumulation)"}
+    if w["preprocess"]:
+        # end to end from the raw patterns: a flipped grey level of the pre-processing moves a score by ~1.6e-5
+        out["max_abs_score_diff_end_to_end"] = float(np.abs(scores[rows] - rs).max())
+        out["best_match_agreement"] = float(np.mean(indices[rows][:, 0] == ri[:, 0]))
+        assert out["max_abs_score_diff_end_to_end"] < 1e-4 and out["best_match_agreement"] > 0.98, out
+    else:
+        ko.assert_topk_parity(scores[rows], indices[rows], rs, ri, atol=1e-5)
+        out["max_abs_score_diff"] = float(np.abs(scores[rows] - rs).max())
+        out["index_agreement"] = float(np.mean(indices[rows] == ri))
+    if large:
+        prow, pat = plant_table(w)
+        assert np.array_equal(indices[prow, 0], pat), "planted copies not found first"
+        assert np.allclose(scores[prow, 0], 1.0, atol=1e-5), scores[prow, 0]
+        out["planted_found"] = int(len(prow))
+    out["seconds"] = round(time.perf_counter() - t0, 2)
+    return out
 
 
 def cpu_baseline(w, exp, dic, bg, mask, n_sample):
@@ -133,6 +185,10 @@ def main():
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample", type=int, default=20000, help="dictionary patterns in the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-rows", type=int, default=None,
+                    help="experimental rows of the timed result that are checked against the C oracle over the whole "
+                         "dictionary before the line is printed (default: 64; 32 for the large workloads; 0 = no check)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the configs[2] leg of the default run")
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-pointer sweep")
     ap.add_argument("--no-generation", action="store_true",
                     help="skip the informational sweep with the dictionary simulated on the device")
@@ -191,7 +247,7 @@ def main():
     d_exp = ctx.dev_alloc(exp.nbytes)
     ctx.h2d(d_exp, exp)
     if large:
-        d_dic = upload_generated_shard(ctx, w, lo, hi)
+        d_dic = upload_generated_shard(ctx, w, lo, hi, exp)
     else:
         shard = np.ascontiguousarray(dic[lo:hi])
         d_dic = ctx.dev_alloc(shard.nbytes)
@@ -275,7 +331,7 @@ def main():
             "peak": F32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": None,
+            "traffic": None,  # HBM bytes are not measurable in-process; see traffic_profiled
             "flops_per_launch": flops_per_launch,
             "avg_launch_ms": round(avg_ms, 4),
             "launches": int(cnt["match_launches"]),
@@ -284,14 +340,16 @@ def main():
         "extra": {
             "comparisons_per_s": round(value * w["n"], 1),
             "prep_ms_per_step": round(cnt["prep_ms"] / a.steps, 4),
+            "preproc_ms_per_step": round(cnt["preproc_ms"] / a.steps, 4),
             "merge_ms_per_step": round(cnt["merge_ms"] / a.steps, 4),
             "best_score_mean": float(scores[:, 0].mean()),
         },
     }
 
-    # HBM-side traffic of the match kernel cannot be read from inside the process; it comes from
-    # the committed rocprofv3 PMC passes of this same command (tools/summarize_pmc.py:
-    # FETCH_SIZE*1024*2 + WRITE_SIZE*1024 per launch, the gfx950 corrections of the microarch guide)
+    # HBM-side traffic of the match kernel cannot be read from inside the process: `traffic` stays
+    # null in the live line.  The number of the committed rocprofv3 PMC passes of this same command
+    # (tools/summarize_pmc.py: FETCH_SIZE*1024*2 + WRITE_SIZE*1024 per launch, the gfx950 corrections
+    # of the microarch guide) is quoted beside it, labelled as what it is: a static, earlier measurement.
     if a.workload == "config2" and world == 1 and a.compute == "f32":
         import glob
 
@@ -299,9 +357,68 @@ def main():
         if pmc:
             with open(pmc[-1]) as f:
                 prof = json.load(f)
-            out["roofline"]["traffic"] = prof.get("match_traffic_bytes_per_launch")
-            out["roofline"]["traffic_source"] = os.path.relpath(pmc[-1], ROOT)
-            out["roofline"]["algorithmic_operand_bytes"] = float(w["n"] * k_kept * 4 + w["m"] * k_kept * 4)
+            out["roofline"]["traffic_profiled"] = {
+                "bytes_per_launch": prof.get("match_traffic_bytes_per_launch"),
+                "kind": "static: read from the committed profile, NOT measured in this run",
+                "source": os.path.relpath(pmc[-1], ROOT),
+            }
+        out["roofline"]["algorithmic_operand_bytes"] = float(w["n"] * k_kept * 4 + w["m"] * k_kept * 4)
+
+    # ---- the result of the timed run is checked before anything is printed
+    n_check = a.check_rows if a.check_rows is not None else (32 if large else 64)
+    if world == 1 and n_check > 0:
+        out["check"] = check_result(w, exp, dic, bg, mask, scores, indices, n_check, large)
+
+    # ---- configs[2] inside the default run: circular signal mask (K = 2819) + static and dynamic
+    # background removal fused with the preparation of the patterns (ONE pre-kernel), then the match
+    if a.workload == "config2" and world == 1 and a.compute == "f32" and not a.no_config3:
+        try:
+            w3 = WORKLOADS["config3"]
+            mask3 = circular_mask(w3["sy"], w3["sx"])
+            c3 = _lib.Context(local_rank)
+            c3.set_problem(w3["sy"], w3["sx"], mask3, metric, w3["keep_n"], compute)
+            c3.set_profiling(True)
+            reps = max(3, min(a.steps, 10))
+            for r in range(reps + 2):
+                if r == 2:
+                    c3.reset_counters()
+                    c3.synchronize()
+                    t0 = time.perf_counter()
+                c3.set_experimental_dev(d_exp, exp.dtype, w3["m"])
+                c3.remove_static_background(bg_f32, _lib.OP_SUBTRACT, False)
+                c3.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
+                c3.push_dictionary_chunk_dev(d_dic, np.float32, n_local, lo)
+                s3, i3 = c3.finalize(w3["keep_n"])
+            c3.synchronize()
+            dt3 = (time.perf_counter() - t0) / reps
+            cnt3 = c3.counters()
+            c3.close()
+            pre_ms = cnt3["preproc_ms"] / max(cnt3["preproc_launches"], 1)
+            # algorithmic bytes of the pre-kernel: the pattern read and written back + its prepared row
+            pre_bytes = w3["m"] * (2 * w3["sy"] * w3["sx"] * exp.dtype.itemsize + cnt3["kpad"] * 4)
+            match_ms3 = cnt3["match_ms"] / max(cnt3["match_launches"], 1)
+            tf3 = cnt3["match_flops"] / max(cnt3["match_launches"], 1) / (match_ms3 * 1e-3) / 1e12
+            out["extra"]["config3"] = {
+                "what": w3["name"],
+                "patterns_per_s": round(w3["m"] / dt3, 1),
+                "ms_per_step": round(dt3 * 1e3, 3),
+                "kept_pixels": int(cnt3["k_kept"]),
+                "match_ms": round(match_ms3, 4),
+                "match_tflops": round(tf3, 2),
+                "match_frac": round(tf3 / F32_MFMA_PEAK_TFLOPS, 4),
+                "prekernel": "kpdi::preproc_fused_kernel<uint8,16> (static + dynamic background + mask gather + normalise)",
+                "prekernel_ms": round(pre_ms, 4),
+                "prekernel_algorithmic_bytes": int(pre_bytes),
+                "prekernel_GBps": round(pre_bytes / (pre_ms * 1e-3) / 1e9, 1) if pre_ms > 0 else None,
+                "prekernel_frac_of_8TBps": round(pre_bytes / (pre_ms * 1e-3) / 8e12, 4) if pre_ms > 0 else None,
+                "dictionary_prep_ms": round(cnt3["prep_ms"] / reps, 4),
+            }
+            if n_check > 0:
+                out["extra"]["config3"]["check"] = check_result(w3, exp, dic, bg, mask3, s3, i3, n_check, False)
+        except AssertionError:
+            raise
+        except Exception as err:  # an informational leg must not cost the bench line
+            out["extra"]["config3_error"] = f"{type(err).__name__}: {err}"
 
     if world == 1 and not a.no_pcie:
         try:
@@ -484,7 +601,7 @@ def main():
             n_sample = min(a.cpu_sample, w["n"])
             if large:
                 n_sample = max(500, min(BLOCK, int(a.cpu_sample * (4096 * 3600) / (w["m"] * w["sy"] * w["sx"]))))
-                dic = dictionary_block(w, 0)
+                dic = dictionary_block(w, 0, exp)
             out["cpu_baseline"] = cpu_baseline(w, exp, dic, bg, mask, n_sample)
         except Exception as err:
             out["cpu_baseline"] = {"value": None, "unit": "patterns/s", "cores": 0, "kind": "port", "sample": "",

@@ -119,6 +119,13 @@ int kpdi_set_experimental_dev(kpdi_ctx *ctx, const void *d_patterns, int dtype,
 int64_t kpdi_n_experimental(kpdi_ctx *ctx);
 
 /* ---- pre-processing of the resident experimental patterns -------------------
+ * Both calls RECORD their step (arguments are validated and copied before they return); the
+ * kernels run when the patterns are needed: fused with the metric's preparation of the
+ * patterns into ONE kernel (static -> truncate -> dynamic -> truncate -> signal-mask gather ->
+ * normalise -> tiled matrix; detectors up to 19 200 pixels, streaming kernels above that)
+ * at the first dictionary chunk, or on their own in kpdi_get_experimental.  One static step
+ * followed by one dynamic step fuse; any other sequence runs step by step.  Results are
+ * identical either way: every step sees the truncated output of the previous one.
  * remove_static_background: pattern/_pattern.py:392-435 (+ :484-509, :96-111).
  * `static_bg`: sy*sx float32 (the caller did `static_bg.astype(float32)`,
  * signals/ebsd.py:547).  Output keeps the input dtype, truncated like `.astype`. */
@@ -336,6 +343,8 @@ typedef struct kpdi_counters {
   int32_t k_kept;       /* kept pixels K */
   double project_ms;    /* master-pattern projection kernels */
   double refine_ms;     /* refinement solve kernels */
+  double preproc_ms;    /* background-removal kernels (incl. the fused preparation of the patterns) */
+  int64_t preproc_launches;
 } kpdi_counters;
 int kpdi_set_profiling(kpdi_ctx *ctx, int on);
 int kpdi_get_counters(kpdi_ctx *ctx, kpdi_counters *out);

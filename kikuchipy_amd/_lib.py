@@ -54,6 +54,8 @@ class Counters(C.Structure):
         ("k_kept", C.c_int32),
         ("project_ms", C.c_double),
         ("refine_ms", C.c_double),
+        ("preproc_ms", C.c_double),
+        ("preproc_launches", C.c_int64),
     ]
 
     def as_dict(self):

@@ -192,8 +192,15 @@ struct kpdi_ctx {
   DevBuf gather_s, gather_i;              // RCCL all-gather target
   PinBuf pin_out;                         // kpdi_finalize: scores + indices on their way to the caller
 
-  // pre-processing scratch
-  DevBuf bg, taps;
+  // pre-processing: kpdi_remove_*_background only RECORD the step; the kernels run (fused with the
+  // preparation of the patterns when those are about to be matched) in flush_preprocess
+  struct PendingPre {
+    bool st = false, dy = false;
+    int st_op = 0, st_scale = 0;
+    float bg_min = 0.f, bg_max = 0.f;
+    int dy_op = 0, reflect = 0, ntaps = 0, centre = 0;
+  } pend;
+  DevBuf bg, taps, inv_map, pre_scratch;
 
   // dictionary generation (project.hip)
   bool have_master = false, have_dc = false;
@@ -214,7 +221,7 @@ struct kpdi_ctx {
 
   // measurement
   bool profiling = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_match, ev_prep, ev_merge, ev_proj;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_match, ev_prep, ev_merge, ev_proj, ev_pre;
   std::vector<hipEvent_t> ev_pool;
   kpdi_counters cnt{};
 
@@ -309,12 +316,71 @@ int choose_nsplit(const kpdi_ctx *c, int row_blocks, int n_tiles, int *rows_per_
   return best_ns;
 }
 
+// Runs the recorded background-removal steps on the resident patterns (in place).  With
+// `with_prep` the metric's preparation of the patterns is fused into the same kernel when the
+// detector allows it (preproc.hip); *prep_done reports whether it was.
+int flush_preprocess(kpdi_ctx *c, bool with_prep, bool *prep_done) {
+  *prep_done = false;
+  if (!c->pend.st && !c->pend.dy) return KPDI_OK;
+  kpdi::PreLaunch a{};
+  a.patterns = c->exp_raw.p;
+  a.dtype = c->exp_dtype;
+  a.n = c->m_all;
+  a.sy = c->sy;
+  a.sx = c->sx;
+  a.do_static = c->pend.st;
+  a.bg = c->bg.as<float>();
+  a.bg_min = c->pend.bg_min;
+  a.bg_max = c->pend.bg_max;
+  a.st_operation = c->pend.st_op;
+  a.scale_bg = c->pend.st_scale;
+  a.do_dynamic = c->pend.dy;
+  a.taps_padded = c->taps.as<double>();
+  a.ntaps = c->pend.ntaps;
+  a.centre = c->pend.centre;
+  a.reflect = c->pend.reflect;
+  a.dy_operation = c->pend.dy_op;
+  dtype_range(c->exp_dtype, &a.omin, &a.omax);
+  a.do_prep = with_prep;
+  if (with_prep) {
+    a.out_row = c->have_nav_mask ? c->inv_map.as<int>() : nullptr;
+    a.pix_map = c->have_sig_mask ? c->pix_map.as<int>() : nullptr;
+    a.k = c->k_kept;
+    a.kpad = c->kpad;
+    a.metric = prep_metric(c);
+    a.operand_form = c->compute;
+    a.out = c->exp_x.as<float>();
+  }
+  if (c->pend.dy && !kpdi::preprocess_fits_fused(c->sy, c->sx, 0)) {
+    a.scratch_floats = kpdi::preprocess_scratch_floats(c->sy, c->sx, c->m_all, nullptr);
+    HIPCHK(c->pre_scratch.reserve(a.scratch_floats * sizeof(float)));
+    a.scratch = c->pre_scratch.as<float>();
+  }
+  {
+    ScopedTimer t(c, &c->ev_pre);
+    hipError_t e = kpdi::launch_preprocess(a, prep_done, c->stream);
+    if (e != hipSuccess)
+      return fail(KPDI_EHIP, "background-removal kernel: %s (dtype %d, %dx%d)", hipGetErrorString(e), c->exp_dtype,
+                  c->sy, c->sx);
+  }
+  c->cnt.preproc_launches += 1;
+  c->pend = kpdi_ctx::PendingPre{};
+  return KPDI_OK;
+}
+
 int prepare_experimental(kpdi_ctx *c) {
   if (c->exp_prepared) return KPDI_OK;
   if (!c->have_exp) return fail(KPDI_EINVAL, "no experimental patterns set");
   if (!c->have_problem) return fail(KPDI_EINVAL, "kpdi_set_problem has not been called");
   HIPCHK(c->exp_x.reserve((size_t)c->m_pad * c->kpad * sizeof(float)));
   HIPCHK(hipMemsetAsync(c->exp_x.p, 0, (size_t)c->m_pad * c->kpad * sizeof(float), c->stream));
+  bool fused = false;
+  int rc = flush_preprocess(c, true, &fused);
+  if (rc) return rc;
+  if (fused) {
+    c->exp_prepared = true;
+    return KPDI_OK;
+  }
   kpdi::PrepLaunch p;
   p.raw = c->exp_raw.p;
   p.dtype = c->exp_dtype;
@@ -590,16 +656,23 @@ int set_experimental_common(kpdi_ctx *c, const void *src, bool src_on_device, in
   c->exp_dtype = dtype;
   c->m_all = m_all;
   c->have_nav_mask = nav_mask != nullptr;
+  c->pend = kpdi_ctx::PendingPre{};  // recorded steps belonged to the previous set
   if (nav_mask) {
-    std::vector<int> rows;
+    if (m_all >= (int64_t)INT_MAX) return fail(KPDI_EINVAL, "too many experimental patterns");
+    std::vector<int> rows, inv((size_t)m_all, -1);  // kept pattern -> source row; source row -> kept pattern or -1
     rows.reserve((size_t)m_all);
     for (int64_t i = 0; i < m_all; ++i)
-      if (!nav_mask[i]) rows.push_back((int)i);
+      if (!nav_mask[i]) {
+        inv[(size_t)i] = (int)rows.size();
+        rows.push_back((int)i);
+      }
     c->m = (int)rows.size();
     HIPCHK(c->row_map.reserve(std::max<size_t>(rows.size(), 1) * sizeof(int)));
+    HIPCHK(c->inv_map.reserve(inv.size() * sizeof(int)));
     if (!rows.empty())
       HIPCHK(hipMemcpyAsync(c->row_map.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));  // `rows` dies at scope exit
+    HIPCHK(hipMemcpyAsync(c->inv_map.p, inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // `rows` / `inv` die at scope exit
   } else {
     if (m_all >= (int64_t)INT_MAX) return fail(KPDI_EINVAL, "too many experimental patterns");
     c->m = (int)m_all;
@@ -796,12 +869,12 @@ int kpdi_destroy(kpdi_ctx *c) {
   c->pin_out.release();
   for (DevBuf *b : {&c->pix_map, &c->exp_raw, &c->row_map, &c->exp_x, &c->dict_raw, &c->dict_y, &c->part_s,
                     &c->part_i, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
-                    &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps,
+                    &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps, &c->inv_map, &c->pre_scratch,
                     &c->mp_packed, &c->dcos, &c->rot, &c->proj_out,
                     &c->ref_raw, &c->ref_map, &c->ref_rowcol, &c->ref_pat, &c->ref_sqn, &c->ref_in, &c->ref_out,
                     &c->ref_idx, &c->osm_idx, &c->osm_out, &c->stage[0], &c->stage[1]})
     b->release();
-  for (auto *l : {&c->ev_match, &c->ev_prep, &c->ev_merge, &c->ev_proj})
+  for (auto *l : {&c->ev_match, &c->ev_prep, &c->ev_merge, &c->ev_proj, &c->ev_pre})
     for (auto &pr : *l) {
       (void)hipEventDestroy(pr.first);
       (void)hipEventDestroy(pr.second);
@@ -853,6 +926,11 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
     HIPCHK(c->pix_map.reserve(keep.size() * sizeof(int)));
     HIPCHK(hipMemcpyAsync(c->pix_map.p, keep.data(), keep.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  if ((c->pend.st || c->pend.dy) && c->have_exp && (sy != c->sy || sx != c->sx)) {
+    bool dummy = false;  // recorded background-removal steps belong to the old detector shape
+    rc = flush_preprocess(c, false, &dummy);
+    if (rc) return rc;
   }
   if (npix != c->npix) c->have_exp = false;  // resident patterns belong to another detector shape
   // the prepared layout of held chunks depends on shape, mask, metric and arithmetic
@@ -918,24 +996,21 @@ int kpdi_remove_static_background(kpdi_ctx *c, const float *static_bg, int opera
   if (operation != KPDI_OP_SUBTRACT && operation != KPDI_OP_DIVIDE) return fail(KPDI_EINVAL, "unknown operation");
   int rc = use_device(c);
   if (rc) return rc;
+  // one static step followed by one dynamic step fuse into a single kernel; anything recorded that
+  // this step cannot follow runs now
+  bool dummy = false;
+  if (c->pend.st || c->pend.dy) {
+    rc = flush_preprocess(c, false, &dummy);
+    if (rc) return rc;
+  }
   HIPCHK(c->bg.reserve((size_t)c->npix * sizeof(float)));
   HIPCHK(hipMemcpyAsync(c->bg.p, static_bg, (size_t)c->npix * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  kpdi::StaticBgLaunch a;
-  a.patterns = c->exp_raw.p;
-  a.dtype = c->exp_dtype;
-  a.n = c->m_all;
-  a.sy = c->sy;
-  a.sx = c->sx;
-  a.bg = c->bg.as<float>();
-  a.bg_min = *std::min_element(static_bg, static_bg + c->npix);
-  a.bg_max = *std::max_element(static_bg, static_bg + c->npix);
-  a.operation = operation;
-  a.scale_bg = scale_bg ? 1 : 0;
-  dtype_range(c->exp_dtype, &a.omin, &a.omax);
-  hipError_t e = kpdi::launch_static_bg(a, c->stream);
-  if (e != hipSuccess)
-    return fail(KPDI_EHIP, "static background kernel: %s (dtype %d, %dx%d)", hipGetErrorString(e), c->exp_dtype, c->sy, c->sx);
   HIPCHK(hipStreamSynchronize(c->stream));  // static_bg may be freed by the caller after return
+  c->pend.st = true;
+  c->pend.st_op = operation;
+  c->pend.st_scale = scale_bg ? 1 : 0;
+  c->pend.bg_min = *std::min_element(static_bg, static_bg + c->npix);
+  c->pend.bg_max = *std::max_element(static_bg, static_bg + c->npix);
   c->exp_prepared = false;
   c->run_valid = false;
   c->final_valid = false;
@@ -985,24 +1060,22 @@ int kpdi_remove_dynamic_background(kpdi_ctx *c, int operation, int filter_domain
   } else {
     return fail(KPDI_EINVAL, "unknown filter domain %d", filter_domain);
   }
-  HIPCHK(c->taps.reserve(taps.size() * sizeof(double)));
-  HIPCHK(hipMemcpyAsync(c->taps.p, taps.data(), taps.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  kpdi::DynamicBgLaunch a;
-  a.patterns = c->exp_raw.p;
-  a.dtype = c->exp_dtype;
-  a.n = c->m_all;
-  a.sy = c->sy;
-  a.sx = c->sx;
-  a.taps_y = a.taps_x = c->taps.as<double>();
-  a.ntaps_y = a.ntaps_x = n;
-  a.centre_y = a.centre_x = centre;
-  a.reflect = reflect;
-  a.operation = operation;
-  dtype_range(c->exp_dtype, &a.omin, &a.omax);
-  hipError_t e = kpdi::launch_dynamic_bg(a, c->stream);
-  if (e != hipSuccess)
-    return fail(KPDI_EHIP, "dynamic background kernel: %s (dtype %d, %dx%d)", hipGetErrorString(e), c->exp_dtype, c->sy, c->sx);
-  HIPCHK(hipStreamSynchronize(c->stream));  // `taps` dies at scope exit
+  bool dummy = false;
+  if (c->pend.dy) {  // a second dynamic step cannot join the recorded one
+    rc = flush_preprocess(c, false, &dummy);
+    if (rc) return rc;
+  }
+  // the kernels read the taps through a window of CONV_R outputs: zero padding on both sides
+  std::vector<double> padded(taps.size() + 2 * (kpdi::CONV_R - 1), 0.0);
+  std::copy(taps.begin(), taps.end(), padded.begin() + (kpdi::CONV_R - 1));
+  HIPCHK(c->taps.reserve(padded.size() * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(c->taps.p, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));  // `padded` dies at scope exit
+  c->pend.dy = true;
+  c->pend.dy_op = operation;
+  c->pend.reflect = reflect;
+  c->pend.ntaps = n;
+  c->pend.centre = centre;
   c->exp_prepared = false;
   c->run_valid = false;
   c->final_valid = false;
@@ -1013,6 +1086,9 @@ int kpdi_get_experimental(kpdi_ctx *c, void *out) {
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
   if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
   int rc = use_device(c);
+  if (rc) return rc;
+  bool dummy = false;
+  rc = flush_preprocess(c, false, &dummy);  // recorded background-removal steps run now
   if (rc) return rc;
   const size_t bytes = (size_t)c->m_all * c->npix * kpdi::dtype_size(c->exp_dtype);
   HIPCHK(hipMemcpyAsync(out, c->exp_raw.p, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -1748,6 +1824,8 @@ int kpdi_get_counters(kpdi_ctx *c, kpdi_counters *out) {
   rc = drain_events(c, c->ev_merge, &c->cnt.merge_ms);
   if (rc) return rc;
   rc = drain_events(c, c->ev_proj, &c->cnt.project_ms);
+  if (rc) return rc;
+  rc = drain_events(c, c->ev_pre, &c->cnt.preproc_ms);
   if (rc) return rc;
   *out = c->cnt;
   return KPDI_OK;

@@ -122,22 +122,34 @@ hipError_t launch_last_column(const float *scores, const int *idx, int m, int st
                               float *bound_score, int *bound_idx, hipStream_t s);
 
 // ---- pattern pre-processing (preproc.hip) ---------------------------------
-struct StaticBgLaunch {
-  void *patterns; int dtype; int64_t n; int sy, sx;
+// static background -> dynamic background -> (optionally) the metric's preparation of the
+// patterns, as ONE kernel per pattern set when the detector fits the LDS (<= 19 200 pixels),
+// else as streaming kernels (any size; the preparation then runs through launch_prep).
+constexpr int CONV_R = 8;  // outputs per thread of the register-tiled 1-D correlations
+struct PreLaunch {
+  void *patterns; int dtype; int64_t n; int sy, sx;  // all patterns of the set, processed in place
+  int do_static;
   const float *bg;   // sy*sx
   float bg_min, bg_max;
-  int operation, scale_bg;
-  float omin, omax;
-};
-hipError_t launch_static_bg(const StaticBgLaunch &a, hipStream_t s);
-struct DynamicBgLaunch {
-  void *patterns; int dtype; int64_t n; int sy, sx;
-  const double *taps_y, *taps_x; int ntaps_y, ntaps_x; int centre_y, centre_x;
+  int st_operation, scale_bg;
+  int do_dynamic;
+  const double *taps_padded;  // [ntaps + 2 * (CONV_R - 1)]: CONV_R - 1 zeros, the taps, CONV_R - 1 zeros
+  int ntaps, centre;
   int reflect;       // 0 = nearest (edge replicate), 1 = scipy 'reflect'
-  int operation;
+  int dy_operation;
   float omin, omax;
+  // fused preparation (PrepLaunch semantics); out_row[i] = prepared row of pattern i or -1
+  // (navigation mask), nullptr = identity
+  int do_prep;
+  const int *out_row, *pix_map;
+  int k, kpad, metric, operand_form;
+  float *out;
+  float *scratch; size_t scratch_floats;  // streaming kernels, see preprocess_scratch_floats
 };
-hipError_t launch_dynamic_bg(const DynamicBgLaunch &a, hipStream_t s);
+// *prep_done tells whether the preparation was fused (else the caller runs launch_prep)
+hipError_t launch_preprocess(const PreLaunch &a, bool *prep_done, hipStream_t s);
+bool preprocess_fits_fused(int sy, int sx, int prepared_cols);
+size_t preprocess_scratch_floats(int sy, int sx, int64_t n, int *grid_out);
 size_t dtype_size(int dtype);
 
 // ---- master-pattern projection (project.hip) --------------------------------

@@ -34,8 +34,7 @@
 // A pattern with zero norm (constant pattern; 0/0 = NaN in the reference, out of
 // contract per SURVEY.md 8(a)) becomes an all-zero row: it scores exactly 0
 // against everything.
-#include "kernels.h"
-#include "../../include/kpdi.h"
+#include "prep_device.h"
 
 #include <algorithm>
 
@@ -49,40 +48,6 @@ size_t dtype_size(int dtype) {
     case KPDI_F64: return 8;
   }
   return 0;
-}
-
-constexpr int NORM_NDP_CENTRED = 2;  // internal value of the `metric` argument, see above
-constexpr int PREP_THREADS = 256;
-constexpr int WAVE_VALUES = 64;  // values per lane of the wave-per-pattern kernels (K <= 4096)
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
-__device__ __forceinline__ float block_sum(float v, float *red) {
-  v = wave_sum(v);
-  const int w = threadIdx.x >> 6;
-  __syncthreads();  // protect `red` from the previous use
-  if ((threadIdx.x & 63) == 0) red[w] = v;
-  __syncthreads();
-  float t = 0.f;
-#pragma unroll
-  for (int i = 0; i < PREP_THREADS / 64; ++i) t += red[i];
-  return t;
-}
-
-template <typename T>
-struct alignas(sizeof(T) * 4) Quad {
-  T v[4];
-};
-
-// ---- float16 form (KPDI_COMPUTE_F16): a row holds 2 * kpad f16, value * 2^12; the 16 KB block of
-// (tile, slab) covers 64 pixels, slot q of a row = pixels 8q..8q+7 of the slab, placed like the f32
-// slot q (prepared_offset of float column 32 * slab + 4 * q)
-__device__ __forceinline__ char *half_slot(float *out, int r, int c, int nslab) {
-  return (char *)(out + prepared_offset(r, ((c >> 6) << 5) + (((c >> 3) & 7) << 2), nslab)) + 2 * (c & 7);
 }
 
 // ---- large detectors: one workgroup per pattern ----------------------------------------
@@ -151,80 +116,6 @@ __device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], flo
       if (c < 2 * kpad) *(_Float16 *)half_slot(out, r, c, nslab) = (_Float16)(v[i] * inv * 4096.f);
     } else if (c < kpad) {
       out[prepared_offset(r, c, nslab)] = (centred && c == k) ? cval : v[i] * inv;
-    }
-  }
-}
-
-// same, v[4*i + e] holds kept pixel 4*(lane + 64*i) + e: float4 stores (full 16-byte slots)
-// `split` = the operand form: 1 stores the split-f16 form directly (see split_f16_kernel below): the
-// lane's four pixels are half of an 8-pixel slot, i.e. 8 bytes of the high-half slot and 8 of the
-// low-half slot; 2 stores the float16 form (half_slot above)
-// NT threads share the pattern: 64 = one wave (`lane` = lane id), PREP_THREADS = the whole
-// workgroup (`lane` = thread id, sums through `red` in LDS)
-template <int NT>
-__device__ __forceinline__ float group_sum(float v, float *red) {
-  if (NT == 64) return wave_sum(v);
-  return block_sum(v, red);
-}
-
-template <int NT = 64>
-__device__ __forceinline__ void normalise_and_store_quads(float (&v)[WAVE_VALUES], float s, int lane, int r, int k,
-                                                          int kpad, int metric, float *out, int split,
-                                                          float *red = nullptr) {
-  const int nslab = kpad / TILE_K;
-  float mean = 0.f;
-  if (metric != KPDI_METRIC_NDP) mean = group_sum<NT>(s, red) / (float)k;
-  float q2 = 0.f;
-#pragma unroll
-  for (int i = 0; i < WAVE_VALUES; ++i) {
-    const int c = 4 * (lane + NT * (i / 4)) + (i & 3);
-    if (c < k) {
-      v[i] -= mean;
-      q2 += v[i] * v[i];
-    } else {
-      v[i] = 0.f;
-    }
-  }
-  q2 = group_sum<NT>(q2, red);
-  const bool centred = metric == NORM_NDP_CENTRED;
-  const float norm = sqrtf(centred ? q2 + (float)k * mean * mean : q2);
-  const float inv = norm > 0.f ? 1.f / norm : 0.f;
-  const float cval = sqrtf((float)k) * mean * inv;
-#pragma unroll
-  for (int i = 0; i < WAVE_VALUES / 4; ++i) {
-    const int c = 4 * (lane + NT * i);
-    if (c < (split == 2 ? 2 * kpad : kpad)) {
-      float4 w;
-      w.x = (centred && c == k) ? cval : v[4 * i] * inv;
-      w.y = (centred && c + 1 == k) ? cval : v[4 * i + 1] * inv;
-      w.z = (centred && c + 2 == k) ? cval : v[4 * i + 2] * inv;
-      w.w = (centred && c + 3 == k) ? cval : v[4 * i + 3] * inv;
-      if (!split) {
-        *reinterpret_cast<float4 *>(out + prepared_offset(r, c, nslab)) = w;
-      } else if (split == 2) {
-        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-        h4 h;
-        h[0] = (_Float16)(w.x * 4096.f);
-        h[1] = (_Float16)(w.y * 4096.f);
-        h[2] = (_Float16)(w.z * 4096.f);
-        h[3] = (_Float16)(w.w * 4096.f);
-        *reinterpret_cast<h4 *>(half_slot(out, r, c, nslab)) = h;  // half of a slot: 8 bytes
-      } else {
-        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-        const float x[4] = {w.x * 4096.f, w.y * 4096.f, w.z * 4096.f, w.w * 4096.f};
-        h4 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          hi[e] = (_Float16)x[e];
-          lo[e] = (_Float16)(x[e] - (float)hi[e]);
-        }
-        const int g8 = (c & 31) >> 3, half = (c & 7) >> 2;  // 8-pixel group of the slab; first / second 4 pixels
-        const int slab_first = c & ~31;                      // any pixel of slot q lies at slab_first + 4 q
-        char *hi_slot = (char *)(out + prepared_offset(r, slab_first + 4 * g8, nslab));
-        char *lo_slot = (char *)(out + prepared_offset(r, slab_first + 4 * (4 + g8), nslab));
-        *reinterpret_cast<h4 *>(hi_slot + 8 * half) = hi;
-        *reinterpret_cast<h4 *>(lo_slot + 8 * half) = lo;
-      }
     }
   }
 }

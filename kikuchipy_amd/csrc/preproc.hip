@@ -1,5 +1,6 @@
-// preproc.hip - static / dynamic background removal of the resident
-// experimental patterns, in place, output in the input dtype.
+// preproc.hip - static / dynamic background removal of the resident experimental
+// patterns, in place (output in the input dtype), FUSED with the pattern
+// preparation of the metric when the patterns are about to be matched.
 //
 // Reference (paths under /root/reference/src/kikuchipy):
 //   _remove_static_background_subtract/_divide   pattern/_pattern.py:392-435
@@ -7,27 +8,45 @@
 //   _remove_background_subtract/_divide          pattern/_pattern.py:484-509
 //   _rescale_with_min_max                        pattern/_pattern.py:96-111
 //   _fft_filter (Barnes)                         filters/fft_barnes.py:155-177
+//   prepare_experimental (ncc / ndp)             indexing/similarity_metrics/_normalized_cross_correlation.py:88-128
 // Arithmetic follows the reference's NumPy evaluation (its `.py_func`): every
 // step in float32, in the same order, IEEE division, no FMA contraction (the
 // library is built with -ffp-contract=off), then `.astype(dtype_out)` =
-// truncation toward zero.
+// truncation toward zero.  Both quantisations of the static -> dynamic chain are
+// kept (the dynamic step sees the truncated output of the static step), so the
+// fused kernel is bit-identical to running the steps one after the other.
 //
 // The Barnes FFT filter with the reference's edge-replicating pad equals a
 // correlation with the (separable, normalised) Gaussian window
-// (tests/test_filters/test_fft_barnes.py:135-173); it is evaluated here as two
-// 1-D passes in LDS with float64 accumulation.  The result differs from the
-// reference's float32 FFT by its FFT round-off (~6e-5 on values ~100), which
-// can flip the final truncation on isolated pixels.
+// (tests/test_filters/test_fft_barnes.py:135-173); it is evaluated as two 1-D
+// passes with float64 accumulation.  The result differs from the reference's
+// float32 FFT by its FFT round-off (~6e-5 on values ~100), which can flip the
+// final truncation on isolated pixels.
 //
-// One workgroup per pattern; pattern + intermediate live in LDS.  HBM-bound:
-// algorithmic bytes = 2 * npix * sizeof(dtype) per pattern.
-#include "kernels.h"
-#include "../../include/kpdi.h"
+// preproc_fused_kernel: ONE WORKGROUP PER PATTERN, one pass over HBM:
+//   raw pattern (vector loads) -> LDS f32 -> static background (two block reductions) -> truncate
+//   -> Gaussian along the rows, written TRANSPOSED so that both 1-D passes read LDS with unit
+//   stride across lanes -> Gaussian along the columns -> remove -> min/max -> rescale ->
+//   truncate -> pattern written back (vector stores) -> [fused prepare_experimental: gather the
+//   kept pixels through the signal mask's pixel map -> mean / norm -> the tiled, swizzled row of
+//   kernels.h].  The 1-D correlations are register tiled: a thread produces CONV_R consecutive
+//   outputs from CONV_R + n - 1 LDS reads (n taps), the taps are wave-uniform (scalar loads from
+//   a zero-padded tap array).
+//   LDS: 8 bytes per pixel -> detectors up to 19 200 pixels (138 x 138).
+// Larger detectors (raw 480 x 480 patterns ...) take the streaming kernels below: the same
+// arithmetic with the pattern re-read from L2 and the intermediate in a global scratch.
+//
+// HBM-bound by design: algorithmic bytes per pattern = 2 * npix * sizeof(dtype) (+ kpad * 4 for
+// the prepared row when fused).
+#include "prep_device.h"
 #include <math.h>
+#include <stdint.h>
+
+#include <algorithm>
 
 namespace kpdi {
 
-constexpr int PP_THREADS = 256;
+constexpr int PP_THREADS = PREP_THREADS;
 
 __device__ __forceinline__ void block_minmax(float &mn, float &mx, float *red) {
 #pragma unroll
@@ -56,45 +75,6 @@ __device__ __forceinline__ T cast_out(float v) {
   return (T)v;  // C truncation == ndarray.astype for in-range values
 }
 
-template <typename T>
-__global__ __launch_bounds__(PP_THREADS) void static_bg_kernel(T *pats, int npix, const float *bg,
-                                                               float bgmin, float bgmax, int operation,
-                                                               int scale_bg, float omin, float omax) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float *x = (float *)smem_raw;
-  __shared__ float red[8];
-  T *p = pats + (size_t)blockIdx.x * npix;
-  const int tid = threadIdx.x;
-  float mn = INFINITY, mx = -INFINITY;
-  for (int i = tid; i < npix; i += PP_THREADS) {
-    const float v = (float)p[i];
-    x[i] = v;
-    mn = fminf(mn, v);
-    mx = fmaxf(mx, v);
-  }
-  float pmin = 0.f, prange = 0.f;
-  const float bgrange = bgmax - bgmin;
-  if (scale_bg) {
-    block_minmax(mn, mx, red);
-    pmin = mn;
-    prange = mx - mn;
-  }
-  mn = INFINITY;
-  mx = -INFINITY;
-  for (int i = tid; i < npix; i += PP_THREADS) {
-    float b = bg[i];
-    if (scale_bg) b = rescale(b, bgmin, bgrange, prange, pmin);
-    const float y = operation == KPDI_OP_SUBTRACT ? x[i] - b : x[i] / b;
-    x[i] = y;
-    mn = fminf(mn, y);
-    mx = fmaxf(mx, y);
-  }
-  block_minmax(mn, mx, red);
-  const float irange = mx - mn;
-  const float orange = omax - omin;
-  for (int i = tid; i < npix; i += PP_THREADS) p[i] = cast_out<T>(rescale(x[i], mn, irange, orange, omin));
-}
-
 __device__ __forceinline__ int wrap_index(int i, int n, int reflect) {
   if (!reflect) return i < 0 ? 0 : (i >= n ? n - 1 : i);
   // scipy.ndimage 'reflect': (d c b a | a b c d | d c b a)
@@ -104,106 +84,347 @@ __device__ __forceinline__ int wrap_index(int i, int n, int reflect) {
   return i < n ? i : period - 1 - i;
 }
 
-template <typename T>
-__global__ __launch_bounds__(PP_THREADS) void dynamic_bg_kernel(T *pats, int sy, int sx, const double *ty,
-                                                                int nty, int cy, const double *tx, int ntx,
-                                                                int cx, int reflect, int operation,
-                                                                float omin, float omax) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int npix = sy * sx;
-  float *x = (float *)smem_raw;  // pattern, later pattern - background
-  float *t = x + npix;           // after the axis-0 pass
-  __shared__ float red[8];
-  T *p = pats + (size_t)blockIdx.x * npix;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < npix; i += PP_THREADS) x[i] = (float)p[i];
-  __syncthreads();
-  // axis 0 (rows)
-  for (int i = tid; i < npix; i += PP_THREADS) {
-    const int r = i / sx, c = i - r * sx;
-    double acc = 0.0;
-    for (int u = 0; u < nty; ++u) acc += ty[u] * (double)x[wrap_index(r + u - cy, sy, reflect) * sx + c];
-    t[i] = (float)acc;
+// 1-D correlation along the SLOW axis of a [len][other] array (element (a, o) at a * other + o);
+// consecutive threads take consecutive `o`, so the loads are unit-stride across lanes.  A job is
+// CONV_R consecutive outputs (a0 .. a0 + CONV_R - 1, o): out(a) = sum_u taps[u] * in(wrap(a + u - centre)),
+// accumulated in float64 (fused multiply-add: the reference's FFT fixes no operation order here) in ascending u.  `tp` is the tap array padded with CONV_R - 1 zeros on
+// both sides (tp[u + CONV_R - 1] = taps[u]): its index below is wave-uniform.
+template <typename Load, typename Store>
+__device__ __forceinline__ void correlate_slow_axis(int len, int other, const double *__restrict__ tp, int n,
+                                                    int centre, int reflect, Load load, Store store) {
+  const int jobs = ((len + CONV_R - 1) / CONV_R) * other;
+  for (int job = threadIdx.x; job < jobs; job += PP_THREADS) {
+    const int o = job % other, a0 = (job / other) * CONV_R;
+    double acc[CONV_R];
+#pragma unroll
+    for (int i = 0; i < CONV_R; ++i) acc[i] = 0.0;
+    for (int j = 0; j < CONV_R + n - 1; ++j) {
+      const double v = (double)load(wrap_index(a0 + j - centre, len, reflect) * other + o);
+#pragma unroll
+      for (int i = 0; i < CONV_R; ++i) acc[i] = __builtin_fma(tp[j - i + CONV_R - 1], v, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < CONV_R; ++i)
+      if (a0 + i < len) store(a0 + i, o, (float)acc[i]);
   }
-  __syncthreads();
-  // axis 1 (columns), then remove the background
+}
+
+struct PreArgs {
+  void *patterns;
+  int64_t n;
+  int sy, sx;
+  int do_static, st_operation, scale_bg;
+  const float *bg;
+  float bg_min, bg_max;
+  int do_dynamic, dy_operation, ntaps, centre, reflect;
+  const double *tp;
+  float omin, omax;
+  int do_prep;
+  const int *out_row, *pix_map;
+  int k, kpad, metric, form;
+  float *out;
+  float *scratch;  // streaming kernels: 2 * npix floats per workgroup
+};
+
+// ---- detectors up to 19 200 pixels: everything in one pass ---------------------------------
+template <typename T, int NV>
+__global__ __launch_bounds__(PP_THREADS) void preproc_fused_kernel(PreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ float red[8];
+  const int sy = a.sy, sx = a.sx, npix = sy * sx;
+  const int npix4 = (npix + 3) & ~3;
+  float *x = (float *)smem_raw;  // the pattern: raw -> after static -> minus background -> final
+  float *tt = x + npix4;         // after the row pass, transposed: tt[c * sy + r]
+  const int tid = threadIdx.x;
+  T *p = (T *)a.patterns + (size_t)blockIdx.x * npix;
+  const bool vec = (npix & 3) == 0 && (((uintptr_t)a.patterns) % (4 * sizeof(T))) == 0;
+  const int nquad = npix4 >> 2;
+  const float orange = a.omax - a.omin;
+
+  // ---- load (+ min / max of the raw pattern for scale_bg)
   float mn = INFINITY, mx = -INFINITY;
+  for (int q = tid; q < nquad; q += PP_THREADS) {
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec) {
+      const Quad<T> u = *reinterpret_cast<const Quad<T> *>(p + 4 * q);
+      w = make_float4((float)u.v[0], (float)u.v[1], (float)u.v[2], (float)u.v[3]);
+    } else {
+      float *wf = &w.x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * q + e < npix) wf[e] = (float)p[4 * q + e];
+    }
+    *reinterpret_cast<float4 *>(x + 4 * q) = w;
+    const float *wf = &w.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * q + e < npix) {
+        mn = fminf(mn, wf[e]);
+        mx = fmaxf(mx, wf[e]);
+      }
+  }
+  // final values of a quad -> LDS (as float) and, when this was the last step, back to memory
+  auto finish = [&](float imin, float irange, bool store) {
+    for (int q = tid; q < nquad; q += PP_THREADS) {
+      float4 w = *reinterpret_cast<const float4 *>(x + 4 * q);
+      float *wf = &w.x;
+      Quad<T> u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        u.v[e] = cast_out<T>(rescale(wf[e], imin, irange, orange, a.omin));
+        wf[e] = (float)u.v[e];
+      }
+      *reinterpret_cast<float4 *>(x + 4 * q) = w;
+      if (store) {
+        if (vec) {
+          *reinterpret_cast<Quad<T> *>(p + 4 * q) = u;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (4 * q + e < npix) p[4 * q + e] = u.v[e];
+        }
+      }
+    }
+  };
+
+  // ---- static background (pattern/_pattern.py:392-435)
+  if (a.do_static) {
+    float pmin = 0.f, prange = 0.f;
+    const float bgrange = a.bg_max - a.bg_min;
+    if (a.scale_bg) {
+      block_minmax(mn, mx, red);
+      pmin = mn;
+      prange = mx - mn;
+    }
+    mn = INFINITY;
+    mx = -INFINITY;
+    for (int q = tid; q < nquad; q += PP_THREADS) {
+      float4 w = *reinterpret_cast<const float4 *>(x + 4 * q);
+      float *wf = &w.x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * q + e < npix) {
+          float b = a.bg[4 * q + e];
+          if (a.scale_bg) b = rescale(b, a.bg_min, bgrange, prange, pmin);
+          const float y = a.st_operation == KPDI_OP_SUBTRACT ? wf[e] - b : wf[e] / b;
+          wf[e] = y;
+          mn = fminf(mn, y);
+          mx = fmaxf(mx, y);
+        }
+      *reinterpret_cast<float4 *>(x + 4 * q) = w;
+    }
+    block_minmax(mn, mx, red);
+    finish(mn, mx - mn, !a.do_dynamic);
+  }
+
+  // ---- dynamic background (pattern/_pattern.py:438-481)
+  if (a.do_dynamic) {
+    __syncthreads();
+    correlate_slow_axis(
+        sy, sx, a.tp, a.ntaps, a.centre, a.reflect, [&](int i) { return x[i]; },
+        [&](int r, int c, float v) { tt[c * sy + r] = v; });
+    __syncthreads();
+    mn = INFINITY;
+    mx = -INFINITY;
+    const int dy_op = a.dy_operation;
+    correlate_slow_axis(
+        sx, sy, a.tp, a.ntaps, a.centre, a.reflect, [&](int i) { return tt[i]; },
+        [&](int c, int r, float b) {
+          const int i = r * sx + c;
+          const float y = dy_op == KPDI_OP_SUBTRACT ? x[i] - b : x[i] / b;
+          x[i] = y;  // only this thread touches x[i] during the pass
+          mn = fminf(mn, y);
+          mx = fmaxf(mx, y);
+        });
+    block_minmax(mn, mx, red);
+    finish(mn, mx - mn, true);
+  }
+
+  // ---- fused preparation: what launch_prep would do with the pattern just written
+  if (a.do_prep) {
+    const int r = a.out_row ? a.out_row[blockIdx.x] : (int)blockIdx.x;
+    if (r >= 0) {  // workgroup-uniform
+      __syncthreads();
+      const int k = a.k;
+      float v[NV];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV / 4; ++i) {
+        const int c = 4 * (tid + PP_THREADS * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float val = 0.f;
+          if (c + e < k) val = x[a.pix_map ? a.pix_map[c + e] : c + e];
+          v[4 * i + e] = val;
+        }
+        s += (v[4 * i] + v[4 * i + 1]) + (v[4 * i + 2] + v[4 * i + 3]);
+      }
+      normalise_and_store_quads<PP_THREADS, NV>(v, s, tid, r, k, a.kpad, a.metric, a.out, a.form, red);
+    }
+  }
+}
+
+// ---- any detector size: the pattern is re-read from memory (L2 after its first touch) ---------
+template <typename T>
+__global__ __launch_bounds__(PP_THREADS) void static_stream_kernel(PreArgs a) {
+  __shared__ float red[8];
+  const int npix = a.sy * a.sx;
+  T *p = (T *)a.patterns + (size_t)blockIdx.x * npix;
+  const int tid = threadIdx.x;
+  const float orange = a.omax - a.omin, bgrange = a.bg_max - a.bg_min;
+  float pmin = 0.f, prange = 0.f;
+  float mn = INFINITY, mx = -INFINITY;
+  if (a.scale_bg) {
+    for (int i = tid; i < npix; i += PP_THREADS) {
+      const float v = (float)p[i];
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
+    }
+    block_minmax(mn, mx, red);
+    pmin = mn;
+    prange = mx - mn;
+  }
+  auto value = [&](int i) {
+    float b = a.bg[i];
+    if (a.scale_bg) b = rescale(b, a.bg_min, bgrange, prange, pmin);
+    const float v = (float)p[i];
+    return a.st_operation == KPDI_OP_SUBTRACT ? v - b : v / b;
+  };
+  mn = INFINITY;
+  mx = -INFINITY;
   for (int i = tid; i < npix; i += PP_THREADS) {
-    const int r = i / sx, c = i - r * sx;
-    double acc = 0.0;
-    for (int v = 0; v < ntx; ++v) acc += tx[v] * (double)t[r * sx + wrap_index(c + v - cx, sx, reflect)];
-    const float b = (float)acc;
-    const float y = operation == KPDI_OP_SUBTRACT ? x[i] - b : x[i] / b;
-    x[i] = y;  // only this thread touches x[i] from here on
+    const float y = value(i);
     mn = fminf(mn, y);
     mx = fmaxf(mx, y);
   }
   block_minmax(mn, mx, red);
   const float irange = mx - mn;
-  const float orange = omax - omin;
-  for (int i = tid; i < npix; i += PP_THREADS) p[i] = cast_out<T>(rescale(x[i], mn, irange, orange, omin));
+  for (int i = tid; i < npix; i += PP_THREADS) p[i] = cast_out<T>(rescale(value(i), mn, irange, orange, a.omin));
 }
 
-template <typename K>
-static hipError_t set_lds(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024)
-    return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+// persistent workgroups; scratch = [gridDim.x][2][npix] floats (row pass transposed | pattern - background)
+template <typename T>
+__global__ __launch_bounds__(PP_THREADS) void dynamic_stream_kernel(PreArgs a) {
+  __shared__ float red[8];
+  const int sy = a.sy, sx = a.sx, npix = sy * sx;
+  float *tt = a.scratch + (size_t)blockIdx.x * 2 * npix;
+  float *yb = tt + npix;
+  const int tid = threadIdx.x;
+  const float orange = a.omax - a.omin;
+  const int dy_op = a.dy_operation;
+  for (int64_t pat = blockIdx.x; pat < a.n; pat += gridDim.x) {
+    T *p = (T *)a.patterns + (size_t)pat * npix;
+    correlate_slow_axis(
+        sy, sx, a.tp, a.ntaps, a.centre, a.reflect, [&](int i) { return (float)p[i]; },
+        [&](int r, int c, float v) { tt[c * sy + r] = v; });
+    __syncthreads();
+    float mn = INFINITY, mx = -INFINITY;
+    correlate_slow_axis(
+        sx, sy, a.tp, a.ntaps, a.centre, a.reflect, [&](int i) { return tt[i]; },
+        [&](int c, int r, float b) {
+          const int i = r * sx + c;
+          const float v = (float)p[i];
+          const float y = dy_op == KPDI_OP_SUBTRACT ? v - b : v / b;
+          yb[i] = y;
+          mn = fminf(mn, y);
+          mx = fmaxf(mx, y);
+        });
+    block_minmax(mn, mx, red);  // (its barriers also order the yb writes before the reads below)
+    const float irange = mx - mn;
+    for (int i = tid; i < npix; i += PP_THREADS) p[i] = cast_out<T>(rescale(yb[i], mn, irange, orange, a.omin));
+    __syncthreads();  // the scratch is reused by the next pattern
+  }
+}
+
+size_t preprocess_scratch_floats(int sy, int sx, int64_t n, int *grid_out) {
+  const int grid = (int)std::min<int64_t>(n, 512);
+  if (grid_out) *grid_out = grid;
+  return (size_t)grid * 2 * (size_t)sy * sx;
+}
+
+bool preprocess_fits_fused(int sy, int sx, int prepared_cols) {
+  const size_t npix4 = ((size_t)sy * sx + 3) & ~(size_t)3;
+  return npix4 * 8 <= 150 * 1024 && prepared_cols <= PP_THREADS * WAVE_VALUES;
+}
+
+template <typename T>
+static hipError_t launch_pre_t(const PreLaunch &l, const PreArgs &a, bool *prep_done, hipStream_t s) {
+  const int cols = l.k + (l.metric == NORM_NDP_CENTRED ? 1 : 0);
+  const int cols_pad = l.operand_form == 2 ? 2 * l.kpad : l.kpad;
+  if (preprocess_fits_fused(l.sy, l.sx, 0)) {
+    // the preparation joins the kernel when a prepared row fits the 64 registers per thread
+    const bool prep = l.do_prep && preprocess_fits_fused(l.sy, l.sx, std::max(cols, cols_pad));
+    PreArgs b = a;
+    b.do_prep = prep;
+    const size_t npix4 = ((size_t)l.sy * l.sx + 3) & ~(size_t)3;
+    const size_t lds = npix4 * 8;
+    const bool small = !prep || std::max(cols, cols_pad) <= PP_THREADS * 16;
+    auto kernel = small ? preproc_fused_kernel<T, 16> : preproc_fused_kernel<T, WAVE_VALUES>;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)l.n), dim3(PP_THREADS), lds, s, b);
+    *prep_done = prep;
+    return hipGetLastError();
+  }
+  *prep_done = false;
+  if (l.do_static) {
+    hipLaunchKernelGGL((static_stream_kernel<T>), dim3((unsigned)l.n), dim3(PP_THREADS), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (l.do_dynamic) {
+    int grid = 0;
+    const size_t need = preprocess_scratch_floats(l.sy, l.sx, l.n, &grid);
+    if (!l.scratch || l.scratch_floats < need) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((dynamic_stream_kernel<T>), dim3((unsigned)grid), dim3(PP_THREADS), 0, s, a);
+    return hipGetLastError();
+  }
   return hipSuccess;
 }
 
-hipError_t launch_static_bg(const StaticBgLaunch &a, hipStream_t s) {
-  if (a.n <= 0) return hipSuccess;
-  const int npix = a.sy * a.sx;
-  const size_t lds = (size_t)npix * 4;
-  if (lds > 150 * 1024) return hipErrorInvalidValue;
-#define KPDI_ST(T)                                                                                     \
-  {                                                                                                    \
-    hipError_t e = set_lds(static_bg_kernel<T>, lds);                                                  \
-    if (e != hipSuccess) return e;                                                                     \
-    hipLaunchKernelGGL((static_bg_kernel<T>), dim3((unsigned)a.n), dim3(PP_THREADS), lds, s,          \
-                       (T *)a.patterns, npix, a.bg, a.bg_min, a.bg_max, a.operation, a.scale_bg,       \
-                       a.omin, a.omax);                                                                \
-    break;                                                                                             \
-  }
-  switch (a.dtype) {
-    case KPDI_U8: KPDI_ST(uint8_t)
-    case KPDI_I8: KPDI_ST(int8_t)
-    case KPDI_U16: KPDI_ST(uint16_t)
-    case KPDI_I16: KPDI_ST(int16_t)
-    case KPDI_F32: KPDI_ST(float)
-    case KPDI_F64: KPDI_ST(double)
+hipError_t launch_preprocess(const PreLaunch &l, bool *prep_done, hipStream_t s) {
+  *prep_done = false;
+  if (l.n <= 0 || (!l.do_static && !l.do_dynamic)) return hipSuccess;
+  if (l.n >= (int64_t)INT32_MAX) return hipErrorInvalidValue;
+  PreArgs a;
+  a.patterns = l.patterns;
+  a.n = l.n;
+  a.sy = l.sy;
+  a.sx = l.sx;
+  a.do_static = l.do_static;
+  a.st_operation = l.st_operation;
+  a.scale_bg = l.scale_bg;
+  a.bg = l.bg;
+  a.bg_min = l.bg_min;
+  a.bg_max = l.bg_max;
+  a.do_dynamic = l.do_dynamic;
+  a.dy_operation = l.dy_operation;
+  a.ntaps = l.ntaps;
+  a.centre = l.centre;
+  a.reflect = l.reflect;
+  a.tp = l.taps_padded;
+  a.omin = l.omin;
+  a.omax = l.omax;
+  a.do_prep = l.do_prep;
+  a.out_row = l.out_row;
+  a.pix_map = l.pix_map;
+  a.k = l.k;
+  a.kpad = l.kpad;
+  a.metric = l.metric;
+  a.form = l.operand_form;
+  a.out = l.out;
+  a.scratch = l.scratch;
+  switch (l.dtype) {
+    case KPDI_U8: return launch_pre_t<uint8_t>(l, a, prep_done, s);
+    case KPDI_I8: return launch_pre_t<int8_t>(l, a, prep_done, s);
+    case KPDI_U16: return launch_pre_t<uint16_t>(l, a, prep_done, s);
+    case KPDI_I16: return launch_pre_t<int16_t>(l, a, prep_done, s);
+    case KPDI_F32: return launch_pre_t<float>(l, a, prep_done, s);
+    case KPDI_F64: return launch_pre_t<double>(l, a, prep_done, s);
     default: return hipErrorInvalidValue;
   }
-#undef KPDI_ST
-  return hipGetLastError();
-}
-
-hipError_t launch_dynamic_bg(const DynamicBgLaunch &a, hipStream_t s) {
-  if (a.n <= 0) return hipSuccess;
-  const int npix = a.sy * a.sx;
-  const size_t lds = (size_t)npix * 8;
-  if (lds > 150 * 1024) return hipErrorInvalidValue;
-#define KPDI_DY(T)                                                                                     \
-  {                                                                                                    \
-    hipError_t e = set_lds(dynamic_bg_kernel<T>, lds);                                                 \
-    if (e != hipSuccess) return e;                                                                     \
-    hipLaunchKernelGGL((dynamic_bg_kernel<T>), dim3((unsigned)a.n), dim3(PP_THREADS), lds, s,         \
-                       (T *)a.patterns, a.sy, a.sx, a.taps_y, a.ntaps_y, a.centre_y,   \
-                       a.taps_x, a.ntaps_x, a.centre_x, a.reflect, a.operation,        \
-                       a.omin, a.omax);                                                                \
-    break;                                                                                             \
-  }
-  switch (a.dtype) {
-    case KPDI_U8: KPDI_DY(uint8_t)
-    case KPDI_I8: KPDI_DY(int8_t)
-    case KPDI_U16: KPDI_DY(uint16_t)
-    case KPDI_I16: KPDI_DY(int16_t)
-    case KPDI_F32: KPDI_DY(float)
-    case KPDI_F64: KPDI_DY(double)
-    default: return hipErrorInvalidValue;
-  }
-#undef KPDI_DY
-  return hipGetLastError();
 }
 
 }  // namespace kpdi
