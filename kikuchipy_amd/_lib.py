@@ -7,6 +7,7 @@ package: if the library is missing, or no gfx950 GPU is visible, calls raise.
 
 import ctypes as C
 import os
+import zlib
 
 import numpy as np
 
@@ -228,6 +229,10 @@ class Context:
         check(load().kpdi_create(int(device), C.byref(self._h)))
         self.device = int(device)
         self._keep = {}  # host arrays the library may still be reading
+        self._keep_n = None       # what kpdi_finalize will write per pattern
+        self._projection_key = None  # simulations.ProjectedDictionary.configure
+        self.result_token = 0     # bumped by every finalize()
+        self._result_crc = None   # (shape, CRC-32) of the indices the last finalize() returned
 
     # -- lifetime
     def close(self):
@@ -257,9 +262,11 @@ class Context:
             raise KpdiError(f"signal mask has {sm.size} elements, detector has {sy * sx}")
         check(load().kpdi_set_problem(self._h, int(sy), int(sx), _ptr(sm), int(metric), int(compute),
                                       int(keep_n)))
+        self._keep_n = int(keep_n)
 
     def set_keep_n(self, keep_n):
         check(load().kpdi_set_keep_n(self._h, int(keep_n)))
+        self._keep_n = int(keep_n)
 
     def set_experimental(self, patterns, navigation_mask=None):
         """patterns: (m_all, sy, sx) or (m_all, sy*sx), C-contiguous."""
@@ -352,6 +359,7 @@ class Context:
         lo = None if lower is None else np.ascontiguousarray(lower, dtype=up.dtype)
         if up.ndim != 2 or (lo is not None and lo.shape != up.shape):
             raise KpdiError("master pattern hemispheres must be 2D arrays of equal shape")
+        self._projection_key = None  # whoever cached "my master pattern is loaded" must load it again
         check(load().kpdi_set_master_pattern(self._h, _ptr(up), _ptr(lo), dtype_code(up.dtype),
                                              up.shape[1], up.shape[0]))
 
@@ -360,11 +368,13 @@ class Context:
         om = np.ascontiguousarray(om_detector_to_sample, dtype=np.float64).ravel()
         if gb.size != 4 or om.size != 9:
             raise KpdiError("gnomonic_bounds must have 4 and om_detector_to_sample 9 elements")
+        self._projection_key = None
         check(load().kpdi_set_detector(self._h, _ptr(gb), float(pcz), int(nrows), int(ncols), _ptr(om)))
         self._dc_npix = int(nrows) * int(ncols)
 
     def set_direction_cosines(self, direction_cosines):
         dc = np.ascontiguousarray(direction_cosines, dtype=np.float64).reshape(-1, 3)
+        self._projection_key = None
         check(load().kpdi_set_direction_cosines(self._h, _ptr(dc), dc.shape[0]))
         self._dc_npix = dc.shape[0]
 
@@ -473,12 +483,36 @@ class Context:
 
     def reset_topk(self):
         check(load().kpdi_reset_topk(self._h))
+        self._result_crc = None
 
-    def finalize(self, keep_n):
+    def holds_result(self, simulation_indices):
+        """Whether `simulation_indices` (n, keep_n) are the lists the last finalize() returned
+        (and that may therefore still be resident in HBM)."""
+        idx = np.ascontiguousarray(simulation_indices, dtype=np.int64)
+        return self._result_crc is not None and self._result_crc == (idx.shape, zlib.crc32(idx))
+
+    def finalize(self, keep_n=None):
+        """(scores (m, keep_n) float32, indices (m, keep_n) int64).  `keep_n` must be the value
+        last given to `set_problem` / `set_keep_n`: that is what the library writes."""
+        if keep_n is None:
+            keep_n = self._keep_n
+        if self._keep_n is None or int(keep_n) != self._keep_n:
+            raise KpdiError(f"finalize(keep_n={keep_n}) but the context keeps {self._keep_n} entries per pattern "
+                            "(set_problem / set_keep_n)")
         m = self.n_experimental
         scores = np.empty((m, keep_n), dtype=np.float32)
         indices = np.empty((m, keep_n), dtype=np.int64)
         check(load().kpdi_finalize(self._h, _ptr(scores), _ptr(indices)))
+        self.result_token += 1
+        self._result_crc = (indices.shape, zlib.crc32(indices))  # names the lists now resident in HBM
+        if indices.size and indices.max() >= 2**31 - 1:
+            # unfilled list entries (index INT_MAX, score -inf): fewer than keep_n candidates ranked, which
+            # only happens when scores are NaN (NaN / inf in the patterns) - the reference propagates
+            # NaN there (SURVEY.md 8(a): out of contract); fail clearly instead of indexing with INT_MAX
+            bad = np.flatnonzero((indices >= 2**31 - 1).any(axis=1))
+            raise KpdiError(f"{bad.size} experimental pattern(s) (first: {bad[0]}) ranked fewer than {keep_n} "
+                            "dictionary patterns: NaN scores (NaN or inf in the patterns?) or a dictionary "
+                            "smaller than keep_n")
         return scores, indices
 
     # -- multi-GPU

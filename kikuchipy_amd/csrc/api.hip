@@ -98,17 +98,30 @@ struct Rccl {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string why;  // why the last load() failed
   bool load() {
     if (lib) return true;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
     for (const char *n : names) {
-      lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-      if (lib) break;
+      h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
     }
-    if (!lib) return false;
-#define KPDI_SYM(field, name)                        \
-  field = (decltype(field))dlsym(lib, name);         \
-  if (!field) return false;
+    if (!h) {
+      const char *e = dlerror();
+      why = e ? e : "librccl.so not found";
+      return false;
+    }
+    // resolve everything into locals; `lib` (= "loaded") is only published on full success
+    Rccl t;
+#define KPDI_SYM(field, name)                                         \
+  t.field = (decltype(t.field))dlsym(h, name);                         \
+  if (!t.field) {                                                     \
+    const char *e = dlerror();                                        \
+    why = std::string("symbol ") + name + ": " + (e ? e : "missing"); \
+    dlclose(h);                                                       \
+    return false;                                                     \
+  }
     KPDI_SYM(GetUniqueId, "ncclGetUniqueId")
     KPDI_SYM(CommInitRank, "ncclCommInitRank")
     KPDI_SYM(CommDestroy, "ncclCommDestroy")
@@ -117,6 +130,14 @@ struct Rccl {
     KPDI_SYM(GroupEnd, "ncclGroupEnd")
     KPDI_SYM(GetErrorString, "ncclGetErrorString")
 #undef KPDI_SYM
+    GetUniqueId = t.GetUniqueId;
+    CommInitRank = t.CommInitRank;
+    CommDestroy = t.CommDestroy;
+    AllGather = t.AllGather;
+    GroupStart = t.GroupStart;
+    GroupEnd = t.GroupEnd;
+    GetErrorString = t.GetErrorString;
+    lib = h;
     return true;
   }
 };
@@ -1746,7 +1767,7 @@ int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
 
 int kpdi_comm_unique_id(uint8_t *id_out) {
   if (!id_out) return fail(KPDI_EINVAL, "id_out is NULL");
-  if (!g_rccl.load()) return fail(KPDI_ECOMM, "cannot load librccl: %s", dlerror());
+  if (!g_rccl.load()) return fail(KPDI_ECOMM, "cannot load librccl: %s", g_rccl.why.c_str());
   static_assert(sizeof(ncclUniqueId) == KPDI_UNIQUE_ID_BYTES, "ncclUniqueId size");
   ncclUniqueId id;
   ncclResult_t r = g_rccl.GetUniqueId(&id);
@@ -1761,7 +1782,7 @@ int kpdi_comm_init(kpdi_ctx *c, int rank, int nranks, const uint8_t *id) {
   if (!id) return fail(KPDI_EINVAL, "id is NULL");
   int rc = use_device(c);
   if (rc) return rc;
-  if (!g_rccl.load()) return fail(KPDI_ECOMM, "cannot load librccl: %s", dlerror());
+  if (!g_rccl.load()) return fail(KPDI_ECOMM, "cannot load librccl: %s", g_rccl.why.c_str());
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof uid);
   ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, uid, rank);

@@ -127,8 +127,10 @@ struct PreArgs {
 };
 
 // ---- detectors up to 19 200 pixels: everything in one pass ---------------------------------
+// `tp` (the padded taps) is a kernel parameter of its own: only a `const __restrict__` kernel argument
+// is known to be invariant, which is what lets the wave-uniform tap reads become scalar loads.
 template <typename T, int NV>
-__global__ __launch_bounds__(PP_THREADS) void preproc_fused_kernel(PreArgs a) {
+__global__ __launch_bounds__(PP_THREADS) void preproc_fused_kernel(PreArgs a, const double *__restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ float red[8];
   const int sy = a.sy, sx = a.sx, npix = sy * sx;
@@ -221,14 +223,14 @@ __global__ __launch_bounds__(PP_THREADS) void preproc_fused_kernel(PreArgs a) {
   if (a.do_dynamic) {
     __syncthreads();
     correlate_slow_axis(
-        sy, sx, a.tp, a.ntaps, a.centre, a.reflect, [&](int i) { return x[i]; },
+        sy, sx, tp, a.ntaps, a.centre, a.reflect, [&](int i) { return x[i]; },
         [&](int r, int c, float v) { tt[c * sy + r] = v; });
     __syncthreads();
     mn = INFINITY;
     mx = -INFINITY;
     const int dy_op = a.dy_operation;
     correlate_slow_axis(
-        sx, sy, a.tp, a.ntaps, a.centre, a.reflect, [&](int i) { return tt[i]; },
+        sx, sy, tp, a.ntaps, a.centre, a.reflect, [&](int i) { return tt[i]; },
         [&](int c, int r, float b) {
           const int i = r * sx + c;
           const float y = dy_op == KPDI_OP_SUBTRACT ? x[i] - b : x[i] / b;
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(PP_THREADS) void static_stream_kernel(PreArgs a) {
 
 // persistent workgroups; scratch = [gridDim.x][2][npix] floats (row pass transposed | pattern - background)
 template <typename T>
-__global__ __launch_bounds__(PP_THREADS) void dynamic_stream_kernel(PreArgs a) {
+__global__ __launch_bounds__(PP_THREADS) void dynamic_stream_kernel(PreArgs a, const double *__restrict__ tp) {
   __shared__ float red[8];
   const int sy = a.sy, sx = a.sx, npix = sy * sx;
   float *tt = a.scratch + (size_t)blockIdx.x * 2 * npix;
@@ -315,12 +317,12 @@ __global__ __launch_bounds__(PP_THREADS) void dynamic_stream_kernel(PreArgs a) {
   for (int64_t pat = blockIdx.x; pat < a.n; pat += gridDim.x) {
     T *p = (T *)a.patterns + (size_t)pat * npix;
     correlate_slow_axis(
-        sy, sx, a.tp, a.ntaps, a.centre, a.reflect, [&](int i) { return (float)p[i]; },
+        sy, sx, tp, a.ntaps, a.centre, a.reflect, [&](int i) { return (float)p[i]; },
         [&](int r, int c, float v) { tt[c * sy + r] = v; });
     __syncthreads();
     float mn = INFINITY, mx = -INFINITY;
     correlate_slow_axis(
-        sx, sy, a.tp, a.ntaps, a.centre, a.reflect, [&](int i) { return tt[i]; },
+        sx, sy, tp, a.ntaps, a.centre, a.reflect, [&](int i) { return tt[i]; },
         [&](int c, int r, float b) {
           const int i = r * sx + c;
           const float v = (float)p[i];
@@ -364,7 +366,7 @@ static hipError_t launch_pre_t(const PreLaunch &l, const PreArgs &a, bool *prep_
       hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kernel, dim3((unsigned)l.n), dim3(PP_THREADS), lds, s, b);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)l.n), dim3(PP_THREADS), lds, s, b, b.tp);
     *prep_done = prep;
     return hipGetLastError();
   }
@@ -378,7 +380,7 @@ static hipError_t launch_pre_t(const PreLaunch &l, const PreArgs &a, bool *prep_
     int grid = 0;
     const size_t need = preprocess_scratch_floats(l.sy, l.sx, l.n, &grid);
     if (!l.scratch || l.scratch_floats < need) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((dynamic_stream_kernel<T>), dim3((unsigned)grid), dim3(PP_THREADS), 0, s, a);
+    hipLaunchKernelGGL((dynamic_stream_kernel<T>), dim3((unsigned)grid), dim3(PP_THREADS), 0, s, a, a.tp);
     return hipGetLastError();
   }
   return hipSuccess;

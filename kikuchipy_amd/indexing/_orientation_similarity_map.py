@@ -30,8 +30,9 @@ def orientation_similarity_map(xmap, n_best=None, simulation_indices_prop="simul
         As in the reference.  Returns float32 of shape `(ny, nx)` or
         `(ny, nx, n_best - from_n_best + 1)`.
     context
-        A `_lib.Context` whose last `finalize()` produced `xmap`: the map is then
-        computed from the best-k lists still resident in HBM.
+        A `_lib.Context` to run on.  If its last `finalize()` produced exactly these
+        simulation indices (checked by CRC), the map is computed from the best-k lists
+        still resident in HBM; otherwise the indices are uploaded as usual.
     """
     if hasattr(xmap, "prop"):
         simulation_indices = np.asarray(xmap.prop[simulation_indices_prop])
@@ -57,8 +58,16 @@ def orientation_similarity_map(xmap, n_best=None, simulation_indices_prop="simul
     offsets = _footprint_offsets(footprint)
     ctx = context if context is not None else _lib.Context(device)
     try:
-        osm = ctx.orientation_similarity_map(None if context is not None else simulation_indices, data_shape, keep_n,
-                                             n_best, from_n_best, offsets, center_index, normalize)
+        osm = None
+        if context is not None and ctx.holds_result(simulation_indices):
+            try:
+                osm = ctx.orientation_similarity_map(None, data_shape, keep_n, n_best, from_n_best, offsets,
+                                                     center_index, normalize)
+            except _lib.KpdiError:  # the lists were dropped meanwhile (new sweep, reset): upload instead
+                osm = None
+        if osm is None:
+            osm = ctx.orientation_similarity_map(simulation_indices, data_shape, keep_n, n_best, from_n_best, offsets,
+                                                 center_index, normalize)
     finally:
         if context is None:
             ctx.close()

@@ -43,7 +43,6 @@ class Communicator:
         self._broadcast = broadcast_bytes or _torch_broadcast_bytes
         self._barrier = barrier or _torch_barrier
         self._all_gather = all_gather or _torch_all_gather
-        self._attached = set()
 
     @classmethod
     def from_env(cls):
@@ -69,12 +68,15 @@ class Communicator:
         return _concat(self._all_gather(array))
 
     def attach(self, ctx):
-        """Create the RCCL communicator of `ctx` once (collective call)."""
-        if self.world_size == 1 or id(ctx) in self._attached:
+        """Create the RCCL communicator of `ctx` once (collective call: every rank must attach
+        its context in the same order).  The attachment is recorded ON the context - not by
+        `id(ctx)`, which CPython hands to the next context once this one is collected: a new
+        context then looked attached, skipped `kpdi_comm_init` and silently merged nothing."""
+        if self.world_size == 1 or getattr(ctx, "_comm", None) is self:
             return
         uid = self.exchange_unique_id(ctx.comm_unique_id)
         ctx.comm_init(self.rank, self.world_size, uid)
-        self._attached.add(id(ctx))
+        ctx._comm = self
 
 
 def init_process_group(backend="gloo"):

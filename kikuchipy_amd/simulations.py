@@ -81,10 +81,14 @@ class ProjectedDictionary:
     # ---- engine
     def configure(self, ctx):
         """Make `ctx` hold this dictionary's master pattern and detector (once)."""
-        key = (id(self.master_upper), id(self.master_lower), id(self.detector))
+        # `Context.set_master_pattern / set_detector / set_direction_cosines` reset the key, so a
+        # refinement on the same context (which loads ITS master pattern) cannot leave a stale match;
+        # the detector enters by value: an in-place change of its PC must reach the engine
+        det = self.detector
+        key = (id(self.master_upper), id(self.master_lower), tuple(np.ravel(det.gnomonic_bounds)), float(det.pcz),
+               det.nrows, det.ncols, tuple(np.ravel(det.detector_to_sample)))
         if getattr(ctx, "_projection_key", None) != key:
             ctx.set_master_pattern(self.master_upper, self.master_lower)
-            det = self.detector
             ctx.set_detector(det.gnomonic_bounds, det.pcz, det.nrows, det.ncols, det.detector_to_sample)
             ctx._projection_key = key
             ctx._projection_refs = (self.master_upper, self.master_lower, det)  # keep the ids alive

@@ -30,6 +30,18 @@ def close_u8(out, ref, max_frac=1e-3):
     return float((d != 0).mean())
 
 
+def grey_levels(out, want, dtype):
+    """uint8: <= 1 grey level on <= 2e-3 of the pixels (synthetic noise patterns flip a little more
+    often than the Ni patterns' 1e-3).  uint16: the reference's float32 FFT round-off (~1e-6 of the
+    value) is a sizeable fraction of one of the 65 535 levels, so many pixels differ - by a few levels
+    at most, i.e. < 1/16 of a uint8 grey level."""
+    d = np.abs(out.astype(np.int64) - want.astype(np.int64))
+    if np.dtype(dtype) == np.uint16:
+        assert d.max() <= 16, d.max()
+    else:
+        assert d.max() <= 1 and (d != 0).mean() <= 2e-3, (d.max(), (d != 0).mean())
+
+
 def codes():
     from kikuchipy_amd import _lib
 
@@ -115,9 +127,7 @@ def test_fused_equals_stepwise(ctx, dtype, shape, masked, navmask, metric, kw):
     elif dtype == np.float32:
         assert np.allclose(u2, want, atol=2e-4)
     else:
-        d = np.abs(u2.astype(np.int64) - want.astype(np.int64))
-        scale = 257 if dtype == np.uint16 else 1
-        assert d.max() <= scale and (d != 0).mean() <= 2e-3
+        grey_levels(u2, want, dtype)
 
 
 def test_recorded_steps_follow_the_patterns(ctx):
@@ -160,9 +170,7 @@ def test_large_detectors_preprocess(ctx, shape, dtype):
     mask = ~ko.circular_window(shape).astype(bool)
     s, i, u, _, cnt = run_pipeline(ctx, exp, bg, dic, fused=True, mask=mask, keep_n=5)
     want = ko.remove_dynamic_background(ko.remove_static_background(exp, bg))
-    d = np.abs(u.astype(np.int64) - want.astype(np.int64))
-    scale = 257 if dtype == np.uint16 else 1
-    assert d.max() <= scale and (d != 0).mean() <= 2e-3, (d.max(), (d != 0).mean())
+    grey_levels(u, want, dtype)
     rs, ri = ko.dictionary_indexing(u, dic, keep_n=5, signal_mask=mask)
     ko.assert_topk_parity(s, i, rs, ri, atol=ATOL)
     # static only is exact at any size

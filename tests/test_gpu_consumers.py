@@ -73,11 +73,23 @@ def test_osm_from_resident_result(synth_inputs):
         scores, idx = ctx.finalize(20)
         got = ka.orientation_similarity_map(idx, shape=(6, 8), n_best=10, context=ctx)
         assert np.array_equal(got, ko.orientation_similarity_map(idx, (6, 8), n_best=10))
+        assert ctx.holds_result(idx)
+        # anything that is NOT what the last finalize() returned is uploaded, never read from the
+        # resident lists (another run's result, a merged or refined map of the same shape ...)
+        other = idx[:, ::-1].copy()
+        assert not ctx.holds_result(other)
+        got = ka.orientation_similarity_map(other, shape=(6, 8), context=ctx)
+        assert np.array_equal(got, ko.orientation_similarity_map(other, (6, 8)))
+        got = ka.orientation_similarity_map(idx[:40], shape=(5, 8), context=ctx)
+        assert np.array_equal(got, ko.orientation_similarity_map(idx[:40], (5, 8)))
+        # the raw ABI still refuses a resident map of the wrong shape / after a reset
         with pytest.raises(_lib.KpdiError, match="resident result is 48 x 20"):
-            ka.orientation_similarity_map(idx[:40], shape=(5, 8), context=ctx)
+            ctx.orientation_similarity_map(None, (5, 8), 20, 20, 20, [[0, 0]], 0, False)
         ctx.reset_topk()
         with pytest.raises(_lib.KpdiError, match="no resident result"):
-            ka.orientation_similarity_map(idx, shape=(6, 8), context=ctx)
+            ctx.orientation_similarity_map(None, (6, 8), 20, 20, 20, [[0, 0]], 0, False)
+        got = ka.orientation_similarity_map(idx, shape=(6, 8), n_best=10, context=ctx)
+        assert np.array_equal(got, ko.orientation_similarity_map(idx, (6, 8), n_best=10))
 
 
 def test_osm_on_indexing_result(synth_inputs):
