@@ -87,6 +87,8 @@ typedef struct kpdi_ctx kpdi_ctx;
 /* ---- library / device ---------------------------------------------------- */
 const char *kpdi_version(void);
 int kpdi_device_count(void);
+/* message of the last failed call made by the CALLING THREAD (thread-local storage: contexts
+ * driven from different threads never see each other's errors; valid until that thread's next call) */
 const char *kpdi_last_error(void);
 
 int kpdi_create(int device_id, kpdi_ctx **out);

@@ -24,6 +24,7 @@ computation (within the 1e-5 parity contract, not a float64 evaluation).
 """
 
 import abc
+import warnings
 
 import numpy as np
 
@@ -205,6 +206,11 @@ class _HipMetric(SimilarityMetric):
         and normalisation (_normalized_cross_correlation.py:88-128) run on the GPU
         when the first dictionary chunk arrives."""
         self.raise_error_if_invalid()
+        if self.dtype == np.float64:
+            warnings.warn(
+                "dtype=float64: the GPU engine evaluates the metric in float32 (f32 matrix cores, float32 "
+                "accumulation) and returns those scores as float64 - within 1e-5 of the reference's float64 "
+                "evaluation, not a float64 computation", UserWarning, stacklevel=2)
         if hasattr(patterns, "compute"):
             patterns = patterns.compute()
         patterns = np.asarray(patterns)

@@ -44,10 +44,110 @@ assert np.array_equal(idx, i_ref), (idx[:2], i_ref[:2])
 assert np.allclose(scores, s_ref, atol=1e-6)
 comm.barrier()
 
+# 2b. the REAL host path of a sharded run: kikuchipy_amd.dictionary_indexing(..., comm=comm) with its
+# shard / chunk intersection, Communicator.attach and the finalize ordering, run under 2 ranks.  The
+# engine behind the `_lib.Context` interface is a stand-in (no GPU here): the oracle computes every
+# pushed chunk, and `finalize` does what kpdi_finalize does with RCCL - all-gather of the per-rank
+# best-k lists + the (score desc, index asc) merge - over gloo.  Like the real context it only
+# gathers when a communicator was attached: a context that missed `comm_init` returns its own
+# shard's lists and the comparison below fails (the id()-reuse bug of round 1).
+import gc  # noqa: E402
+
+import kikuchipy_amd as ka  # noqa: E402
+from kikuchipy_amd.indexing.similarity_metrics import NormalizedCrossCorrelationMetric, NormalizedDotProductMetric  # noqa: E402
+
+
+class OracleEngineContext:
+    live = 0
+
+    def __init__(self):
+        self.comm = None
+        self.pushed = []
+        OracleEngineContext.live += 1
+
+    def __del__(self):
+        OracleEngineContext.live -= 1
+
+    def set_problem(self, sy, sx, signal_mask, metric, keep_n, compute):
+        self.sig, self.mask, self.metric, self.keep_n = (sy, sx), signal_mask, {0: "ncc", 1: "ndp"}[metric], keep_n
+        self.scores = None
+
+    def set_keep_n(self, keep_n):
+        self.keep_n = keep_n
+        self.scores = None
+
+    def set_experimental(self, patterns, navigation_mask=None):
+        nav = None if navigation_mask is None else np.asarray(navigation_mask, dtype=bool).ravel()
+        self.exp = patterns if nav is None else patterns[~nav]
+        self.scores = None
+
+    @property
+    def n_experimental(self):
+        return len(self.exp)
+
+    @staticmethod
+    def comm_unique_id():
+        return bytes(range(128))
+
+    def comm_init(self, rank, nranks, uid):
+        assert uid == bytes(range(128)) and nranks == 2
+        self.comm = (rank, nranks)
+
+    def push_dictionary_chunk(self, patterns, global_start):
+        self.pushed.append((global_start, len(patterns)))
+        k = min(self.keep_n, len(patterns))
+        s, i = ko.dictionary_indexing(self.exp, patterns, metric=self.metric, keep_n=k, signal_mask=self.mask)
+        if self.scores is None:
+            self.scores = np.full((len(self.exp), self.keep_n), -np.inf, dtype=np.float32)
+            self.idx = np.full((len(self.exp), self.keep_n), np.iinfo(np.int64).max, dtype=np.int64)
+        self.scores, self.idx = ko.merge_topk(self.scores, self.idx, s, i + global_start, self.keep_n)
+
+    def finalize(self, keep_n):
+        assert keep_n == self.keep_n
+        if self.comm is None:
+            return self.scores, self.idx
+        box = [None, None]
+        dist.all_gather_object(box, (self.scores, self.idx))
+        s = np.full_like(self.scores, -np.inf)
+        i = np.full_like(self.idx, np.iinfo(np.int64).max)
+        for s_r, i_r in box:
+            s, i = ko.merge_topk(s, i, s_r, i_r, keep_n)
+        return s, i
+
+
+exp4 = exp.reshape(3, 7, 12, 12)
+nav = np.zeros((3, 7), dtype=bool)
+nav[1, 2:5] = True
+sig = np.zeros((12, 12), dtype=bool)
+sig[:2] = True
+for call, (Metric, name, kw) in enumerate([
+        (NormalizedCrossCorrelationMetric, "ncc", dict(n_per_iteration=97)),            # chunks straddle the shard boundary
+        (NormalizedCrossCorrelationMetric, "ncc", dict(n_per_iteration=97)),            # same again: a NEW context each call
+        (NormalizedDotProductMetric, "ndp", dict(n_per_iteration=None, navigation_mask=nav, signal_mask=sig)),
+        (NormalizedCrossCorrelationMetric, "ncc", dict(n_per_iteration=250)),
+]):
+    fake = OracleEngineContext()
+    res = ka.dictionary_indexing(exp4, dic, metric=Metric(context=fake), keep_n=k, comm=comm, verbose=False, **kw)
+    assert fake.comm == (comm.rank, 2), "Communicator.attach did not reach the new context"
+    # this rank pushed exactly its shard, cut at the reference's chunk boundaries
+    assert sum(n for _, n in fake.pushed) == hi - lo and min(a for a, _ in fake.pushed) == lo
+    assert max(a + n for a, n in fake.pushed) == hi
+    per = kw["n_per_iteration"] or len(dic)
+    assert all(a // per == (a + n - 1) // per for a, n in fake.pushed)
+    s_one, i_one = ko.dictionary_indexing(exp4, dic, metric=name, keep_n=k, navigation_mask=kw.get("navigation_mask"),
+                                          signal_mask=kw.get("signal_mask"))
+    if kw.get("navigation_mask") is not None:
+        s_one, i_one, _ = ko.scatter_navigation_mask(s_one, i_one, kw["navigation_mask"], k)
+    assert np.array_equal(res.simulation_indices, i_one), (call, res.simulation_indices[:2], i_one[:2])
+    assert np.allclose(res.scores, s_one, atol=1e-6)
+    del fake, res
+    gc.collect()  # the next context may now get this one's id()
+assert OracleEngineContext.live == 0
+comm.barrier()
+
 # 3. refinement sharded over the map's patterns: every rank solves its block, the rows are
 # gathered over the control plane.  A stand-in context (the oracle's objective + SciPy, i.e. the
 # reference's own solver) replaces the GPU engine, which is absent here.
-import kikuchipy_amd as ka  # noqa: E402
 from kikuchipy_amd.indexing._refinement import refine, rotation_from_euler  # noqa: E402
 
 

@@ -172,3 +172,88 @@ def test_filters_window():
     assert np.allclose(gw, np.outer(ko.gaussian_window_1d(30, 7.5), ko.gaussian_window_1d(30, 7.5)))
     with pytest.raises(NotImplementedError, match="supports 'circular'"):
         ka.filters.Window("modified_hann", (5, 5))
+
+
+# ---------------------------------------------------------------------------------------------
+# a10: the hand-over to orix' CrystalMap (indexing/_dictionary_indexing.py:141-167 of the reference)
+class _Recorder:
+    """Stands in for orix' CrystalMap / Rotation (orix is not installed): records its arguments,
+    like the stub the golden generator runs the reference with (oracle/ref_shim.py:_Recorder)."""
+
+    def __init__(self, *args, **kwargs):
+        self.args, self.kw = args, kwargs
+
+
+@pytest.fixture
+def orix_stub(monkeypatch):
+    import sys
+    import types
+
+    calls = []
+
+    def create_coordinate_arrays(shape, step_sizes=None):
+        calls.append((tuple(shape), tuple(step_sizes)))
+        return {"x": np.arange(int(np.prod(shape))), "coords_of": tuple(shape)}, int(np.prod(shape))
+
+    orix, cm, qu = types.ModuleType("orix"), types.ModuleType("orix.crystal_map"), types.ModuleType("orix.quaternion")
+    cm.CrystalMap, cm.create_coordinate_arrays, qu.Rotation = _Recorder, create_coordinate_arrays, _Recorder
+    orix.crystal_map, orix.quaternion = cm, qu
+    for name, mod in (("orix", orix), ("orix.crystal_map", cm), ("orix.quaternion", qu)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    return calls
+
+
+@pytest.mark.parametrize("keep_n,masked", [(3, False), (3, True), (1, True), (1, False)])
+def test_to_crystal_map_hands_over_what_the_reference_does(orix_stub, keep_n, masked):
+    from kikuchipy_amd.indexing._dictionary_indexing import DictionaryIndexingResult
+
+    rng = np.random.default_rng(1)
+    nav_shape, n_dict = (3, 4), 50
+    n_all = 12
+    in_data = np.ones(n_all, dtype=bool)
+    if masked:
+        in_data[[1, 5, 6]] = False
+    m = int(in_data.sum())
+    idx = rng.integers(0, n_dict, (m, keep_n))
+    scores = np.sort(rng.random((m, keep_n)).astype(np.float32), axis=1)[:, ::-1]
+    dict_rot = rng.standard_normal((n_dict, 4))
+    # what dictionary_indexing() assembles (reference :142-166)
+    if masked:
+        s_all = np.zeros((n_all, keep_n), np.float32)
+        i_all = np.zeros((n_all, keep_n), np.int64)
+        rot = np.zeros((n_all, keep_n, 4))
+        rot[..., 0] = 1
+        s_all[in_data], i_all[in_data], rot[in_data] = scores, idx, dict_rot[idx]
+        if keep_n == 1:
+            s_all, i_all, rot = s_all.squeeze(), i_all.squeeze(), rot.reshape(-1, 4)
+    else:
+        s_all, i_all, rot = scores, idx, dict_rot[idx]
+    res = DictionaryIndexingResult(s_all, i_all, nav_shape, (1.5, 2.0), in_data, keep_n, rotations=rot,
+                                   phase_name="ni", scan_unit="um")
+    phases = object()
+    xmap = res.to_crystal_map(phase_list=phases)
+    assert orix_stub == [((3, 4), (1.5, 2.0))]                    # create_coordinate_arrays(nav_shape, step_sizes)
+    kw = xmap.kw
+    assert kw["phase_list"] is phases and kw["coords_of"] == (3, 4)  # CrystalMap(phase_list=..., **xmap_kw)
+    assert set(kw["prop"]) == {"scores", "simulation_indices"}
+    assert kw["prop"]["scores"] is s_all and kw["prop"]["simulation_indices"] is i_all
+    r = kw["rotations"].args[0]                                   # Rotation(quaternions)
+    if masked:
+        assert np.array_equal(kw["is_in_data"], in_data)
+        flat = r.reshape(n_all, keep_n, 4)
+        assert np.array_equal(flat[in_data], dict_rot[idx])       # rot[nav_mask] = rotations[simulation_indices]
+        assert np.all(flat[~in_data] == [1, 0, 0, 0])             # Rotation.identity elsewhere
+        assert r.shape == ((n_all, 4) if keep_n == 1 else (n_all, keep_n, 4))
+        assert kw["prop"]["scores"].shape == ((n_all,) if keep_n == 1 else (n_all, keep_n))
+    else:
+        assert "is_in_data" not in kw
+        assert np.array_equal(r, dict_rot[idx])
+    assert xmap.scan_unit == "um"
+
+
+def test_to_crystal_map_needs_rotations(orix_stub):
+    from kikuchipy_amd.indexing._dictionary_indexing import DictionaryIndexingResult
+
+    res = DictionaryIndexingResult(np.zeros((2, 1)), np.zeros((2, 1), int), (2,), (1,), np.ones(2, bool), 1)
+    with pytest.raises(ValueError, match="dictionary_rotations"):
+        res.to_crystal_map()
