@@ -32,6 +32,8 @@ def load():
                                                    C.c_int64, _f32p, _i64p]
         lib.kpdi_c_prepare_f64.argtypes = [_f32p, C.c_int64, C.c_int64, _i64p, C.c_int64, C.c_int, _f32p]
         lib.kpdi_c_init_topk.argtypes = [_f32p, _i64p, C.c_int64]
+        lib.kpdi_c_match_topk_fast.argtypes = lib.kpdi_c_match_topk.argtypes
+        lib.kpdi_c_prepare_f32.argtypes = lib.kpdi_c_prepare_f64.argtypes
         _lib = lib
     return _lib
 
@@ -77,4 +79,37 @@ def rows_topk_f64(exp, dictionary_chunks, rows, metric, keep_n, signal_mask=None
             y = prepare_f64(chunk[s:s + step], metric, signal_mask)
             lib.kpdi_c_match_topk_rows_f64(_p(x, _f32p), _p(local, _i64p), len(rows), _p(y, _f32p), y.shape[0],
                                            y.shape[1], keep_n, int(start) + s, _p(scores, _f32p), _p(idx, _i64p))
+    return scores, idx
+
+
+def openmp_port(exp, dic, metric="ncc", keep_n=20, n_per_iteration=None, signal_mask=None):
+    """The TIMING variant in C: the reference's chunk loop with every stage on all host cores
+    (OpenMP; AVX2 + FMA register-tiled dot products, float32) - bench.py's `cpu_baseline`
+    "c_openmp".  Returns (scores, indices)."""
+    lib = load()
+    n = dic.shape[0]
+    if n_per_iteration is None:
+        n_per_iteration = n
+    keep_n = min(keep_n, n)
+    code = {"ncc": 0, "ndp": 1}[metric]
+    pix, pp = None, None
+    if signal_mask is not None:
+        pix = np.ascontiguousarray(np.flatnonzero(~np.asarray(signal_mask, dtype=bool).ravel()), dtype=np.int64)
+        pp = _p(pix, _i64p)
+
+    def prep(raw):
+        raw = np.ascontiguousarray(np.asarray(raw).reshape(len(raw), -1), dtype=np.float32)
+        k = raw.shape[1] if pix is None else pix.size
+        out = np.empty((raw.shape[0], k), dtype=np.float32)
+        lib.kpdi_c_prepare_f32(_p(raw, _f32p), raw.shape[0], raw.shape[1], pp, k, code, _p(out, _f32p))
+        return out
+
+    x = prep(exp.reshape((-1,) + exp.shape[-2:]))
+    scores = np.empty((x.shape[0], keep_n), np.float32)
+    idx = np.empty((x.shape[0], keep_n), np.int64)
+    lib.kpdi_c_init_topk(_p(scores, _f32p), _p(idx, _i64p), scores.size)
+    for start in range(0, n, n_per_iteration):
+        y = prep(dic[start:start + n_per_iteration])
+        lib.kpdi_c_match_topk_fast(_p(x, _f32p), _p(y, _f32p), x.shape[0], y.shape[0], y.shape[1], keep_n, start,
+                                   _p(scores, _f32p), _p(idx, _i64p))
     return scores, idx
