@@ -200,6 +200,8 @@ struct kpdi_ctx {
 
   // top-k state
   DevBuf part_s, part_i;       // partial lists of one match launch
+  DevBuf tail_s, tail_i;       // partial lists of the quarter-tile tail launch (match.hip: ROWT = 1)
+  int tail_nsplit = 0;         // lists per pattern / 2 of the last run_match's tail launch, 0 = none
   DevBuf run_s[2], run_i[2];   // running best-k ping-pong
   int run_cur = 0;
   bool run_valid = false;
@@ -437,8 +439,23 @@ int ensure_running(kpdi_ctx *c) {
 }
 
 // one match launch over the prepared chunk -> partial lists
+//
+// Tail: the dictionary tiles of a row block are shared by `nsplit` workgroups; when their number is a
+// small non-multiple of nsplit (a rank's share of a sharded dictionary: 98 tiles over 16 workgroups)
+// whole tiles would leave most workgroups idle during the last round (makespan 7 tile-times for 6.1 of
+// work).  The last n_tiles % nsplit tiles are then handed out as QUARTER tiles by a second launch of the
+// kernel's 32-row form, whose lists join the merge as a third source.
 int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int nsplit, int rows_per_launch,
-              int list_len, int64_t global_start, const float *bound_s, const int *bound_i) {
+              int list_len, int64_t global_start, const float *bound_s, const int *bound_i, bool allow_tail = false) {
+  const int row_blocks_all = c->m_pad / kpdi::TILE_EXP;
+  int tail_tiles = 0;
+  c->tail_nsplit = 0;
+  if (allow_tail && c->compute == KPDI_COMPUTE_F32 && bound_s == nullptr && row_blocks_all <= rows_per_launch &&
+      !getenv("KPDI_NO_TAIL")) {
+    const int rounds = n_tiles / nsplit, rem = n_tiles % nsplit;
+    if (rounds >= 1 && rounds < 32 && rem > 0 && 4 * rem <= 3 * nsplit) tail_tiles = rem;
+  }
+  const int n_main = n_tiles - tail_tiles;
   const size_t part = (size_t)c->m_pad * 2 * nsplit * list_len;
   HIPCHK(c->part_s.reserve(part * sizeof(float)));
   HIPCHK(c->part_i.reserve(part * sizeof(int)));
@@ -446,7 +463,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   ml.dict = dict_y;
   ml.exp = c->exp_x.as<float>();
   ml.kpad = c->kpad;
-  ml.n_tiles = n_tiles;
+  ml.n_tiles = n_main;
   ml.n_valid = n_chunk;
   ml.m_pad = c->m_pad;
   ml.nsplit = nsplit;
@@ -478,7 +495,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   const char *tg_env = getenv("KPDI_TILE_GROUPS");
   ml.tile_groups = (tg_env && atoi(tg_env) == 8 && nsplit % 8 == 0) ? 8 : 1;
   const size_t ctr_bytes = (size_t)(c->m_pad / kpdi::TILE_EXP) * ml.tile_groups * sizeof(unsigned);
-  HIPCHK(c->tile_ctr.reserve(ctr_bytes));
+  HIPCHK(c->tile_ctr.reserve(2 * ctr_bytes));  // second half: the tail launch
   // every workgroup's first three draws are fixed (match.hip), the counters start behind them
   HIPCHK(kpdi::launch_fill_u32(c->tile_ctr.as<unsigned>(), 3u * (unsigned)(nsplit / ml.tile_groups),
                                (int64_t)(ctr_bytes / sizeof(unsigned)), c->stream));
@@ -507,6 +524,29 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
     if (two) {
       HIPCHK(hipEventRecord(c->ev_join, c->stream2));
       HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    }
+    if (tail_tiles > 0) {
+      // 32-row units over the rows [n_main * 128, n_chunk): the same shared bound (a slot then holds the
+      // larger of a main list's and a tail list's published entry - still backed by that many candidates)
+      const int units = (std::min(n_chunk, n_tiles * kpdi::TILE_DICT) - n_main * kpdi::TILE_DICT + 31) / 32;
+      const int ns_t = std::min(nsplit, units);
+      const size_t part_t = (size_t)c->m_pad * 2 * ns_t * list_len;
+      HIPCHK(c->tail_s.reserve(part_t * sizeof(float)));
+      HIPCHK(c->tail_i.reserve(part_t * sizeof(int)));
+      kpdi::MatchLaunch tl = ml;
+      tl.row_tiles = 1;
+      tl.row_base = n_main * kpdi::TILE_DICT;
+      tl.n_tiles = units;
+      tl.nsplit = ns_t;
+      tl.tile_groups = 1;
+      tl.part_scores = c->tail_s.as<float>();
+      tl.part_idx = c->tail_i.as<int>();
+      tl.tile_ctr = c->tile_ctr.as<unsigned>() + ctr_bytes / sizeof(unsigned);
+      HIPCHK(kpdi::launch_fill_u32(tl.tile_ctr, 3u * (unsigned)ns_t, (int64_t)row_blocks, c->stream));
+      tl.row_first = 0;
+      tl.rows = row_blocks;
+      HIPCHK(kpdi::launch_match(tl, c->stream));
+      c->tail_nsplit = ns_t;
     }
   }
   c->cnt.match_launches += 1;
@@ -598,7 +638,7 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
 
   if (k <= kpdi::KMAX_LIMIT) {
     const int len = kpdi::match_list_len(k);
-    rc = run_match(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, len, global_start, nullptr, nullptr);
+    rc = run_match(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, len, global_start, nullptr, nullptr, true);
     if (rc) return rc;
     mg.src_scores[1] = c->part_s.as<float>();
     mg.src_idx[1] = c->part_i.as<int>();
@@ -607,6 +647,15 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
     mg.src_row_stride[1] = 2 * nsplit * len;
     mg.src_list_stride[1] = len;
     mg.n_src = 2;
+    if (c->tail_nsplit > 0) {
+      mg.src_scores[2] = c->tail_s.as<float>();
+      mg.src_idx[2] = c->tail_i.as<int>();
+      mg.src_lists[2] = 2 * c->tail_nsplit;
+      mg.src_len[2] = len;
+      mg.src_row_stride[2] = 2 * c->tail_nsplit * len;
+      mg.src_list_stride[2] = len;
+      mg.n_src = 3;
+    }
   } else {
     // keep_n > 32: passes of 32 ranks; pass p only admits candidates ranked
     // strictly after the last entry of pass p-1
@@ -889,7 +938,7 @@ int kpdi_destroy(kpdi_ctx *c) {
   release_held(c);
   c->pin_out.release();
   for (DevBuf *b : {&c->pix_map, &c->exp_raw, &c->row_map, &c->exp_x, &c->dict_raw, &c->dict_y, &c->part_s,
-                    &c->part_i, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
+                    &c->part_i, &c->tail_s, &c->tail_i, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
                     &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps, &c->inv_map, &c->pre_scratch,
                     &c->mp_packed, &c->dcos, &c->rot, &c->proj_out,
                     &c->ref_raw, &c->ref_map, &c->ref_rowcol, &c->ref_pat, &c->ref_sqn, &c->ref_in, &c->ref_out,

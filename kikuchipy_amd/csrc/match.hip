@@ -66,6 +66,7 @@ struct MatchArgs {
   const float *dict;
   const float *exp;
   int kpad, n_tiles, n_valid, nsplit, idx_base, row_first;
+  int row_base;  // ROWT = 1 (32-row tail units): dictionary row of unit 0, a multiple of 32
   float *part_scores;
   int *part_idx;
   const float *bound_score;
@@ -171,7 +172,7 @@ __device__ __forceinline__ float next_up(float f) {
 // last entry), and only a register in which some lane does takes the exact path (valid
 // row, multi-pass bound, insertion).  The register index r is a scalar loop counter
 // (relative VGPR addressing), so there is one copy of the insertion code per accumulator.
-template <int KMAX, bool BOUNDED, int FORM>
+template <int KMAX, bool BOUNDED, int FORM, int ROWT>
 __device__ __forceinline__ void scan_tile(f32x16 (&acc)[4], float (&best)[KMAX], int (&best_idx)[KMAX],
                                           float gthr, float ub, int ub_idx, int row0, int n_valid,
                                           int idx_base) {
@@ -180,7 +181,7 @@ __device__ __forceinline__ void scan_tile(f32x16 (&acc)[4], float (&best)[KMAX],
   // v > best[KMAX-1]  <=>  v >= nextafter(best[KMAX-1], +inf)   (scores are finite)
   float thr = fmaxf(gthr, next_up(best[KMAX - 1]));
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
+  for (int rt = 0; rt < ROWT; ++rt) {
     if (FORM == 2) {
       // float16 form: first a screen over the 16 registers with plain (unrolled) compares - bit r of
       // `hot` = some lane of register r reaches the threshold as it stands now - then only those
@@ -285,7 +286,14 @@ __device__ __forceinline__ void issue_piece(const char *gd, const char *ge, size
 #define KPDI_LANE_BASE goff
 #endif
 
-template <int KMAX, bool BOUNDED, int FORM>
+// ROWT = row tiles of 32 dictionary patterns per unit of work: 4 = a whole 128-pattern tile; 1 = the
+// TAIL form (f32 only): the last n_tiles % nsplit tiles of a row block are handed out as quarter
+// tiles, so that a launch whose tile count is a small non-multiple of its workgroups (a rank's
+// share of a dictionary sharded over several GPUs) ends within a quarter tile-time of its even share.
+// A quarter of a 16 KB slab block is its contiguous 4 KB piece q (rows 32q .. 32q + 31: slots
+// 256q .. 256q + 255, same swizzle), i.e. ONE LDS-DMA piece per wave; everything else is the tile
+// code with the row-tile loops cut to one.
+template <int KMAX, bool BOUNDED, int FORM, int ROWT = 4>
 __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -296,6 +304,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
   // kernel arguments into locals (nothing below takes the address of `a`)
   const float *a_dict = a.dict;
   const int n_tiles = a.n_tiles, n_valid = a.n_valid, idx_base = a.idx_base;
+  const int row_base = a.row_base;
   unsigned *gthr_arr = a.gthr;
   const int kpad = a.kpad;
   const int nslab = kpad / TILE_K;
@@ -381,7 +390,12 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
   {                                                                                              \
     int t_ = ld_pos == 0 ? t0 : (ld_pos == 1 ? t1 : t2);                                         \
     t_ = t_ < last_tile ? t_ : last_tile; /* past the end: harmless re-load, no branch */        \
-    gd = dict_base + (size_t)t_ * tile_bytes + (size_t)ld_slab * SLAB_BYTES;                     \
+    if (ROWT == 4) {                                                                             \
+      gd = dict_base + (size_t)t_ * tile_bytes + (size_t)ld_slab * SLAB_BYTES;                   \
+    } else { /* unit t_ = 32 rows from row_base + 32 t_: block (row >> 7), quarter (row >> 5) & 3 */ \
+      const int row_ = row_base + 32 * t_;                                                       \
+      gd = dict_base + (size_t)(row_ >> 7) * tile_bytes + (size_t)ld_slab * SLAB_BYTES + ((row_ >> 5) & 3) * 4096; \
+    }                                                                                            \
     ge = exp_base + (size_t)ld_slab * SLAB_BYTES;                                                \
   }
 #define KPDI_CURSOR_ADVANCE()                                  \
@@ -394,12 +408,16 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
   }
     // ---- prologue: slabs 0 and 1 in flight, then everything landed and visible
     KPDI_CURSOR_SET();
+    // (ROWT = 1: the dictionary part of a slab is its one 4 KB quarter = piece 0 of every wave)
+#define KPDI_PIECE_LIVE(p) (ROWT == 4 || (p) == 0 || (p) >= 4)
 #pragma unroll
-    for (int p = 0; p < 12; ++p) issue_piece(gd, ge, tile_bytes, smem + ld_stage * STAGE_BYTES, wv, p KPDI_GOFF_ARG);
+    for (int p = 0; p < 12; ++p)
+      if (KPDI_PIECE_LIVE(p)) issue_piece(gd, ge, tile_bytes, smem + ld_stage * STAGE_BYTES, wv, p KPDI_GOFF_ARG);
     KPDI_CURSOR_ADVANCE();
     KPDI_CURSOR_SET();
 #pragma unroll
-    for (int p = 0; p < 12; ++p) issue_piece(gd, ge, tile_bytes, smem + ld_stage * STAGE_BYTES, wv, p KPDI_GOFF_ARG);
+    for (int p = 0; p < 12; ++p)
+      if (KPDI_PIECE_LIVE(p)) issue_piece(gd, ge, tile_bytes, smem + ld_stage * STAGE_BYTES, wv, p KPDI_GOFF_ARG);
     KPDI_CURSOR_ADVANCE();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -410,7 +428,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
     constexpr bool SPLIT = FORM == 1;
     f32x4 fa[2][SPLIT ? 8 : 4], fb[2][SPLIT ? 4 : 2];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) fa[0][rt] = *(const f32x4 *)(smem + rt * 4096 + frag[0]);
+    for (int rt = 0; rt < ROWT; ++rt) fa[0][rt] = *(const f32x4 *)(smem + rt * 4096 + frag[0]);
 #pragma unroll
     for (int c = 0; c < 2; ++c) fb[0][c] = *(const f32x4 *)(smem + exp_frag + c * 4096 + frag[0]);
     if (SPLIT) {
@@ -428,7 +446,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
       // instead of being shuttled between register classes every step)
       f32x16 acc0[4], acc1[4];
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
+      for (int rt = 0; rt < ROWT; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[rt][r] = acc1[rt][r] = 0.f;
 #pragma clang loop unroll(disable)
@@ -525,7 +543,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) {
+          for (int rt = 0; rt < ROWT; ++rt) {
             mfma_acc(acc0[rt], fa[cur][rt][j], fb[cur][0][j]);
             mfma_acc(acc1[rt], fa[cur][rt][j], fb[cur][1][j]);
           }
@@ -533,14 +551,14 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
           // ... the fragments of the next pixel group (for kg = 3: of the next slab)
           if (j < 2) {
             const char *src = kg < 3 ? ls + frag[kg + 1] : ls_next + frag[0];
-            fa[cur ^ 1][2 * j] = *(const f32x4 *)(src + (2 * j) * 4096);
-            fa[cur ^ 1][2 * j + 1] = *(const f32x4 *)(src + (2 * j + 1) * 4096);
+            if (2 * j < ROWT) fa[cur ^ 1][2 * j] = *(const f32x4 *)(src + (2 * j) * 4096);
+            if (2 * j + 1 < ROWT) fa[cur ^ 1][2 * j + 1] = *(const f32x4 *)(src + (2 * j + 1) * 4096);
             fb[cur ^ 1][j] = *(const f32x4 *)(src + exp_frag + j * 4096);
           }
           // ... and the slab two steps ahead: this wave's 12 LDS-DMA pieces
           if (kg == 2) {
-            issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * j KPDI_GOFF_ARG);
-            issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * j + 1 KPDI_GOFF_ARG);
+            if (KPDI_PIECE_LIVE(2 * j)) issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * j KPDI_GOFF_ARG);
+            if (KPDI_PIECE_LIVE(2 * j + 1)) issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * j + 1 KPDI_GOFF_ARG);
           }
           if (kg == 3) issue_piece(gd, ge, tile_bytes, ld_base, wv, 8 + j KPDI_GOFF_ARG);
           __builtin_amdgcn_sched_barrier(0);
@@ -552,19 +570,19 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
       }  // slabs
       // the last MFMAs (16 passes) must have written the accumulators before they are read
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
+      for (int rt = 0; rt < ROWT; ++rt)
         asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc0[rt]), "+a"(acc1[rt]));
       {
         // ---- epilogue of the tile
-        const int row0 = t0 * TILE_DICT + 4 * (lane >> 5);
+        const int row0 = (ROWT == 4 ? t0 * TILE_DICT : row_base + 32 * t0) + 4 * (lane >> 5);
         float pub0 = best0[0], pub1 = best1[0];  // entry bound_rank-1 before the scan
 #pragma unroll
         for (int j = 1; j < KMAX; ++j) {
           pub0 = j == bound_rank - 1 ? best0[j] : pub0;
           pub1 = j == bound_rank - 1 ? best1[j] : pub1;
         }
-        scan_tile<KMAX, BOUNDED, FORM>(acc0, best0, bidx0, g0, ub0, ubi0, row0, n_valid, idx_base);
-        scan_tile<KMAX, BOUNDED, FORM>(acc1, best1, bidx1, g1, ub1, ubi1, row0, n_valid, idx_base);
+        scan_tile<KMAX, BOUNDED, FORM, ROWT>(acc0, best0, bidx0, g0, ub0, ubi0, row0, n_valid, idx_base);
+        scan_tile<KMAX, BOUNDED, FORM, ROWT>(acc1, best1, bidx1, g1, ub1, ubi1, row0, n_valid, idx_base);
         // publish the list entry the bound is built from, if it rose
         float now0 = best0[0], now1 = best1[0];
 #pragma unroll
@@ -613,17 +631,17 @@ int match_list_len(int k) {
 
 int match_blocks_per_cu() { return 1; }
 
-template <int KMAX, bool BOUNDED, int FORM>
+template <int KMAX, bool BOUNDED, int FORM, int ROWT = 4>
 static hipError_t launch_t(const MatchArgs &args, int grid, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)match_topk_kernel<KMAX, BOUNDED, FORM>,
+    hipError_t e = hipFuncSetAttribute((const void *)match_topk_kernel<KMAX, BOUNDED, FORM, ROWT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 32);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((match_topk_kernel<KMAX, BOUNDED, FORM>), dim3(grid), dim3(MATCH_THREADS), LDS_BYTES + 32, s,
-                     args);
+  hipLaunchKernelGGL((match_topk_kernel<KMAX, BOUNDED, FORM, ROWT>), dim3(grid), dim3(MATCH_THREADS), LDS_BYTES + 32,
+                     s, args);
   return hipGetLastError();
 }
 
@@ -646,8 +664,19 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   g.bound_grouped = a.bound_grouped;
   g.tile_ctr = a.tile_ctr;
   g.tile_groups = a.tile_groups;
+  g.row_base = a.row_base;
   const int grid = a.rows * a.nsplit;
   const bool bounded = a.bound_score != nullptr;
+  if (a.row_tiles == 1) {  // tail form: f32, single pass
+    if (a.operand_form != 0 || bounded || (a.row_base & 31)) return hipErrorInvalidValue;
+    switch (a.list_len) {
+      case 1: return launch_t<1, false, 0, 1>(g, grid, s);
+      case 8: return launch_t<8, false, 0, 1>(g, grid, s);
+      case 20: return launch_t<20, false, 0, 1>(g, grid, s);
+      case 32: return launch_t<32, false, 0, 1>(g, grid, s);
+      default: return hipErrorInvalidValue;
+    }
+  }
 #define KPDI_CASE(K)                                                                             \
   case K:                                                                                        \
     if (a.operand_form == 2) return bounded ? launch_t<K, true, 2>(g, grid, s) : launch_t<K, false, 2>(g, grid, s); \

@@ -248,8 +248,8 @@ def test_sharded_sweep_equals_full_sweep(synth_inputs):
     with _lib.Context(0) as c:
         ref_s, ref_i = run_engine(c, exp, dic, keep_n=k)
         parts = []
-        for r in range(4):
-            lo, hi = shard_range(len(dic), r, 4)
+        for r in range(8):
+            lo, hi = shard_range(len(dic), r, 8)
             c.set_problem(60, 60, None, _lib.METRIC_NCC, k)
             c.set_experimental(exp)
             c.push_dictionary_chunk(dic[lo:hi], lo)
@@ -259,6 +259,36 @@ def test_sharded_sweep_equals_full_sweep(synth_inputs):
     order = np.lexsort((i, -s), axis=1)[:, :k]
     assert np.array_equal(np.take_along_axis(i, order, 1), ref_i)
     assert np.array_equal(np.take_along_axis(s, order, 1), ref_s)
+
+
+@pytest.mark.parametrize("n,metric,k", [(12500, "ncc", 20), (12500 + 128 * 5 + 3, "ndp", 8), (25000, "ncc", 1)])
+def test_quarter_tile_tail(n, metric, k, monkeypatch):
+    """A rank's share of configs[1] sharded over 8 (4) GPUs: 98 (196) dictionary tiles over the 16 workgroups
+    of a row block.  The last n_tiles % 16 tiles are swept as QUARTER tiles by the kernel's 32-row form
+    (api.hip: run_match); the result is bit-identical to whole tiles, incl. a partly filled last unit."""
+    from kikuchipy_amd import _lib
+
+    rng = np.random.default_rng(21)
+    exp = rng.integers(0, 256, (4096, 60, 60), dtype=np.uint8)
+    dic = rng.random((n, 60, 60), dtype=np.float32)
+    dic[n - 5] = exp[77].astype(np.float32)  # planted into the tail units
+    dic[n - 200] = exp[4000].astype(np.float32)
+    code = {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[metric]
+    res = {}
+    with _lib.Context(0) as c:
+        for tail in (True, False):
+            if not tail:
+                monkeypatch.setenv("KPDI_NO_TAIL", "1")
+            c.set_problem(60, 60, None, code, k)
+            c.set_experimental(exp)
+            c.push_dictionary_chunk(dic, 1000)
+            res[tail] = c.finalize(k)
+    assert np.array_equal(res[True][1], res[False][1]) and np.array_equal(res[True][0], res[False][0])
+    s, i = res[True]
+    assert i[77, 0] == 1000 + n - 5 and i[4000, 0] == 1000 + n - 200
+    rows = np.array([0, 77, 1234, 4000, 4095])
+    rs, ri = ko.dictionary_indexing(exp[rows], dic, metric=metric, keep_n=k)
+    ko.assert_topk_parity(s[rows], i[rows] - 1000, rs, ri, atol=ATOL)
 
 
 @pytest.mark.parametrize("k,metric", [(20, "ncc"), (40, "ndp")])
