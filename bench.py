@@ -148,9 +148,16 @@ def cpu_baseline(w, exp, dic, bg, mask, n_sample):
     `value` is the faster of the two."""
     from oracle import c_oracle, cpu_port
 
-    cores = os.cpu_count() or 1
-    blas = cpu_port.blas_threads()
+    visible = os.cpu_count() or 1
+    cores = c_oracle.effective_cpus()  # what the cgroup quota / affinity mask really grant
+    blas = min(cpu_port.blas_threads(), cores)
     n_proc = max(1, cores // max(blas, 1))
+    try:
+        from threadpoolctl import threadpool_limits
+
+        threadpool_limits(limits=blas, user_api="blas")
+    except Exception:
+        pass
     t0 = time.perf_counter()
     pp_time = 0.0
     if w["preprocess"]:
@@ -175,7 +182,7 @@ def cpu_baseline(w, exp, dic, bg, mask, n_sample):
     variants["c_openmp"] = {
         "patterns_per_s": w["m"] / (t_c * w["n"] / n_sample + pp_time),
         "sample_seconds": round(t_c, 2),
-        "how": f"oracle/kpdi_oracle_c.c kpdi_c_match_topk_fast, OpenMP over {cores} cores, AVX2 + FMA",
+        "how": f"oracle/kpdi_oracle_c.c kpdi_c_match_topk_fast, OpenMP over {cores} threads, AVX2 + FMA",
     }
     best = max(variants, key=lambda k: variants[k]["patterns_per_s"])
     return {
@@ -186,7 +193,8 @@ def cpu_baseline(w, exp, dic, bg, mask, n_sample):
         "best_variant": best,
         "variants": variants,
         "sample": (f"{w['m']} exp x first {n_sample} dict patterns, n_per_iteration=2000, scaled linearly to "
-                   f"N={w['n']}; host: {cores} cores, BLAS pool {blas} threads"
+                   f"N={w['n']}; host: {visible} logical CPUs visible, {cores} usable (cgroup CPU quota / affinity), "
+                   f"BLAS pool {blas} threads"
                    + (f"; pre-processing (NumPy oracle) timed on 256 patterns, scaled to all cores "
                       f"({pp_time:.2f} s)" if w["preprocess"] else "")),
         "measured_seconds": round(time.perf_counter() - t0, 2),

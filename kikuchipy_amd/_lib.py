@@ -7,7 +7,6 @@ package: if the library is missing, or no gfx950 GPU is visible, calls raise.
 
 import ctypes as C
 import os
-import zlib
 
 import numpy as np
 
@@ -232,7 +231,7 @@ class Context:
         self._keep_n = None       # what kpdi_finalize will write per pattern
         self._projection_key = None  # simulations.ProjectedDictionary.configure
         self.result_token = 0     # bumped by every finalize()
-        self._result_crc = None   # (shape, CRC-32) of the indices the last finalize() returned
+        self._last_indices = None  # the indices the last finalize() returned
 
     # -- lifetime
     def close(self):
@@ -483,13 +482,16 @@ class Context:
 
     def reset_topk(self):
         check(load().kpdi_reset_topk(self._h))
-        self._result_crc = None
+        self._last_indices = None
 
     def holds_result(self, simulation_indices):
         """Whether `simulation_indices` (n, keep_n) are the lists the last finalize() returned
         (and that may therefore still be resident in HBM)."""
-        idx = np.ascontiguousarray(simulation_indices, dtype=np.int64)
-        return self._result_crc is not None and self._result_crc == (idx.shape, zlib.crc32(idx))
+        last = self._last_indices
+        if last is None:
+            return False
+        idx = np.asarray(simulation_indices)
+        return idx.shape == last.shape and np.array_equal(idx, last)
 
     def finalize(self, keep_n=None):
         """(scores (m, keep_n) float32, indices (m, keep_n) int64).  `keep_n` must be the value
@@ -504,8 +506,8 @@ class Context:
         indices = np.empty((m, keep_n), dtype=np.int64)
         check(load().kpdi_finalize(self._h, _ptr(scores), _ptr(indices)))
         self.result_token += 1
-        self._result_crc = (indices.shape, zlib.crc32(indices))  # names the lists now resident in HBM
-        if indices.size and indices.max() >= 2**31 - 1:
+        self._last_indices = indices  # what is now resident in HBM (holds_result)
+        if indices.size and indices[:, -1].max() >= 2**31 - 1:  # unfilled entries rank last
             # unfilled list entries (index INT_MAX, score -inf): fewer than keep_n candidates ranked, which
             # only happens when scores are NaN (NaN / inf in the patterns) - the reference propagates
             # NaN there (out of contract); fail clearly instead of indexing with INT_MAX

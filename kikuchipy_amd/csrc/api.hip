@@ -396,7 +396,14 @@ int prepare_experimental(kpdi_ctx *c) {
   if (!c->have_exp) return fail(KPDI_EINVAL, "no experimental patterns set");
   if (!c->have_problem) return fail(KPDI_EINVAL, "kpdi_set_problem has not been called");
   HIPCHK(c->exp_x.reserve((size_t)c->m_pad * c->kpad * sizeof(float)));
-  HIPCHK(hipMemsetAsync(c->exp_x.p, 0, (size_t)c->m_pad * c->kpad * sizeof(float), c->stream));
+  {
+    // the preparation kernels write every column of every valid row; only the rows beyond m need zeros
+    // (from the start of the 128-pattern tile m falls into: a tile's rows are interleaved)
+    const size_t first = (size_t)(c->m / kpdi::TILE_DICT) * kpdi::TILE_DICT;
+    if (first < (size_t)c->m_pad)
+      HIPCHK(hipMemsetAsync(c->exp_x.as<float>() + first * c->kpad, 0, ((size_t)c->m_pad - first) * c->kpad * sizeof(float),
+                            c->stream));
+  }
   bool fused = false;
   int rc = flush_preprocess(c, true, &fused);
   if (rc) return rc;

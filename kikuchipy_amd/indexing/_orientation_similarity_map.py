@@ -31,7 +31,7 @@ def orientation_similarity_map(xmap, n_best=None, simulation_indices_prop="simul
         `(ny, nx, n_best - from_n_best + 1)`.
     context
         A `_lib.Context` to run on.  If its last `finalize()` produced exactly these
-        simulation indices (checked by CRC), the map is computed from the best-k lists
+        simulation indices (compared element by element), the map is computed from the best-k lists
         still resident in HBM; otherwise the indices are uploaded as usual.
     """
     if hasattr(xmap, "prop"):

@@ -20,6 +20,34 @@ _f32p, _i64p = C.POINTER(C.c_float), C.POINTER(C.c_int64)
 _lib = None
 
 
+def effective_cpus():
+    """CPUs this process can actually use: visible CPUs, limited by the affinity mask and by the
+    cgroup CPU quota (the GPU boxes show 256 logical CPUs under a 16-CPU quota; more runnable
+    threads than that only get throttled)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]) + 0.5)))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def load():
     global _lib
     if _lib is None:
@@ -32,6 +60,8 @@ def load():
                                                    C.c_int64, _f32p, _i64p]
         lib.kpdi_c_prepare_f64.argtypes = [_f32p, C.c_int64, C.c_int64, _i64p, C.c_int64, C.c_int, _f32p]
         lib.kpdi_c_init_topk.argtypes = [_f32p, _i64p, C.c_int64]
+        lib.kpdi_c_set_threads.argtypes = [C.c_int]
+        lib.kpdi_c_set_threads(effective_cpus())
         lib.kpdi_c_match_topk_fast.argtypes = lib.kpdi_c_match_topk.argtypes
         lib.kpdi_c_prepare_f32.argtypes = lib.kpdi_c_prepare_f64.argtypes
         _lib = lib

@@ -16,9 +16,15 @@
  */
 #include <immintrin.h>
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* OpenMP threads of everything below (a container's CPU quota can be far below its visible cores) */
+void kpdi_c_set_threads(int n) {
+  if (n > 0) omp_set_num_threads(n);
+}
 
 /* rows: n x k, in place.  metric 0 = ncc (subtract mean first), 1 = ndp. */
 void kpdi_c_normalize(float *rows, int64_t n, int64_t k, int metric) {

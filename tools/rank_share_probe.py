@@ -28,7 +28,7 @@ with _lib.Context(0) as ctx:
     for tail in (True, False):
         if not tail:
             os.environ["KPDI_NO_TAIL"] = "1"
-        for ranks in (1, 2, 4, 8, 16):
+        for ranks in [int(x) for x in os.environ.get("RANKS", "1,2,4,8,16").split(",")]:
             lo, hi = shard_range(n, 0, ranks)
             ctx.set_profiling(True)
             reps = 20
@@ -45,6 +45,8 @@ with _lib.Context(0) as ctx:
             ctx.set_profiling(False)
             if ranks == 1 and tail:
                 t1 = dt
+            if t1 is None:
+                t1 = float(os.environ.get("T1_MS", "21.97"))
             key = f"{ranks}" + ("" if tail else "_whole_tiles_only")
             out["ranks"][key] = {
                 "shard_patterns": hi - lo, "tiles": -(-(hi - lo) // 128), "ms_per_step": round(dt, 4),
