@@ -201,6 +201,7 @@ struct kpdi_ctx {
   // top-k state
   DevBuf part_s, part_i;       // partial lists of one match launch
   DevBuf tail_s, tail_i;       // partial lists of the quarter-tile tail launch (match.hip: ROWT = 1)
+  DevBuf list16;               // float16 form: home of the per-lane lists during a launch (match16.hip)
   int tail_nsplit = 0;         // lists per pattern / 2 of the last run_match's tail launch, 0 = none
   DevBuf run_s[2], run_i[2];   // running best-k ping-pong
   int run_cur = 0;
@@ -309,6 +310,9 @@ void dtype_range(int dtype, float *omin, float *omax) {
 int prep_metric(const kpdi_ctx *c) {
   return c->metric == KPDI_METRIC_NDP && c->compute != KPDI_COMPUTE_F16 ? 2 : c->metric;
 }
+
+// patterns per dictionary tile of the match kernel in use (the float16 form has its own kernel)
+int dict_tile(const kpdi_ctx *c) { return c->compute == KPDI_COMPUTE_F16 ? kpdi::F16_TILE : kpdi::TILE_DICT; }
 
 int use_device(kpdi_ctx *c) {
   HIPCHK(hipSetDevice(c->device));
@@ -463,7 +467,9 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
     if (rounds >= 1 && rounds < 32 && rem > 0 && 4 * rem <= 3 * nsplit) tail_tiles = rem;
   }
   const int n_main = n_tiles - tail_tiles;
-  const size_t part = (size_t)c->m_pad * 2 * nsplit * list_len;
+  const bool f16 = c->compute == KPDI_COMPUTE_F16;
+  const int lists_per_split = f16 ? 4 : 2;  // match16.hip: two waves share a pattern's dictionary rows
+  const size_t part = (size_t)c->m_pad * lists_per_split * nsplit * list_len;
   HIPCHK(c->part_s.reserve(part * sizeof(float)));
   HIPCHK(c->part_i.reserve(part * sizeof(int)));
   kpdi::MatchLaunch ml;
@@ -484,7 +490,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   {
     // the published ranks are only comparable under one plan: (re)initialise when it changes
     int rank, grouped, used;
-    kpdi::bound_plan(2 * nsplit, list_len, &rank, &grouped, &used);
+    kpdi::bound_plan(lists_per_split * nsplit, list_len, &rank, &grouped, &used);
     const int key = (rank << 8) | (grouped << 7) | used;
     if (key != c->bound_key || bound_s != nullptr) {
       HIPCHK(c->gthr.reserve((size_t)c->m_pad * kpdi::BOUND_SLOTS * sizeof(unsigned)));
@@ -523,10 +529,21 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
       HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
     int j = 0;
+    if (f16)
+      HIPCHK(c->list16.reserve(2 * (two ? 2 : 1) *
+                               kpdi::match16_scratch_bytes(std::min(rows_per_launch, row_blocks) * nsplit, list_len)));
     for (int r0 = 0; r0 < row_blocks; r0 += rows_per_launch, ++j) {
       ml.row_first = r0;
       ml.rows = std::min(rows_per_launch, row_blocks - r0);
-      HIPCHK(kpdi::launch_match(ml, (two && (j & 1)) ? c->stream2 : c->stream));
+      hipStream_t st = (two && (j & 1)) ? c->stream2 : c->stream;
+      if (f16) {
+        // launches on the two streams overlap: each stream has its own list scratch
+        char *scratch = (char *)c->list16.p +
+                        ((two && (j & 1)) ? 2 * kpdi::match16_scratch_bytes(std::min(rows_per_launch, row_blocks) * nsplit, list_len) : 0);
+        HIPCHK(kpdi::launch_match16(ml, scratch, st));
+      } else {
+        HIPCHK(kpdi::launch_match(ml, st));
+      }
     }
     if (two) {
       HIPCHK(hipEventRecord(c->ev_join, c->stream2));
@@ -566,11 +583,12 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
 // raw chunk (device) -> prepared layout at `out` (n_pad rows of kpad floats, tiles of 128 patterns);
 // `out` may point into a larger buffer at a tile boundary
 int prepare_chunk(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, float *out) {
-  const int n_pad = kpdi::round_up(n_chunk, kpdi::TILE_DICT);
-  const int n_tiles = n_pad / kpdi::TILE_DICT;
-  if (n_pad > n_chunk)  // rows of the last 128-pattern tile are interleaved: clear the whole tile
-    HIPCHK(hipMemsetAsync(out + (size_t)(n_tiles - 1) * kpdi::TILE_DICT * c->kpad, 0,
-                          (size_t)kpdi::TILE_DICT * c->kpad * sizeof(float), c->stream));
+  const int tile = dict_tile(c);
+  const int n_pad = kpdi::round_up(n_chunk, tile);
+  const int n_tiles = n_pad / tile;
+  if (n_pad > n_chunk)  // rows of the last tile are interleaved: clear the whole tile
+    HIPCHK(hipMemsetAsync(out + (size_t)(n_tiles - 1) * tile * c->kpad, 0, (size_t)tile * c->kpad * sizeof(float),
+                          c->stream));
   kpdi::PrepLaunch p;
   p.raw = d_patterns;
   p.dtype = dtype;
@@ -607,7 +625,7 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
   if (rc) return rc;
   if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
   if (c->m == 0) return KPDI_OK;
-  HIPCHK(c->dict_y.reserve((size_t)kpdi::round_up(n_chunk, kpdi::TILE_DICT) * c->kpad * sizeof(float)));
+  HIPCHK(c->dict_y.reserve((size_t)kpdi::round_up(n_chunk, dict_tile(c)) * c->kpad * sizeof(float)));
   rc = prepare_chunk(c, d_patterns, dtype, n_chunk, c->dict_y.as<float>());
   if (rc) return rc;
   return sweep_prepared(c, c->dict_y.as<float>(), n_chunk, global_start);
@@ -619,7 +637,7 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
   if (rc) return rc;
   rc = ensure_running(c);
   if (rc) return rc;
-  const int n_tiles = kpdi::round_up(n_chunk, kpdi::TILE_DICT) / kpdi::TILE_DICT;
+  const int n_tiles = kpdi::round_up(n_chunk, dict_tile(c)) / dict_tile(c);
 
   const int row_blocks = c->m_pad / kpdi::TILE_EXP;
   int rows_per_launch = row_blocks;
@@ -649,9 +667,10 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
     if (rc) return rc;
     mg.src_scores[1] = c->part_s.as<float>();
     mg.src_idx[1] = c->part_i.as<int>();
-    mg.src_lists[1] = 2 * nsplit;
+    const int lps = c->compute == KPDI_COMPUTE_F16 ? 4 : 2;  // lists per pattern and split (run_match)
+    mg.src_lists[1] = lps * nsplit;
     mg.src_len[1] = len;
-    mg.src_row_stride[1] = 2 * nsplit * len;
+    mg.src_row_stride[1] = lps * nsplit * len;
     mg.src_list_stride[1] = len;
     mg.n_src = 2;
     if (c->tail_nsplit > 0) {
@@ -687,9 +706,10 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
       pm.n_src = 1;
       pm.src_scores[0] = c->part_s.as<float>();
       pm.src_idx[0] = c->part_i.as<int>();
-      pm.src_lists[0] = 2 * nsplit;
+      const int lps = c->compute == KPDI_COMPUTE_F16 ? 4 : 2;
+      pm.src_lists[0] = lps * nsplit;
       pm.src_len[0] = len;
-      pm.src_row_stride[0] = 2 * nsplit * len;
+      pm.src_row_stride[0] = lps * nsplit * len;
       pm.src_list_stride[0] = len;
       pm.out_scores = c->loc_s.as<float>();
       pm.out_idx = c->loc_i.as<int>();
@@ -848,6 +868,7 @@ std::vector<int64_t> upload_pieces(const kpdi_ctx *c, int64_t n_chunk, size_t ro
       if (swept < best - 1e-9) best = swept, piece = p;
     }
   }
+  if (c->compute == KPDI_COMPUTE_F16) piece = (piece + 1) / 2 * 2;  // whole 256-pattern tiles of match16.hip
   std::vector<int64_t> out;
   for (int64_t left = n_chunk, per = piece * kpdi::TILE_DICT; left > 0; left -= per) out.push_back(std::min(per, left));
   return out;
@@ -857,7 +878,7 @@ std::vector<int64_t> upload_pieces(const kpdi_ctx *c, int64_t n_chunk, size_t ro
 int new_held_chunk(kpdi_ctx *c, int64_t n_chunk, int64_t global_start, float **out) {
   c->held.emplace_back();
   kpdi_ctx::HeldChunk &h = c->held.back();
-  const hipError_t e = h.y.reserve((size_t)kpdi::round_up(n_chunk, kpdi::TILE_DICT) * c->kpad * sizeof(float));
+  const hipError_t e = h.y.reserve((size_t)kpdi::round_up(n_chunk, dict_tile(c)) * c->kpad * sizeof(float));
   if (e != hipSuccess) {
     c->held.pop_back();
     return fail(KPDI_ENOMEM, "no device memory for a resident chunk of %lld patterns: %s", (long long)n_chunk,
@@ -945,7 +966,7 @@ int kpdi_destroy(kpdi_ctx *c) {
   release_held(c);
   c->pin_out.release();
   for (DevBuf *b : {&c->pix_map, &c->exp_raw, &c->row_map, &c->exp_x, &c->dict_raw, &c->dict_y, &c->part_s,
-                    &c->part_i, &c->tail_s, &c->tail_i, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
+                    &c->part_i, &c->tail_s, &c->tail_i, &c->list16, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
                     &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps, &c->inv_map, &c->pre_scratch,
                     &c->mp_packed, &c->dcos, &c->rot, &c->proj_out,
                     &c->ref_raw, &c->ref_map, &c->ref_rowcol, &c->ref_pat, &c->ref_sqn, &c->ref_in, &c->ref_out,
@@ -1020,10 +1041,10 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   c->npix = npix;
   c->have_sig_mask = signal_mask != nullptr;
   c->k_kept = signal_mask ? (int)keep.size() : npix;
-  // floats per prepared row; the float16 form packs two pixels into one: 64-pixel slabs.  `ndp`
-  // rows carry one extra column (prep.hip: centred evaluation), except in the float16 form
+  // floats per prepared row; the float16 form packs two pixels into one float: steps of 48 pixels
+  // (match16.hip).  `ndp` rows carry one extra column (prep.hip: centred evaluation), except in the float16 form
   c->kpad = compute_dtype == KPDI_COMPUTE_F16
-                ? kpdi::round_up(c->k_kept, 2 * kpdi::TILE_K) / 2
+                ? kpdi::round_up(c->k_kept, kpdi::F16_STEP) / 2
                 : kpdi::round_up(c->k_kept + (metric == KPDI_METRIC_NDP ? 1 : 0), kpdi::TILE_K);
   c->metric = metric;
   c->compute = compute_dtype;

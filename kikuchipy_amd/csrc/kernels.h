@@ -12,6 +12,11 @@ constexpr int TILE_K = 32;      // pixels per LDS slab
 constexpr int MATCH_THREADS = 256;
 constexpr int KMAX_LIMIT = 32;  // longest register-resident list of one pass
 
+// ---- the float16 form (KPDI_COMPUTE_F16) has its own kernel and layout (match16.hip, prep_device.h: half_slot)
+constexpr int F16_TILE = 256;     // patterns per tile, dictionary and experimental side alike
+constexpr int F16_STEP = 48;      // pixels (float16) per LDS step = 6 planes of 8 pixels = 3 MFMA k-steps of 16
+constexpr int MATCH16_THREADS = 512;
+
 inline int round_up(int64_t v, int64_t m) { return (int)(((v + m - 1) / m) * m); }
 
 // ---- layout of a PREPARED pattern matrix (what prep.hip writes and match.hip reads).
@@ -77,6 +82,10 @@ inline void bound_plan(int lists, int list_len, int *rank, int *grouped, int *us
 // slots [0, used) <- key(-inf), slots [used, 32) <- key(+inf), for m_pad patterns
 hipError_t launch_init_bound(unsigned *gthr, int m_pad, int used_slots, hipStream_t s);
 hipError_t launch_match(const MatchLaunch &a, hipStream_t s);
+// float16 form: tiles of F16_TILE dictionary patterns, lists per pattern = 4 * nsplit;
+// `list_scratch`: match16_scratch_bytes(grid, list_len) bytes (the lists' home during the launch)
+hipError_t launch_match16(const MatchLaunch &a, void *list_scratch, hipStream_t s);
+size_t match16_scratch_bytes(int grid, int list_len);
 int match_blocks_per_cu();
 
 // ---- pattern preparation (prep.hip): cast -> gather rows/pixels -> normalise --

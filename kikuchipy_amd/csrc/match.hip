@@ -45,126 +45,15 @@
 //    value one f16 (times 2^12), a slab = 64 pixels = 4 steps of one MFMA per accumulator.
 //
 // Algorithmic work per launch: 2 * M * n_chunk * K flops (K = kept pixels).
-#include "kernels.h"
-#include <limits.h>
-#include <math.h>
+#include "match_device.h"
 #include <stdlib.h>
 
 namespace kpdi {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SLAB_BYTES = TILE_DICT * TILE_K * 4;  // 128 patterns x 32 pixels: 16 KB
 constexpr int STAGE_BYTES = 3 * SLAB_BYTES;          // dictionary slab + 2 experimental slabs
 constexpr int NSTAGE = 3;
 constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;      // 144 KB ring (+ 32 B control words)
-
-__device__ __forceinline__ float key_score32(unsigned u);
-
-struct MatchArgs {
-  const float *dict;
-  const float *exp;
-  int kpad, n_tiles, n_valid, nsplit, idx_base, row_first;
-  int row_base;  // ROWT = 1 (32-row tail units): dictionary row of unit 0, a multiple of 32
-  float *part_scores;
-  int *part_idx;
-  const float *bound_score;
-  const int *bound_idx;
-  unsigned *tile_ctr;  // [row blocks][tile_groups] next draw to hand out; 3 * nsplit / tile_groups at launch
-  int tile_groups;
-  unsigned *gthr;      // [m_pad][BOUND_SLOTS] published list ranks (monotone keys), see shared_bound()
-  int bound_rank;      // which entry (1-based) of its list a workgroup lane publishes
-  int bound_grouped;   // 1: all 32 slots are in use and bound_rank == 1 (grouped form)
-};
-
-// ---- shared rejection bound -------------------------------------------------------------
-// A score T may be used to reject candidates (v < T cannot enter the final top-KMAX) whenever
-// at least KMAX candidates >= T are known to exist.  Lists cover disjoint candidates, and a
-// list whose j-th best is b holds j candidates >= b.  Every list publishes its j-th best
-// (key, atomic max) into slot (list % 32) of its pattern's 128-byte line; then
-//   * plain form   (fewer than 32 lists, j = ceil(KMAX / lists)): T = min over the used slots
-//     (j * lists >= KMAX candidates); unused slots hold the key of +inf;
-//   * grouped form (>= 32 lists, j = 1): the slots are split into >= KMAX groups; every group
-//     maximum is one list's best, so T = min over groups of the group maximum is backed by
-//     >= KMAX distinct candidates.  This is far tighter than any single list's KMAX-th best:
-//     it sits near the true global KMAX-th best instead of ~lists*KMAX places below it.
-// The bound is only a FILTER: monotone and valid however stale, no ordering or coherence
-// needed, and it persists across the chunks of a sweep.
-template <int KMAX>
-__device__ __forceinline__ float shared_bound(const unsigned *line, bool grouped) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  unsigned k[BOUND_SLOTS];
-#pragma unroll
-  for (int c = 0; c < BOUND_SLOTS / 4; ++c) {
-    const u32x4 q = __builtin_nontemporal_load((const u32x4 *)line + c);  // L2, not the stale L1
-#pragma unroll
-    for (int e = 0; e < 4; ++e) k[4 * c + e] = q[e];
-  }
-  unsigned t = 0xffffffffu;
-  if (grouped) {
-    // G groups, G = smallest supported count >= KMAX: 1, 8, 20 (12 pairs + 8 singles), 32
-    constexpr int G = KMAX <= 1 ? 1 : (KMAX <= 8 ? 8 : (KMAX <= 20 ? 20 : 32));
-    if (G == 20) {
-#pragma unroll
-      for (int g = 0; g < 12; ++g) t = min(t, max(k[2 * g], k[2 * g + 1]));
-#pragma unroll
-      for (int i = 24; i < 32; ++i) t = min(t, k[i]);
-    } else {
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        unsigned m = 0;
-#pragma unroll
-        for (int i = g; i < BOUND_SLOTS; i += G) m = max(m, k[i]);
-        t = min(t, m);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < BOUND_SLOTS; ++i) t = min(t, k[i]);
-  }
-  return key_score32(t);
-}
-
-// float <-> unsigned key, order preserving (same map as merge.hip)
-__device__ __forceinline__ unsigned score_key(float s) {
-  const unsigned u = __float_as_uint(s);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key_score32(unsigned u) {
-  return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
-}
-
-// Insert (v, idx) into a descending sorted list; precondition v > s[KMAX-1].
-// Equal scores keep arrival order (candidates arrive by increasing dictionary
-// index), which is the engine's tie rule: lower dictionary index first.
-// new s[j] = median(s[j-1], s[j], v) because s[j-1] >= s[j].  Branch-free: the index
-// selects are bit blends the compiler folds to v_cndmask (nested ?: came out as ~20
-// exec-mask branches per insertion).
-__device__ __forceinline__ int blend(int mask, int if_set, int if_clear) {
-  return (if_set & mask) | (if_clear & ~mask);
-}
-
-template <int KMAX>
-__device__ __forceinline__ void list_insert(float (&s)[KMAX], int (&id)[KMAX], float v, int idx) {
-  int above[KMAX];  // all ones where v ranks above entry j (monotone in j: 0..0 1..1)
-#pragma unroll
-  for (int j = 0; j < KMAX; ++j) above[j] = (v > s[j]) ? -1 : 0;
-#pragma unroll
-  for (int j = KMAX - 1; j >= 1; --j) {
-    id[j] = blend(above[j], blend(above[j - 1], id[j - 1], idx), id[j]);
-    s[j] = __builtin_amdgcn_fmed3f(s[j - 1], s[j], v);
-  }
-  id[0] = blend(above[0], idx, id[0]);
-  s[0] = fmaxf(s[0], v);
-}
-
-// smallest float above f (f finite or -inf)
-__device__ __forceinline__ float next_up(float f) {
-  const unsigned u = __float_as_uint(f);
-  if (f == 0.f) return __uint_as_float(1u);
-  return __uint_as_float((u & 0x80000000u) ? u - 1u : u + 1u);
-}
 
 // One accumulator column group (32 patterns) of the epilogue: 64 candidates per lane by
 // increasing dictionary index.  Steady state is ONE compare + branch per accumulator

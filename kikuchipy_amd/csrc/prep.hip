@@ -78,7 +78,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const T *raw, int np
   const float cval = sqrtf((float)k) * mean * inv;
   if (form == 2) {
     for (int c = tid; c < 2 * kpad; c += PREP_THREADS)
-      *(_Float16 *)half_slot(out, r, c, nslab) =
+      *(_Float16 *)half_slot(out, r, c, kpad) =
           (_Float16)((c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv * 4096.f : 0.f);
     return;
   }
@@ -113,7 +113,7 @@ __device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], flo
   for (int i = 0; i < WAVE_VALUES; ++i) {
     const int c = lane + 64 * i;
     if (form == 2) {
-      if (c < 2 * kpad) *(_Float16 *)half_slot(out, r, c, nslab) = (_Float16)(v[i] * inv * 4096.f);
+      if (c < 2 * kpad) *(_Float16 *)half_slot(out, r, c, kpad) = (_Float16)(v[i] * inv * 4096.f);
     } else if (c < kpad) {
       out[prepared_offset(r, c, nslab)] = (centred && c == k) ? cval : v[i] * inv;
     }
@@ -298,12 +298,14 @@ hipError_t launch_split_f16(float *prepared, int n_rows_pad, int kpad, hipStream
 hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   if (a.n_out <= 0) return hipSuccess;
   const int cols = a.k + (a.metric == NORM_NDP_CENTRED ? 1 : 0);  // columns of a row that are not padding
-  const bool wave_path = cols <= 64 * WAVE_VALUES;
+  // columns a row-owning wave / workgroup has to write: everything up to the padded row length
+  const int span = std::max(cols, a.operand_form == 2 ? 2 * a.kpad : a.kpad);
+  const bool wave_path = span <= 64 * WAVE_VALUES;
   const bool vec_ok = (a.npix % 4) == 0 && ((uintptr_t)a.raw % (4 * dtype_size(a.dtype))) == 0;
   const bool vec4 = wave_path && a.pix_map == nullptr && (a.k % 4) == 0 && vec_ok;
   const bool staged = wave_path && a.pix_map != nullptr && vec_ok && a.npix <= 64 * WAVE_VALUES;
   // larger detectors, still register-resident: one workgroup per pattern
-  const bool block_path = !wave_path && cols <= PREP_THREADS * WAVE_VALUES;
+  const bool block_path = !wave_path && span <= PREP_THREADS * WAVE_VALUES;
   const bool block_vec = block_path && a.pix_map == nullptr && (a.k % 4) == 0 && vec_ok;
   const bool block_masked = block_path && a.pix_map != nullptr;
   const size_t staged_lds = (size_t)(((a.k + 3) & ~3) + 4 * a.npix) * 4;

@@ -34,11 +34,16 @@ struct alignas(sizeof(T) * 4) Quad {
   T v[4];
 };
 
-// ---- float16 form (KPDI_COMPUTE_F16): a row holds 2 * kpad f16, value * 2^12; the 16 KB block of
-// (tile, slab) covers 64 pixels, slot q of a row = pixels 8q..8q+7 of the slab, placed like the f32
-// slot q (prepared_offset of float column 32 * slab + 4 * q)
-__device__ __forceinline__ char *half_slot(float *out, int r, int c, int nslab) {
-  return (char *)(out + prepared_offset(r, ((c >> 6) << 5) + (((c >> 3) & 7) << 2), nslab)) + 2 * (c & 7);
+// ---- float16 form (KPDI_COMPUTE_F16): a row holds 2 * kpad f16, value * 2^12, in the layout of
+// match16.hip (kernels.h: F16_TILE / F16_STEP): patterns in tiles of 256, pixels in steps of 48; one
+// (tile, step) block = 24 KB contiguous = [6 planes][256 rows][8 pixels]: plane p holds pixels
+// 8p .. 8p + 7 of the step for all 256 rows, 16 bytes per row.  `kpad` = floats per row (= 24 per step).
+__device__ __forceinline__ char *half_slot(float *out, int r, int c, int kpad) {
+  const int nsteps = (2 * kpad) / F16_STEP;
+  const int step = c / F16_STEP, cs = c - step * F16_STEP;
+  const size_t block = (size_t)(r >> 8) * nsteps + step;
+  return (char *)out + block * (size_t)(F16_TILE * F16_STEP * 2) + (cs >> 3) * (F16_TILE * 16) + (r & 255) * 16 +
+         (cs & 7) * 2;
 }
 
 // same, v[4*i + e] holds kept pixel 4*(lane + 64*i) + e: float4 stores (full 16-byte slots)
@@ -94,7 +99,7 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[NV], float 
         h[1] = (_Float16)(w.y * 4096.f);
         h[2] = (_Float16)(w.z * 4096.f);
         h[3] = (_Float16)(w.w * 4096.f);
-        *reinterpret_cast<h4 *>(half_slot(out, r, c, nslab)) = h;  // half of a slot: 8 bytes
+        *reinterpret_cast<h4 *>(half_slot(out, r, c, kpad)) = h;  // half of a slot: 8 bytes
       } else {
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         const float x[4] = {w.x * 4096.f, w.y * 4096.f, w.z * 4096.f, w.w * 4096.f};
