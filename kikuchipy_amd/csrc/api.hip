@@ -170,6 +170,7 @@ struct kpdi_ctx {
   DevBuf pix_map;  // int[k_kept]
   int metric = KPDI_METRIC_NCC;
   int compute = KPDI_COMPUTE_F32;
+  int f16_waves = 8;  // variant of the float16 kernel (match16.hip), fixed per problem: KPDI_F16_WAVES = 8 | 4
   int keep_n = 0;
 
   // experimental
@@ -312,7 +313,11 @@ int prep_metric(const kpdi_ctx *c) {
 }
 
 // patterns per dictionary tile of the match kernel in use (the float16 form has its own kernel)
-int dict_tile(const kpdi_ctx *c) { return c->compute == KPDI_COMPUTE_F16 ? kpdi::F16_TILE : kpdi::TILE_DICT; }
+int dict_tile(const kpdi_ctx *c) {
+  return c->compute == KPDI_COMPUTE_F16 ? kpdi::f16_geometry(c->f16_waves).dict_tile : kpdi::TILE_DICT;
+}
+// lists per pattern and dictionary split the match kernel writes
+int lists_per_split(const kpdi_ctx *c) { return c->compute == KPDI_COMPUTE_F16 ? c->f16_waves / 2 : 2; }
 
 int use_device(kpdi_ctx *c) {
   HIPCHK(hipSetDevice(c->device));
@@ -325,7 +330,8 @@ int use_device(kpdi_ctx *c) {
 // experimental sets take several launches.  The plan minimises the makespan counted in
 // tiles: launches * ceil(n_tiles / nsplit), plus a small per-launch cost.
 int choose_nsplit(const kpdi_ctx *c, int row_blocks, int n_tiles, int *rows_per_launch) {
-  const int cap = c->n_cu * kpdi::match_blocks_per_cu();
+  // (the 4-wave float16 variant runs two workgroups per CU)
+  const int cap = c->n_cu * (c->compute == KPDI_COMPUTE_F16 && c->f16_waves == 4 ? 2 : kpdi::match_blocks_per_cu());
   int best_ns = 1, best_rpl = std::max(1, std::min(row_blocks, cap));
   double best_cost = 1e30;
   for (int ns = 1; ns <= std::min(cap, n_tiles); ++ns) {
@@ -376,6 +382,7 @@ int flush_preprocess(kpdi_ctx *c, bool with_prep, bool *prep_done) {
     a.kpad = c->kpad;
     a.metric = prep_metric(c);
     a.operand_form = c->compute;
+    a.f16_step = kpdi::f16_geometry(c->f16_waves).step;
     a.out = c->exp_x.as<float>();
   }
   if (c->pend.dy && !kpdi::preprocess_fits_fused(c->sy, c->sx, 0)) {
@@ -426,6 +433,8 @@ int prepare_experimental(kpdi_ctx *c) {
   p.n_out = c->m;
   p.metric = prep_metric(c);
   p.operand_form = c->compute;
+  p.f16_rows = kpdi::F16_TILE;
+  p.f16_step = kpdi::f16_geometry(c->f16_waves).step;
   p.out = c->exp_x.as<float>();
   {
     ScopedTimer t(c, &c->ev_prep);
@@ -468,7 +477,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   }
   const int n_main = n_tiles - tail_tiles;
   const bool f16 = c->compute == KPDI_COMPUTE_F16;
-  const int lists_per_split = f16 ? 4 : 2;  // match16.hip: two waves share a pattern's dictionary rows
+  const int lists_per_split = ::lists_per_split(c);
   const size_t part = (size_t)c->m_pad * lists_per_split * nsplit * list_len;
   HIPCHK(c->part_s.reserve(part * sizeof(float)));
   HIPCHK(c->part_i.reserve(part * sizeof(int)));
@@ -529,18 +538,17 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
       HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
     int j = 0;
-    if (f16)
-      HIPCHK(c->list16.reserve(2 * (two ? 2 : 1) *
-                               kpdi::match16_scratch_bytes(std::min(rows_per_launch, row_blocks) * nsplit, list_len)));
+    const size_t scratch16 =
+        f16 ? 2 * kpdi::match16_scratch_bytes(std::min(rows_per_launch, row_blocks) * nsplit, c->f16_waves, list_len) : 0;
+    if (f16) HIPCHK(c->list16.reserve((two ? 2 : 1) * scratch16));
     for (int r0 = 0; r0 < row_blocks; r0 += rows_per_launch, ++j) {
       ml.row_first = r0;
       ml.rows = std::min(rows_per_launch, row_blocks - r0);
       hipStream_t st = (two && (j & 1)) ? c->stream2 : c->stream;
       if (f16) {
         // launches on the two streams overlap: each stream has its own list scratch
-        char *scratch = (char *)c->list16.p +
-                        ((two && (j & 1)) ? 2 * kpdi::match16_scratch_bytes(std::min(rows_per_launch, row_blocks) * nsplit, list_len) : 0);
-        HIPCHK(kpdi::launch_match16(ml, scratch, st));
+        char *scratch = (char *)c->list16.p + ((two && (j & 1)) ? scratch16 : 0);
+        HIPCHK(kpdi::launch_match16(ml, c->f16_waves, scratch, st));
       } else {
         HIPCHK(kpdi::launch_match(ml, st));
       }
@@ -600,6 +608,8 @@ int prepare_chunk(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chun
   p.n_out = (int)n_chunk;
   p.metric = prep_metric(c);
   p.operand_form = c->compute;
+  p.f16_rows = kpdi::f16_geometry(c->f16_waves).dict_tile;
+  p.f16_step = kpdi::f16_geometry(c->f16_waves).step;
   p.out = out;
   {
     ScopedTimer t(c, &c->ev_prep);
@@ -667,7 +677,7 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
     if (rc) return rc;
     mg.src_scores[1] = c->part_s.as<float>();
     mg.src_idx[1] = c->part_i.as<int>();
-    const int lps = c->compute == KPDI_COMPUTE_F16 ? 4 : 2;  // lists per pattern and split (run_match)
+    const int lps = lists_per_split(c);
     mg.src_lists[1] = lps * nsplit;
     mg.src_len[1] = len;
     mg.src_row_stride[1] = lps * nsplit * len;
@@ -706,7 +716,7 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
       pm.n_src = 1;
       pm.src_scores[0] = c->part_s.as<float>();
       pm.src_idx[0] = c->part_i.as<int>();
-      const int lps = c->compute == KPDI_COMPUTE_F16 ? 4 : 2;
+      const int lps = lists_per_split(c);
       pm.src_lists[0] = lps * nsplit;
       pm.src_len[0] = len;
       pm.src_row_stride[0] = lps * nsplit * len;
@@ -1032,9 +1042,12 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   }
   if (npix != c->npix) c->have_exp = false;  // resident patterns belong to another detector shape
   // the prepared layout of held chunks depends on shape, mask, metric and arithmetic
+  int waves = 8;
+  if (const char *e = getenv("KPDI_F16_WAVES")) waves = atoi(e) == 4 ? 4 : 8;
   if (!c->have_problem || sy != c->sy || sx != c->sx || metric != c->metric || compute_dtype != c->compute ||
-      (signal_mask != nullptr) != c->have_sig_mask || keep != c->kept_pixels)
+      (signal_mask != nullptr) != c->have_sig_mask || keep != c->kept_pixels || waves != c->f16_waves)
     release_held(c);
+  c->f16_waves = waves;
   c->kept_pixels = keep;
   c->sy = sy;
   c->sx = sx;
@@ -1044,7 +1057,7 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   // floats per prepared row; the float16 form packs two pixels into one float: steps of 48 pixels
   // (match16.hip).  `ndp` rows carry one extra column (prep.hip: centred evaluation), except in the float16 form
   c->kpad = compute_dtype == KPDI_COMPUTE_F16
-                ? kpdi::round_up(c->k_kept, kpdi::F16_STEP) / 2
+                ? kpdi::round_up(c->k_kept, kpdi::f16_geometry(c->f16_waves).step) / 2
                 : kpdi::round_up(c->k_kept + (metric == KPDI_METRIC_NDP ? 1 : 0), kpdi::TILE_K);
   c->metric = metric;
   c->compute = compute_dtype;

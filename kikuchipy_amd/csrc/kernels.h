@@ -13,9 +13,16 @@ constexpr int MATCH_THREADS = 256;
 constexpr int KMAX_LIMIT = 32;  // longest register-resident list of one pass
 
 // ---- the float16 form (KPDI_COMPUTE_F16) has its own kernel and layout (match16.hip, prep_device.h: half_slot)
-constexpr int F16_TILE = 256;     // patterns per tile, dictionary and experimental side alike
-constexpr int F16_STEP = 48;      // pixels (float16) per LDS step = 6 planes of 8 pixels = 3 MFMA k-steps of 16
-constexpr int MATCH16_THREADS = 512;
+// Two variants (match16.hip): 8 waves = one workgroup per CU, 256 x 256 tiles, steps of 48 pixels; 4 waves = two
+// workgroups per CU, 128 (dictionary) x 256 tiles, steps of 32 pixels.
+constexpr int F16_TILE = 256;     // experimental patterns per tile; dictionary patterns per tile of the 8-wave variant
+constexpr int F16_STEP = 48;      // pixels (float16) per LDS step of the 8-wave variant
+struct F16Geometry {
+  int waves;      // 8 or 4
+  int dict_tile;  // dictionary patterns per tile: 32 * 4 * (waves / 4)
+  int step;       // pixels per step
+};
+inline F16Geometry f16_geometry(int waves) { return waves == 4 ? F16Geometry{4, 128, 32} : F16Geometry{8, 256, 48}; }
 
 inline int round_up(int64_t v, int64_t m) { return (int)(((v + m - 1) / m) * m); }
 
@@ -84,8 +91,8 @@ hipError_t launch_init_bound(unsigned *gthr, int m_pad, int used_slots, hipStrea
 hipError_t launch_match(const MatchLaunch &a, hipStream_t s);
 // float16 form: tiles of F16_TILE dictionary patterns, lists per pattern = 4 * nsplit;
 // `list_scratch`: match16_scratch_bytes(grid, list_len) bytes (the lists' home during the launch)
-hipError_t launch_match16(const MatchLaunch &a, void *list_scratch, hipStream_t s);
-size_t match16_scratch_bytes(int grid, int list_len);
+hipError_t launch_match16(const MatchLaunch &a, int waves, void *list_scratch, hipStream_t s);
+size_t match16_scratch_bytes(int grid, int waves, int list_len);
 int match_blocks_per_cu();
 
 // ---- pattern preparation (prep.hip): cast -> gather rows/pixels -> normalise --
@@ -102,6 +109,7 @@ struct PrepLaunch {
   float *out;          // (>= n_out, kpad)
   int operand_form;    // 0 = f32; 1 = split-f16 (KPDI_COMPUTE_F16X2); 2 = f16 (KPDI_COMPUTE_F16): `kpad` then
                        // counts pairs of pixels (the row holds 2 * kpad float16)
+  int f16_rows = F16_TILE, f16_step = F16_STEP;  // float16 form: patterns per tile / pixels per step of the layout
 };
 hipError_t launch_prep(const PrepLaunch &a, hipStream_t s);
 // in place: prepared f32 rows [0, n_rows_pad) x kpad -> split-f16 form (KPDI_COMPUTE_F16X2): every
@@ -154,6 +162,7 @@ struct PreLaunch {
   int do_prep;
   const int *out_row, *pix_map;
   int k, kpad, metric, operand_form;
+  int f16_step = F16_STEP;  // float16 form: pixels per step of the layout (experimental tiles hold 256 patterns)
   float *out;
   float *scratch; size_t scratch_floats;  // streaming kernels, see preprocess_scratch_floats
 };

@@ -32,30 +32,73 @@
 
 namespace kpdi {
 
-constexpr int BLOCK16 = F16_TILE * F16_STEP * 2;  // one (tile, step) block: 24 KB
-constexpr int STAGE16 = 2 * BLOCK16;              // dictionary block + experimental block
-constexpr int NSTAGE16 = 3;
-constexpr int LDS16 = NSTAGE16 * STAGE16;         // 144 KB (+ 32 B control words)
-constexpr int KSTEPS16 = F16_STEP / 16;           // MFMA k-steps per step: 3
+// Geometry of a variant: WAVES = 8 -> one 512-thread workgroup per CU, tile 256 x 256, steps of 48 pixels
+// (3 k-steps), ring 3 x 48 KB; WAVES = 4 -> two 256-thread workgroups per CU, tile 128 (dictionary) x 256,
+// steps of 32 pixels (2 k-steps), ring 3 x 24 KB each.  Two waves per SIMD either way.
+template <int WAVES>
+struct Geo {
+  static constexpr int DT = 32 * 4 * (WAVES / 4);      // dictionary patterns per tile
+  static constexpr int BK = WAVES == 8 ? 48 : 32;      // pixels per step
+  static constexpr int KS = BK / 16;                   // MFMA k-steps per step
+  static constexpr int DBLOCK = DT * BK * 2;           // dictionary (tile, step) block, bytes
+  static constexpr int EBLOCK = F16_TILE * BK * 2;     // experimental (tile, step) block, bytes
+  static constexpr int STAGE = DBLOCK + EBLOCK;
+  static constexpr int NSTAGE = 3;
+  static constexpr int LDS = NSTAGE * STAGE;           // 144 KB / 72 KB (+ 32 B control words)
+  static constexpr int PIECES = STAGE / 1024 / WAVES;  // LDS-DMA pieces per wave and step: 6
+  static constexpr int DPIECES = DBLOCK / 1024 / WAVES;  // ... of which dictionary: 3 (8 waves) / 2 (4 waves)
+};
 
 // acc += A x B for 16 pixels, A and B = 8 f16 per lane (one 16-byte LDS read); accumulator pinned to
 // the accumulation registers, `s_nop 1` = the VALU-write -> MFMA-operand hazard hipcc does not pad
 // inside an asm statement (match.hip: mfma_acc)
 __device__ __forceinline__ void mfma16(f32x16 &c, const f32x4 &a, const f32x4 &b) {
+#if !defined(KPDI16_ACC_A)  // accumulators in architectural VGPRs (measured: bare MFMA loop 1.41 vs 1.74 ms, and the epilogue reads them without v_accvgpr_read)
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#elif defined(KPDI16_NO_NOP)  // the operands come from ds_read (lgkmcnt), never from a VALU write
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#else
   asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#endif
 }
 
-// One of a wave's six 1 KB LDS-DMA pieces of a stage (i = 0..2 dictionary block, 3..5 experimental
-// block); piece q = wv + 8 * (i % 3) of the block's 24.  `gd` / `ge`: wave-uniform block addresses.
+// One of a wave's 1 KB LDS-DMA pieces of a stage (i < DPIECES: dictionary block, else experimental
+// block); piece q = wv + WAVES * i' of its block.  `gd` / `ge`: wave-uniform block addresses.
+template <int WAVES>
 __device__ __forceinline__ void issue_piece16(const char *gd, const char *ge, char *stage_base, int wv, int i,
                                               unsigned goff) {
-  const bool is_exp = i >= 3;
-  const int q = wv + 8 * (is_exp ? i - 3 : i);
+  typedef Geo<WAVES> G;
+  const bool is_exp = i >= G::DPIECES;
+  const int q = wv + WAVES * (is_exp ? i - G::DPIECES : i);
   __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)(is_exp ? ge : gd), 0, 0x7fffffff, 0x00020000);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(
-      rsrc, (__attribute__((address_space(3))) void *)(stage_base + (is_exp ? BLOCK16 : 0) + q * 1024), 16, (int)goff,
-      q * 1024, 0, 0);
+      rsrc, (__attribute__((address_space(3))) void *)(stage_base + (is_exp ? G::DBLOCK : 0) + q * 1024), 16,
+      (int)goff, q * 1024, 0, 0);
+}
+
+// element r (wave-uniform, runtime) of a 16-register accumulator without register-relative addressing:
+// a select tree on the bits of r (15 v_cndmask with scalar conditions)
+__device__ __forceinline__ float pick16(const f32x16 &a, int r) {
+  float t8[8], t4[4], t2[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t8[i] = (r & 1) ? a[2 * i + 1] : a[2 * i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t4[i] = (r & 2) ? t8[2 * i + 1] : t8[2 * i];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) t2[i] = (r & 4) ? t4[2 * i + 1] : t4[2 * i];
+  return (r & 8) ? t2[1] : t2[0];
+}
+
+// Entry j of a list in its scratch home: `base` is wave-uniform; accesses are grouped in chunks of 16
+// entries (4 KB = the immediate-offset range of a global access with a scalar base) whose base pointer is
+// made opaque to the optimiser: otherwise it materialises one 64-bit address register PER ENTRY, hoists
+// them out of the tile loop and spills them (1.2 KB of scratch per lane, a third of the kernel's time).
+template <typename T>
+__device__ __forceinline__ T *chunk_base(T *base, int chunk) {
+  T *p = base + chunk * 16 * 64;
+  asm volatile("" : "+s"(p));
+  return p;
 }
 
 // One column group's 4 accumulators (128 dictionary rows x 32 patterns; 64 candidates per lane by
@@ -77,7 +120,11 @@ __device__ __forceinline__ void scan16(f32x16 (&acc)[4], float (&best)[KMAX], in
     while (hot != 0) {
       const int r = __builtin_ctz(hot);
       hot &= hot - 1;
+#ifdef KPDI16_PICK
+      const float v = pick16(acc[rt], r) * unscale + 0.f;
+#else
       const float v = acc[rt][r] * unscale + 0.f;  // -0 -> +0 so that ties compare as the merge does
+#endif
       const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
       const int idx = idx_base + lrow;
       bool ok = lrow < n_valid && v >= thr;
@@ -101,40 +148,54 @@ __device__ __forceinline__ bool any_candidate(const f32x16 (&acc)[4], float thr)
   return __builtin_amdgcn_ballot_w64(any) != 0;
 }
 
-template <int KMAX, bool BOUNDED>
-__global__ __launch_bounds__(MATCH16_THREADS, 2) void match16_kernel(MatchArgs a, float *ls_scores, int *ls_idx) {
+template <int KMAX, bool BOUNDED, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, float *ls_scores, int *ls_idx) {
+  typedef Geo<WAVES> G;
+  // waves that issue one L2 prefetch load per step: a block holds DBLOCK / 128 lines = 64 per wave
+  constexpr int PF_WAVES = (G::DBLOCK + G::EBLOCK) / 128 / 64;  // 6 (8-wave variant)
+  (void)PF_WAVES;
+  constexpr int BLOCK16 = G::DBLOCK, STAGE16 = G::STAGE, NSTAGE16 = G::NSTAGE, LDS16 = G::LDS, KSTEPS16 = G::KS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0 .. WAVES - 1
   const int wr = wv >> 2, wc = wv & 3;
   const int sp = blockIdx.x % a.nsplit;
   const int rb = a.row_first + blockIdx.x / a.nsplit;
   const int n_tiles = a.n_tiles, n_valid = a.n_valid, idx_base = a.idx_base;
-  const int nsteps = (2 * a.kpad) / F16_STEP;
-  const size_t tile_bytes = (size_t)nsteps * BLOCK16;  // one 256-pattern tile, all steps
+  const int nsteps = (2 * a.kpad) / G::BK;
+  const size_t tile_bytes = (size_t)nsteps * G::DBLOCK;   // one dictionary tile, all steps
+  const size_t etile_bytes = (size_t)nsteps * G::EBLOCK;  // one 256-pattern experimental tile
   unsigned *tile_ctr = a.tile_ctr + rb;
   volatile int *ctrl = (volatile int *)(smem + LDS16);  // control words behind the ring
   const unsigned goff = (unsigned)lane * 16u;
-  const char *exp_base = (const char *)a.exp + (size_t)rb * tile_bytes;
+  const char *exp_base = (const char *)a.exp + (size_t)rb * etile_bytes;
   const char *dict_base = (const char *)a.dict;
 
   // LDS -> MFMA fragments: lane l reads row (l & 31) of a 32-row group, plane 2 ks + (l >> 5)
-  const unsigned fa_off = (unsigned)((lane >> 5) * (F16_TILE * 16) + (wr * 128 + (lane & 31)) * 16);
+  const unsigned fa_off = (unsigned)((lane >> 5) * (G::DT * 16) + (wr * 128 + (lane & 31)) * 16);
   const unsigned fb_off = (unsigned)(BLOCK16 + (lane >> 5) * (F16_TILE * 16) + (wc * 64 + (lane & 31)) * 16);
-#define KPDI_FA(base, rt, ks) (*(const f32x4 *)((base) + fa_off + (rt) * 512 + (ks) * (2 * F16_TILE * 16)))
+#define KPDI_FA(base, rt, ks) (*(const f32x4 *)((base) + fa_off + (rt) * 512 + (ks) * (2 * G::DT * 16)))
 #define KPDI_FB(base, cg, ks) (*(const f32x4 *)((base) + fb_off + (cg) * 512 + (ks) * (2 * F16_TILE * 16)))
 
   // ---- this lane's two lists (column groups 0 / 1: patterns m_lane, m_lane + 32; it sees the rows
   // 4 (lane >> 5) + {0..3} + 8 j of every 32-row group of its wave's 128 rows).  Their home is the
   // scratch: entry j of list (workgroup, wave, cg) at [((wg * 8 + wave) * 2 + cg) * KMAX + j][lane].
   const int m_lane = rb * F16_TILE + wc * 64 + (lane & 31);
-  float *home_s = ls_scores + (((size_t)blockIdx.x * 8 + wv) * 2) * KMAX * 64 + lane;
-  int *home_i = ls_idx + (((size_t)blockIdx.x * 8 + wv) * 2) * KMAX * 64 + lane;
+  // (wave-uniform base pointers + a 32-bit lane offset: scalar-base addressing, no per-entry 64-bit
+  // address registers - hoisted out of the tile loop they were spilled, 900 bytes per lane)
+  float *home_s = ls_scores + (((size_t)blockIdx.x * WAVES + wv) * 2) * KMAX * 64;
+  int *home_i = ls_idx + (((size_t)blockIdx.x * WAVES + wv) * 2) * KMAX * 64;
+  const unsigned ulane = (unsigned)lane;
 #pragma unroll
-  for (int j = 0; j < 2 * KMAX; ++j) {
-    home_s[j * 64] = -INFINITY;
-    home_i[j * 64] = INT_MAX;
+  for (int c = 0; c < (2 * KMAX + 15) / 16; ++c) {
+    float *ps = chunk_base(home_s, c);
+    int *pi = chunk_base(home_i, c);
+#pragma unroll
+    for (int j = 16 * c; j < 2 * KMAX && j < 16 * c + 16; ++j) {
+      ps[(j - 16 * c) * 64 + ulane] = -INFINITY;
+      pi[(j - 16 * c) * 64 + ulane] = INT_MAX;
+    }
   }
   float last0 = -INFINITY, last1 = -INFINITY;  // the lists' last entries: all the main loop keeps of them
   float ub0 = INFINITY, ub1 = INFINITY;
@@ -147,26 +208,36 @@ __global__ __launch_bounds__(MATCH16_THREADS, 2) void match16_kernel(MatchArgs a
   }
   const unsigned *line0 = a.gthr + (size_t)m_lane * BOUND_SLOTS;
   const unsigned *line1 = line0 + 32 * BOUND_SLOTS;
-  const int list_id = sp * 4 + wr * 2 + (lane >> 5);
+  const int list_id = sp * (WAVES / 2) + wr * 2 + (lane >> 5);
   const int my_slot = list_id & (BOUND_SLOTS - 1);
   const int bound_rank = a.bound_rank;
   const bool bound_grouped = a.bound_grouped != 0;
   float g0 = -INFINITY, g1 = -INFINITY;
 
-  // ---- dictionary tiles are handed out dynamically as in match.hip: t0 = tile being computed, t1 / t2
-  // the next two (loads run two steps ahead); a workgroup's first three tiles are fixed
+  // ---- dictionary tiles: t0 = tile being computed, t1 / t2 the next two (loads run two steps ahead).
+  // STATIC hand-out: split sp takes the tiles sp, sp + nsplit, sp + 2 nsplit ...  Block b runs on XCD
+  // b % 8 and nsplit is a multiple of 8 whenever the chip is full, so the workgroups of ALL row blocks
+  // with the same split share an XCD and walk the SAME dictionary tiles at the same pace: a dictionary
+  // block crosses the fabric once and is served to the other row blocks by that XCD's L2 (with the
+  // dynamic hand-out of match.hip every row block re-fetched it: 16 x the dictionary per launch, which
+  // the f32 kernel's 1.2 TB/s tolerates and this kernel's 6+ TB/s did not).  -DKPDI16_DYNAMIC_TILES
+  // restores the counters for comparison.
   int t0 = sp, t1 = sp + a.nsplit, t2 = sp + 2 * a.nsplit;
   if (t0 < n_tiles) {
     const int last_tile = n_tiles - 1;
     int ld_pos = 0, ld_step = 0, ld_stage = 0;
     int fetched = 0, tp = 0;
+    (void)fetched;
+    (void)tp;
+    (void)tile_ctr;
+    (void)ctrl;
     const char *gd = nullptr, *ge = nullptr;
 #define KPDI16_CURSOR_SET()                                                          \
   {                                                                                  \
     int t_ = ld_pos == 0 ? t0 : (ld_pos == 1 ? t1 : t2);                             \
     t_ = t_ < last_tile ? t_ : last_tile; /* past the end: harmless re-load */       \
-    gd = dict_base + (size_t)t_ * tile_bytes + (size_t)ld_step * BLOCK16;            \
-    ge = exp_base + (size_t)ld_step * BLOCK16;                                       \
+    gd = dict_base + (size_t)t_ * tile_bytes + (size_t)ld_step * G::DBLOCK;          \
+    ge = exp_base + (size_t)ld_step * G::EBLOCK;                                     \
   }
 #define KPDI16_CURSOR_ADVANCE()                                \
   {                                                            \
@@ -179,11 +250,11 @@ __global__ __launch_bounds__(MATCH16_THREADS, 2) void match16_kernel(MatchArgs a
     // ---- prologue: steps 0 and 1 in flight, then landed and visible
     KPDI16_CURSOR_SET();
 #pragma unroll
-    for (int i = 0; i < 6; ++i) issue_piece16(gd, ge, smem + ld_stage * STAGE16, wv, i, goff);
+    for (int i = 0; i < G::PIECES; ++i) issue_piece16<WAVES>(gd, ge, smem + ld_stage * STAGE16, wv, i, goff);
     KPDI16_CURSOR_ADVANCE();
     KPDI16_CURSOR_SET();
 #pragma unroll
-    for (int i = 0; i < 6; ++i) issue_piece16(gd, ge, smem + ld_stage * STAGE16, wv, i, goff);
+    for (int i = 0; i < G::PIECES; ++i) issue_piece16<WAVES>(gd, ge, smem + ld_stage * STAGE16, wv, i, goff);
     KPDI16_CURSOR_ADVANCE();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -208,7 +279,9 @@ __global__ __launch_bounds__(MATCH16_THREADS, 2) void match16_kernel(MatchArgs a
         const char *ls = smem + stage * STAGE16;
         const int nstage = stage == NSTAGE16 - 1 ? 0 : stage + 1;
         const char *ls_next = smem + nstage * STAGE16;
+#ifdef KPDI16_DYNAMIC_TILES
         if (step == 0 && tid == 0) fetched = (int)atomicAdd(tile_ctr, 1u);
+#endif
         if (step == nsteps - 1) {  // landed by the next wait, used in the epilogue
           g0 = shared_bound<KMAX>(line0, bound_grouped);
           g1 = shared_bound<KMAX>(line1, bound_grouped);
@@ -221,9 +294,21 @@ __global__ __launch_bounds__(MATCH16_THREADS, 2) void match16_kernel(MatchArgs a
             // ---- the step's only synchronisation point: this wave's pieces of step + 1 (issued during
             // the previous step) have landed; after the barrier step + 1 is complete in LDS and every
             // wave is past the previous step, whose stage is refilled below
+#ifdef KPDI16_PREFETCH
+            // the L2 prefetch load issued after the previous step's pieces may stay in flight (loads
+            // complete in issue order); in a tile's last step the bound loads are younger still: wait for all
+            if (wv < PF_WAVES && step != nsteps - 1)
+              asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // (not __syncthreads: its fence would wait vmcnt(0))
+#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef KPDI16_DYNAMIC_TILES
             if (step == 0 && tid == 0) ctrl[4 + tp] = fetched;
+#endif
             __syncthreads();
+#endif
           }
           const int nk = ks == KSTEPS16 - 1 ? 0 : ks + 1;         // fragments read during this k-step
           const char *src = ks == KSTEPS16 - 1 ? ls_next : ls;    // ... of the next step for the last one
@@ -233,36 +318,86 @@ __global__ __launch_bounds__(MATCH16_THREADS, 2) void match16_kernel(MatchArgs a
             mfma16(acc1[rt], fa[ks][rt], fb[ks][1]);
             // in the shadow of these MFMAs: a fragment of the next k-step and, after the barrier,
             // this wave's 6 LDS-DMA pieces of the step two ahead
+#ifndef KPDI16_NO_READS
             fa[nk][rt] = KPDI_FA(src, rt, nk);
             if (rt == 1) fb[nk][0] = KPDI_FB(src, 0, nk);
             if (rt == 3) fb[nk][1] = KPDI_FB(src, 1, nk);
-            if (ks >= 1 && rt < 3) issue_piece16(gd, ge, ld_base, wv, (ks - 1) * 3 + rt, goff);
+#endif
+#ifndef KPDI16_NO_DMA
+            // (8 waves: 3 pieces in each of the k-steps 1 and 2; 4 waves: all 6 in k-step 1, after the barrier)
+#ifdef KPDI16_STAGGER  // the two waves of a SIMD (wr = 0 / 1) issue their pieces in different k-steps
+            if (KSTEPS16 == 3 && ks == 1 + wr && rt < 3) {
+              issue_piece16<WAVES>(gd, ge, ld_base, wv, 2 * rt, goff);
+              issue_piece16<WAVES>(gd, ge, ld_base, wv, 2 * rt + 1, goff);
+            }
+#else
+            if (KSTEPS16 == 3 && ks >= 1 && rt < 3) issue_piece16<WAVES>(gd, ge, ld_base, wv, (ks - 1) * 3 + rt, goff);
+#endif
+            if (KSTEPS16 == 2 && ks == 1) {
+              if (rt < 3) issue_piece16<WAVES>(gd, ge, ld_base, wv, 2 * rt, goff);
+              if (rt < 3) issue_piece16<WAVES>(gd, ge, ld_base, wv, 2 * rt + 1, goff);
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+#ifdef KPDI16_PREFETCH
+        // ---- L2 prefetch: touch every 128-byte line of the blocks the LDS-DMA will ask for KPDI16_PREFETCH
+        // steps after the ones just issued, with one plain load per wave whose result is never read, so
+        // that the pieces find them in this XCD's L2 (~700 cycles) instead of the Infinity Cache / HBM
+        // (2000+: more than the ring can cover).  Waves 0-2 take the dictionary block, 3-5 the experimental one.
+        if (wv < PF_WAVES) {
+          int ps = ld_step + KPDI16_PREFETCH, pp = ld_pos;
+          if (ps >= nsteps) {
+            ps -= nsteps;
+            ++pp;
+          }
+          int pt = pp == 0 ? t0 : (pp == 1 ? t1 : (pp == 2 ? t2 : t2 + a.nsplit));
+          pt = pt < last_tile ? pt : last_tile;
+          const bool pe = wv >= PF_WAVES / 2;
+          const char *pb = pe ? exp_base + (size_t)ps * G::EBLOCK : dict_base + (size_t)pt * tile_bytes + (size_t)ps * G::DBLOCK;
+          const char *pa = pb + ((pe ? wv - PF_WAVES / 2 : wv) * 64 + lane) * 128;
+          int dummy;
+          asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(pa) : "memory");
+        }
+#endif
         KPDI16_CURSOR_ADVANCE();
         stage = nstage;
       }  // steps
       // the last MFMAs (8 passes) must have written the accumulators before they are read
 #pragma unroll
+#ifndef KPDI16_ACC_A
+      for (int rt = 0; rt < 4; ++rt) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc0[rt]), "+v"(acc1[rt]));
+#else
       for (int rt = 0; rt < 4; ++rt) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc0[rt]), "+a"(acc1[rt]));
+#endif
       {
         // ---- epilogue of the tile: a list is only brought into registers when a candidate reaches it
-        const int row0 = t0 * F16_TILE + wr * 128 + 4 * (lane >> 5);
+        const int row0 = t0 * G::DT + wr * 128 + 4 * (lane >> 5);
 #pragma unroll
         for (int cg = 0; cg < 2; ++cg) {
           f32x16(&acc)[4] = cg == 0 ? acc0 : acc1;
           const float gthr = cg == 0 ? g0 : g1;
           float &last = cg == 0 ? last0 : last1;
+#ifdef KPDI16_NO_EPILOGUE
+          asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+          if (false) {
+#else
           if (any_candidate(acc, fmaxf(gthr, next_up(last)))) {
+#endif
             float best[KMAX];
             int bidx[KMAX];
             float *hs = home_s + cg * KMAX * 64;
             int *hi = home_i + cg * KMAX * 64;
 #pragma unroll
-            for (int j = 0; j < KMAX; ++j) {
-              best[j] = hs[j * 64];
-              bidx[j] = hi[j * 64];
+            for (int c = 0; c < (KMAX + 15) / 16; ++c) {
+              const float *ps = chunk_base(hs, c);
+              const int *pi = chunk_base(hi, c);
+#pragma unroll
+              for (int j = 16 * c; j < KMAX && j < 16 * c + 16; ++j) {
+                best[j] = ps[(j - 16 * c) * 64 + ulane];
+                bidx[j] = pi[(j - 16 * c) * 64 + ulane];
+              }
             }
             float pub = best[0];  // entry bound_rank - 1 before the scan
 #pragma unroll
@@ -270,9 +405,14 @@ __global__ __launch_bounds__(MATCH16_THREADS, 2) void match16_kernel(MatchArgs a
             scan16<KMAX, BOUNDED>(acc, best, bidx, gthr, cg == 0 ? ub0 : ub1, cg == 0 ? ubi0 : ubi1, row0, n_valid,
                                   idx_base);
 #pragma unroll
-            for (int j = 0; j < KMAX; ++j) {
-              hs[j * 64] = best[j];
-              hi[j * 64] = bidx[j];
+            for (int c = 0; c < (KMAX + 15) / 16; ++c) {
+              float *ps = chunk_base(hs, c);
+              int *pi = chunk_base(hi, c);
+#pragma unroll
+              for (int j = 16 * c; j < KMAX && j < 16 * c + 16; ++j) {
+                ps[(j - 16 * c) * 64 + ulane] = best[j];
+                pi[(j - 16 * c) * 64 + ulane] = bidx[j];
+              }
             }
             last = best[KMAX - 1];
             float now = best[0];
@@ -285,8 +425,12 @@ __global__ __launch_bounds__(MATCH16_THREADS, 2) void match16_kernel(MatchArgs a
         }
         t0 = t1;
         t1 = t2;
+#ifdef KPDI16_DYNAMIC_TILES
         t2 = __builtin_amdgcn_readfirstlane(ctrl[4 + tp]);  // published at this tile's first barrier
         tp ^= 1;
+#else
+        t2 += a.nsplit;
+#endif
         --ld_pos;
         if (t0 >= n_tiles) break;
       }
@@ -295,38 +439,61 @@ __global__ __launch_bounds__(MATCH16_THREADS, 2) void match16_kernel(MatchArgs a
 
   // ---- lists -> [m_pad][4 * nsplit][KMAX] for the merge kernel
   {
-    const int lists = 4 * a.nsplit;
+    const int lists = (WAVES / 2) * a.nsplit;
 #pragma unroll
     for (int cg = 0; cg < 2; ++cg) {
       const size_t o = ((size_t)(m_lane + 32 * cg) * lists + (size_t)list_id) * KMAX;
 #pragma unroll
-      for (int j = 0; j < KMAX; ++j) {
-        a.part_scores[o + j] = home_s[(cg * KMAX + j) * 64];
-        a.part_idx[o + j] = home_i[(cg * KMAX + j) * 64];
+      for (int c = 0; c < (KMAX + 15) / 16; ++c) {
+        const float *ps = chunk_base(home_s + cg * KMAX * 64, c);
+        const int *pi = chunk_base(home_i + cg * KMAX * 64, c);
+#pragma unroll
+        for (int j = 16 * c; j < KMAX && j < 16 * c + 16; ++j) {
+          a.part_scores[o + j] = ps[(j - 16 * c) * 64 + ulane];
+          a.part_idx[o + j] = pi[(j - 16 * c) * 64 + ulane];
+        }
       }
     }
   }
 }
 
-size_t match16_scratch_bytes(int grid, int list_len) { return (size_t)grid * 8 * 2 * list_len * 64 * sizeof(float); }
+size_t match16_scratch_bytes(int grid, int waves, int list_len) {
+  return (size_t)grid * waves * 2 * list_len * 64 * sizeof(float);
+}
 
-template <int KMAX, bool BOUNDED>
+template <int KMAX, bool BOUNDED, int WAVES>
 static hipError_t launch16_t(const MatchArgs &args, int grid, void *scratch, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)match16_kernel<KMAX, BOUNDED>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS16 + 32);
+    hipError_t e = hipFuncSetAttribute((const void *)match16_kernel<KMAX, BOUNDED, WAVES>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Geo<WAVES>::LDS + 32);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   // scratch: scores of all lists, then their indices
   float *ls = (float *)scratch;
-  int *li = (int *)((char *)scratch + match16_scratch_bytes(grid, KMAX));
-  hipLaunchKernelGGL((match16_kernel<KMAX, BOUNDED>), dim3(grid), dim3(MATCH16_THREADS), LDS16 + 32, s, args, ls, li);
+  int *li = (int *)((char *)scratch + match16_scratch_bytes(grid, WAVES, KMAX));
+  hipLaunchKernelGGL((match16_kernel<KMAX, BOUNDED, WAVES>), dim3(grid), dim3(64 * WAVES), Geo<WAVES>::LDS + 32, s, args,
+                     ls, li);
   return hipGetLastError();
 }
 
-hipError_t launch_match16(const MatchLaunch &a, void *list_scratch, hipStream_t s) {
+template <int WAVES>
+static hipError_t launch16_w(const MatchLaunch &a, const MatchArgs &g, void *scratch, hipStream_t s) {
+  const int grid = a.rows * a.nsplit;
+  const bool bounded = a.bound_score != nullptr;
+  switch (a.list_len) {
+    case 1: return bounded ? launch16_t<1, true, WAVES>(g, grid, scratch, s) : launch16_t<1, false, WAVES>(g, grid, scratch, s);
+    case 8: return bounded ? launch16_t<8, true, WAVES>(g, grid, scratch, s) : launch16_t<8, false, WAVES>(g, grid, scratch, s);
+    case 20:
+      return bounded ? launch16_t<20, true, WAVES>(g, grid, scratch, s) : launch16_t<20, false, WAVES>(g, grid, scratch, s);
+    case 32:
+      return bounded ? launch16_t<32, true, WAVES>(g, grid, scratch, s) : launch16_t<32, false, WAVES>(g, grid, scratch, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_match16(const MatchLaunch &a, int waves, void *list_scratch, hipStream_t s) {
   if (a.operand_form != 2 || a.row_tiles != 4 || !list_scratch) return hipErrorInvalidValue;
   MatchArgs g;
   g.dict = a.dict;
@@ -347,17 +514,7 @@ hipError_t launch_match16(const MatchLaunch &a, void *list_scratch, hipStream_t 
   g.bound_grouped = a.bound_grouped;
   g.tile_ctr = a.tile_ctr;
   g.tile_groups = 1;
-  const int grid = a.rows * a.nsplit;
-  const bool bounded = a.bound_score != nullptr;
-  switch (a.list_len) {
-    case 1: return bounded ? launch16_t<1, true>(g, grid, list_scratch, s) : launch16_t<1, false>(g, grid, list_scratch, s);
-    case 8: return bounded ? launch16_t<8, true>(g, grid, list_scratch, s) : launch16_t<8, false>(g, grid, list_scratch, s);
-    case 20:
-      return bounded ? launch16_t<20, true>(g, grid, list_scratch, s) : launch16_t<20, false>(g, grid, list_scratch, s);
-    case 32:
-      return bounded ? launch16_t<32, true>(g, grid, list_scratch, s) : launch16_t<32, false>(g, grid, list_scratch, s);
-    default: return hipErrorInvalidValue;
-  }
+  return waves == 4 ? launch16_w<4>(a, g, list_scratch, s) : launch16_w<8>(a, g, list_scratch, s);
 }
 
 }  // namespace kpdi

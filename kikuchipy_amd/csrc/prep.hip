@@ -76,9 +76,9 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const T *raw, int np
   const float norm = sqrtf(centred ? q + (float)k * mean * mean : q);
   const float inv = norm > 0.f ? 1.f / norm : 0.f;
   const float cval = sqrtf((float)k) * mean * inv;
-  if (form == 2) {
+  if ((form & 0xff) == 2) {
     for (int c = tid; c < 2 * kpad; c += PREP_THREADS)
-      *(_Float16 *)half_slot(out, r, c, kpad) =
+      *(_Float16 *)half_slot(out, r, c, kpad, form) =
           (_Float16)((c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv * 4096.f : 0.f);
     return;
   }
@@ -112,8 +112,8 @@ __device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], flo
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES; ++i) {
     const int c = lane + 64 * i;
-    if (form == 2) {
-      if (c < 2 * kpad) *(_Float16 *)half_slot(out, r, c, kpad) = (_Float16)(v[i] * inv * 4096.f);
+    if ((form & 0xff) == 2) {
+      if (c < 2 * kpad) *(_Float16 *)half_slot(out, r, c, kpad, form) = (_Float16)(v[i] * inv * 4096.f);
     } else if (c < kpad) {
       out[prepared_offset(r, c, nslab)] = (centred && c == k) ? cval : v[i] * inv;
     }
@@ -301,6 +301,8 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   // columns a row-owning wave / workgroup has to write: everything up to the padded row length
   const int span = std::max(cols, a.operand_form == 2 ? 2 * a.kpad : a.kpad);
   const bool wave_path = span <= 64 * WAVE_VALUES;
+  // what the kernels are told: the float16 form carries its block geometry
+  const int form = a.operand_form == 2 ? f16_form(a.f16_rows, a.f16_step) : a.operand_form;
   const bool vec_ok = (a.npix % 4) == 0 && ((uintptr_t)a.raw % (4 * dtype_size(a.dtype))) == 0;
   const bool vec4 = wave_path && a.pix_map == nullptr && (a.k % 4) == 0 && vec_ok;
   const bool staged = wave_path && a.pix_map != nullptr && vec_ok && a.npix <= 64 * WAVE_VALUES;
@@ -315,7 +317,7 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
 #define KPDI_PREP(T)                                                                                     \
   if (vec4)                                                                                              \
     hipLaunchKernelGGL((prep_wave_kernel<T, 4>), grid, block, 0, s, (const T *)a.raw, a.npix,           \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, a.operand_form);        \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form);        \
   else if (staged) {                                                                                     \
     if (staged_lds > 64 * 1024) {                                                                        \
       hipError_t e = hipFuncSetAttribute((const void *)prep_wave_masked_kernel<T>,                       \
@@ -323,19 +325,19 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
       if (e != hipSuccess) return e;                                                                     \
     }                                                                                                    \
     hipLaunchKernelGGL((prep_wave_masked_kernel<T>), grid, block, staged_lds, s, (const T *)a.raw,      \
-                       a.npix, a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, a.operand_form); \
+                       a.npix, a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form); \
   } else if (wave_path)                                                                                  \
     hipLaunchKernelGGL((prep_wave_kernel<T, 1>), grid, block, 0, s, (const T *)a.raw, a.npix,           \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, a.operand_form == 2 ? 2 : 0); \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, a.operand_form == 2 ? form : 0); \
   else if (block_vec)                                                                                    \
     hipLaunchKernelGGL((prep_block_kernel<T, false>), grid, block, 0, s, (const T *)a.raw, a.npix,      \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, a.operand_form);                 \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, form);                 \
   else if (block_masked)                                                                                 \
     hipLaunchKernelGGL((prep_block_kernel<T, true>), grid, block, 0, s, (const T *)a.raw, a.npix,       \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, a.operand_form);                 \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, form);                 \
   else                                                                                                   \
     hipLaunchKernelGGL((prep_kernel<T>), grid, block, 0, s, (const T *)a.raw, a.npix, a.row_map,        \
-                       a.pix_map, a.k, a.kpad, a.metric, a.out, a.operand_form == 2 ? 2 : 0);            \
+                       a.pix_map, a.k, a.kpad, a.metric, a.out, a.operand_form == 2 ? form : 0);            \
   break;
   switch (a.dtype) {
     case KPDI_U8: KPDI_PREP(uint8_t)

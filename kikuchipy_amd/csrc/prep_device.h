@@ -35,15 +35,20 @@ struct alignas(sizeof(T) * 4) Quad {
 };
 
 // ---- float16 form (KPDI_COMPUTE_F16): a row holds 2 * kpad f16, value * 2^12, in the layout of
-// match16.hip (kernels.h: F16_TILE / F16_STEP): patterns in tiles of 256, pixels in steps of 48; one
-// (tile, step) block = 24 KB contiguous = [6 planes][256 rows][8 pixels]: plane p holds pixels
-// 8p .. 8p + 7 of the step for all 256 rows, 16 bytes per row.  `kpad` = floats per row (= 24 per step).
-__device__ __forceinline__ char *half_slot(float *out, int r, int c, int kpad) {
-  const int nsteps = (2 * kpad) / F16_STEP;
-  const int step = c / F16_STEP, cs = c - step * F16_STEP;
-  const size_t block = (size_t)(r >> 8) * nsteps + step;
-  return (char *)out + block * (size_t)(F16_TILE * F16_STEP * 2) + (cs >> 3) * (F16_TILE * 16) + (r & 255) * 16 +
-         (cs & 7) * 2;
+// match16.hip: patterns in tiles of R rows (256, or 128 for the dictionary of the 4-wave variant),
+// pixels in steps of B (48 or 32); one (tile, step) block is contiguous and stored PLANE-major:
+// [B / 8 planes][R rows][8 pixels] - plane p holds pixels 8p .. 8p + 7 of the step for all rows, 16 bytes
+// per row.  `form` carries the geometry: bits 0-7 = 2, bits 8-15 = log2(R), bits 16-23 = B
+// (f16_form below); `kpad` = floats per row (= B / 2 per step).
+__host__ __device__ inline int f16_form(int tile_rows, int step) {
+  return 2 | ((tile_rows == 128 ? 7 : 8) << 8) | (step << 16);
+}
+__device__ __forceinline__ char *half_slot(float *out, int r, int c, int kpad, int form) {
+  const int lr = (form >> 8) & 0xff, bk = (form >> 16) & 0xff;
+  const int nsteps = (2 * kpad) / bk;
+  const int step = c / bk, cs = c - step * bk;
+  const size_t block = (size_t)(r >> lr) * nsteps + step;
+  return (char *)out + ((block * bk) << (lr + 1)) + (((cs >> 3) << lr) + (r & ((1 << lr) - 1))) * 16 + (cs & 7) * 2;
 }
 
 // same, v[4*i + e] holds kept pixel 4*(lane + 64*i) + e: float4 stores (full 16-byte slots)
@@ -84,7 +89,7 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[NV], float 
 #pragma unroll
   for (int i = 0; i < NV / 4; ++i) {
     const int c = 4 * (lane + NT * i);
-    if (c < (split == 2 ? 2 * kpad : kpad)) {
+    if (c < ((split & 0xff) == 2 ? 2 * kpad : kpad)) {
       float4 w;
       w.x = (centred && c == k) ? cval : v[4 * i] * inv;
       w.y = (centred && c + 1 == k) ? cval : v[4 * i + 1] * inv;
@@ -92,14 +97,14 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[NV], float 
       w.w = (centred && c + 3 == k) ? cval : v[4 * i + 3] * inv;
       if (!split) {
         *reinterpret_cast<float4 *>(out + prepared_offset(r, c, nslab)) = w;
-      } else if (split == 2) {
+      } else if ((split & 0xff) == 2) {
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         h4 h;
         h[0] = (_Float16)(w.x * 4096.f);
         h[1] = (_Float16)(w.y * 4096.f);
         h[2] = (_Float16)(w.z * 4096.f);
         h[3] = (_Float16)(w.w * 4096.f);
-        *reinterpret_cast<h4 *>(half_slot(out, r, c, kpad)) = h;  // half of a slot: 8 bytes
+        *reinterpret_cast<h4 *>(half_slot(out, r, c, kpad, split)) = h;  // half of a slot: 8 bytes
       } else {
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         const float x[4] = {w.x * 4096.f, w.y * 4096.f, w.z * 4096.f, w.w * 4096.f};

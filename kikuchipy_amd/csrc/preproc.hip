@@ -415,7 +415,7 @@ hipError_t launch_preprocess(const PreLaunch &l, bool *prep_done, hipStream_t s)
   a.k = l.k;
   a.kpad = l.kpad;
   a.metric = l.metric;
-  a.form = l.operand_form;
+  a.form = l.operand_form == 2 ? f16_form(F16_TILE, l.f16_step) : l.operand_form;
   a.out = l.out;
   a.scratch = l.scratch;
   switch (l.dtype) {
