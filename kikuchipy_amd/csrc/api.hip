@@ -539,7 +539,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
     }
     int j = 0;
     const size_t scratch16 =
-        f16 ? 2 * kpdi::match16_scratch_bytes(std::min(rows_per_launch, row_blocks) * nsplit, c->f16_waves, list_len) : 0;
+        f16 ? kpdi::match16_scratch_bytes(std::min(rows_per_launch, row_blocks) * nsplit, c->f16_waves, list_len) : 0;
     if (f16) HIPCHK(c->list16.reserve((two ? 2 : 1) * scratch16));
     for (int r0 = 0; r0 < row_blocks; r0 += rows_per_launch, ++j) {
       ml.row_first = r0;

@@ -137,16 +137,10 @@ __device__ __forceinline__ void scan16(f32x16 (&acc)[4], float (&best)[KMAX], in
   }
 }
 
-// does any lane of the wave hold a candidate of this column group that reaches its threshold?
-__device__ __forceinline__ bool any_candidate(const f32x16 (&acc)[4], float thr) {
-  constexpr float unscale = 0x1p-24f;
-  bool any = false;
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) any = any || (acc[rt][r] * unscale + 0.f >= thr);
-  return __builtin_amdgcn_ballot_w64(any) != 0;
-}
+#ifndef KPDI16_CAP
+#define KPDI16_CAP 8
+#endif
+constexpr int CAND_CAP = KPDI16_CAP;  // buffered candidates per lane and column group between two list updates
 
 template <int KMAX, bool BOUNDED, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, float *ls_scores, int *ls_idx) {
@@ -197,7 +191,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
       pi[(j - 16 * c) * 64 + ulane] = INT_MAX;
     }
   }
+  // candidate buffers behind the lists: [((wg * WAVES + wave) * 2 + cg) * CAND_CAP + slot][lane]
+  const size_t n_list_entries = (size_t)gridDim.x * WAVES * 2 * KMAX * 64;
+  float *buf_s = ls_scores + n_list_entries + (((size_t)blockIdx.x * WAVES + wv) * 2) * CAND_CAP * 64;
+  int *buf_i = ls_idx + n_list_entries + (((size_t)blockIdx.x * WAVES + wv) * 2) * CAND_CAP * 64;
   float last0 = -INFINITY, last1 = -INFINITY;  // the lists' last entries: all the main loop keeps of them
+  int cnt0 = 0, cnt1 = 0;                      // buffered candidates
+  float pub0 = -INFINITY, pub1 = -INFINITY;    // what this lane's lists have published into the shared bound
   float ub0 = INFINITY, ub1 = INFINITY;
   int ubi0 = -1, ubi1 = -1;
   if (BOUNDED) {
@@ -372,55 +372,123 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
       for (int rt = 0; rt < 4; ++rt) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc0[rt]), "+a"(acc1[rt]));
 #endif
       {
-        // ---- epilogue of the tile: a list is only brought into registers when a candidate reaches it
+        // ---- epilogue of the tile.  Steady state (per column group): the 64 accumulator registers are
+        // compared with the pre-scaled threshold (a v_max3 tree per 16 registers first) and the few
+        // candidates that pass are APPENDED to the lane's candidate buffer in the scratch - the sorted list
+        // itself is only loaded, updated and stored when a buffer is full (the first tiles of a launch,
+        // rarely afterwards) and at the end.  The waves of a workgroup run in lockstep (one barrier per
+        // step), so every cycle spent here is lost on the matrix pipe: a list update per tile cost 23 %.
         const int row0 = t0 * G::DT + wr * 128 + 4 * (lane >> 5);
 #pragma unroll
         for (int cg = 0; cg < 2; ++cg) {
           f32x16(&acc)[4] = cg == 0 ? acc0 : acc1;
           const float gthr = cg == 0 ? g0 : g1;
           float &last = cg == 0 ? last0 : last1;
+          int &cnt = cg == 0 ? cnt0 : cnt1;
+          float &pub = cg == 0 ? pub0 : pub1;
+          const float ub = cg == 0 ? ub0 : ub1;
+          const int ubi = cg == 0 ? ubi0 : ubi1;
 #ifdef KPDI16_NO_EPILOGUE
           asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
-          if (false) {
-#else
-          if (any_candidate(acc, fmaxf(gthr, next_up(last)))) {
+          continue;
 #endif
+          constexpr float unscale = 0x1p-24f;
+          const float thr = fmaxf(gthr, next_up(last));
+          const float thr_raw = thr * 0x1p24f;  // exact: the accumulators hold 2^24 * score
+          float *bs = buf_s + cg * CAND_CAP * 64;
+          int *bi = buf_i + cg * CAND_CAP * 64;
+          int c = cnt;
+          bool overflow = false;
+          float mx = -INFINITY;
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) {
+            float m = acc[rt][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][r]);
+            if (__builtin_amdgcn_ballot_w64(m >= thr_raw) == 0) continue;  // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
+              const float v = acc[rt][r] * unscale + 0.f;  // -0 -> +0 so that ties compare as the merge does
+              const int idx = idx_base + lrow;
+              bool ok = acc[rt][r] >= thr_raw && lrow < n_valid;
+              if (BOUNDED) ok = ok && (v < ub || (v == ub && idx > ubi));
+              if (ok) {
+                if (c < CAND_CAP) {
+                  bs[c * 64 + ulane] = v;
+                  bi[c * 64 + ulane] = idx;
+                  ++c;
+                  mx = fmaxf(mx, v);
+                } else {
+                  overflow = true;
+                }
+              }
+            }
+          }
+#ifdef KPDI16_NO_OVERFLOW
+          overflow = false;
+#endif
+#ifdef KPDI16_SLOW_FIRST_ONLY
+          if (t0 != sp) overflow = false;
+#endif
+#ifdef KPDI16_SLOW_NOT_FIRST
+          if (t0 == sp) overflow = false;
+#endif
+          if (__builtin_amdgcn_ballot_w64(overflow) == 0) {
+            cnt = c;
+            // grouped form of the shared bound (every list publishes its best entry): the best buffered
+            // candidate counts as well
+            if (bound_rank == 1 && mx > pub) {
+              pub = mx;
+              __hip_atomic_fetch_max(const_cast<unsigned *>(cg == 0 ? line0 : line1) + my_slot, score_key(mx),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          } else {
+            // ---- a buffer is full: list <- buffered candidates of the earlier tiles (in arrival order), then
+            // this tile's accumulators the direct way (what was appended from this tile above is dropped)
             float best[KMAX];
             int bidx[KMAX];
             float *hs = home_s + cg * KMAX * 64;
             int *hi = home_i + cg * KMAX * 64;
 #pragma unroll
-            for (int c = 0; c < (KMAX + 15) / 16; ++c) {
-              const float *ps = chunk_base(hs, c);
-              const int *pi = chunk_base(hi, c);
+            for (int q = 0; q < (KMAX + 15) / 16; ++q) {
+              const float *ps = chunk_base(hs, q);
+              const int *pi = chunk_base(hi, q);
 #pragma unroll
-              for (int j = 16 * c; j < KMAX && j < 16 * c + 16; ++j) {
-                best[j] = ps[(j - 16 * c) * 64 + ulane];
-                bidx[j] = pi[(j - 16 * c) * 64 + ulane];
+              for (int j = 16 * q; j < KMAX && j < 16 * q + 16; ++j) {
+                best[j] = ps[(j - 16 * q) * 64 + ulane];
+                bidx[j] = pi[(j - 16 * q) * 64 + ulane];
               }
             }
-            float pub = best[0];  // entry bound_rank - 1 before the scan
+#pragma unroll 1
+            for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt) != 0; ++i) {
+              if (i < cnt) {
+                const float v = bs[i * 64 + ulane];
+                const int id = bi[i * 64 + ulane];
+                if (v > best[KMAX - 1]) list_insert<KMAX>(best, bidx, v, id);
+              }
+            }
+            cnt = 0;
+            scan16<KMAX, BOUNDED>(acc, best, bidx, gthr, ub, ubi, row0, n_valid, idx_base);
 #pragma unroll
-            for (int j = 1; j < KMAX; ++j) pub = j == bound_rank - 1 ? best[j] : pub;
-            scan16<KMAX, BOUNDED>(acc, best, bidx, gthr, cg == 0 ? ub0 : ub1, cg == 0 ? ubi0 : ubi1, row0, n_valid,
-                                  idx_base);
+            for (int q = 0; q < (KMAX + 15) / 16; ++q) {
+              float *ps = chunk_base(hs, q);
+              int *pi = chunk_base(hi, q);
 #pragma unroll
-            for (int c = 0; c < (KMAX + 15) / 16; ++c) {
-              float *ps = chunk_base(hs, c);
-              int *pi = chunk_base(hi, c);
-#pragma unroll
-              for (int j = 16 * c; j < KMAX && j < 16 * c + 16; ++j) {
-                ps[(j - 16 * c) * 64 + ulane] = best[j];
-                pi[(j - 16 * c) * 64 + ulane] = bidx[j];
+              for (int j = 16 * q; j < KMAX && j < 16 * q + 16; ++j) {
+                ps[(j - 16 * q) * 64 + ulane] = best[j];
+                pi[(j - 16 * q) * 64 + ulane] = bidx[j];
               }
             }
             last = best[KMAX - 1];
-            float now = best[0];
+            float now = best[0];  // the entry the shared bound is built from
 #pragma unroll
             for (int j = 1; j < KMAX; ++j) now = j == bound_rank - 1 ? best[j] : now;
-            if (now > pub)  // publish the list entry the shared bound is built from, if it rose
+            if (now > pub) {
+              pub = now;
               __hip_atomic_fetch_max(const_cast<unsigned *>(cg == 0 ? line0 : line1) + my_slot, score_key(now),
                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           }
         }
         t0 = t1;
@@ -437,28 +505,50 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
     }
   }
 
-  // ---- lists -> [m_pad][4 * nsplit][KMAX] for the merge kernel
+  // ---- candidates still buffered join their lists, then lists -> [m_pad][lists][KMAX] for the merge kernel
   {
     const int lists = (WAVES / 2) * a.nsplit;
 #pragma unroll
     for (int cg = 0; cg < 2; ++cg) {
+      const int cnt = cg == 0 ? cnt0 : cnt1;
+      float best[KMAX];
+      int bidx[KMAX];
+#pragma unroll
+      for (int q = 0; q < (KMAX + 15) / 16; ++q) {
+        const float *ps = chunk_base(home_s + cg * KMAX * 64, q);
+        const int *pi = chunk_base(home_i + cg * KMAX * 64, q);
+#pragma unroll
+        for (int j = 16 * q; j < KMAX && j < 16 * q + 16; ++j) {
+          best[j] = ps[(j - 16 * q) * 64 + ulane];
+          bidx[j] = pi[(j - 16 * q) * 64 + ulane];
+        }
+      }
+      const float *bs = buf_s + cg * CAND_CAP * 64;
+      const int *bi = buf_i + cg * CAND_CAP * 64;
+#pragma unroll 1
+      for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt) != 0; ++i) {
+        if (i < cnt) {
+          const float v = bs[i * 64 + ulane];
+          const int id = bi[i * 64 + ulane];
+          if (v > best[KMAX - 1]) list_insert<KMAX>(best, bidx, v, id);
+        }
+      }
       const size_t o = ((size_t)(m_lane + 32 * cg) * lists + (size_t)list_id) * KMAX;
 #pragma unroll
-      for (int c = 0; c < (KMAX + 15) / 16; ++c) {
-        const float *ps = chunk_base(home_s + cg * KMAX * 64, c);
-        const int *pi = chunk_base(home_i + cg * KMAX * 64, c);
-#pragma unroll
-        for (int j = 16 * c; j < KMAX && j < 16 * c + 16; ++j) {
-          a.part_scores[o + j] = ps[(j - 16 * c) * 64 + ulane];
-          a.part_idx[o + j] = pi[(j - 16 * c) * 64 + ulane];
-        }
+      for (int j = 0; j < KMAX; ++j) {
+        a.part_scores[o + j] = best[j];
+        a.part_idx[o + j] = bidx[j];
       }
     }
   }
 }
 
+// floats (and as many ints) the kernel keeps per launch: the lists and the candidate buffers behind them
+static size_t scratch16_entries(int grid, int waves, int list_len) {
+  return (size_t)grid * waves * 2 * (list_len + CAND_CAP) * 64;
+}
 size_t match16_scratch_bytes(int grid, int waves, int list_len) {
-  return (size_t)grid * waves * 2 * list_len * 64 * sizeof(float);
+  return scratch16_entries(grid, waves, list_len) * (sizeof(float) + sizeof(int));
 }
 
 template <int KMAX, bool BOUNDED, int WAVES>
@@ -472,7 +562,7 @@ static hipError_t launch16_t(const MatchArgs &args, int grid, void *scratch, hip
   }
   // scratch: scores of all lists, then their indices
   float *ls = (float *)scratch;
-  int *li = (int *)((char *)scratch + match16_scratch_bytes(grid, WAVES, KMAX));
+  int *li = (int *)(ls + scratch16_entries(grid, WAVES, KMAX));
   hipLaunchKernelGGL((match16_kernel<KMAX, BOUNDED, WAVES>), dim3(grid), dim3(64 * WAVES), Geo<WAVES>::LDS + 32, s, args,
                      ls, li);
   return hipGetLastError();
