@@ -207,7 +207,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-sample", type=int, default=20000, help="dictionary patterns in the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="dictionary patterns in the CPU baseline sample (default: sized for ~10 s of CPU work on this "
+                         "host's usable cores, at most the whole dictionary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check-rows", type=int, default=None,
                     help="experimental rows of the timed result that are checked against the C oracle over the whole "
@@ -621,10 +623,14 @@ def main():
 
     if world == 1 and not a.no_cpu_baseline:
         try:
-            # bounded: ~the flops of configs[1]'s sample whatever the workload
-            n_sample = min(a.cpu_sample, w["n"])
+            # bounded: ~10 s of CPU work on this host (20 000 dictionary patterns of configs[1] take ~4.5 s on 8
+            # cores with either variant), whatever the workload; never more than the dictionary
+            from oracle import c_oracle
+
+            sample = a.cpu_sample or int(20000 * c_oracle.effective_cpus() / 8)
+            n_sample = min(sample, w["n"])
             if large:
-                n_sample = max(500, min(BLOCK, int(a.cpu_sample * (4096 * 3600) / (w["m"] * w["sy"] * w["sx"]))))
+                n_sample = max(500, min(BLOCK, int(sample * (4096 * 3600) / (w["m"] * w["sy"] * w["sx"]))))
                 dic = dictionary_block(w, 0, exp)
             out["cpu_baseline"] = cpu_baseline(w, exp, dic, bg, mask, n_sample)
         except Exception as err:
