@@ -458,6 +458,27 @@ int ensure_running(kpdi_ctx *c) {
   return KPDI_OK;
 }
 
+// How the 8 XCDs tile a launch's rows x nsplit workgroups (match_device.h: block_rb_sp): among the grids
+// (xr x xs = 8) that divide both extents, the one whose XCDs stream the fewest operand bytes per tile round -
+// (rows / xr) experimental blocks of 256 patterns + (nsplit / xs) dictionary tiles.  0 x 0 = plain mapping
+// (KPDI_XCD_GRID=0 forces it).
+void plan_xcd_grid(int rows, int nsplit, int tile_dict, int *xr, int *xs) {
+  *xr = *xs = 0;
+  if (getenv("KPDI_XCD_GRID") && atoi(getenv("KPDI_XCD_GRID")) == 0) return;
+  if ((rows * nsplit) % 8 != 0) return;
+  long best = -1;
+  for (int r = 1; r <= 8; r *= 2) {
+    const int sgrid = 8 / r;
+    if (rows % r != 0 || nsplit % sgrid != 0) continue;
+    const long cost = (long)(rows / r) * kpdi::TILE_EXP + (long)(nsplit / sgrid) * tile_dict;
+    if (best < 0 || cost < best) {
+      best = cost;
+      *xr = r;
+      *xs = sgrid;
+    }
+  }
+}
+
 // one match launch over the prepared chunk -> partial lists
 //
 // Tail: the dictionary tiles of a row block are shared by `nsplit` workgroups; when their number is a
@@ -510,16 +531,21 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
     ml.bound_grouped = grouped;
   }
   ml.gthr = c->gthr.as<unsigned>();
-  // XCD-affine tile groups (KPDI_TILE_GROUPS=8) are an experiment kept for measurement: they
-  // make the workgroups of one XCD take the same dictionary tiles in every row block, but the
-  // workgroups drift apart by more than the 4 MB L2 holds, so the fabric traffic only drops
-  // from 26.4 to 25.0 GB per config-2 launch and the time not at all (profiles/r01_summary.md).
-  const char *tg_env = getenv("KPDI_TILE_GROUPS");
-  ml.tile_groups = (tg_env && atoi(tg_env) == 8 && nsplit % 8 == 0) ? 8 : 1;
-  const size_t ctr_bytes = (size_t)(c->m_pad / kpdi::TILE_EXP) * ml.tile_groups * sizeof(unsigned);
+  // Tile hand-out (match.hip): a workgroup's first `fixed_draws` tiles are fixed (sp, sp + nsplit, ...) so that
+  // the workgroups sharing an XCD stream the same operands at the same pace (the XCD's L2 then serves them:
+  // 26 -> ~12 GB crossing the fabric per config-2 launch); the last ~20 % are drawn from the row block's counter,
+  // which evens out the speeds at the end (all tiles fixed left CUs idle for the last ~10 % of the launch).
+  // KPDI_FIXED_FRAC overrides the fixed share.
+  ml.tile_groups = 1;
+  {
+    double frac = 0.8;
+    if (const char *e = getenv("KPDI_FIXED_FRAC")) frac = atof(e);
+    const int per_wg = n_main / nsplit;
+    ml.fixed_draws = (tail_tiles > 0 || n_main % nsplit == 0) && frac > 0 ? per_wg + 1 : std::max(3, (int)(frac * per_wg));
+  }
+  const size_t ctr_bytes = (size_t)(c->m_pad / kpdi::TILE_EXP) * sizeof(unsigned);
   HIPCHK(c->tile_ctr.reserve(2 * ctr_bytes));  // second half: the tail launch
-  // every workgroup's first three draws are fixed (match.hip), the counters start behind them
-  HIPCHK(kpdi::launch_fill_u32(c->tile_ctr.as<unsigned>(), 3u * (unsigned)(nsplit / ml.tile_groups),
+  HIPCHK(kpdi::launch_fill_u32(c->tile_ctr.as<unsigned>(), (unsigned)ml.fixed_draws * (unsigned)nsplit,
                                (int64_t)(ctr_bytes / sizeof(unsigned)), c->stream));
   ml.tile_ctr = c->tile_ctr.as<unsigned>();
   const int row_blocks = c->m_pad / kpdi::TILE_EXP;
@@ -544,6 +570,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
     for (int r0 = 0; r0 < row_blocks; r0 += rows_per_launch, ++j) {
       ml.row_first = r0;
       ml.rows = std::min(rows_per_launch, row_blocks - r0);
+      plan_xcd_grid(ml.rows, nsplit, dict_tile(c), &ml.xcd_rows, &ml.xcd_splits);
       hipStream_t st = (two && (j & 1)) ? c->stream2 : c->stream;
       if (f16) {
         // launches on the two streams overlap: each stream has its own list scratch
@@ -571,6 +598,8 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
       tl.n_tiles = units;
       tl.nsplit = ns_t;
       tl.tile_groups = 1;
+      tl.fixed_draws = 3;
+      tl.xcd_rows = tl.xcd_splits = 0;
       tl.part_scores = c->tail_s.as<float>();
       tl.part_idx = c->tail_i.as<int>();
       tl.tile_ctr = c->tile_ctr.as<unsigned>() + ctr_bytes / sizeof(unsigned);

@@ -66,8 +66,10 @@ struct MatchLaunch {
   // launch_init_bound at the start of a sweep (and of every bounded pass)
   unsigned *gthr;
   int bound_rank, bound_grouped;  // from bound_plan()
-  unsigned *tile_ctr;  // [m_pad / TILE_EXP][tile_groups] dynamic tile counters, zeroed before every launch
-  int tile_groups;     // 8 = XCD-affine hand-out (nsplit % 8 == 0), 1 = one counter per row block
+  unsigned *tile_ctr;  // [m_pad / TILE_EXP] dynamic tile counters, set to fixed_draws * nsplit before every launch
+  int tile_groups;     // (unused)
+  int fixed_draws = 3; // tiles per workgroup that are fixed (sp + j * nsplit) before it draws from the counter
+  int xcd_rows = 0, xcd_splits = 0;  // XCD grid over a launch's (row block, split) workgroups, 0 = plain mapping
   int operand_form;    // 0 = f32, 1 = split-f16 (KPDI_COMPUTE_F16X2), 2 = f16 (KPDI_COMPUTE_F16), see match.hip
   int row_tiles = 4;   // 4: units of work = 128-pattern tiles; 1: the tail form - 32-pattern units (f32 only)
   int row_base = 0;    // tail form: dictionary row (of this chunk) of unit 0, a multiple of 32; `n_tiles` counts units

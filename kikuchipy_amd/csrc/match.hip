@@ -188,8 +188,9 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int sp = blockIdx.x % a.nsplit;
-  const int rb = a.row_first + blockIdx.x / a.nsplit;
+  int sp, rb;
+  block_rb_sp(a, blockIdx.x, &rb, &sp);
+  rb += a.row_first;
   // kernel arguments into locals (nothing below takes the address of `a`)
   const float *a_dict = a.dict;
   const int n_tiles = a.n_tiles, n_valid = a.n_valid, idx_base = a.idx_base;
@@ -197,12 +198,12 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
   unsigned *gthr_arr = a.gthr;
   const int kpad = a.kpad;
   const int nslab = kpad / TILE_K;
-  // Tiles are handed out per (row block, tile group): with `tile_groups` = 8 the workgroups of
-  // XCD x (block id % 8 == split % 8 == x, nsplit being a multiple of 8) take the tiles
-  // t % 8 == x of EVERY row block, so a dictionary tile crosses the fabric once per XCD-resident
-  // L2 instead of once per row block; within a group the hand-out stays dynamic.
-  const int tgroups = a.tile_groups, tg = sp % tgroups;
-  unsigned *tile_ctr = a.tile_ctr + rb * tgroups + tg;
+  // Tiles: a workgroup's first `fixed_draws` are fixed (sp, sp + nsplit, ...: the workgroups an XCD hosts walk
+  // the same dictionary tiles at the same pace, see block_rb_sp), the last ones are drawn from the row block's
+  // counter, which evens out the speeds at the end of the launch.
+  unsigned *tile_ctr = a.tile_ctr + rb;
+  const int fixed_draws = a.fixed_draws;
+  int drawn = 3;  // t0, t1, t2 below are draws 0, 1, 2
   volatile int *ctrl = (volatile int *)(smem + LDS_BYTES);  // control words behind the ring
 
   const unsigned goff = (unsigned)lane * 16u;
@@ -258,12 +259,9 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
   // <= 3 tiles per workgroup took about one tile-time more than its share (4096 x 2048 / 4096 /
   // 6144 patterns: 1.00 / 1.48 / 1.96 ms before, 0.57 / 1.06 / 1.59 ms now).  Everything after
   // is drawn while the previous tile is computed.
-  {
-    const int group = a.nsplit / tgroups, r = sp / tgroups;
-    t0 = r * tgroups + tg;
-    t1 = (r + group) * tgroups + tg;
-    t2 = (r + 2 * group) * tgroups + tg;
-  }
+  t0 = sp;
+  t1 = sp + a.nsplit;
+  t2 = sp + 2 * a.nsplit;
   if (t0 >= n_tiles) goto write_out;
 
   {
@@ -343,7 +341,10 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
       const char *ls = smem + stage * STAGE_BYTES;
       const int nstage = stage == NSTAGE - 1 ? 0 : stage + 1;
       const char *ls_next = smem + nstage * STAGE_BYTES;
-      if (slab == 0 && tid == 0) fetched = (int)atomicAdd(tile_ctr, 1u) * tgroups + tg;
+      if (slab == 0) {
+        if (tid == 0) fetched = drawn < fixed_draws ? sp + drawn * a.nsplit : (int)atomicAdd(tile_ctr, 1u);
+        ++drawn;
+      }
       if (slab == nslab - 1) {  // landed by the mid-step wait, used in the epilogue
         g0 = shared_bound<KMAX>(line0, bound_grouped);
         g1 = shared_bound<KMAX>(line1, bound_grouped);
@@ -552,7 +553,11 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   g.bound_rank = a.bound_rank;
   g.bound_grouped = a.bound_grouped;
   g.tile_ctr = a.tile_ctr;
-  g.tile_groups = a.tile_groups;
+  g.tile_groups = 1;
+  g.fixed_draws = a.fixed_draws < 3 ? 3 : a.fixed_draws;
+  g.xcd_rows = a.xcd_rows;
+  g.xcd_splits = a.xcd_splits;
+  g.rows = a.rows;
   g.row_base = a.row_base;
   const int grid = a.rows * a.nsplit;
   const bool bounded = a.bound_score != nullptr;

@@ -154,8 +154,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0 .. WAVES - 1
   const int wr = wv >> 2, wc = wv & 3;
-  const int sp = blockIdx.x % a.nsplit;
-  const int rb = a.row_first + blockIdx.x / a.nsplit;
+  int sp, rb;
+  block_rb_sp(a, blockIdx.x, &rb, &sp);
+  rb += a.row_first;
   const int n_tiles = a.n_tiles, n_valid = a.n_valid, idx_base = a.idx_base;
   const int nsteps = (2 * a.kpad) / G::BK;
   const size_t tile_bytes = (size_t)nsteps * G::DBLOCK;   // one dictionary tile, all steps
@@ -604,6 +605,10 @@ hipError_t launch_match16(const MatchLaunch &a, int waves, void *list_scratch, h
   g.bound_grouped = a.bound_grouped;
   g.tile_ctr = a.tile_ctr;
   g.tile_groups = 1;
+  g.fixed_draws = 1 << 30;
+  g.xcd_rows = a.xcd_rows;
+  g.xcd_splits = a.xcd_splits;
+  g.rows = a.rows;
   return waves == 4 ? launch16_w<4>(a, g, list_scratch, s) : launch16_w<8>(a, g, list_scratch, s);
 }
 

@@ -22,12 +22,33 @@ struct MatchArgs {
   int *part_idx;
   const float *bound_score;
   const int *bound_idx;
-  unsigned *tile_ctr;  // [row blocks][tile_groups] next draw to hand out; 3 * nsplit / tile_groups at launch
-  int tile_groups;
+  unsigned *tile_ctr;  // [row blocks] next tile to hand out dynamically; fixed_draws * nsplit at launch
+  int tile_groups;     // (unused: 1)
+  // A workgroup's first `fixed_draws` tiles are fixed (split sp: sp, sp + nsplit, ...), the rest is drawn
+  // from the row block's counter.  xcd_rows x xcd_splits = 8 arranges the 8 XCDs as a grid over the launch's
+  // (row block, split) workgroups (block_rb_sp below); xcd_rows = 0: block b -> (b / nsplit, b % nsplit).
+  int fixed_draws, xcd_rows, xcd_splits, rows;
   unsigned *gthr;      // [m_pad][BOUND_SLOTS] published list ranks (monotone keys), see shared_bound()
   int bound_rank;      // which entry (1-based) of its list a workgroup lane publishes
   int bound_grouped;   // 1: all 32 slots are in use and bound_rank == 1 (grouped form)
 };
+
+// Block id -> (row block of the launch, dictionary split).  Block b runs on XCD b % 8 (observed, used for
+// speed only); the XCDs tile the (rows x nsplit) grid of workgroups as xcd_rows x xcd_splits rectangles, so
+// that an XCD hosts (rows / xcd_rows) row blocks x (nsplit / xcd_splits) splits: its L2 then serves a
+// dictionary tile to all its row blocks and an experimental slab to all its splits - with fixed draws and
+// workgroups advancing at the same pace the operands cross the fabric once per XCD, not once per workgroup.
+__device__ __forceinline__ void block_rb_sp(const MatchArgs &a, int b, int *rb, int *sp) {
+  if (a.xcd_rows == 0) {
+    *sp = b % a.nsplit;
+    *rb = b / a.nsplit;
+    return;
+  }
+  const int x = b & 7, j = b >> 3;
+  const int rx = a.rows / a.xcd_rows, sx = a.nsplit / a.xcd_splits;
+  *rb = (x / a.xcd_splits) * rx + j % rx;
+  *sp = (x % a.xcd_splits) * sx + j / rx;
+}
 
 // ---- shared rejection bound -------------------------------------------------------------
 // A score T may be used to reject candidates (v < T cannot enter the final top-KMAX) whenever
