@@ -96,7 +96,7 @@ def circular_mask(sy, sx):
     return np.sqrt((yy - sy // 2) ** 2 + (xx - sx // 2) ** 2) > max(sy // 2, sx // 2)
 
 
-def check_result(w, exp, dic, bg, mask, scores, indices, n_rows, large):
+def check_result(w, exp, dic, bg, mask, scores, indices, n_rows, large, compute="f32"):
     """The result of the timed run against the C oracle (oracle/kpdi_oracle_c.c, float64-accumulated
     dot products, OpenMP over the host cores) on a sample of experimental rows over the WHOLE
     dictionary, plus the planted copies of the large workloads.  The oracle is the checker here,
@@ -120,6 +120,11 @@ def check_result(w, exp, dic, bg, mask, scores, indices, n_rows, large):
         out["max_abs_score_diff_end_to_end"] = float(np.abs(scores[rows] - rs).max())
         out["best_match_agreement"] = float(np.mean(indices[rows][:, 0] == ri[:, 0]))
         assert out["max_abs_score_diff_end_to_end"] < 1e-4 and out["best_match_agreement"] > 0.98, out
+    elif compute == "f16":
+        # the opt-in REDUCED-PRECISION arithmetic: its documented bound, not the 1e-5 contract
+        out["max_abs_score_diff"] = float(np.abs(scores[rows] - rs).max())
+        out["best_match_agreement"] = float(np.mean(indices[rows][:, 0] == ri[:, 0]))
+        assert out["max_abs_score_diff"] < 2e-3 and out["best_match_agreement"] > 0.9, out
     else:
         ko.assert_topk_parity(scores[rows], indices[rows], rs, ri, atol=1e-5)
         out["max_abs_score_diff"] = float(np.abs(scores[rows] - rs).max())
@@ -127,7 +132,7 @@ def check_result(w, exp, dic, bg, mask, scores, indices, n_rows, large):
     if large:
         prow, pat = plant_table(w)
         assert np.array_equal(indices[prow, 0], pat), "planted copies not found first"
-        assert np.allclose(scores[prow, 0], 1.0, atol=1e-5), scores[prow, 0]
+        assert np.allclose(scores[prow, 0], 1.0, atol=2e-3 if compute == "f16" else 1e-5), scores[prow, 0]
         out["planted_found"] = int(len(prow))
     out["seconds"] = round(time.perf_counter() - t0, 2)
     return out
@@ -393,7 +398,7 @@ def main():
     # ---- the result of the timed run is checked before anything is printed
     n_check = a.check_rows if a.check_rows is not None else (32 if large else 64)
     if world == 1 and n_check > 0:
-        out["check"] = check_result(w, exp, dic, bg, mask, scores, indices, n_check, large)
+        out["check"] = check_result(w, exp, dic, bg, mask, scores, indices, n_check, large, a.compute)
 
     # ---- configs[2] inside the default run: circular signal mask (K = 2819) + static and dynamic
     # background removal fused with the preparation of the patterns (ONE pre-kernel), then the match

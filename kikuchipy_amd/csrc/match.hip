@@ -41,8 +41,7 @@
 //    the 16-byte slots hold 8 float16 (high halves in slots 0-3 of a row-slab, low halves
 //    in 4-7), a slab is 2 steps of 16 pixels with three v_mfma_f32_32x32x16_f16 per
 //    accumulator (hi.hi + hi.lo + lo.hi), and the epilogue rescales by 2^-24.
-//  * FORM = 2 is the opt-in plain float16 form (KPDI_COMPUTE_F16, reduced precision): every
-//    value one f16 (times 2^12), a slab = 64 pixels = 4 steps of one MFMA per accumulator.
+//  * The opt-in plain float16 form (KPDI_COMPUTE_F16) has a kernel of its own: match16.hip.
 //
 // Algorithmic work per launch: 2 * M * n_chunk * K flops (K = kept pixels).
 #include "match_device.h"
@@ -65,29 +64,16 @@ template <int KMAX, bool BOUNDED, int FORM, int ROWT>
 __device__ __forceinline__ void scan_tile(f32x16 (&acc)[4], float (&best)[KMAX], int (&best_idx)[KMAX],
                                           float gthr, float ub, int ub_idx, int row0, int n_valid,
                                           int idx_base) {
-  // float16 operands (split or not) are stored scaled by 2^12 each: the accumulators hold 2^24 * score
+  // float16 operands (split form) are stored scaled by 2^12 each: the accumulators hold 2^24 * score
   constexpr float unscale = FORM != 0 ? 0x1p-24f : 1.f;
   // v > best[KMAX-1]  <=>  v >= nextafter(best[KMAX-1], +inf)   (scores are finite)
   float thr = fmaxf(gthr, next_up(best[KMAX - 1]));
 #pragma unroll
   for (int rt = 0; rt < ROWT; ++rt) {
-    if (FORM == 2) {
-      // float16 form: first a screen over the 16 registers with plain (unrolled) compares - bit r of
-      // `hot` = some lane of register r reaches the threshold as it stands now - then only those
-      // registers go through the loop with the scalar register index (relative VGPR addressing,
-      // ~100 cycles per visit for the index mode switches).  The threshold only rises while the
-      // tile is scanned, so the screen is conservative and the loop re-tests every lane.  Measured:
-      // float16 4.30 -> 3.84 ms at config 2; f32 unchanged (20.97 ms: its scan time, 2.7 % of the
-      // launch, is the insertions themselves), split-f16 8.04 -> 8.6 ms - so only here.
-      unsigned hot = 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        hot |= __builtin_amdgcn_ballot_w64(acc[rt][r] * unscale + 0.f >= thr) != 0 ? (1u << r) : 0u;
 #pragma unroll 1
-      while (hot != 0) {
-        const int r = __builtin_ctz(hot);
-        hot &= hot - 1;
-        const float v = acc[rt][r] * unscale + 0.f;
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc[rt][r] * unscale + 0.f;  // -0 -> +0 so that ties compare as the merge does
+      if (__builtin_amdgcn_ballot_w64(v >= thr) != 0) {
         const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
         const int idx = idx_base + lrow;
         bool ok = lrow < n_valid && v >= thr;
@@ -95,21 +81,6 @@ __device__ __forceinline__ void scan_tile(f32x16 (&acc)[4], float (&best)[KMAX],
         if (ok) {
           list_insert<KMAX>(best, best_idx, v, idx);
           thr = fmaxf(gthr, next_up(best[KMAX - 1]));
-        }
-      }
-    } else {
-#pragma unroll 1
-      for (int r = 0; r < 16; ++r) {
-        const float v = acc[rt][r] * unscale + 0.f;  // -0 -> +0 so that ties compare as the merge does
-        if (__builtin_amdgcn_ballot_w64(v >= thr) != 0) {
-          const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
-          const int idx = idx_base + lrow;
-          bool ok = lrow < n_valid && v >= thr;
-          if (BOUNDED) ok = ok && (v < ub || (v == ub && idx > ub_idx));
-          if (ok) {
-            list_insert<KMAX>(best, best_idx, v, idx);
-            thr = fmaxf(gthr, next_up(best[KMAX - 1]));
-          }
         }
       }
     }
@@ -387,36 +358,6 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
             }
           }
         }
-      } else if (FORM == 2) {
-        // ---- float16 slab: 64 pixels, one 16-byte slot = 8 f16 of a row; 4 steps of 16 pixels,
-        // one v_mfma_f32_32x32x16_f16 per accumulator and step.  Same stage / barrier / piece
-        // schedule as the f32 slab below.
-#pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
-          const int cur = kg & 1;
-          if (kg == 2) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (slab == 0 && tid == 0) ctrl[4 + tp] = fetched;
-            __syncthreads();
-          }
-          const char *src = kg < 3 ? ls + frag[kg + 1] : ls_next + frag[0];
-#pragma unroll
-          for (int rt = 0; rt < 4; ++rt) {
-            mfma_acc_h(acc0[rt], fa[cur][rt], fb[cur][0]);
-            mfma_acc_h(acc1[rt], fa[cur][rt], fb[cur][1]);
-            // in the shadow of these MFMAs: the fragments of the next step and, after the barrier,
-            // this wave's 12 LDS-DMA pieces of the slab two steps ahead
-            fa[cur ^ 1][rt] = *(const f32x4 *)(src + rt * 4096);
-            if (rt == 1) fb[cur ^ 1][0] = *(const f32x4 *)(src + exp_frag);
-            if (rt == 3) fb[cur ^ 1][1] = *(const f32x4 *)(src + exp_frag + 4096);
-            if (kg == 2) {
-              issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * rt KPDI_GOFF_ARG);
-              issue_piece(gd, ge, tile_bytes, ld_base, wv, 2 * rt + 1 KPDI_GOFF_ARG);
-            }
-            if (kg == 3) issue_piece(gd, ge, tile_bytes, ld_base, wv, 8 + rt KPDI_GOFF_ARG);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
       } else {
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg) {
@@ -561,6 +502,7 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   g.row_base = a.row_base;
   const int grid = a.rows * a.nsplit;
   const bool bounded = a.bound_score != nullptr;
+  if (a.operand_form == 2) return hipErrorInvalidValue;  // the float16 form has its own kernel: launch_match16
   if (a.row_tiles == 1) {  // tail form: f32, single pass
     if (a.operand_form != 0 || bounded || (a.row_base & 31)) return hipErrorInvalidValue;
     switch (a.list_len) {
@@ -573,7 +515,6 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   }
 #define KPDI_CASE(K)                                                                             \
   case K:                                                                                        \
-    if (a.operand_form == 2) return bounded ? launch_t<K, true, 2>(g, grid, s) : launch_t<K, false, 2>(g, grid, s); \
     if (a.operand_form == 1) return bounded ? launch_t<K, true, 1>(g, grid, s) : launch_t<K, false, 1>(g, grid, s); \
     return bounded ? launch_t<K, true, 0>(g, grid, s) : launch_t<K, false, 0>(g, grid, s);
   switch (a.list_len) {

@@ -65,14 +65,16 @@ for name, row in stats.items():
         k["clock_ghz_profiled"] = (k["GRBM_GUI_ACTIVE"] / 8) / (k["avg_ms"] * 1e-3) / 1e9
     summary["kernels"][name] = k
 
-match = next((n for n in summary["kernels"] if "match_topk_kernel" in n), None)
+match = next((n for n in summary["kernels"] if "match_topk_kernel<20, false, 0, 4>" in n), None) or \
+    next((n for n in summary["kernels"] if "match_topk_kernel" in n), None)
 if match:
     mk = summary["kernels"][match]
     summary["match_kernel"] = match
     summary["match_traffic_bytes_per_launch"] = mk.get("fetch_bytes_per_launch", 0) + mk.get("write_bytes_per_launch", 0)
 json.dump(summary, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
 
-lines = [f"# rocprofv3 summary {tag}: `python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pcie --no-generation` (tools/collect_profiles.sh)", "",
+lines = [f"# rocprofv3 summary {tag}: `python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pcie` (tools/collect_profiles.sh; "
+         "one --kernel-trace --stats pass and three --pmc passes of the same command; fetch = FETCH_SIZE x 1024 x 2, the gfx950 correction)", "",
          "| kernel | calls | avg ms | % | fetch GB/launch | write GB/launch | MFMA busy | clock GHz |",
          "|---|---|---|---|---|---|---|---|"]
 for name, k in summary["kernels"].items():
