@@ -18,11 +18,11 @@
 //    screens the accumulators against the threshold held in ONE register per list and only then loads
 //    a list, inserts, and stores it back.  That is what frees the registers for two waves per SIMD.
 //  * Operands (prep_device.h: half_slot): patterns in tiles of 256, pixels in steps of 48; a
-//    (tile, step) block is 24 KB contiguous, stored PLANE-major: [6 planes][256 rows][8 pixels].  A
-//    lane's MFMA fragment (row l & 31 of a 32-row group, pixels 8 (l >> 5) .. + 7 of a 16-pixel k-step)
-//    is one 16-byte ds_read_b128 at plane * 4096 + row * 16: within every 16-lane group of the
-//    instruction the rows are distinct mod 16 -> 16 distinct bank quads, conflict-free WITHOUT a swizzle,
-//    and a block is copied verbatim by 24 lane-linear 1 KB LDS-DMA pieces.
+//    (tile, step) block is 24 KB contiguous, stored PLANE-major: [3 k-steps][256 rows][16 pixels].  A
+//    lane's MFMA fragment (row l & 31 of a 32-row group, pixels 8 (l >> 5) .. + 7 of the k-step) is one
+//    16-byte ds_read_b128 at plane * 8192 + row * 32 + half * 16, the two halves swapped for rows with
+//    bit 3 set: within every 16-lane group of the instruction the 16 reads hit 16 distinct bank quads
+//    (SQ_LDS_BANK_CONFLICT = 0), and a block is copied verbatim by 24 lane-linear 1 KB LDS-DMA pieces.
 //  * LDS = ring of three 48 KB stages (dictionary block + experimental block), filled two steps ahead by
 //    6 pieces per wave and step; one barrier per step (after its first k-step), as in match.hip.
 //
@@ -167,11 +167,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
   const char *exp_base = (const char *)a.exp + (size_t)rb * etile_bytes;
   const char *dict_base = (const char *)a.dict;
 
-  // LDS -> MFMA fragments: lane l reads row (l & 31) of a 32-row group, plane 2 ks + (l >> 5)
-  const unsigned fa_off = (unsigned)((lane >> 5) * (G::DT * 16) + (wr * 128 + (lane & 31)) * 16);
-  const unsigned fb_off = (unsigned)(BLOCK16 + (lane >> 5) * (F16_TILE * 16) + (wc * 64 + (lane & 31)) * 16);
-#define KPDI_FA(base, rt, ks) (*(const f32x4 *)((base) + fa_off + (rt) * 512 + (ks) * (2 * G::DT * 16)))
-#define KPDI_FB(base, cg, ks) (*(const f32x4 *)((base) + fb_off + (cg) * 512 + (ks) * (2 * F16_TILE * 16)))
+  // LDS -> MFMA fragments: lane l reads row (l & 31) of a 32-row group in plane ks: the 16-byte half
+  // (l >> 5) of the row's 32 bytes, halves swapped for rows with bit 3 set (prep_device.h: half_slot)
+  const unsigned half_off = (unsigned)((((lane >> 5) ^ (lane >> 3)) & 1) * 16);
+  const unsigned fa_off = (unsigned)((wr * 128 + (lane & 31)) * 32) + half_off;
+  const unsigned fb_off = (unsigned)(BLOCK16 + (wc * 64 + (lane & 31)) * 32) + half_off;
+#define KPDI_FA(base, rt, ks) (*(const f32x4 *)((base) + fa_off + (rt) * 1024 + (ks) * (G::DT * 32)))
+#define KPDI_FB(base, cg, ks) (*(const f32x4 *)((base) + fb_off + (cg) * 1024 + (ks) * (F16_TILE * 32)))
 
   // ---- this lane's two lists (column groups 0 / 1: patterns m_lane, m_lane + 32; it sees the rows
   // 4 (lane >> 5) + {0..3} + 8 j of every 32-row group of its wave's 128 rows).  Their home is the

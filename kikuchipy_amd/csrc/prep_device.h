@@ -37,18 +37,26 @@ struct alignas(sizeof(T) * 4) Quad {
 // ---- float16 form (KPDI_COMPUTE_F16): a row holds 2 * kpad f16, value * 2^12, in the layout of
 // match16.hip: patterns in tiles of R rows (256, or 128 for the dictionary of the 4-wave variant),
 // pixels in steps of B (48 or 32); one (tile, step) block is contiguous and stored PLANE-major:
-// [B / 8 planes][R rows][8 pixels] - plane p holds pixels 8p .. 8p + 7 of the step for all rows, 16 bytes
-// per row.  `form` carries the geometry: bits 0-7 = 2, bits 8-15 = log2(R), bits 16-23 = B
-// (f16_form below); `kpad` = floats per row (= B / 2 per step).
+// [B / 16 planes][R rows][16 pixels] - plane p holds the 16 pixels of k-step p of the step for all rows,
+// 32 bytes per row, its two 16-byte halves (pixels 0-7 / 8-15 = what the lanes 0-31 / 32-63 of an MFMA
+// operand read) swapped for rows with bit 3 set.  That swap makes every 16-lane group of a ds_read_b128
+// (rows r .. of one plane) hit 16 distinct bank quads; 32 contiguous bytes per pattern and plane - a whole
+// 128-byte line for 4 consecutive patterns - is what the preparation kernels can write efficiently (with
+// 16-byte planes the 8 patterns sharing a line were written ~10 us apart: 2.4 TB/s at 120 x 120).
+// `form` carries the geometry: bits 0-7 = 2, bits 8-15 = log2(R), bits 16-23 = B (f16_form below);
+// `kpad` = floats per row (= B / 2 per step).
 __host__ __device__ inline int f16_form(int tile_rows, int step) {
   return 2 | ((tile_rows == 128 ? 7 : 8) << 8) | (step << 16);
 }
 __device__ __forceinline__ char *half_slot(float *out, int r, int c, int kpad, int form) {
   const int lr = (form >> 8) & 0xff, bk = (form >> 16) & 0xff;
-  const int nsteps = (2 * kpad) / bk;
-  const int step = c / bk, cs = c - step * bk;
+  // (divisions by a constant: a runtime divisor costs ~25 instructions per stored slot)
+  const int nsteps = bk == 48 ? (2 * kpad) / 48 : (2 * kpad) / 32;
+  const int step = bk == 48 ? c / 48 : c / 32, cs = c - step * bk;
   const size_t block = (size_t)(r >> lr) * nsteps + step;
-  return (char *)out + ((block * bk) << (lr + 1)) + (((cs >> 3) << lr) + (r & ((1 << lr) - 1))) * 16 + (cs & 7) * 2;
+  const int row = r & ((1 << lr) - 1);
+  return (char *)out + ((block * bk) << (lr + 1)) + (((cs >> 4) << lr) + row) * 32 + ((((cs >> 3) ^ (row >> 3)) & 1) << 4) +
+         (cs & 7) * 2;
 }
 
 // same, v[4*i + e] holds kept pixel 4*(lane + 64*i) + e: float4 stores (full 16-byte slots)
