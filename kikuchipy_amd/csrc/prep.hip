@@ -126,14 +126,9 @@ __device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], flo
 template <typename T, int VEC>
 __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, int npix, const int *row_map,
                                                                  const int *pix_map, int k, int kpad,
-                                                                 int metric, int n_out, float *out, int split,
-                                                                 int passes) {
-  // `passes` consecutive groups of 4 patterns per workgroup: 2 for the float16 form, whose layout
-  // (prep_device.h: half_slot) puts the 16-byte pieces of 8 consecutive patterns into one 128-byte line -
-  // written by ONE workgroup, i.e. through one XCD's L2, the line leaves for memory whole
+                                                                 int metric, int n_out, float *out, int split) {
   const int lane = threadIdx.x & 63;
-  for (int pass = 0; pass < passes; ++pass) {
-  const int r = (blockIdx.x * passes + pass) * (PREP_THREADS / 64) + (threadIdx.x >> 6);
+  const int r = blockIdx.x * (PREP_THREADS / 64) + (threadIdx.x >> 6);
   if (r >= n_out) return;
   const int64_t src = row_map ? row_map[r] : r;
   const T *p = raw + src * (int64_t)npix;
@@ -163,7 +158,6 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, i
     }
     normalise_and_store(v, s, lane, r, k, kpad, metric, out, split);
   }
-  }
 }
 
 // ---- 4096 < K <= 16384 kept pixels (up to 128x128 detectors): one workgroup per pattern ----
@@ -173,13 +167,10 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, i
 template <typename T, bool MASKED>
 __global__ __launch_bounds__(PREP_THREADS) void prep_block_kernel(const T *raw, int npix, const int *row_map,
                                                                   const int *pix_map, int k, int kpad,
-                                                                  int metric, int n_out, float *out, int split,
-                                                                  int passes) {
+                                                                  int metric, float *out, int split) {
   __shared__ float red[PREP_THREADS / 64];
   const int tid = threadIdx.x;
-  for (int pass = 0; pass < passes; ++pass) {  // (float16 form: 8 consecutive patterns, see prep_wave_kernel)
-  const int r = blockIdx.x * passes + pass;
-  if (r >= n_out) return;
+  const int r = blockIdx.x;
   const int64_t src = row_map ? row_map[r] : r;
   const T *p = raw + src * (int64_t)npix;
   float v[WAVE_VALUES];
@@ -200,7 +191,6 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_block_kernel(const T *raw, 
     s += (v[4 * i] + v[4 * i + 1]) + (v[4 * i + 2] + v[4 * i + 3]);
   }
   normalise_and_store_quads<PREP_THREADS>(v, s, tid, r, k, kpad, metric, out, split, red);
-  }
 }
 
 // ---- one wave per pattern, signal mask, row staged in LDS -------------------------------
@@ -209,8 +199,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_block_kernel(const T *raw, 
 template <typename T>
 __global__ __launch_bounds__(PREP_THREADS) void prep_wave_masked_kernel(const T *raw, int npix, const int *row_map,
                                                                         const int *pix_map, int k, int kpad,
-                                                                        int metric, int n_out, float *out, int split,
-                                                                        int passes) {
+                                                                        int metric, int n_out, float *out, int split) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int *map = (int *)smem_raw;
   const int map_words = (k + 3) & ~3;
@@ -219,9 +208,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_masked_kernel(const T 
   for (int c = threadIdx.x; c < map_words; c += PREP_THREADS) map[c] = c < k ? pix_map[c] : 0;
   __syncthreads();
   const int ngroups = (n_out + 3) / 4;
-  // (`passes` consecutive groups per turn: float16 form, see prep_wave_kernel)
-  for (int g0 = blockIdx.x * passes; g0 < ngroups; g0 += gridDim.x * passes)
-  for (int g = g0; g < g0 + passes && g < ngroups; ++g) {
+  for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const int r = g * 4 + wv;
     const bool live = r < n_out;
     if (live) {
@@ -325,14 +312,12 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   const bool block_masked = block_path && a.pix_map != nullptr;
   const size_t staged_lds = (size_t)(((a.k + 3) & ~3) + 4 * a.npix) * 4;
   dim3 block(PREP_THREADS);
-  const int wpasses = a.operand_form == 2 ? 2 : 1, bpasses = a.operand_form == 2 ? 8 : 1;
-  dim3 grid(wave_path ? ((a.n_out + 3) / 4 + wpasses - 1) / wpasses
-                      : ((block_vec || block_masked) ? (a.n_out + bpasses - 1) / bpasses : a.n_out));
-  if (staged) grid = dim3(std::min(((a.n_out + 3) / 4 + wpasses - 1) / wpasses, 2048));
+  dim3 grid(wave_path ? (a.n_out + 3) / 4 : a.n_out);
+  if (staged) grid = dim3(std::min((a.n_out + 3) / 4, 2048));
 #define KPDI_PREP(T)                                                                                     \
   if (vec4)                                                                                              \
     hipLaunchKernelGGL((prep_wave_kernel<T, 4>), grid, block, 0, s, (const T *)a.raw, a.npix,           \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form, wpasses);        \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form);        \
   else if (staged) {                                                                                     \
     if (staged_lds > 64 * 1024) {                                                                        \
       hipError_t e = hipFuncSetAttribute((const void *)prep_wave_masked_kernel<T>,                       \
@@ -340,16 +325,16 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
       if (e != hipSuccess) return e;                                                                     \
     }                                                                                                    \
     hipLaunchKernelGGL((prep_wave_masked_kernel<T>), grid, block, staged_lds, s, (const T *)a.raw,      \
-                       a.npix, a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form, wpasses); \
+                       a.npix, a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form); \
   } else if (wave_path)                                                                                  \
     hipLaunchKernelGGL((prep_wave_kernel<T, 1>), grid, block, 0, s, (const T *)a.raw, a.npix,           \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, a.operand_form == 2 ? form : 0, wpasses); \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, a.operand_form == 2 ? form : 0); \
   else if (block_vec)                                                                                    \
     hipLaunchKernelGGL((prep_block_kernel<T, false>), grid, block, 0, s, (const T *)a.raw, a.npix,      \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form, bpasses);                 \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, form);                 \
   else if (block_masked)                                                                                 \
     hipLaunchKernelGGL((prep_block_kernel<T, true>), grid, block, 0, s, (const T *)a.raw, a.npix,       \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form, bpasses);                 \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, form);                 \
   else                                                                                                   \
     hipLaunchKernelGGL((prep_kernel<T>), grid, block, 0, s, (const T *)a.raw, a.npix, a.row_map,        \
                        a.pix_map, a.k, a.kpad, a.metric, a.out, a.operand_form == 2 ? form : 0);            \

@@ -4,7 +4,8 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/r02
 mkdir -p $O
 cd $R
-bash tools/collect_profiles.sh r02 > $O/collect.log 2>&1
+bash tools/collect_profiles.sh r02 --no-config3 > $O/collect.log 2>&1
+bash tools/collect_profiles.sh r02_config3 --workload config3 >> $O/collect.log 2>&1
 python bench.py --steps 20 --warmup 3 > $O/bench_n1.json 2> $O/bench_n1.err
 python bench.py --workload config3 --steps 20 --warmup 3 --no-pcie --no-generation > $O/bench_config3.json 2> $O/bench_config3.err
 python tools/rank_share_probe.py $O/rank_share.json > $O/rank_share.log 2>&1

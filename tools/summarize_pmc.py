@@ -2,10 +2,10 @@
 
     python tools/summarize_pmc.py gpurun_out r01
 
-Reads  <dir>/prof_<tag>/bench_kernel_stats.csv      (--kernel-trace --stats)
-       <dir>/pmc_fetch/bench_counter_collection.csv (--pmc FETCH_SIZE)
-       <dir>/pmc_write/bench_counter_collection.csv (--pmc WRITE_SIZE)
-       <dir>/pmc_sq/bench_counter_collection.csv    (--pmc SQ_* GRBM_GUI_ACTIVE)
+Reads  <dir>/prof_<tag>/stats/bench_kernel_stats.csv          (--kernel-trace --stats)
+       <dir>/prof_<tag>/pmc_fetch/bench_counter_collection.csv (--pmc FETCH_SIZE)
+       <dir>/prof_<tag>/pmc_write/bench_counter_collection.csv (--pmc WRITE_SIZE)
+       <dir>/prof_<tag>/pmc_sq/bench_counter_collection.csv    (--pmc SQ_* GRBM_GUI_ACTIVE)
 Writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json and
 profiles/<tag>_summary.md.
 
@@ -29,7 +29,7 @@ os.makedirs(out, exist_ok=True)
 
 
 def counters(name):
-    path = os.path.join(src, name, "bench_counter_collection.csv")
+    path = os.path.join(src, f"prof_{tag}", name, "bench_counter_collection.csv")
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     if not os.path.exists(path):
         return agg
@@ -42,12 +42,13 @@ def mean(v):
     return sum(v) / len(v) if v else None
 
 
-stats_src = os.path.join(src, f"prof_{tag}", "bench_kernel_stats.csv")
+stats_src = os.path.join(src, f"prof_{tag}", "stats", "bench_kernel_stats.csv")
+command = open(os.path.join(src, f"prof_{tag}", "command.txt")).read().strip().replace(root + "/", "")
 shutil.copy(stats_src, os.path.join(out, f"{tag}_kernel_stats.csv"))
 stats = {r["Name"]: r for r in csv.DictReader(open(stats_src))}
 
 fetch, write, sq = counters("pmc_fetch"), counters("pmc_write"), counters("pmc_sq")
-summary = {"tag": tag, "kernels": {}}
+summary = {"tag": tag, "command": command, "kernels": {}}
 for name, row in stats.items():
     k = {"calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) / 1e6,
          "percentage": float(row["Percentage"])}
@@ -73,7 +74,7 @@ if match:
     summary["match_traffic_bytes_per_launch"] = mk.get("fetch_bytes_per_launch", 0) + mk.get("write_bytes_per_launch", 0)
 json.dump(summary, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
 
-lines = [f"# rocprofv3 summary {tag}: `python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pcie` (tools/collect_profiles.sh; "
+lines = [f"# rocprofv3 summary {tag}: `{command}` (tools/collect_profiles.sh; "
          "one --kernel-trace --stats pass and three --pmc passes of the same command; fetch = FETCH_SIZE x 1024 x 2, the gfx950 correction)", "",
          "| kernel | calls | avg ms | % | fetch GB/launch | write GB/launch | MFMA busy | clock GHz |",
          "|---|---|---|---|---|---|---|---|"]
