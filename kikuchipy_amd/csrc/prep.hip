@@ -123,7 +123,7 @@ __device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], flo
 // ---- one wave per pattern, values straight from global memory ---------------------------
 // VEC = 4: no signal mask and K % 4 == 0 -> 4-element vector loads / float4 stores.
 // VEC = 1: scalar gather through the pixel map.
-template <typename T, int VEC>
+template <typename T, int VEC, bool H16>
 __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, int npix, const int *row_map,
                                                                  const int *pix_map, int k, int kpad,
                                                                  int metric, int n_out, float *out, int split) {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, i
         s += v[4 * i + e];
       }
     }
-    normalise_and_store_quads(v, s, lane, r, k, kpad, metric, out, split);
+    normalise_and_store_quads<64, WAVE_VALUES, H16>(v, s, lane, r, k, kpad, metric, out, split);
   } else {
 #pragma unroll
     for (int i = 0; i < WAVE_VALUES; ++i) {
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, i
 // The same register-resident scheme with 256 threads x 64 values: every pixel is read once
 // (vector loads when there is no signal mask, else a gather through the pixel map - the row
 // is then served by L2 after its first touch) and stored once as whole 16-byte slots.
-template <typename T, bool MASKED>
+template <typename T, bool MASKED, bool H16>
 __global__ __launch_bounds__(PREP_THREADS) void prep_block_kernel(const T *raw, int npix, const int *row_map,
                                                                   const int *pix_map, int k, int kpad,
                                                                   int metric, float *out, int split) {
@@ -190,13 +190,13 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_block_kernel(const T *raw, 
     }
     s += (v[4 * i] + v[4 * i + 1]) + (v[4 * i + 2] + v[4 * i + 3]);
   }
-  normalise_and_store_quads<PREP_THREADS>(v, s, tid, r, k, kpad, metric, out, split, red);
+  normalise_and_store_quads<PREP_THREADS, WAVE_VALUES, H16>(v, s, tid, r, k, kpad, metric, out, split, red);
 }
 
 // ---- one wave per pattern, signal mask, row staged in LDS -------------------------------
 // LDS: [k ints pixel map][4 waves x npix floats].  Workgroups are persistent over groups of
 // 4 patterns, so the pixel map is staged once per workgroup.
-template <typename T>
+template <typename T, bool H16>
 __global__ __launch_bounds__(PREP_THREADS) void prep_wave_masked_kernel(const T *raw, int npix, const int *row_map,
                                                                         const int *pix_map, int k, int kpad,
                                                                         int metric, int n_out, float *out, int split) {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_masked_kernel(const T 
         v[4 * i + 3] = c + 3 < k ? row[px.w] : 0.f;
         s += (v[4 * i] + v[4 * i + 1]) + (v[4 * i + 2] + v[4 * i + 3]);
       }
-      normalise_and_store_quads(v, s, lane, r, k, kpad, metric, out, split);
+      normalise_and_store_quads<64, WAVE_VALUES, H16>(v, s, lane, r, k, kpad, metric, out, split);
     }
     __syncthreads();  // rows are overwritten by the next group
   }
@@ -314,30 +314,36 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   dim3 block(PREP_THREADS);
   dim3 grid(wave_path ? (a.n_out + 3) / 4 : a.n_out);
   if (staged) grid = dim3(std::min((a.n_out + 3) / 4, 2048));
-#define KPDI_PREP(T)                                                                                     \
+#define KPDI_PREP_H(T, H)                                                                                \
   if (vec4)                                                                                              \
-    hipLaunchKernelGGL((prep_wave_kernel<T, 4>), grid, block, 0, s, (const T *)a.raw, a.npix,           \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form);        \
+    hipLaunchKernelGGL((prep_wave_kernel<T, 4, H>), grid, block, 0, s, (const T *)a.raw, a.npix,        \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form);               \
   else if (staged) {                                                                                     \
     if (staged_lds > 64 * 1024) {                                                                        \
-      hipError_t e = hipFuncSetAttribute((const void *)prep_wave_masked_kernel<T>,                       \
+      hipError_t e = hipFuncSetAttribute((const void *)prep_wave_masked_kernel<T, H>,                    \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)staged_lds);   \
       if (e != hipSuccess) return e;                                                                     \
     }                                                                                                    \
-    hipLaunchKernelGGL((prep_wave_masked_kernel<T>), grid, block, staged_lds, s, (const T *)a.raw,      \
-                       a.npix, a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form); \
+    hipLaunchKernelGGL((prep_wave_masked_kernel<T, H>), grid, block, staged_lds, s, (const T *)a.raw,   \
+                       a.npix, a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form);       \
   } else if (wave_path)                                                                                  \
-    hipLaunchKernelGGL((prep_wave_kernel<T, 1>), grid, block, 0, s, (const T *)a.raw, a.npix,           \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, a.operand_form == 2 ? form : 0); \
+    hipLaunchKernelGGL((prep_wave_kernel<T, 1, H>), grid, block, 0, s, (const T *)a.raw, a.npix,        \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, H ? form : 0);       \
   else if (block_vec)                                                                                    \
-    hipLaunchKernelGGL((prep_block_kernel<T, false>), grid, block, 0, s, (const T *)a.raw, a.npix,      \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, form);                 \
+    hipLaunchKernelGGL((prep_block_kernel<T, false, H>), grid, block, 0, s, (const T *)a.raw, a.npix,   \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, form);                        \
   else if (block_masked)                                                                                 \
-    hipLaunchKernelGGL((prep_block_kernel<T, true>), grid, block, 0, s, (const T *)a.raw, a.npix,       \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, form);                 \
+    hipLaunchKernelGGL((prep_block_kernel<T, true, H>), grid, block, 0, s, (const T *)a.raw, a.npix,    \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, form);                        \
   else                                                                                                   \
     hipLaunchKernelGGL((prep_kernel<T>), grid, block, 0, s, (const T *)a.raw, a.npix, a.row_map,        \
-                       a.pix_map, a.k, a.kpad, a.metric, a.out, a.operand_form == 2 ? form : 0);            \
+                       a.pix_map, a.k, a.kpad, a.metric, a.out, H ? form : 0);
+#define KPDI_PREP(T)                  \
+  if (a.operand_form == 2) {          \
+    KPDI_PREP_H(T, true)              \
+  } else {                            \
+    KPDI_PREP_H(T, false)             \
+  }                                   \
   break;
   switch (a.dtype) {
     case KPDI_U8: KPDI_PREP(uint8_t)
@@ -352,6 +358,7 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
     default: return hipErrorInvalidValue;
   }
 #undef KPDI_PREP
+#undef KPDI_PREP_H
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   // paths that store whole float4 slots write the split-f16 form themselves; the others are

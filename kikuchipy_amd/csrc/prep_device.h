@@ -50,9 +50,12 @@ __host__ __device__ inline int f16_form(int tile_rows, int step) {
 }
 __device__ __forceinline__ char *half_slot(float *out, int r, int c, int kpad, int form) {
   const int lr = (form >> 8) & 0xff, bk = (form >> 16) & 0xff;
-  // (divisions by a constant: a runtime divisor costs ~25 instructions per stored slot)
-  const int nsteps = bk == 48 ? (2 * kpad) / 48 : (2 * kpad) / 32;
-  const int step = bk == 48 ? c / 48 : c / 32, cs = c - step * bk;
+  // c / bk as ONE v_mul_hi_u32 (exact for c < 10^7): a runtime divisor costs ~25 instructions per stored slot,
+  // and that code sits - unrolled 16 times - in every preparation kernel, whatever the form (it slowed the
+  // masked f32 preparation from 0.79 to 1.33 ms)
+  const unsigned magic = bk == 48 ? 89478486u : 134217728u;  // ceil(2^32 / 48), 2^32 / 32
+  const int nsteps = (int)__umulhi(2u * (unsigned)kpad, magic);
+  const int step = (int)__umulhi((unsigned)c, magic), cs = c - step * bk;
   const size_t block = (size_t)(r >> lr) * nsteps + step;
   const int row = r & ((1 << lr) - 1);
   return (char *)out + ((block * bk) << (lr + 1)) + (((cs >> 4) << lr) + row) * 32 + ((((cs >> 3) ^ (row >> 3)) & 1) << 4) +
@@ -71,7 +74,10 @@ __device__ __forceinline__ float group_sum(float v, float *red) {
   return block_sum(v, red);
 }
 
-template <int NT = 64, int NV = WAVE_VALUES>
+// H16: the kernel was instantiated FOR the float16 form (split & 0xff == 2) / for the other two forms: with one
+// body for all three, the float16 stores' address arithmetic - unrolled 16 times - raised the f32 kernels
+// from 170-204 to 256 registers and the masked f32 preparation from 0.79 to 1.33 ms.
+template <int NT = 64, int NV = WAVE_VALUES, bool H16 = false>
 __device__ __forceinline__ void normalise_and_store_quads(float (&v)[NV], float s, int lane, int r, int k,
                                                           int kpad, int metric, float *out, int split,
                                                           float *red = nullptr) {
@@ -97,15 +103,15 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[NV], float 
 #pragma unroll
   for (int i = 0; i < NV / 4; ++i) {
     const int c = 4 * (lane + NT * i);
-    if (c < ((split & 0xff) == 2 ? 2 * kpad : kpad)) {
+    if (c < (H16 ? 2 * kpad : kpad)) {
       float4 w;
       w.x = (centred && c == k) ? cval : v[4 * i] * inv;
       w.y = (centred && c + 1 == k) ? cval : v[4 * i + 1] * inv;
       w.z = (centred && c + 2 == k) ? cval : v[4 * i + 2] * inv;
       w.w = (centred && c + 3 == k) ? cval : v[4 * i + 3] * inv;
-      if (!split) {
+      if (!H16 && !split) {
         *reinterpret_cast<float4 *>(out + prepared_offset(r, c, nslab)) = w;
-      } else if ((split & 0xff) == 2) {
+      } else if (H16) {
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         h4 h;
         h[0] = (_Float16)(w.x * 4096.f);

@@ -129,7 +129,7 @@ struct PreArgs {
 // ---- detectors up to 19 200 pixels: everything in one pass ---------------------------------
 // `tp` (the padded taps) is a kernel parameter of its own: only a `const __restrict__` kernel argument
 // is known to be invariant, which is what lets the wave-uniform tap reads become scalar loads.
-template <typename T, int NV>
+template <typename T, int NV, bool H16>
 __global__ __launch_bounds__(PP_THREADS) void preproc_fused_kernel(PreArgs a, const double *__restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ float red[8];
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(PP_THREADS) void preproc_fused_kernel(PreArgs a, co
         }
         s += (v[4 * i] + v[4 * i + 1]) + (v[4 * i + 2] + v[4 * i + 3]);
       }
-      normalise_and_store_quads<PP_THREADS, NV>(v, s, tid, r, k, a.kpad, a.metric, a.out, a.form, red);
+      normalise_and_store_quads<PP_THREADS, NV, H16>(v, s, tid, r, k, a.kpad, a.metric, a.out, a.form, red);
     }
   }
 }
@@ -361,7 +361,9 @@ static hipError_t launch_pre_t(const PreLaunch &l, const PreArgs &a, bool *prep_
     const size_t npix4 = ((size_t)l.sy * l.sx + 3) & ~(size_t)3;
     const size_t lds = npix4 * 8;
     const bool small = !prep || std::max(cols, cols_pad) <= PP_THREADS * 16;
-    auto kernel = small ? preproc_fused_kernel<T, 16> : preproc_fused_kernel<T, WAVE_VALUES>;
+    const bool h16 = prep && l.operand_form == 2;
+    auto kernel = small ? (h16 ? preproc_fused_kernel<T, 16, true> : preproc_fused_kernel<T, 16, false>)
+                        : (h16 ? preproc_fused_kernel<T, WAVE_VALUES, true> : preproc_fused_kernel<T, WAVE_VALUES, false>);
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
