@@ -18,6 +18,10 @@ for case in range(n_cases):
         sy, sx = int(rng.integers(64, 133)), int(rng.integers(64, 133))
     m = int(rng.choice([1, 3, 40, 257, 600, 1500]))
     n = int(rng.choice([1, 5, 127, 128, 129, 900, 4000]))
+    if rng.random() < 0.12:  # a full chip of row blocks x splits: XCD grid, fixed + drawn tiles, quarter-tile tail
+        sy, sx = int(rng.integers(4, 14)), int(rng.integers(4, 14))
+        m = int(rng.choice([2048, 4096, 4100, 8192]))
+        n = int(rng.choice([12500, 6250, 25000 + int(rng.integers(0, 300)), 3000]))
     k = int(min(n, rng.choice([1, 2, 8, 20, 21, 33, 64])))
     metric = str(rng.choice(["ncc", "ndp"]))
     mode = int(rng.choice([_lib.COMPUTE_F32, _lib.COMPUTE_F16X2, _lib.COMPUTE_F16]))
@@ -36,6 +40,17 @@ for case in range(n_cases):
     chunk = int(rng.choice([n, max(1, n // 3), 100]))
     ctx.set_problem(sy, sx, sig, {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[metric], k, mode)
     ctx.set_experimental(exp, nav)
+    pre = ""
+    if rng.random() < 0.25 and dt_e in (np.uint8, np.uint16) and sy >= 4 and sx >= 4:
+        # recorded background removal, fused with the preparation at the first chunk; the oracle is then fed
+        # the engine's own pre-processed patterns (the pre-processing itself: tests/test_gpu_config3.py)
+        if rng.random() < 0.7:
+            ctx.remove_static_background((rng.random((sy, sx)) * 200 + 1).astype(np.float32), int(rng.integers(0, 2)),
+                                         bool(rng.integers(0, 2)))
+            pre += "S"
+        if rng.random() < 0.7:
+            ctx.remove_dynamic_background(int(rng.integers(0, 2)), int(rng.integers(0, 2)), 0.0, 4.0)
+            pre += "D"
     if rng.random() < 0.3:  # resident dictionary: prepared chunks held, then swept
         for a in range(0, n, chunk):
             ctx.hold_dictionary_chunk(dic[a:a + chunk], a)
@@ -45,6 +60,8 @@ for case in range(n_cases):
         for a in range(0, n, chunk):
             ctx.push_dictionary_chunk(dic[a:a + chunk], a)
     s, i = ctx.finalize(k)
+    if pre:
+        exp = ctx.get_experimental()
     e = exp if nav is None else exp[~nav]
     rs, ri = ko.dictionary_indexing(e, dic, metric=metric, keep_n=k, n_per_iteration=chunk, signal_mask=sig)
     try:
@@ -85,5 +102,6 @@ for case in range(n_cases):
         print(f"FAIL case {case}: {sy}x{sx} m={m} n={n} k={k} {metric} mode={mode} {dt_e.__name__}/{dt_d.__name__} "
               f"sig={sig is not None} nav={nav is not None} chunk={chunk}: {err}")
         sys.exit(1)
-    print(f"ok {case}: {sy}x{sx} m={m} n={n} k={k} {metric} mode={mode} chunk={chunk} max|d|={np.abs(s - rs).max():.1e}", flush=True)
+    print(f"ok {case}: {sy}x{sx} m={m} n={n} k={k} {metric} mode={mode} chunk={chunk} pre={pre or '-'} "
+          f"max|d|={np.abs(s - rs).max():.1e}", flush=True)
 print("STRESS_OK")
