@@ -193,6 +193,105 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_block_kernel(const T *raw, 
   normalise_and_store_quads<PREP_THREADS, WAVE_VALUES, H16>(v, s, tid, r, k, kpad, metric, out, split, red);
 }
 
+// ---- float16 form, 4096 < K <= 16384: FOUR patterns per 1024-thread workgroup ------------------
+// In the float16 layout (prep_device.h: half_slot) a pattern owns 32 contiguous bytes per 16-pixel plane and
+// four consecutive patterns share each 128-byte line.  One workgroup per pattern (prep_block_kernel) writes
+// 32-byte pieces of lines whose other pieces arrive from other workgroups at other times: 1.9 TB/s on the
+// 28.8 GB dictionary of configs[4].  Here every 256-thread group normalises one of four consecutive patterns
+// in registers (as prep_block_kernel), the float16 rows are staged in LDS, and the workgroup writes them out
+// as whole lines.  LDS: 4 x (2 * kpad + 8) float16.
+constexpr int PREP16_THREADS = 1024;
+template <typename T, bool MASKED>
+__global__ __launch_bounds__(PREP16_THREADS) void prep16_block4_kernel(const T *raw, int npix, const int *row_map,
+                                                                       const int *pix_map, int k, int kpad,
+                                                                       int metric, int n_out, float *out, int form) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ float red[PREP16_THREADS / 64];
+  const int tid = threadIdx.x, g = tid >> 8, t = tid & 255, wave = tid >> 6;
+  const int r = blockIdx.x * 4 + g;
+  const bool live = r < n_out;
+  const int row_halves = 2 * kpad + 8;  // + 16 bytes: the four rows start in different banks
+  _Float16 *stage = (_Float16 *)smem_raw + (size_t)g * row_halves;
+  float v[WAVE_VALUES];
+  float s = 0.f;
+  if (live) {
+    const int64_t src = row_map ? row_map[r] : r;
+    const T *p = raw + src * (int64_t)npix;
+#pragma unroll
+    for (int i = 0; i < WAVE_VALUES / 4; ++i) {
+      const int c = 4 * (t + 256 * i);
+      if (!MASKED) {
+        Quad<T> q;
+        q.v[0] = q.v[1] = q.v[2] = q.v[3] = (T)0;
+        if (c < k) q = *reinterpret_cast<const Quad<T> *>(p + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * i + e] = (float)q.v[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * i + e] = c + e < k ? (float)p[pix_map[c + e]] : 0.f;
+      }
+      s += (v[4 * i] + v[4 * i + 1]) + (v[4 * i + 2] + v[4 * i + 3]);
+    }
+  }
+  // sums over the 4 waves of a group
+  auto group_total = [&](float x) {
+    x = wave_sum(x);
+    __syncthreads();
+    if ((tid & 63) == 0) red[wave] = x;
+    __syncthreads();
+    return (red[4 * g] + red[4 * g + 1]) + (red[4 * g + 2] + red[4 * g + 3]);
+  };
+  float mean = 0.f;
+  if (metric != KPDI_METRIC_NDP) mean = group_total(s) / (float)k;
+  float q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < WAVE_VALUES; ++i) {
+    const int c = 4 * (t + 256 * (i / 4)) + (i & 3);
+    if (c < k) {
+      v[i] -= mean;
+      q2 += v[i] * v[i];
+    } else {
+      v[i] = 0.f;
+    }
+  }
+  q2 = group_total(q2);
+  const float norm = sqrtf(q2);
+  const float inv = norm > 0.f ? 4096.f / norm : 0.f;  // float16 operands are stored scaled by 2^12
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int i = 0; i < WAVE_VALUES / 4; ++i) {
+    const int c = 4 * (t + 256 * i);
+    if (c < 2 * kpad) {
+      h4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (_Float16)(v[4 * i + e] * inv);
+      *reinterpret_cast<h4 *>(stage + c) = h;
+    }
+  }
+  __syncthreads();
+  // ---- write-out: plane P of the four rows = one 128-byte line (rows 4b .. 4b+3 of a tile, 32 bytes each, the two
+  // 16-byte halves of a row swapped when its bit 3 is set - the same for all four); 16 threads per line, 8 bytes each
+  const int lr = (form >> 8) & 0xff, bk = (form >> 16) & 0xff;
+  const unsigned magic = bk == 48 ? 89478486u : 134217728u;
+  const int nsteps = (int)__umulhi(2u * (unsigned)kpad, magic);
+  const int r0 = blockIdx.x * 4;
+  const int row0 = r0 & ((1 << lr) - 1);
+  const int swz = (row0 >> 3) & 1;
+  const int planes = (2 * kpad) / 16, planes_per_step = bk / 16;
+  const int j = tid & 15, row = j >> 2, piece = j & 3;  // piece: 8 bytes = 4 pixels of the row's 32 bytes
+  const int px = (((piece >> 1) ^ swz) << 3) + ((piece & 1) << 2);
+  for (int P = tid >> 4; P < planes; P += PREP16_THREADS / 16) {
+    const int step = (int)__umulhi((unsigned)(16 * P), magic);
+    const int pl = P - step * planes_per_step;
+    const size_t block = (size_t)(r0 >> lr) * nsteps + step;
+    char *line = (char *)out + ((block * bk) << (lr + 1)) + (((size_t)pl << lr) + row0) * 32;
+    if (r0 + row < n_out || true) {  // rows beyond n_out hold zeros (their group staged zeros): keeps the line whole
+      const _Float16 *srcp = (const _Float16 *)smem_raw + (size_t)row * row_halves + 16 * P + px;
+      *reinterpret_cast<h4 *>(line + 32 * row + 8 * piece) = *reinterpret_cast<const h4 *>(srcp);
+    }
+  }
+}
+
 // ---- one wave per pattern, signal mask, row staged in LDS -------------------------------
 // LDS: [k ints pixel map][4 waves x npix floats].  Workgroups are persistent over groups of
 // 4 patterns, so the pixel map is staged once per workgroup.
@@ -339,7 +438,16 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
     hipLaunchKernelGGL((prep_kernel<T>), grid, block, 0, s, (const T *)a.raw, a.npix, a.row_map,        \
                        a.pix_map, a.k, a.kpad, a.metric, a.out, H ? form : 0);
 #define KPDI_PREP(T)                  \
-  if (a.operand_form == 2) {          \
+  if (a.operand_form == 2 && (block_vec || block_masked)) {                                              \
+    const size_t lds16 = (size_t)4 * (2 * a.kpad + 8) * 2;                                               \
+    auto k16 = block_masked ? prep16_block4_kernel<T, true> : prep16_block4_kernel<T, false>;            \
+    if (lds16 > 64 * 1024) {                                                                             \
+      hipError_t e = hipFuncSetAttribute((const void *)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16); \
+      if (e != hipSuccess) return e;                                                                     \
+    }                                                                                                    \
+    hipLaunchKernelGGL(k16, dim3((a.n_out + 3) / 4), dim3(PREP16_THREADS), lds16, s, (const T *)a.raw, a.npix, \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form);               \
+  } else if (a.operand_form == 2) {   \
     KPDI_PREP_H(T, true)              \
   } else {                            \
     KPDI_PREP_H(T, false)             \
