@@ -317,7 +317,7 @@ int dict_tile(const kpdi_ctx *c) {
   return c->compute == KPDI_COMPUTE_F16 ? kpdi::f16_geometry(c->f16_waves).dict_tile : kpdi::TILE_DICT;
 }
 // lists per pattern and dictionary split the match kernel writes
-int lists_per_split(const kpdi_ctx *c) { return c->compute == KPDI_COMPUTE_F16 ? c->f16_waves / 2 : 2; }
+int lists_per_split(const kpdi_ctx *c) { return c->compute == KPDI_COMPUTE_F16 ? 4 : 2; }
 
 int use_device(kpdi_ctx *c) {
   HIPCHK(hipSetDevice(c->device));
@@ -331,7 +331,7 @@ int use_device(kpdi_ctx *c) {
 // tiles: launches * ceil(n_tiles / nsplit), plus a small per-launch cost.
 int choose_nsplit(const kpdi_ctx *c, int row_blocks, int n_tiles, int *rows_per_launch) {
   // (the 4-wave float16 variant runs two workgroups per CU)
-  const int cap = c->n_cu * (c->compute == KPDI_COMPUTE_F16 && c->f16_waves == 4 ? 2 : kpdi::match_blocks_per_cu());
+  const int cap = c->n_cu * kpdi::match_blocks_per_cu();
   int best_ns = 1, best_rpl = std::max(1, std::min(row_blocks, cap));
   double best_cost = 1e30;
   for (int ns = 1; ns <= std::min(cap, n_tiles); ++ns) {
@@ -453,7 +453,7 @@ int ensure_running(kpdi_ctx *c) {
   }
   c->run_cur = 0;
   HIPCHK(kpdi::launch_fill_topk(c->run_s[0].as<float>(), c->run_i[0].as<int>(), (int64_t)n, c->stream));
-  c->bound_key = -1;  // a new sweep starts without a shared bound
+  if (!getenv("KPDI_KEEP_BOUND")) c->bound_key = -1;  // a new sweep starts without a shared bound (KPDI_KEEP_BOUND: timing experiment)
   c->run_valid = true;
   return KPDI_OK;
 }

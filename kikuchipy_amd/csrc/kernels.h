@@ -22,7 +22,7 @@ struct F16Geometry {
   int dict_tile;  // dictionary patterns per tile: 32 * 4 * (waves / 4)
   int step;       // pixels per step
 };
-inline F16Geometry f16_geometry(int waves) { return waves == 4 ? F16Geometry{4, 128, 32} : F16Geometry{8, 256, 48}; }
+inline F16Geometry f16_geometry(int waves) { return F16Geometry{waves == 4 ? 4 : 8, F16_TILE, F16_STEP}; }
 
 inline int round_up(int64_t v, int64_t m) { return (int)(((v + m - 1) / m) * m); }
 

@@ -32,34 +32,40 @@
 
 namespace kpdi {
 
-// Geometry of a variant: WAVES = 8 -> one 512-thread workgroup per CU, tile 256 x 256, steps of 48 pixels
-// (3 k-steps), ring 3 x 48 KB; WAVES = 4 -> two 256-thread workgroups per CU, tile 128 (dictionary) x 256,
-// steps of 32 pixels (2 k-steps), ring 3 x 24 KB each.  Two waves per SIMD either way.
+// Geometry of a variant.  Both share the operand layout (tiles of 256 patterns, steps of 48 pixels = 3 k-steps,
+// a (tile, step) block of 24 KB) and the 256 x 256 workgroup tile over a ring of three 48 KB stages:
+//   WAVES = 8: two waves per SIMD, wave tile 128 x 64  = 8 accumulators (128 architectural VGPRs), 6 fragment
+//              reads per 8 MFMAs, 6 LDS-DMA pieces per wave and step;
+//   WAVES = 4: one wave per SIMD, wave tile 128 x 128 = 16 accumulators (256 AGPRs), 8 fragment reads per 16
+//              MFMAs (0.5 instead of 0.75 per MFMA: the LDS is what bounds the 8-wave form), 12 pieces per wave.
 template <int WAVES>
 struct Geo {
-  static constexpr int DT = 32 * 4 * (WAVES / 4);      // dictionary patterns per tile
-  static constexpr int BK = WAVES == 8 ? 48 : 32;      // pixels per step
+  static constexpr int DT = F16_TILE;                  // dictionary patterns per tile
+  static constexpr int BK = F16_STEP;                  // pixels per step
   static constexpr int KS = BK / 16;                   // MFMA k-steps per step
   static constexpr int DBLOCK = DT * BK * 2;           // dictionary (tile, step) block, bytes
   static constexpr int EBLOCK = F16_TILE * BK * 2;     // experimental (tile, step) block, bytes
   static constexpr int STAGE = DBLOCK + EBLOCK;
   static constexpr int NSTAGE = 3;
-  static constexpr int LDS = NSTAGE * STAGE;           // 144 KB / 72 KB (+ 32 B control words)
-  static constexpr int PIECES = STAGE / 1024 / WAVES;  // LDS-DMA pieces per wave and step: 6
-  static constexpr int DPIECES = DBLOCK / 1024 / WAVES;  // ... of which dictionary: 3 (8 waves) / 2 (4 waves)
+  static constexpr int LDS = NSTAGE * STAGE;           // 144 KB (+ 32 B control words)
+  static constexpr int NCG = WAVES == 8 ? 2 : 4;       // column groups (32 experimental patterns) of a wave tile
+  static constexpr int WCOLS = 32 * NCG;               // experimental patterns of a wave tile
+  static constexpr int WC = F16_TILE / WCOLS;          // waves side by side
+  static constexpr int PIECES = STAGE / 1024 / WAVES;  // LDS-DMA pieces per wave and step: 6 / 12
+  static constexpr int DPIECES = DBLOCK / 1024 / WAVES;  // ... of which dictionary: 3 / 6
+  static constexpr bool ACC_A = WAVES == 4;            // accumulators in AGPRs
 };
 
-// acc += A x B for 16 pixels, A and B = 8 f16 per lane (one 16-byte LDS read); accumulator pinned to
-// the accumulation registers, `s_nop 1` = the VALU-write -> MFMA-operand hazard hipcc does not pad
-// inside an asm statement (match.hip: mfma_acc)
+// acc += A x B for 16 pixels, A and B = 8 f16 per lane (one 16-byte LDS read).  The operands come from
+// ds_read (lgkmcnt), never from a VALU write: no hazard padding needed inside the asm statement.
+// 8-wave form: accumulators in architectural VGPRs (bare MFMA loop 1.41 vs 1.74 ms in AGPRs, and the
+// epilogue reads them without v_accvgpr_read); 4-wave form: 256 accumulation registers = the AGPR file.
+template <bool ACC_A>
 __device__ __forceinline__ void mfma16(f32x16 &c, const f32x4 &a, const f32x4 &b) {
-#if !defined(KPDI16_ACC_A)  // accumulators in architectural VGPRs (measured: bare MFMA loop 1.41 vs 1.74 ms, and the epilogue reads them without v_accvgpr_read)
-  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-#elif defined(KPDI16_NO_NOP)  // the operands come from ds_read (lgkmcnt), never from a VALU write
-  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-#else
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-#endif
+  if (ACC_A)
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
 // One of a wave's 1 KB LDS-DMA pieces of a stage (i < DPIECES: dictionary block, else experimental
@@ -75,19 +81,6 @@ __device__ __forceinline__ void issue_piece16(const char *gd, const char *ge, ch
   __builtin_amdgcn_raw_ptr_buffer_load_lds(
       rsrc, (__attribute__((address_space(3))) void *)(stage_base + (is_exp ? G::DBLOCK : 0) + q * 1024), 16,
       (int)goff, q * 1024, 0, 0);
-}
-
-// element r (wave-uniform, runtime) of a 16-register accumulator without register-relative addressing:
-// a select tree on the bits of r (15 v_cndmask with scalar conditions)
-__device__ __forceinline__ float pick16(const f32x16 &a, int r) {
-  float t8[8], t4[4], t2[2];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) t8[i] = (r & 1) ? a[2 * i + 1] : a[2 * i];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) t4[i] = (r & 2) ? t8[2 * i + 1] : t8[2 * i];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) t2[i] = (r & 4) ? t4[2 * i + 1] : t4[2 * i];
-  return (r & 8) ? t2[1] : t2[0];
 }
 
 // Entry j of a list in its scratch home: `base` is wave-uniform; accesses are grouped in chunks of 16
@@ -120,11 +113,7 @@ __device__ __forceinline__ void scan16(f32x16 (&acc)[4], float (&best)[KMAX], in
     while (hot != 0) {
       const int r = __builtin_ctz(hot);
       hot &= hot - 1;
-#ifdef KPDI16_PICK
-      const float v = pick16(acc[rt], r) * unscale + 0.f;
-#else
       const float v = acc[rt][r] * unscale + 0.f;  // -0 -> +0 so that ties compare as the merge does
-#endif
       const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
       const int idx = idx_base + lrow;
       bool ok = lrow < n_valid && v >= thr;
@@ -137,23 +126,30 @@ __device__ __forceinline__ void scan16(f32x16 (&acc)[4], float (&best)[KMAX], in
   }
 }
 
+// Candidate buffers (per lane and column group, in the scratch behind the lists).  Grouped form of the shared
+// bound (>= 32 lists per pattern, every list publishes its BEST entry - which needs no sorted list): the
+// buffer takes everything that passes the bound, including all 64 candidates of the first tile, and the sorted
+// list is built ONCE, at the end, from the buffered candidates that pass the FINAL bound (a handful): no list is
+// loaded, updated or stored inside the tile loop unless a buffer overflows (adversarial data: long runs of
+// equal scores).  After the first tile the bound sits near the 3 % quantile (the minimum over 32 slots of the
+// best of 128 candidates), then rises like 1 / tiles: ~7 further candidates per lane over a whole launch.
+// Plain form (few lists; a list publishes its j-th best, j > 1): the list is needed, the buffer holds 8.
 #ifndef KPDI16_CAP
-#define KPDI16_CAP 8
+#define KPDI16_CAP 96
 #endif
-constexpr int CAND_CAP = KPDI16_CAP;  // buffered candidates per lane and column group between two list updates
+constexpr int CAND_CAP = KPDI16_CAP;  // a multiple of 16
+constexpr int CAND_CAP_PLAIN = 8;
 
 template <int KMAX, bool BOUNDED, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, float *ls_scores, int *ls_idx) {
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArgs a, float *ls_scores, int *ls_idx) {
   typedef Geo<WAVES> G;
-  // waves that issue one L2 prefetch load per step: a block holds DBLOCK / 128 lines = 64 per wave
-  constexpr int PF_WAVES = (G::DBLOCK + G::EBLOCK) / 128 / 64;  // 6 (8-wave variant)
-  (void)PF_WAVES;
-  constexpr int BLOCK16 = G::DBLOCK, STAGE16 = G::STAGE, NSTAGE16 = G::NSTAGE, LDS16 = G::LDS, KSTEPS16 = G::KS;
+  constexpr int NCG = G::NCG;
+  constexpr int BLOCK16 = G::DBLOCK, STAGE16 = G::STAGE, NSTAGE16 = G::NSTAGE, KSTEPS16 = G::KS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0 .. WAVES - 1
-  const int wr = wv >> 2, wc = wv & 3;
+  const int wr = wv / G::WC, wc = wv % G::WC;
   int sp, rb;
   block_rb_sp(a, blockIdx.x, &rb, &sp);
   rb += a.row_first;
@@ -161,8 +157,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
   const int nsteps = (2 * a.kpad) / G::BK;
   const size_t tile_bytes = (size_t)nsteps * G::DBLOCK;   // one dictionary tile, all steps
   const size_t etile_bytes = (size_t)nsteps * G::EBLOCK;  // one 256-pattern experimental tile
-  unsigned *tile_ctr = a.tile_ctr + rb;
-  volatile int *ctrl = (volatile int *)(smem + LDS16);  // control words behind the ring
   const unsigned goff = (unsigned)lane * 16u;
   const char *exp_base = (const char *)a.exp + (size_t)rb * etile_bytes;
   const char *dict_base = (const char *)a.dict;
@@ -171,51 +165,54 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
   // (l >> 5) of the row's 32 bytes, halves swapped for rows with bit 3 set (prep_device.h: half_slot)
   const unsigned half_off = (unsigned)((((lane >> 5) ^ (lane >> 3)) & 1) * 16);
   const unsigned fa_off = (unsigned)((wr * 128 + (lane & 31)) * 32) + half_off;
-  const unsigned fb_off = (unsigned)(BLOCK16 + (wc * 64 + (lane & 31)) * 32) + half_off;
+  const unsigned fb_off = (unsigned)(BLOCK16 + (wc * G::WCOLS + (lane & 31)) * 32) + half_off;
 #define KPDI_FA(base, rt, ks) (*(const f32x4 *)((base) + fa_off + (rt) * 1024 + (ks) * (G::DT * 32)))
 #define KPDI_FB(base, cg, ks) (*(const f32x4 *)((base) + fb_off + (cg) * 1024 + (ks) * (F16_TILE * 32)))
 
-  // ---- this lane's two lists (column groups 0 / 1: patterns m_lane, m_lane + 32; it sees the rows
+  // ---- this lane's NCG lists (column group cg: pattern m_lane + 32 cg; it sees the rows
   // 4 (lane >> 5) + {0..3} + 8 j of every 32-row group of its wave's 128 rows).  Their home is the
-  // scratch: entry j of list (workgroup, wave, cg) at [((wg * 8 + wave) * 2 + cg) * KMAX + j][lane].
-  const int m_lane = rb * F16_TILE + wc * 64 + (lane & 31);
+  // scratch: entry j of list (workgroup, wave, cg) at [((wg * WAVES + wave) * NCG + cg) * KMAX + j][lane].
+  const int m_lane = rb * F16_TILE + wc * G::WCOLS + (lane & 31);
   // (wave-uniform base pointers + a 32-bit lane offset: scalar-base addressing, no per-entry 64-bit
   // address registers - hoisted out of the tile loop they were spilled, 900 bytes per lane)
-  float *home_s = ls_scores + (((size_t)blockIdx.x * WAVES + wv) * 2) * KMAX * 64;
-  int *home_i = ls_idx + (((size_t)blockIdx.x * WAVES + wv) * 2) * KMAX * 64;
+  float *home_s = ls_scores + (((size_t)blockIdx.x * WAVES + wv) * NCG) * KMAX * 64;
+  int *home_i = ls_idx + (((size_t)blockIdx.x * WAVES + wv) * NCG) * KMAX * 64;
   const unsigned ulane = (unsigned)lane;
 #pragma unroll
-  for (int c = 0; c < (2 * KMAX + 15) / 16; ++c) {
+  for (int c = 0; c < (NCG * KMAX + 15) / 16; ++c) {
     float *ps = chunk_base(home_s, c);
     int *pi = chunk_base(home_i, c);
 #pragma unroll
-    for (int j = 16 * c; j < 2 * KMAX && j < 16 * c + 16; ++j) {
+    for (int j = 16 * c; j < NCG * KMAX && j < 16 * c + 16; ++j) {
       ps[(j - 16 * c) * 64 + ulane] = -INFINITY;
       pi[(j - 16 * c) * 64 + ulane] = INT_MAX;
     }
   }
-  // candidate buffers behind the lists: [((wg * WAVES + wave) * 2 + cg) * CAND_CAP + slot][lane]
-  const size_t n_list_entries = (size_t)gridDim.x * WAVES * 2 * KMAX * 64;
-  float *buf_s = ls_scores + n_list_entries + (((size_t)blockIdx.x * WAVES + wv) * 2) * CAND_CAP * 64;
-  int *buf_i = ls_idx + n_list_entries + (((size_t)blockIdx.x * WAVES + wv) * 2) * CAND_CAP * 64;
-  float last0 = -INFINITY, last1 = -INFINITY;  // the lists' last entries: all the main loop keeps of them
-  int cnt0 = 0, cnt1 = 0;                      // buffered candidates
-  float pub0 = -INFINITY, pub1 = -INFINITY;    // what this lane's lists have published into the shared bound
-  float ub0 = INFINITY, ub1 = INFINITY;
-  int ubi0 = -1, ubi1 = -1;
-  if (BOUNDED) {
-    ub0 = a.bound_score[m_lane];
-    ubi0 = a.bound_idx[m_lane];
-    ub1 = a.bound_score[m_lane + 32];
-    ubi1 = a.bound_idx[m_lane + 32];
+  // candidate buffers behind the lists: [((wg * WAVES + wave) * NCG + cg) * CAND_CAP + slot][lane]
+  const size_t n_list_entries = (size_t)gridDim.x * WAVES * NCG * KMAX * 64;
+  float *buf_s = ls_scores + n_list_entries + (((size_t)blockIdx.x * WAVES + wv) * NCG) * CAND_CAP * 64;
+  int *buf_i = ls_idx + n_list_entries + (((size_t)blockIdx.x * WAVES + wv) * NCG) * CAND_CAP * 64;
+  // per list, all the main loop keeps in registers: its last entry, the number of buffered candidates,
+  // what it has published into the shared bound
+  float last[NCG], pub[NCG], ub[NCG], g[NCG];
+  int cnt[NCG], ubi[NCG];
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg) {
+    last[cg] = pub[cg] = g[cg] = -INFINITY;
+    cnt[cg] = 0;
+    ub[cg] = INFINITY;
+    ubi[cg] = -1;
+    if (BOUNDED) {
+      ub[cg] = a.bound_score[m_lane + 32 * cg];
+      ubi[cg] = a.bound_idx[m_lane + 32 * cg];
+    }
   }
-  const unsigned *line0 = a.gthr + (size_t)m_lane * BOUND_SLOTS;
-  const unsigned *line1 = line0 + 32 * BOUND_SLOTS;
-  const int list_id = sp * (WAVES / 2) + wr * 2 + (lane >> 5);
+  const unsigned *line0 = a.gthr + (size_t)m_lane * BOUND_SLOTS;  // column group cg: + 32 cg BOUND_SLOTS
+  const int list_id = sp * 4 + wr * 2 + (lane >> 5);
   const int my_slot = list_id & (BOUND_SLOTS - 1);
   const int bound_rank = a.bound_rank;
   const bool bound_grouped = a.bound_grouped != 0;
-  float g0 = -INFINITY, g1 = -INFINITY;
+  const int cap = bound_rank == 1 ? CAND_CAP : CAND_CAP_PLAIN;
 
   // ---- dictionary tiles: t0 = tile being computed, t1 / t2 the next two (loads run two steps ahead).
   // STATIC hand-out: split sp takes the tiles sp, sp + nsplit, sp + 2 nsplit ...  Block b runs on XCD
@@ -223,17 +220,21 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
   // with the same split share an XCD and walk the SAME dictionary tiles at the same pace: a dictionary
   // block crosses the fabric once and is served to the other row blocks by that XCD's L2 (with the
   // dynamic hand-out of match.hip every row block re-fetched it: 16 x the dictionary per launch, which
-  // the f32 kernel's 1.2 TB/s tolerates and this kernel's 6+ TB/s did not).  -DKPDI16_DYNAMIC_TILES
-  // restores the counters for comparison.
+  // the f32 kernel's 1.2 TB/s tolerates and this kernel's 6+ TB/s did not).
+  // timing-only ablations: the same block every step (always an L2 hit)
+#if defined(KPDI16_E_FIXED) && defined(KPDI16_D_FIXED)
+#define KPDI16_ABLATE_ADDR ge = exp_base; gd = dict_base;
+#elif defined(KPDI16_E_FIXED)
+#define KPDI16_ABLATE_ADDR ge = exp_base;
+#elif defined(KPDI16_D_FIXED)
+#define KPDI16_ABLATE_ADDR gd = dict_base;
+#else
+#define KPDI16_ABLATE_ADDR
+#endif
   int t0 = sp, t1 = sp + a.nsplit, t2 = sp + 2 * a.nsplit;
   if (t0 < n_tiles) {
     const int last_tile = n_tiles - 1;
     int ld_pos = 0, ld_step = 0, ld_stage = 0;
-    int fetched = 0, tp = 0;
-    (void)fetched;
-    (void)tp;
-    (void)tile_ctr;
-    (void)ctrl;
     const char *gd = nullptr, *ge = nullptr;
 #define KPDI16_CURSOR_SET()                                                          \
   {                                                                                  \
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
     t_ = t_ < last_tile ? t_ : last_tile; /* past the end: harmless re-load */       \
     gd = dict_base + (size_t)t_ * tile_bytes + (size_t)ld_step * G::DBLOCK;          \
     ge = exp_base + (size_t)ld_step * G::EBLOCK;                                     \
+    KPDI16_ABLATE_ADDR                                                               \
   }
 #define KPDI16_CURSOR_ADVANCE()                                \
   {                                                            \
@@ -263,31 +265,39 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
     __syncthreads();
 
     // fragments of the three k-steps of a step, each in its own registers (static indices)
-    f32x4 fa[KSTEPS16][4], fb[KSTEPS16][2];
+    f32x4 fa[KSTEPS16][4], fb[KSTEPS16][NCG];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) fa[0][rt] = KPDI_FA(smem, rt, 0);
 #pragma unroll
-    for (int cg = 0; cg < 2; ++cg) fb[0][cg] = KPDI_FB(smem, cg, 0);
+    for (int cg = 0; cg < NCG; ++cg) fb[0][cg] = KPDI_FB(smem, cg, 0);
 
     int stage = 0;
+    int tiles_done = 0, refresh_at = 0;
 #pragma clang loop unroll(disable)
     for (;;) {  // dictionary tiles
-      f32x16 acc0[4], acc1[4];  // column group 0 / 1
+      f32x16 acc[NCG][4];  // [column group][32-row group]
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
+      for (int cg = 0; cg < NCG; ++cg)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[rt][r] = acc1[rt][r] = 0.f;
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[cg][rt][r] = 0.f;
 #pragma clang loop unroll(disable)
       for (int step = 0; step < nsteps; ++step) {
         const char *ls = smem + stage * STAGE16;
         const int nstage = stage == NSTAGE16 - 1 ? 0 : stage + 1;
         const char *ls_next = smem + nstage * STAGE16;
-#ifdef KPDI16_DYNAMIC_TILES
-        if (step == 0 && tid == 0) fetched = (int)atomicAdd(tile_ctr, 1u);
-#endif
-        if (step == nsteps - 1) {  // landed by the next wait, used in the epilogue
-          g0 = shared_bound<KMAX>(line0, bound_grouped);
-          g1 = shared_bound<KMAX>(line1, bound_grouped);
+        if (step == nsteps - 1 && tiles_done >= refresh_at) {
+          // the shared bound of this wave's patterns, for the epilogue: all lines in flight, then reduced (a wait
+          // of one memory latency that nothing hides - the waves run in lockstep); refreshed after the tiles
+          // 0, 1, 2, 4, 7, 11, 17, 26 ... of a workgroup: the bound rises like the logarithm of the candidates
+          // seen, and a bound that is a few tiles old lets 1.5 x as many of the ~0.1 candidates per lane pass
+          BoundHalf raw[NCG];
+#pragma unroll
+          for (int cg = 0; cg < NCG; ++cg) bound_load_half(raw[cg], line0 + 32 * cg * BOUND_SLOTS, lane >> 5);
+#pragma unroll
+          for (int cg = 0; cg < NCG; ++cg) g[cg] = bound_reduce_half<KMAX>(raw[cg], bound_grouped, lane >> 5);
+          refresh_at = tiles_done + 1 + (tiles_done >> 1);
         }
         KPDI16_CURSOR_SET();
         char *ld_base = smem + ld_stage * STAGE16;
@@ -297,19 +307,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
             // ---- the step's only synchronisation point: this wave's pieces of step + 1 (issued during
             // the previous step) have landed; after the barrier step + 1 is complete in LDS and every
             // wave is past the previous step, whose stage is refilled below
-#ifdef KPDI16_PREFETCH
-            // the L2 prefetch load issued after the previous step's pieces may stay in flight (loads
-            // complete in issue order); in a tile's last step the bound loads are younger still: wait for all
-            if (wv < PF_WAVES && step != nsteps - 1)
-              asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // (not __syncthreads: its fence would wait vmcnt(0))
-#else
+#ifndef KPDI16_NO_BARRIER
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef KPDI16_DYNAMIC_TILES
-            if (step == 0 && tid == 0) ctrl[4 + tp] = fetched;
-#endif
             __syncthreads();
 #endif
           }
@@ -317,63 +316,46 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
           const char *src = ks == KSTEPS16 - 1 ? ls_next : ls;    // ... of the next step for the last one
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt) {
-            mfma16(acc0[rt], fa[ks][rt], fb[ks][0]);
-            mfma16(acc1[rt], fa[ks][rt], fb[ks][1]);
-            // in the shadow of these MFMAs: a fragment of the next k-step and, after the barrier,
-            // this wave's 6 LDS-DMA pieces of the step two ahead
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg) mfma16<G::ACC_A>(acc[cg][rt], fa[ks][rt], fb[ks][cg]);
+            // in the shadow of these MFMAs: fragments of the next k-step and, after the barrier,
+            // this wave's LDS-DMA pieces of the step two ahead
 #ifndef KPDI16_NO_READS
-            fa[nk][rt] = KPDI_FA(src, rt, nk);
-            if (rt == 1) fb[nk][0] = KPDI_FB(src, 0, nk);
-            if (rt == 3) fb[nk][1] = KPDI_FB(src, 1, nk);
+            if (NCG == 4) {
+              fa[nk][rt] = KPDI_FA(src, rt, nk);
+              fb[nk][rt] = KPDI_FB(src, rt, nk);
+            } else {
+              fa[nk][rt] = KPDI_FA(src, rt, nk);
+              if (rt == 1) fb[nk][0] = KPDI_FB(src, 0, nk);
+              if (rt == 3) fb[nk][1] = KPDI_FB(src, 1, nk);
+            }
 #endif
 #ifndef KPDI16_NO_DMA
-            // (8 waves: 3 pieces in each of the k-steps 1 and 2; 4 waves: all 6 in k-step 1, after the barrier)
-#ifdef KPDI16_STAGGER  // the two waves of a SIMD (wr = 0 / 1) issue their pieces in different k-steps
-            if (KSTEPS16 == 3 && ks == 1 + wr && rt < 3) {
-              issue_piece16<WAVES>(gd, ge, ld_base, wv, 2 * rt, goff);
-              issue_piece16<WAVES>(gd, ge, ld_base, wv, 2 * rt + 1, goff);
-            }
-#else
-            if (KSTEPS16 == 3 && ks >= 1 && rt < 3) issue_piece16<WAVES>(gd, ge, ld_base, wv, (ks - 1) * 3 + rt, goff);
-#endif
-            if (KSTEPS16 == 2 && ks == 1) {
-              if (rt < 3) issue_piece16<WAVES>(gd, ge, ld_base, wv, 2 * rt, goff);
-              if (rt < 3) issue_piece16<WAVES>(gd, ge, ld_base, wv, 2 * rt + 1, goff);
+            if (WAVES == 8) {  // 3 pieces in each of the k-steps 1 and 2
+              if (ks >= 1 && rt < 3) issue_piece16<WAVES>(gd, ge, ld_base, wv, (ks - 1) * 3 + rt, goff);
+            } else {           // 6 in each
+              if (ks >= 1) {
+                issue_piece16<WAVES>(gd, ge, ld_base, wv, (ks - 1) * 6 + rt, goff);
+                if (rt < 2) issue_piece16<WAVES>(gd, ge, ld_base, wv, (ks - 1) * 6 + 4 + rt, goff);
+              }
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-#ifdef KPDI16_PREFETCH
-        // ---- L2 prefetch: touch every 128-byte line of the blocks the LDS-DMA will ask for KPDI16_PREFETCH
-        // steps after the ones just issued, with one plain load per wave whose result is never read, so
-        // that the pieces find them in this XCD's L2 (~700 cycles) instead of the Infinity Cache / HBM
-        // (2000+: more than the ring can cover).  Waves 0-2 take the dictionary block, 3-5 the experimental one.
-        if (wv < PF_WAVES) {
-          int ps = ld_step + KPDI16_PREFETCH, pp = ld_pos;
-          if (ps >= nsteps) {
-            ps -= nsteps;
-            ++pp;
-          }
-          int pt = pp == 0 ? t0 : (pp == 1 ? t1 : (pp == 2 ? t2 : t2 + a.nsplit));
-          pt = pt < last_tile ? pt : last_tile;
-          const bool pe = wv >= PF_WAVES / 2;
-          const char *pb = pe ? exp_base + (size_t)ps * G::EBLOCK : dict_base + (size_t)pt * tile_bytes + (size_t)ps * G::DBLOCK;
-          const char *pa = pb + ((pe ? wv - PF_WAVES / 2 : wv) * 64 + lane) * 128;
-          int dummy;
-          asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(pa) : "memory");
-        }
-#endif
         KPDI16_CURSOR_ADVANCE();
         stage = nstage;
       }  // steps
       // the last MFMAs (8 passes) must have written the accumulators before they are read
 #pragma unroll
-#ifndef KPDI16_ACC_A
-      for (int rt = 0; rt < 4; ++rt) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc0[rt]), "+v"(acc1[rt]));
-#else
-      for (int rt = 0; rt < 4; ++rt) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc0[rt]), "+a"(acc1[rt]));
-#endif
+      for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          if (G::ACC_A)
+            asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[cg][rt]));
+          else
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[cg][rt]));
+        }
       {
         // ---- epilogue of the tile.  Steady state (per column group): the 64 accumulator registers are
         // compared with the pre-scaled threshold (a v_max3 tree per 16 registers first) and the few
@@ -383,43 +365,42 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
         // step), so every cycle spent here is lost on the matrix pipe: a list update per tile cost 23 %.
         const int row0 = t0 * G::DT + wr * 128 + 4 * (lane >> 5);
 #pragma unroll
-        for (int cg = 0; cg < 2; ++cg) {
-          f32x16(&acc)[4] = cg == 0 ? acc0 : acc1;
-          const float gthr = cg == 0 ? g0 : g1;
-          float &last = cg == 0 ? last0 : last1;
-          int &cnt = cg == 0 ? cnt0 : cnt1;
-          float &pub = cg == 0 ? pub0 : pub1;
-          const float ub = cg == 0 ? ub0 : ub1;
-          const int ubi = cg == 0 ? ubi0 : ubi1;
-#ifdef KPDI16_NO_EPILOGUE
-          asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+        for (int cg = 0; cg < NCG; ++cg) {
+#ifdef KPDI16_NO_EPILOGUE  // (the MFMAs are asm volatile: they stay)
+          continue;
+#endif
+#ifdef KPDI16_SCREEN_NONE  // the bound is loaded and reduced, nothing is screened
+          if (g[cg] == 12345.f) cnt[cg] = 1;
           continue;
 #endif
           constexpr float unscale = 0x1p-24f;
-          const float thr = fmaxf(gthr, next_up(last));
+          const float thr = fmaxf(g[cg], next_up(last[cg]));
           const float thr_raw = thr * 0x1p24f;  // exact: the accumulators hold 2^24 * score
           float *bs = buf_s + cg * CAND_CAP * 64;
           int *bi = buf_i + cg * CAND_CAP * 64;
-          int c = cnt;
+          unsigned *line = const_cast<unsigned *>(line0) + 32 * cg * BOUND_SLOTS;
+          int c = cnt[cg];
           bool overflow = false;
           float mx = -INFINITY;
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt) {
-            float m = acc[rt][0];
+            float m = acc[cg][rt][0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][r]);
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[cg][rt][r]);
             if (__builtin_amdgcn_ballot_w64(m >= thr_raw) == 0) continue;  // wave-uniform
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
-              const float v = acc[rt][r] * unscale + 0.f;  // -0 -> +0 so that ties compare as the merge does
+              const float v = acc[cg][rt][r] * unscale + 0.f;  // -0 -> +0 so that ties compare as the merge does
               const int idx = idx_base + lrow;
-              bool ok = acc[rt][r] >= thr_raw && lrow < n_valid;
-              if (BOUNDED) ok = ok && (v < ub || (v == ub && idx > ubi));
+              bool ok = acc[cg][rt][r] >= thr_raw && lrow < n_valid;
+              if (BOUNDED) ok = ok && (v < ub[cg] || (v == ub[cg] && idx > ubi[cg]));
               if (ok) {
-                if (c < CAND_CAP) {
+                if (c < cap) {
+#ifndef KPDI16_NO_APPEND_STORES
                   bs[c * 64 + ulane] = v;
                   bi[c * 64 + ulane] = idx;
+#endif
                   ++c;
                   mx = fmaxf(mx, v);
                 } else {
@@ -428,23 +409,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
               }
             }
           }
-#ifdef KPDI16_NO_OVERFLOW
-          overflow = false;
-#endif
-#ifdef KPDI16_SLOW_FIRST_ONLY
-          if (t0 != sp) overflow = false;
-#endif
-#ifdef KPDI16_SLOW_NOT_FIRST
-          if (t0 == sp) overflow = false;
-#endif
           if (__builtin_amdgcn_ballot_w64(overflow) == 0) {
-            cnt = c;
+            cnt[cg] = c;
             // grouped form of the shared bound (every list publishes its best entry): the best buffered
             // candidate counts as well
-            if (bound_rank == 1 && mx > pub) {
-              pub = mx;
-              __hip_atomic_fetch_max(const_cast<unsigned *>(cg == 0 ? line0 : line1) + my_slot, score_key(mx),
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (bound_rank == 1 && mx > pub[cg]) {
+              pub[cg] = mx;
+              __hip_atomic_fetch_max(line + my_slot, score_key(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           } else {
             // ---- a buffer is full: list <- buffered candidates of the earlier tiles (in arrival order), then
@@ -464,15 +435,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
               }
             }
 #pragma unroll 1
-            for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt) != 0; ++i) {
-              if (i < cnt) {
+            for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt[cg]) != 0; ++i) {
+              if (i < cnt[cg]) {
                 const float v = bs[i * 64 + ulane];
                 const int id = bi[i * 64 + ulane];
                 if (v > best[KMAX - 1]) list_insert<KMAX>(best, bidx, v, id);
               }
             }
-            cnt = 0;
-            scan16<KMAX, BOUNDED>(acc, best, bidx, gthr, ub, ubi, row0, n_valid, idx_base);
+            cnt[cg] = 0;
+            scan16<KMAX, BOUNDED>(acc[cg], best, bidx, g[cg], ub[cg], ubi[cg], row0, n_valid, idx_base);
 #pragma unroll
             for (int q = 0; q < (KMAX + 15) / 16; ++q) {
               float *ps = chunk_base(hs, q);
@@ -483,37 +454,32 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
                 pi[(j - 16 * q) * 64 + ulane] = bidx[j];
               }
             }
-            last = best[KMAX - 1];
+            last[cg] = best[KMAX - 1];
             float now = best[0];  // the entry the shared bound is built from
 #pragma unroll
             for (int j = 1; j < KMAX; ++j) now = j == bound_rank - 1 ? best[j] : now;
-            if (now > pub) {
-              pub = now;
-              __hip_atomic_fetch_max(const_cast<unsigned *>(cg == 0 ? line0 : line1) + my_slot, score_key(now),
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (now > pub[cg]) {
+              pub[cg] = now;
+              __hip_atomic_fetch_max(line + my_slot, score_key(now), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
         }
+        ++tiles_done;
         t0 = t1;
         t1 = t2;
-#ifdef KPDI16_DYNAMIC_TILES
-        t2 = __builtin_amdgcn_readfirstlane(ctrl[4 + tp]);  // published at this tile's first barrier
-        tp ^= 1;
-#else
         t2 += a.nsplit;
-#endif
         --ld_pos;
         if (t0 >= n_tiles) break;
       }
     }
   }
 
-  // ---- candidates still buffered join their lists, then lists -> [m_pad][lists][KMAX] for the merge kernel
+  // ---- the buffered candidates that pass the FINAL shared bound join their lists (in arrival order = by
+  // increasing dictionary index), then lists -> [m_pad][lists][KMAX] for the merge kernel
   {
-    const int lists = (WAVES / 2) * a.nsplit;
+    const int lists = 4 * a.nsplit;
 #pragma unroll
-    for (int cg = 0; cg < 2; ++cg) {
-      const int cnt = cg == 0 ? cnt0 : cnt1;
+    for (int cg = 0; cg < NCG; ++cg) {
       float best[KMAX];
       int bidx[KMAX];
 #pragma unroll
@@ -526,14 +492,36 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
           bidx[j] = pi[(j - 16 * q) * 64 + ulane];
         }
       }
-      const float *bs = buf_s + cg * CAND_CAP * 64;
-      const int *bi = buf_i + cg * CAND_CAP * 64;
+      // a candidate below the bound has KMAX better ones somewhere among the pattern's lists
+      const float tf = shared_bound<KMAX>(line0 + 32 * cg * BOUND_SLOTS, bound_grouped);
 #pragma unroll 1
-      for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt) != 0; ++i) {
-        if (i < cnt) {
-          const float v = bs[i * 64 + ulane];
-          const int id = bi[i * 64 + ulane];
-          if (v > best[KMAX - 1]) list_insert<KMAX>(best, bidx, v, id);
+      for (int base = 0; __builtin_amdgcn_ballot_w64(base < cnt[cg]) != 0; base += 16) {
+        const float *ps = chunk_base(buf_s + (cg * CAND_CAP + base) * 64, 0);  // 16 entries in flight, not one
+        const int *pi = chunk_base(buf_i + (cg * CAND_CAP + base) * 64, 0);
+        f32x16 vs;
+        int ids[16];
+        unsigned hot = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const bool in = base + e < cnt[cg];
+          vs[e] = in ? ps[e * 64 + ulane] : -INFINITY;
+          ids[e] = in ? pi[e * 64 + ulane] : INT_MAX;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          hot |= __builtin_amdgcn_ballot_w64(vs[e] >= tf && vs[e] > best[KMAX - 1]) != 0 ? (1u << e) : 0u;
+#pragma unroll 1
+        while (hot != 0) {
+          const int e = __builtin_ctz(hot);
+          hot &= hot - 1;
+          float v = vs[0];
+          int id = ids[0];
+#pragma unroll
+          for (int q = 1; q < 16; ++q) {  // (wave-uniform e: scalar compares)
+            v = e == q ? vs[q] : v;
+            id = e == q ? ids[q] : id;
+          }
+          if (v >= tf && v > best[KMAX - 1]) list_insert<KMAX>(best, bidx, v, id);
         }
       }
       const size_t o = ((size_t)(m_lane + 32 * cg) * lists + (size_t)list_id) * KMAX;
@@ -548,7 +536,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match16_kernel(MatchArgs a, flo
 
 // floats (and as many ints) the kernel keeps per launch: the lists and the candidate buffers behind them
 static size_t scratch16_entries(int grid, int waves, int list_len) {
-  return (size_t)grid * waves * 2 * (list_len + CAND_CAP) * 64;
+  (void)waves;  // waves x column groups per wave = 16 lists per lane position in both forms
+  return (size_t)grid * 16 * (list_len + CAND_CAP) * 64;
 }
 size_t match16_scratch_bytes(int grid, int waves, int list_len) {
   return scratch16_entries(grid, waves, list_len) * (sizeof(float) + sizeof(int));

@@ -98,6 +98,60 @@ __device__ __forceinline__ float shared_bound(const unsigned *line, bool grouped
   return key_score32(t);
 }
 
+__device__ __forceinline__ float key_score32(unsigned u);
+// The same bound with HALF the loads per lane, for wave layouts in which lanes l and l + 32 look at the same
+// pattern (match16.hip): lane half h loads slots [16 h, 16 h + 16), reduces its groups, and the two halves are
+// combined across the wave (ds_bpermute, no LDS memory).  bound_load_half() only issues the loads - several
+// lines can be in flight before the first bound_reduce_half() waits for one.
+struct BoundHalf {
+  unsigned k[BOUND_SLOTS / 2];
+};
+__device__ __forceinline__ void bound_load_half(BoundHalf &r, const unsigned *line, int half) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int c = 0; c < BOUND_SLOTS / 8; ++c) {
+    const u32x4 q = __builtin_nontemporal_load((const u32x4 *)line + half * (BOUND_SLOTS / 8) + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.k[4 * c + e] = q[e];
+  }
+}
+template <int KMAX>
+__device__ __forceinline__ float bound_reduce_half(const BoundHalf &r, bool grouped, int half) {
+  constexpr int G = KMAX <= 1 ? 1 : (KMAX <= 8 ? 8 : (KMAX <= 20 ? 20 : 32));
+  constexpr int H = BOUND_SLOTS / 2;
+  unsigned t;
+  if (grouped && G == 1) {  // one group: the maximum of everything
+    t = 0;
+#pragma unroll
+    for (int i = 0; i < H; ++i) t = max(t, r.k[i]);
+    t = max(t, (unsigned)__shfl_xor((int)t, 32, 64));
+  } else if (grouped && G == 8) {  // group g = slots g, g + 8 (this half), g + 16, g + 24 (the other half)
+    unsigned m[8];
+    t = 0xffffffffu;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      m[g] = max(r.k[g], r.k[g + 8]);
+      m[g] = max(m[g], (unsigned)__shfl_xor((int)m[g], 32, 64));
+      t = min(t, m[g]);
+    }
+  } else {
+    t = 0xffffffffu;
+    if (grouped && G == 20) {  // 12 pairs (slots 0 .. 23) + 8 singles (24 .. 31): every group lies in one half
+#pragma unroll
+      for (int g = 0; g < H / 2; ++g) {
+        const unsigned pair = max(r.k[2 * g], r.k[2 * g + 1]);
+        const unsigned singles = min(r.k[2 * g], r.k[2 * g + 1]);
+        t = min(t, (half == 1 && g >= 4) ? singles : pair);
+      }
+    } else {  // plain form, or 32 groups of one slot
+#pragma unroll
+      for (int i = 0; i < H; ++i) t = min(t, r.k[i]);
+    }
+    t = min(t, (unsigned)__shfl_xor((int)t, 32, 64));
+  }
+  return key_score32(t);
+}
+
 // float <-> unsigned key, order preserving (same map as merge.hip)
 __device__ __forceinline__ unsigned score_key(float s) {
   const unsigned u = __float_as_uint(s);
