@@ -543,6 +543,41 @@ def main():
         except Exception as err:  # an informational leg must not cost the bench line
             out["extra"][key + "_error"] = f"{type(err).__name__}: {err}"
 
+    if world == 1 and not a.no_generation and a.compute == "f32":
+        try:
+            # informational: float64 arithmetic (the reference's dtype=float64) - the f32 sweep as the screen,
+            # float64 rescoring of keep_n + 12 candidates per pattern from the raw patterns (csrc/rescore.hip).
+            c64 = _lib.Context(local_rank)
+            c64.set_problem(w["sy"], w["sx"], mask, metric, w["keep_n"], _lib.COMPUTE_F64)
+            c64.set_profiling(True)
+            for r in range(4):
+                if r == 1:
+                    c64.reset_counters()
+                    c64.synchronize()
+                    t0 = time.perf_counter()
+                c64.set_experimental_dev(d_exp, exp.dtype, w["m"])
+                if w["preprocess"]:
+                    c64.remove_static_background(bg_f32, _lib.OP_SUBTRACT, False)
+                    c64.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
+                c64.push_dictionary_chunk_dev(d_dic, np.float32, n_local, lo)
+                s64, i64 = c64.finalize(w["keep_n"])
+            dt64 = (time.perf_counter() - t0) / 3
+            cnt64 = c64.counters()
+            c64.close()
+            out["extra"]["float64_mode"] = {
+                "what": "KPDI_COMPUTE_F64 (dtype=float64): f32 MFMA screen + float64 rescoring of keep_n + 12 candidates "
+                        "per pattern and chunk, certified",
+                "patterns_per_s": round(w["m"] / dt64, 1),
+                "match_ms": round(cnt64["match_ms"] / 3, 3),
+                "rescore_ms": round(cnt64["rescore_ms"] / 3, 3),
+                "extra_screening_passes": int(cnt64["rescore_extra_passes"]),
+                "uncertified_patterns": int(cnt64["uncertified_patterns"]),
+                "max_abs_score_diff_vs_f32": float(np.abs(s64 - scores).max()),
+                "index_mismatch_fraction_vs_f32": float(np.mean(i64 != indices)),
+            }
+        except Exception as err:  # an informational leg must not cost the bench line
+            out["extra"]["float64_mode_error"] = f"{type(err).__name__}: {err}"
+
     if world == 1 and not a.no_generation:
         try:
             # informational: the dictionary is SIMULATED on the device inside the step

@@ -76,6 +76,13 @@ typedef struct kpdi_ctx kpdi_ctx;
  * 4e-6 - OUTSIDE the 1e-5 contract, and near-ties rank differently (1.3 % of the best-20 entries
  * of a random dictionary); a few 1e-4 for small K. */
 #define KPDI_COMPUTE_F16 2
+/* FLOAT64 ARITHMETIC (the reference's `dtype=float64`, _similarity_metric.py:244-253): scores are those of a
+ * float64 evaluation (to ~1e-15; summation order differs from a dgemm's), returned by kpdi_finalize_f64.  The
+ * KPDI_COMPUTE_F32 path screens keep_n + 12 candidates per pattern and chunk, csrc/rescore.hip rescores them in
+ * double from the RAW patterns, keeps the best keep_n in double and certifies that no unscreened candidate can
+ * belong to them (more screening passes where it cannot; kpdi_counters.uncertified_patterns counts what is
+ * left, 0 in practice).  Needs the raw chunk: not available for resident (held) dictionaries. */
+#define KPDI_COMPUTE_F64 3
 
 /* background operations (`operation=` of remove_*_background) */
 #define KPDI_OP_SUBTRACT 0
@@ -163,6 +170,8 @@ int kpdi_reset_topk(kpdi_ctx *ctx);
  * all-gathers the per-shard lists over RCCL and merges them, so all ranks get
  * the same, global result. */
 int kpdi_finalize(kpdi_ctx *ctx, float *scores_out, int64_t *indices_out);
+/* KPDI_COMPUTE_F64: the float64 scores (kpdi_finalize then returns them rounded to float32) */
+int kpdi_finalize_f64(kpdi_ctx *ctx, double *scores_out, int64_t *indices_out);
 
 /* ---- dictionary generation on the device ------------------
  * EBSDMasterPattern.get_patterns (signals/ebsd_master_pattern.py:95-330): project a
@@ -347,6 +356,9 @@ typedef struct kpdi_counters {
   double refine_ms;     /* refinement solve kernels */
   double preproc_ms;    /* background-removal kernels (incl. the fused preparation of the patterns) */
   int64_t preproc_launches;
+  double rescore_ms;             /* KPDI_COMPUTE_F64: float64 rescoring + merge kernels */
+  int64_t rescore_extra_passes;  /* ... screening passes beyond the first keep_n + 12 candidates of a chunk */
+  int64_t uncertified_patterns;  /* ... (pattern, chunk) pairs whose best-k could not be certified; 0 in practice */
 } kpdi_counters;
 int kpdi_set_profiling(kpdi_ctx *ctx, int on);
 int kpdi_get_counters(kpdi_ctx *ctx, kpdi_counters *out);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KPDI_LIB_PATH") or os.path.join(_HERE, "csrc", "libkpdi.so")
 
 METRIC_NCC, METRIC_NDP = 0, 1
-COMPUTE_F32, COMPUTE_F16X2, COMPUTE_F16 = 0, 1, 2
+COMPUTE_F32, COMPUTE_F16X2, COMPUTE_F16, COMPUTE_F64 = 0, 1, 2, 3
 OP_SUBTRACT, OP_DIVIDE = 0, 1
 DOMAIN_FREQUENCY, DOMAIN_SPATIAL = 0, 1
 UNIQUE_ID_BYTES = 128
@@ -56,6 +56,9 @@ class Counters(C.Structure):
         ("refine_ms", C.c_double),
         ("preproc_ms", C.c_double),
         ("preproc_launches", C.c_int64),
+        ("rescore_ms", C.c_double),
+        ("rescore_extra_passes", C.c_int64),
+        ("uncertified_patterns", C.c_int64),
     ]
 
     def as_dict(self):
@@ -123,6 +126,7 @@ SIGNATURES = {
     "kpdi_set_experimental_h5ebsd": (_i, [_vp, C.c_char_p, C.c_char_p, _vp]),
     "kpdi_reset_topk": (_i, [_vp]),
     "kpdi_finalize": (_i, [_vp, _vp, _vp]),
+    "kpdi_finalize_f64": (_i, [_vp, _vp, _vp]),
     "kpdi_comm_unique_id": (_i, [_vp]),
     "kpdi_comm_init": (_i, [_vp, _i, _i, _vp]),
     "kpdi_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
@@ -229,6 +233,7 @@ class Context:
         self.device = int(device)
         self._keep = {}  # host arrays the library may still be reading
         self._keep_n = None       # what kpdi_finalize will write per pattern
+        self._compute = COMPUTE_F32
         self._projection_key = None  # simulations.ProjectedDictionary.configure
         self.result_token = 0     # bumped by every finalize()
         self._last_indices = None  # the indices the last finalize() returned
@@ -262,6 +267,7 @@ class Context:
         check(load().kpdi_set_problem(self._h, int(sy), int(sx), _ptr(sm), int(metric), int(compute),
                                       int(keep_n)))
         self._keep_n = int(keep_n)
+        self._compute = int(compute)
 
     def set_keep_n(self, keep_n):
         check(load().kpdi_set_keep_n(self._h, int(keep_n)))
@@ -494,7 +500,7 @@ class Context:
         return idx.shape == last.shape and np.array_equal(idx, last)
 
     def finalize(self, keep_n=None):
-        """(scores (m, keep_n) float32, indices (m, keep_n) int64).  `keep_n` must be the value
+        """(scores (m, keep_n) float32 - float64 with COMPUTE_F64 -, indices (m, keep_n) int64).  `keep_n` must be the value
         last given to `set_problem` / `set_keep_n`: that is what the library writes."""
         if keep_n is None:
             keep_n = self._keep_n
@@ -502,9 +508,13 @@ class Context:
             raise KpdiError(f"finalize(keep_n={keep_n}) but the context keeps {self._keep_n} entries per pattern "
                             "(set_problem / set_keep_n)")
         m = self.n_experimental
-        scores = np.empty((m, keep_n), dtype=np.float32)
         indices = np.empty((m, keep_n), dtype=np.int64)
-        check(load().kpdi_finalize(self._h, _ptr(scores), _ptr(indices)))
+        if self._compute == COMPUTE_F64:  # float64 arithmetic: the rescored scores (csrc/rescore.hip)
+            scores = np.empty((m, keep_n), dtype=np.float64)
+            check(load().kpdi_finalize_f64(self._h, _ptr(scores), _ptr(indices)))
+        else:
+            scores = np.empty((m, keep_n), dtype=np.float32)
+            check(load().kpdi_finalize(self._h, _ptr(scores), _ptr(indices)))
         self.result_token += 1
         self._last_indices = indices  # what is now resident in HBM (holds_result)
         if indices.size and indices[:, -1].max() >= 2**31 - 1:  # unfilled entries rank last

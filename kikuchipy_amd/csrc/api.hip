@@ -215,6 +215,12 @@ struct kpdi_ctx {
   DevBuf tile_ctr;                        // dynamic tile counters of the match kernel
   DevBuf loc_s, loc_i, bound_s, bound_i;  // multi-pass (keep_n > 32)
   DevBuf gather_s, gather_i;              // RCCL all-gather target
+  // float64 arithmetic (KPDI_COMPUTE_F64): the f32 path screens, rescore.hip rescores and keeps the best-k in double
+  bool exact64 = false;
+  DevBuf run64_s, run64_i;                // running float64 best-k [m][keep_n]
+  DevBuf cand64;                          // float64 scores of the screened candidates [m][columns]
+  DevBuf cert64;                          // [0]: bits of max |f32 - f64| over the sweep; [1]: uncertified patterns of a merge
+  DevBuf gather64_s, gather64_i, final64_s, final64_i;
   PinBuf pin_out;                         // kpdi_finalize: scores + indices on their way to the caller
 
   // pre-processing: kpdi_remove_*_background only RECORD the step; the kernels run (fused with the
@@ -246,7 +252,7 @@ struct kpdi_ctx {
 
   // measurement
   bool profiling = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_match, ev_prep, ev_merge, ev_proj, ev_pre;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_match, ev_prep, ev_merge, ev_proj, ev_pre, ev_rescore;
   std::vector<hipEvent_t> ev_pool;
   kpdi_counters cnt{};
 
@@ -453,7 +459,14 @@ int ensure_running(kpdi_ctx *c) {
   }
   c->run_cur = 0;
   HIPCHK(kpdi::launch_fill_topk(c->run_s[0].as<float>(), c->run_i[0].as<int>(), (int64_t)n, c->stream));
-  if (!getenv("KPDI_KEEP_BOUND")) c->bound_key = -1;  // a new sweep starts without a shared bound (KPDI_KEEP_BOUND: timing experiment)
+  if (c->exact64) {
+    HIPCHK(c->run64_s.reserve(std::max<size_t>(n, 1) * sizeof(double)));
+    HIPCHK(c->run64_i.reserve(std::max<size_t>(n, 1) * sizeof(int)));
+    HIPCHK(kpdi::launch_fill_topk64(c->run64_s.as<double>(), c->run64_i.as<int>(), (int64_t)n, c->stream));
+    HIPCHK(c->cert64.reserve(2 * sizeof(unsigned)));
+    HIPCHK(hipMemsetAsync(c->cert64.p, 0, 2 * sizeof(unsigned), c->stream));
+  }
+  c->bound_key = -1;  // a new sweep starts without a shared bound
   c->run_valid = true;
   return KPDI_OK;
 }
@@ -656,7 +669,8 @@ int check_chunk_args(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_sta
   return KPDI_OK;
 }
 
-int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_start);
+int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_start, const void *raw = nullptr,
+                   int raw_dtype = 0);
 void release_held(kpdi_ctx *c);
 
 int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start) {
@@ -667,11 +681,127 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
   HIPCHK(c->dict_y.reserve((size_t)kpdi::round_up(n_chunk, dict_tile(c)) * c->kpad * sizeof(float)));
   rc = prepare_chunk(c, d_patterns, dtype, n_chunk, c->dict_y.as<float>());
   if (rc) return rc;
-  return sweep_prepared(c, c->dict_y.as<float>(), n_chunk, global_start);
+  return sweep_prepared(c, c->dict_y.as<float>(), n_chunk, global_start, d_patterns, dtype);
+}
+
+// One screening pass over a prepared chunk: the ranks [done, done + kp) of every pattern WITHIN this chunk ->
+// columns done .. of loc_s / loc_i (row stride `stride`); pass p only admits candidates ranked strictly
+// after the last entry of pass p-1 (bound_s / bound_i = the last column so far)
+int local_pass(kpdi_ctx *c, const float *y, int n_chunk, int n_tiles, int nsplit, int rows_per_launch,
+               int64_t global_start, int done, int kp, int stride) {
+  const int len = kpdi::match_list_len(kp);
+  c->bound_key = -1;  // each pass ranks a different slice: its shared bound starts from scratch
+  int rc = run_match(c, y, n_chunk, n_tiles, nsplit, rows_per_launch, len, global_start,
+                     done ? c->bound_s.as<float>() : nullptr, done ? c->bound_i.as<int>() : nullptr);
+  if (rc) return rc;
+  kpdi::MergeLaunch pm{};
+  pm.m = c->m;
+  pm.k = kp;
+  pm.n_src = 1;
+  pm.src_scores[0] = c->part_s.as<float>();
+  pm.src_idx[0] = c->part_i.as<int>();
+  const int lps = lists_per_split(c);
+  pm.src_lists[0] = lps * nsplit;
+  pm.src_len[0] = len;
+  pm.src_row_stride[0] = lps * nsplit * len;
+  pm.src_list_stride[0] = len;
+  pm.out_scores = c->loc_s.as<float>();
+  pm.out_idx = c->loc_i.as<int>();
+  pm.out_stride = stride;
+  pm.out_offset = done;
+  {
+    ScopedTimer t(c, &c->ev_merge);
+    HIPCHK(kpdi::launch_merge(pm, c->stream));
+  }
+  HIPCHK(kpdi::launch_last_column(c->loc_s.as<float>(), c->loc_i.as<int>(), c->m, stride, done + kp - 1,
+                                  c->bound_s.as<float>(), c->bound_i.as<int>(), c->stream));
+  return KPDI_OK;
+}
+
+// float64 arithmetic (rescore.hip): screen keep_n + 12 candidates of the chunk in f32, rescore them in double from
+// the raw patterns, merge into the running float64 best-k, certify; uncertified patterns get up to EXTRA64 more
+// screening passes of 32 candidates
+constexpr int MARGIN64 = 12, EXTRA64 = 3;
+int sweep_exact64(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_start, const void *raw, int raw_dtype,
+                  int n_tiles, int nsplit, int rows_per_launch) {
+  const int k = c->keep_n;
+  if ((int64_t)k + MARGIN64 > 4096) return fail(KPDI_EINVAL, "float64 arithmetic supports keep_n <= %d", 4096 - MARGIN64);
+  const int cap = kpdi::round_up(k + MARGIN64, kpdi::KMAX_LIMIT) + kpdi::KMAX_LIMIT * EXTRA64;
+  const size_t n = (size_t)c->m * cap;
+  HIPCHK(c->loc_s.reserve(n * sizeof(float)));
+  HIPCHK(c->loc_i.reserve(n * sizeof(int)));
+  HIPCHK(c->cand64.reserve(n * sizeof(double)));
+  HIPCHK(c->bound_s.reserve((size_t)c->m_pad * sizeof(float)));
+  HIPCHK(c->bound_i.reserve((size_t)c->m_pad * sizeof(int)));
+  HIPCHK(kpdi::launch_fill_topk(c->bound_s.as<float>(), c->bound_i.as<int>(), c->m_pad, c->stream));
+  HIPCHK(kpdi::launch_fill_topk(c->loc_s.as<float>(), c->loc_i.as<int>(), (int64_t)n, c->stream));
+  unsigned *cert = c->cert64.as<unsigned>();
+  int done = 0, extra = 0, uncertified = 0;
+  int64_t target = std::min<int64_t>((int64_t)k + MARGIN64, n_chunk);
+  for (;;) {
+    while (done < target) {
+      const int kp = (int)std::min<int64_t>(kpdi::KMAX_LIMIT, target - done);
+      int rc = local_pass(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, global_start, done, kp, cap);
+      if (rc) return rc;
+      ScopedTimer t(c, &c->ev_rescore);
+      kpdi::RescoreLaunch r{};
+      r.exp_raw = c->exp_raw.p;
+      r.exp_dtype = c->exp_dtype;
+      r.row_map = c->have_nav_mask ? c->row_map.as<int>() : nullptr;
+      r.dict_raw = raw;
+      r.dict_dtype = raw_dtype;
+      r.n_chunk = n_chunk;
+      r.global_start = global_start;
+      r.pix_map = c->have_sig_mask ? c->pix_map.as<int>() : nullptr;
+      r.k = c->k_kept;
+      r.npix = c->npix;
+      r.metric = c->metric;
+      r.m = c->m;
+      r.cand_s = c->loc_s.as<float>();
+      r.cand_i = c->loc_i.as<int>();
+      r.cand_stride = cap;
+      r.cand_offset = done;
+      r.n_cand = kp;
+      r.cand_s64 = c->cand64.as<double>();
+      r.max_diff = cert;
+      HIPCHK(kpdi::launch_rescore(r, c->stream));
+      HIPCHK(hipMemsetAsync(cert + 1, 0, sizeof(unsigned), c->stream));
+      kpdi::Merge64Launch g{};
+      g.m = c->m;
+      g.k = k;
+      g.run_s = c->run64_s.as<double>();
+      g.run_i = c->run64_i.as<int>();
+      g.cand_s64 = c->cand64.as<double>() + done;
+      g.cand_i = c->loc_i.as<int>() + done;
+      g.lists = 1;
+      g.len = kp;
+      g.row_stride = cap;
+      g.list_stride = 0;
+      g.out_s = c->run64_s.as<double>();
+      g.out_i = c->run64_i.as<int>();
+      g.cand_s32 = c->loc_s.as<float>();
+      g.s32_stride = cap;
+      g.s32_col = done + kp - 1;
+      g.enumerated_all = done + kp >= n_chunk;
+      g.max_diff = cert;
+      g.eps_floor = 1e-6f;
+      g.uncertified = (int *)(cert + 1);
+      HIPCHK(kpdi::launch_merge64(g, c->stream));
+      done += kp;
+    }
+    HIPCHK(hipMemcpyAsync(&uncertified, cert + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (uncertified == 0 || done >= n_chunk || extra == EXTRA64) break;
+    target = std::min<int64_t>((int64_t)done + kpdi::KMAX_LIMIT, n_chunk);
+    ++extra;
+    c->cnt.rescore_extra_passes += 1;
+  }
+  c->cnt.uncertified_patterns += uncertified;
+  return KPDI_OK;
 }
 
 // every experimental pattern against one prepared chunk, merged into the running best-k
-int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_start) {
+int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_start, const void *raw, int raw_dtype) {
   int rc = prepare_experimental(c);
   if (rc) return rc;
   rc = ensure_running(c);
@@ -682,6 +812,13 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
   int rows_per_launch = row_blocks;
   const int nsplit = choose_nsplit(c, row_blocks, n_tiles, &rows_per_launch);
   const int k = c->keep_n;
+  if (c->exact64) {
+    if (!raw)
+      return fail(KPDI_EINVAL, "float64 arithmetic rescoring reads the RAW dictionary patterns: resident (held) chunks keep "
+                               "only the prepared form - push the chunks instead");
+    c->final_valid = false;
+    return sweep_exact64(c, y, n_chunk, global_start, raw, raw_dtype, n_tiles, nsplit, rows_per_launch);
+  }
   const int cur = c->run_cur, nxt = cur ^ 1;
   c->final_valid = false;
 
@@ -733,33 +870,9 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
     const int kk = (int)std::min<int64_t>(k, n_chunk);
     if (kk < k) HIPCHK(kpdi::launch_fill_topk(c->loc_s.as<float>(), c->loc_i.as<int>(), (int64_t)n, c->stream));
     for (int done = 0; done < kk; done += kpdi::KMAX_LIMIT) {
-      const int kp = std::min(kpdi::KMAX_LIMIT, kk - done);
-      const int len = kpdi::match_list_len(kp);
-      c->bound_key = -1;  // each pass ranks a different slice: its shared bound starts from scratch
-      rc = run_match(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, len, global_start,
-                     done ? c->bound_s.as<float>() : nullptr, done ? c->bound_i.as<int>() : nullptr);
+      rc = local_pass(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, global_start, done,
+                      std::min(kpdi::KMAX_LIMIT, kk - done), k);
       if (rc) return rc;
-      kpdi::MergeLaunch pm{};
-      pm.m = c->m;
-      pm.k = kp;
-      pm.n_src = 1;
-      pm.src_scores[0] = c->part_s.as<float>();
-      pm.src_idx[0] = c->part_i.as<int>();
-      const int lps = lists_per_split(c);
-      pm.src_lists[0] = lps * nsplit;
-      pm.src_len[0] = len;
-      pm.src_row_stride[0] = lps * nsplit * len;
-      pm.src_list_stride[0] = len;
-      pm.out_scores = c->loc_s.as<float>();
-      pm.out_idx = c->loc_i.as<int>();
-      pm.out_stride = k;
-      pm.out_offset = done;
-      {
-        ScopedTimer t(c, &c->ev_merge);
-        HIPCHK(kpdi::launch_merge(pm, c->stream));
-      }
-      HIPCHK(kpdi::launch_last_column(c->loc_s.as<float>(), c->loc_i.as<int>(), c->m, k, done + kp - 1,
-                                      c->bound_s.as<float>(), c->bound_i.as<int>(), c->stream));
     }
     mg.src_scores[1] = c->loc_s.as<float>();
     mg.src_idx[1] = c->loc_i.as<int>();
@@ -1011,7 +1124,7 @@ int kpdi_destroy(kpdi_ctx *c) {
                     &c->ref_raw, &c->ref_map, &c->ref_rowcol, &c->ref_pat, &c->ref_sqn, &c->ref_in, &c->ref_out,
                     &c->ref_idx, &c->osm_idx, &c->osm_out, &c->stage[0], &c->stage[1]})
     b->release();
-  for (auto *l : {&c->ev_match, &c->ev_prep, &c->ev_merge, &c->ev_proj, &c->ev_pre})
+  for (auto *l : {&c->ev_match, &c->ev_prep, &c->ev_merge, &c->ev_proj, &c->ev_pre, &c->ev_rescore})
     for (auto &pr : *l) {
       (void)hipEventDestroy(pr.first);
       (void)hipEventDestroy(pr.second);
@@ -1049,8 +1162,12 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
   if (sy <= 0 || sx <= 0) return fail(KPDI_EINVAL, "detector shape (%d, %d) must be positive", sy, sx);
   if (metric != KPDI_METRIC_NCC && metric != KPDI_METRIC_NDP) return fail(KPDI_EINVAL, "unknown metric %d", metric);
-  if (compute_dtype != KPDI_COMPUTE_F32 && compute_dtype != KPDI_COMPUTE_F16X2 && compute_dtype != KPDI_COMPUTE_F16)
+  if (compute_dtype != KPDI_COMPUTE_F32 && compute_dtype != KPDI_COMPUTE_F16X2 && compute_dtype != KPDI_COMPUTE_F16 &&
+      compute_dtype != KPDI_COMPUTE_F64)
     return fail(KPDI_EINVAL, "unknown compute dtype %d", compute_dtype);
+  // float64 arithmetic = the f32 path as the screen + rescoring in double (rescore.hip)
+  const bool exact64 = compute_dtype == KPDI_COMPUTE_F64;
+  if (exact64) compute_dtype = KPDI_COMPUTE_F32;
   if (keep_n <= 0) return fail(KPDI_EINVAL, "keep_n must be >= 1");
   int rc = use_device(c);
   if (rc) return rc;
@@ -1090,6 +1207,7 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
                 : kpdi::round_up(c->k_kept + (metric == KPDI_METRIC_NDP ? 1 : 0), kpdi::TILE_K);
   c->metric = metric;
   c->compute = compute_dtype;
+  c->exact64 = exact64;
   c->keep_n = keep_n;
   c->have_problem = true;
   c->exp_prepared = false;
@@ -1818,6 +1936,74 @@ int kpdi_reset_topk(kpdi_ctx *c) {
   return KPDI_OK;
 }
 
+}  // extern "C"
+namespace {
+// float64 arithmetic: the running double lists (all-gathered and merged over the ranks) to the host;
+// exactly one of scores64 / scores32 is set
+int finalize64(kpdi_ctx *c, double *scores64, float *scores32, int64_t *indices_out) {
+  const int k = c->keep_n;
+  const size_t n = (size_t)c->m * k;
+  const double *d_s = c->run64_s.as<double>();
+  const int *d_i = c->run64_i.as<int>();
+  if (c->comm) {
+    HIPCHK(c->gather64_s.reserve(n * c->nranks * sizeof(double)));
+    HIPCHK(c->gather64_i.reserve(n * c->nranks * sizeof(int)));
+    HIPCHK(c->final64_s.reserve(n * sizeof(double)));
+    HIPCHK(c->final64_i.reserve(n * sizeof(int)));
+    ncclResult_t r = g_rccl.GroupStart();
+    if (r == ncclSuccess) r = g_rccl.AllGather(d_s, c->gather64_s.p, n, ncclFloat64, c->comm, c->stream);
+    if (r == ncclSuccess) r = g_rccl.AllGather(d_i, c->gather64_i.p, n, ncclInt32, c->comm, c->stream);
+    ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) return fail(KPDI_ECOMM, "RCCL all-gather failed: %s", g_rccl.GetErrorString(r));
+    kpdi::Merge64Launch g{};
+    g.m = c->m;
+    g.k = k;
+    g.cand_s64 = c->gather64_s.as<double>();
+    g.cand_i = c->gather64_i.as<int>();
+    g.lists = c->nranks;
+    g.len = k;
+    g.row_stride = k;
+    g.list_stride = (int64_t)n;
+    g.out_s = c->final64_s.as<double>();
+    g.out_i = c->final64_i.as<int>();
+    {
+      ScopedTimer t(c, &c->ev_merge);
+      HIPCHK(kpdi::launch_merge64(g, c->stream));
+    }
+    d_s = c->final64_s.as<double>();
+    d_i = c->final64_i.as<int>();
+  }
+  c->final_idx = d_i;
+  c->final_valid = true;
+  std::vector<double> hs(n);
+  std::vector<int> hi(n);
+  HIPCHK(hipMemcpyAsync(hs.data(), d_s, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(hi.data(), d_i, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < n; ++i) {
+    if (scores64) scores64[i] = hs[i];
+    if (scores32) scores32[i] = (float)hs[i];
+    indices_out[i] = (int64_t)hi[i];
+  }
+  return KPDI_OK;
+}
+}  // namespace
+extern "C" {
+
+int kpdi_finalize_f64(kpdi_ctx *c, double *scores_out, int64_t *indices_out) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!c->have_exp || !c->have_problem) return fail(KPDI_EINVAL, "nothing to finalise");
+  if (!scores_out || !indices_out) return fail(KPDI_EINVAL, "output pointer is NULL");
+  if (!c->exact64) return fail(KPDI_EINVAL, "kpdi_finalize_f64 needs a problem set up with KPDI_COMPUTE_F64");
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (c->m == 0) return KPDI_OK;
+  rc = ensure_running(c);  // a rank that pushed nothing contributes empty lists
+  if (rc) return rc;
+  return finalize64(c, scores_out, nullptr, indices_out);
+}
+
 int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
   if (!c->have_exp || !c->have_problem) return fail(KPDI_EINVAL, "nothing to finalise");
@@ -1827,6 +2013,7 @@ int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
   if (c->m == 0) return KPDI_OK;
   rc = ensure_running(c);  // a rank that pushed nothing contributes empty lists
   if (rc) return rc;
+  if (c->exact64) return finalize64(c, nullptr, scores_out, indices_out);
   const int k = c->keep_n;
   const size_t n = (size_t)c->m * k;
   const float *d_s = c->run_s[c->run_cur].as<float>();
@@ -1966,6 +2153,8 @@ int kpdi_get_counters(kpdi_ctx *c, kpdi_counters *out) {
   rc = drain_events(c, c->ev_proj, &c->cnt.project_ms);
   if (rc) return rc;
   rc = drain_events(c, c->ev_pre, &c->cnt.preproc_ms);
+  if (rc) return rc;
+  rc = drain_events(c, c->ev_rescore, &c->cnt.rescore_ms);
   if (rc) return rc;
   *out = c->cnt;
   return KPDI_OK;

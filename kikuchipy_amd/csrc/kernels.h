@@ -142,6 +142,46 @@ hipError_t launch_fill_u32(unsigned *p, unsigned value, int64_t n, hipStream_t s
 hipError_t launch_last_column(const float *scores, const int *idx, int m, int stride, int col,
                               float *bound_score, int *bound_idx, hipStream_t s);
 
+// ---- float64 arithmetic: rescoring of screened candidates (rescore.hip) -------
+struct RescoreLaunch {
+  const void *exp_raw;   // the experimental patterns as handed over (after recorded pre-processing), [m_all][npix]
+  int exp_dtype;
+  const int *row_map;    // kept pattern -> source row (navigation mask), or nullptr
+  const void *dict_raw;  // the raw dictionary chunk [n_chunk][npix]
+  int dict_dtype;
+  int64_t n_chunk, global_start;
+  const int *pix_map;    // kept pixel -> detector pixel (signal mask), or nullptr
+  int k, npix, metric;   // kept pixels, detector pixels, KPDI_METRIC_*
+  int m;
+  const float *cand_s;   // screened candidates [m][cand_stride], this pass: columns cand_offset .. + n_cand
+  const int *cand_i;     // global dictionary indices (INT_MAX: none)
+  int cand_stride, cand_offset, n_cand;
+  double *cand_s64;      // out, same layout as cand_s
+  unsigned *max_diff;    // bits of the largest |f32 score - f64 score| seen (atomic max)
+};
+hipError_t launch_rescore(const RescoreLaunch &a, hipStream_t s);
+
+struct Merge64Launch {
+  int m, k;
+  const double *run_s;   // running best-k [m][k] or nullptr
+  const int *run_i;
+  const double *cand_s64;  // `lists` lists of `len` entries per pattern
+  const int *cand_i;
+  int lists, len;
+  int64_t row_stride, list_stride;
+  double *out_s;         // [m][k]; may alias run_s / run_i
+  int *out_i;
+  // certification (uncertified == nullptr: none): the f32 score of the last screened candidate of a pattern
+  const float *cand_s32;
+  int s32_stride, s32_col;
+  int enumerated_all;    // every pattern of the chunk has been rescored
+  const unsigned *max_diff;
+  float eps_floor;
+  int *uncertified;      // counter (atomic add)
+};
+hipError_t launch_merge64(const Merge64Launch &a, hipStream_t s);
+hipError_t launch_fill_topk64(double *scores, int *idx, int64_t n, hipStream_t s);
+
 // ---- pattern pre-processing (preproc.hip) ---------------------------------
 // static background -> dynamic background -> (optionally) the metric's preparation of the
 // patterns, as ONE kernel per pattern set when the detector fits the LDS (<= 19 200 pixels),

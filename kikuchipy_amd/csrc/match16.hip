@@ -60,12 +60,23 @@ struct Geo {
 // ds_read (lgkmcnt), never from a VALU write: no hazard padding needed inside the asm statement.
 // 8-wave form: accumulators in architectural VGPRs (bare MFMA loop 1.41 vs 1.74 ms in AGPRs, and the
 // epilogue reads them without v_accvgpr_read); 4-wave form: 256 accumulation registers = the AGPR file.
+//
+// The asm statement hides the MFMA from the compiler's hazard recogniser: whatever the compiler places behind it
+// that touches the accumulator (a register copy, a spill) would read it before the matrix pipe has written it
+// (8 passes: 11 wait states).  KPDI16_MFMA_NOPS puts those wait states into the statement itself; the shipped
+// build instead keeps every accumulator in its registers throughout the loop, which tools/check_mfma_loops.py
+// (run by the test suite) verifies on the generated code of every instantiation.
+#ifdef KPDI16_MFMA_NOPS
+#define KPDI16_MFMA_TAIL "\n\ts_nop 11"
+#else
+#define KPDI16_MFMA_TAIL
+#endif
 template <bool ACC_A>
 __device__ __forceinline__ void mfma16(f32x16 &c, const f32x4 &a, const f32x4 &b) {
   if (ACC_A)
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" KPDI16_MFMA_TAIL : "+a"(c) : "v"(a), "v"(b));
   else
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" KPDI16_MFMA_TAIL : "+v"(c) : "v"(a), "v"(b));
 }
 
 // One of a wave's 1 KB LDS-DMA pieces of a stage (i < DPIECES: dictionary block, else experimental
@@ -194,18 +205,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
   int *buf_i = ls_idx + n_list_entries + (((size_t)blockIdx.x * WAVES + wv) * NCG) * CAND_CAP * 64;
   // per list, all the main loop keeps in registers: its last entry, the number of buffered candidates,
   // what it has published into the shared bound
-  float last[NCG], pub[NCG], ub[NCG], g[NCG];
-  int cnt[NCG], ubi[NCG];
+  float last[NCG], pub[NCG], g[NCG];
+  int cnt[NCG];
 #pragma unroll
   for (int cg = 0; cg < NCG; ++cg) {
     last[cg] = pub[cg] = g[cg] = -INFINITY;
     cnt[cg] = 0;
-    ub[cg] = INFINITY;
-    ubi[cg] = -1;
-    if (BOUNDED) {
-      ub[cg] = a.bound_score[m_lane + 32 * cg];
-      ubi[cg] = a.bound_idx[m_lane + 32 * cg];
-    }
   }
   const unsigned *line0 = a.gthr + (size_t)m_lane * BOUND_SLOTS;  // column group cg: + 32 cg BOUND_SLOTS
   const int list_id = sp * 4 + wr * 2 + (lane >> 5);
@@ -374,6 +379,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
           continue;
 #endif
           constexpr float unscale = 0x1p-24f;
+          // BOUNDED: the pass admits what ranks strictly after (ub, ubi); read here, not carried through the
+          // MFMA loop in registers (there is none to spare: tools/check_mfma_loops.py)
+          float ub_cg = INFINITY;
+          int ubi_cg = -1;
+          if (BOUNDED) {
+            ub_cg = a.bound_score[m_lane + 32 * cg];
+            ubi_cg = a.bound_idx[m_lane + 32 * cg];
+          }
           const float thr = fmaxf(g[cg], next_up(last[cg]));
           const float thr_raw = thr * 0x1p24f;  // exact: the accumulators hold 2^24 * score
           float *bs = buf_s + cg * CAND_CAP * 64;
@@ -394,7 +407,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
               const float v = acc[cg][rt][r] * unscale + 0.f;  // -0 -> +0 so that ties compare as the merge does
               const int idx = idx_base + lrow;
               bool ok = acc[cg][rt][r] >= thr_raw && lrow < n_valid;
-              if (BOUNDED) ok = ok && (v < ub[cg] || (v == ub[cg] && idx > ubi[cg]));
+              if (BOUNDED) ok = ok && (v < ub_cg || (v == ub_cg && idx > ubi_cg));
               if (ok) {
                 if (c < cap) {
 #ifndef KPDI16_NO_APPEND_STORES
@@ -443,7 +456,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
               }
             }
             cnt[cg] = 0;
-            scan16<KMAX, BOUNDED>(acc[cg], best, bidx, g[cg], ub[cg], ubi[cg], row0, n_valid, idx_base);
+            scan16<KMAX, BOUNDED>(acc[cg], best, bidx, g[cg], ub_cg, ubi_cg, row0, n_valid, idx_base);
 #pragma unroll
             for (int q = 0; q < (KMAX + 15) / 16; ++q) {
               float *ps = chunk_base(hs, q);
@@ -570,7 +583,9 @@ static hipError_t launch16_w(const MatchLaunch &a, const MatchArgs &g, void *scr
     case 20:
       return bounded ? launch16_t<20, true, WAVES>(g, grid, scratch, s) : launch16_t<20, false, WAVES>(g, grid, scratch, s);
     case 32:
-      return bounded ? launch16_t<32, true, WAVES>(g, grid, scratch, s) : launch16_t<32, false, WAVES>(g, grid, scratch, s);
+      // (the bounded 32-entry form of the one-wave-per-SIMD variant does not fit its registers - an accumulator
+      // would live in scratch, tools/check_mfma_loops.py - so that launch runs the 8-wave kernel: same operands, same lists)
+      return bounded ? launch16_t<32, true, 8>(g, grid, scratch, s) : launch16_t<32, false, WAVES>(g, grid, scratch, s);
     default: return hipErrorInvalidValue;
   }
 }

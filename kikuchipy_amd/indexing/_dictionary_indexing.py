@@ -83,7 +83,7 @@ def _is_lazy(a):
 
 
 def prepare_metric(metric, navigation_mask, signal_mask, dtype, rechunk, n_experimental,
-                   n_dictionary_patterns, device=0, compute="f32"):
+                   n_dictionary_patterns, device=0, compute=None):
     """EBSD._prepare_metric (signals/ebsd.py:3049-3088)."""
     if isinstance(metric, str) and metric in METRICS:
         metric = METRICS[metric](device=device, compute=compute)
@@ -132,7 +132,7 @@ def dictionary_indexing(
     device=0,
     comm=None,
     verbose=True,
-    compute="f32",
+    compute=None,
 ):
     """Index experimental patterns against a dictionary of simulated patterns.
 
@@ -157,8 +157,10 @@ def dictionary_indexing(
         What the reference takes from the signals' axes managers and from
         `dictionary.xmap` (rotations as an (N, 4) quaternion array).
     compute
-        "f32" (default) or the opt-in "f16x2" arithmetic of the match kernel, see
-        `NormalizedCrossCorrelationMetric`; ignored when `metric` is an instance.
+        Arithmetic of the match kernel: None (default) = "f64" when `dtype` is float64 (float64
+        arithmetic like the reference: float32 screening + float64 rescoring), else "f32"; or the
+        opt-in "f16x2" / "f16", see `NormalizedCrossCorrelationMetric`; ignored when `metric` is an
+        instance.
     comm
         `kikuchipy_amd.parallel.Communicator` to shard the dictionary over
         ranks (one process per GPU).  Every rank must pass the same arrays; each

@@ -53,6 +53,11 @@ class ResidentDictionary:
             metric = METRICS[metric](device=device, compute=compute)
         if not isinstance(metric, _HipMetric):
             raise ValueError("a resident dictionary needs one of the GPU metrics of kikuchipy_amd")
+        if metric.compute == "f64":
+            raise ValueError("compute='f64' rescoring reads the raw dictionary patterns; a resident dictionary keeps only "
+                             "their prepared form - index with the dictionary itself instead")
+        if metric.compute is None:
+            metric.compute = "f32"  # (dtype=float64 then returns float32 arithmetic as float64, with a warning)
         if signal_mask is not None and not isinstance(signal_mask, np.ndarray):
             raise ValueError("The signal mask must be a NumPy array")
         if dictionary_rotations is not None:

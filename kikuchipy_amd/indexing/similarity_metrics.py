@@ -18,9 +18,9 @@ ONE fused launch sequence (normalise chunk -> f32 MFMA GEMM with in-register
 top-k -> merge) and memoises both results.  The (M x N) similarity matrix is
 never formed.
 
-Arithmetic is float32 on the MFMA pipe.  `dtype=float64` is accepted like in the
-reference; scores are then returned as float64 values of the float32
-computation (within the 1e-5 parity contract, not a float64 evaluation).
+Arithmetic is float32 on the MFMA pipe; with `dtype=float64` (as in the reference:
+float64 arithmetic) the float32 path only screens candidates, which are rescored
+in float64 from the raw patterns and certified (`compute="f64"`, csrc/rescore.hip).
 """
 
 import abc
@@ -148,20 +148,25 @@ class _HipMetric(SimilarityMetric):
     _sign = 1
     _metric_code = None
 
-    COMPUTE_MODES = {"f32": _lib.COMPUTE_F32, "f16x2": _lib.COMPUTE_F16X2, "f16": _lib.COMPUTE_F16}
+    COMPUTE_MODES = {"f32": _lib.COMPUTE_F32, "f16x2": _lib.COMPUTE_F16X2, "f16": _lib.COMPUTE_F16,
+                     "f64": _lib.COMPUTE_F64}
 
-    def __init__(self, *args, device=0, context=None, compute="f32", **kwargs):
+    def __init__(self, *args, device=0, context=None, compute=None, **kwargs):
         """compute
-            Arithmetic of the match kernel (not part of the reference's interface):
-            "f32" (default) = exact float32 products on the f32 matrix cores; "f16x2" = every
+            Arithmetic of the match kernel (not part of the reference's interface).  None (default):
+            follows `dtype` like the reference does - "f64" for `dtype=float64`, else "f32".
+            "f64" = float64 arithmetic: the float32 path screens keep_n + 12 candidates per pattern and
+            dictionary chunk, those are rescored in float64 from the raw patterns and the result is
+            certified (csrc/rescore.hip); scores agree with a float64 evaluation to ~1e-15.
+            "f32" = exact float32 products on the f32 matrix cores; "f16x2" = every
             prepared value split into two float16 (22 significant bits), three float16
             matrix-core products per term, float32 accumulation: ~2.5x the throughput, scores
             within ~1e-6 of the float32 path; "f16" = every prepared value rounded to ONE float16
             (reduced precision: scores within ~1e-3, near-ties may rank differently), one float16
             matrix-core product per term."""
         super().__init__(*args, **kwargs)
-        if compute not in self.COMPUTE_MODES:
-            raise ValueError(f"compute must be one of {sorted(self.COMPUTE_MODES)}, not {compute!r}")
+        if compute is not None and compute not in self.COMPUTE_MODES:
+            raise ValueError(f"compute must be one of {sorted(self.COMPUTE_MODES)} or None, not {compute!r}")
         self.compute = compute
         self._device = device
         self._ctx = context
@@ -176,6 +181,13 @@ class _HipMetric(SimilarityMetric):
             self._ctx = _lib.Context(self._device)
         return self._ctx
 
+    @property
+    def effective_compute(self):
+        """The arithmetic in use: `compute`, or what `dtype` asks for when that is None."""
+        if self.compute is not None:
+            return self.compute
+        return "f64" if np.dtype(self.dtype) == np.float64 else "f32"
+
     def _set_problem(self, sig_shape, keep_n):
         sm = None if self.signal_mask is None else np.asarray(self.signal_mask)
         if sm is not None and sm.shape != tuple(sig_shape):
@@ -183,7 +195,7 @@ class _HipMetric(SimilarityMetric):
                 f"The signal mask shape {sm.shape} and the detector shape {tuple(sig_shape)} must be identical"
             )
         self.context.set_problem(sig_shape[0], sig_shape[1], sm, self._metric_code, keep_n,
-                                 self.COMPUTE_MODES[self.compute])
+                                 self.COMPUTE_MODES[self.effective_compute])
         self._problem = tuple(sig_shape)
 
     def _match_chunk(self, patterns, k):
@@ -206,11 +218,12 @@ class _HipMetric(SimilarityMetric):
         and normalisation (_normalized_cross_correlation.py:88-128) run on the GPU
         when the first dictionary chunk arrives."""
         self.raise_error_if_invalid()
-        if self.dtype == np.float64:
+        if np.dtype(self.dtype) == np.float64 and self.effective_compute != "f64":
             warnings.warn(
-                "dtype=float64: the GPU engine evaluates the metric in float32 (f32 matrix cores, float32 "
-                "accumulation) and returns those scores as float64 - within 1e-5 of the reference's float64 "
-                "evaluation, not a float64 computation", UserWarning, stacklevel=2)
+                f"dtype=float64 with compute={self.effective_compute!r}: the metric is evaluated in that arithmetic "
+                "and the scores are returned as float64 values of it - within the parity contract of the "
+                "reference's float64 evaluation, not a float64 computation (compute=None or 'f64' is one)",
+                UserWarning, stacklevel=2)
         if hasattr(patterns, "compute"):
             patterns = patterns.compute()
         patterns = np.asarray(patterns)

@@ -162,7 +162,7 @@ class EBSD:
     # ------------------------------------------------------------------ indexing
     def dictionary_indexing(self, dictionary, metric="ncc", keep_n=20, n_per_iteration=None,
                             navigation_mask=None, signal_mask=None, rechunk=False, dtype=None, *,
-                            comm=None, verbose=True, compute="f32"):
+                            comm=None, verbose=True, compute=None):
         """See `kikuchipy_amd.dictionary_indexing`; `dictionary` is an `EBSD`
         with a 1-D navigation axis and an `xmap` of equal size."""
         from kikuchipy_amd.indexing._resident_dictionary import ResidentDictionary

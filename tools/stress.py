@@ -24,7 +24,7 @@ for case in range(n_cases):
         n = int(rng.choice([12500, 6250, 25000 + int(rng.integers(0, 300)), 3000]))
     k = int(min(n, rng.choice([1, 2, 8, 20, 21, 33, 64])))
     metric = str(rng.choice(["ncc", "ndp"]))
-    mode = int(rng.choice([_lib.COMPUTE_F32, _lib.COMPUTE_F16X2, _lib.COMPUTE_F16]))
+    mode = int(rng.choice([_lib.COMPUTE_F32, _lib.COMPUTE_F16X2, _lib.COMPUTE_F16, _lib.COMPUTE_F64]))
     dt_e = rng.choice([np.uint8, np.uint16, np.float32, np.float64])
     dt_d = rng.choice([np.float32, np.uint8, np.float64])
     exp = (rng.random((m, sy, sx)) * 250 + 1).astype(dt_e)
@@ -51,7 +51,7 @@ for case in range(n_cases):
         if rng.random() < 0.7:
             ctx.remove_dynamic_background(int(rng.integers(0, 2)), int(rng.integers(0, 2)), 0.0, 4.0)
             pre += "D"
-    if rng.random() < 0.3:  # resident dictionary: prepared chunks held, then swept
+    if rng.random() < 0.3 and mode != _lib.COMPUTE_F64:  # resident dictionary: prepared chunks held, then swept
         for a in range(0, n, chunk):
             ctx.hold_dictionary_chunk(dic[a:a + chunk], a)
         ctx.sweep_held()
@@ -63,9 +63,14 @@ for case in range(n_cases):
     if pre:
         exp = ctx.get_experimental()
     e = exp if nav is None else exp[~nav]
-    rs, ri = ko.dictionary_indexing(e, dic, metric=metric, keep_n=k, n_per_iteration=chunk, signal_mask=sig)
+    rs, ri = ko.dictionary_indexing(e, dic, metric=metric, keep_n=k, n_per_iteration=chunk, signal_mask=sig,
+                                    dtype=np.float64 if mode == _lib.COMPUTE_F64 else np.float32)
     try:
-        if mode == _lib.COMPUTE_F16:
+        if mode == _lib.COMPUTE_F64:
+            # float64 arithmetic: scores to 1e-12, indices exact wherever the scores are not within that of each other
+            assert s.dtype == np.float64 and np.abs(s - rs).max() <= 1e-12 and ctx.counters()["uncertified_patterns"] == 0
+            ko.assert_topk_parity(s, i, rs, ri, atol=1e-12, tie=4e-12)
+        elif mode == _lib.COMPUTE_F16:
             # reduced precision: the scores only (11-bit operands: a few 1e-4 at small K), order not compared
             assert np.abs(s - rs).max() < 2e-3 and np.all(np.diff(s, axis=1) <= 0) and i.min() >= 0 and i.max() < n
         else:
