@@ -126,9 +126,22 @@ class RefinementResult:
 
 
 # --------------------------------------------------------------------------- set-up
+# method -> (type, supports bounds, package), `SUPPORTED_OPTIMIZATION_METHODS` of indexing/_refinement/__init__.py:32-70
+_METHOD_INFO = {
+    "minimize": ("local", True, "scipy"),
+    "ln_neldermead": ("local", True, "nlopt"),
+    "basinhopping": ("global", False, "scipy"),
+    "differential_evolution": ("global", True, "scipy"),
+    "dual_annealing": ("global", True, "scipy"),
+    "shgo": ("global", True, "scipy"),
+}
+
+
 def _nelder_mead_options(method, method_kwargs, initial_step, maxeval):
     """`_RefinementSetup.set_optimization_parameters`
-    (indexing/_refinement/_refinement.py:1053-1139) for the one supported method."""
+    (indexing/_refinement/_refinement.py:1053-1139) for the method that runs ENTIRELY on the
+    device: SciPy's Nelder-Mead with its plain options.  Raises NotImplementedError for
+    everything else - `_optimization_plan` then drives the optimiser on the host."""
     method = (method or "minimize").lower()
     if method not in SUPPORTED_OPTIMIZATION_METHODS:
         raise ValueError(
@@ -160,6 +173,106 @@ def _nelder_mead_options(method, method_kwargs, initial_step, maxeval):
                 maxiter=options.get("maxiter"), maxfev=options.get("maxfev")), shown
 
 
+class _HostOptimizer:
+    """Every optimiser of the reference other than plain Nelder-Mead (SciPy local methods with their
+    options, the SciPy global methods, NLopt's LN_NELDERMEAD): the OPTIMISER runs on the host exactly as
+    in the reference (indexing/_refinement/_solvers.py:79-250, :464-600: same call, same keyword
+    arguments), the OBJECTIVE - master-pattern projection + NCC of one pattern - is one call into the
+    device per evaluation (`kpdi_refine_objective`).  Slow next to the on-device simplex search (one
+    launch and one synchronisation per evaluation) but complete."""
+
+    def __init__(self, method, method_kwargs, initial_step, rtol, maxeval, mode):
+        self.method = method
+        self.type, self.supports_bounds, self.package = _METHOD_INFO[method]
+        self.mode = mode
+        self.rtol, self.maxeval, self.initial_step = rtol, maxeval, None
+        self.kwargs = dict(method_kwargs or {})
+        if self.package == "nlopt":
+            try:
+                import nlopt  # noqa: F401
+            except ImportError as err:  # verify_dependency_or_raise("nlopt", ...) in the reference
+                raise ImportError(f"Optimization method {method.upper()!r} requires the optional dependency 'nlopt'") from err
+            self.method_name = method.upper()
+            if initial_step is not None:
+                step = np.atleast_1d(initial_step)
+                if step.size != {"ori": 1, "pc": 1, "ori_pc": 2}[mode]:
+                    raise ValueError("The initial step must be a single number when refining orientations or PCs and a "
+                                     "list of two numbers when refining both")
+                self.initial_step = [float(v) for v in np.repeat(step, 3)]
+        else:
+            if method == "minimize" and "method" not in self.kwargs:
+                self.kwargs["method"] = "Nelder-Mead"
+            self.method_name = self.kwargs.get("method", method) if method == "minimize" else method
+            if method == "basinhopping":
+                self.kwargs.setdefault("minimizer_kwargs", {})
+
+    @property
+    def shown_kwargs(self):
+        return self.kwargs
+
+    def run(self, fun, x0, bounds):
+        """One optimisation; returns (fun, nfev, nit, x)."""
+        if self.package == "nlopt":
+            import nlopt
+
+            opt = nlopt.opt(self.method_name, len(x0))
+            opt.set_ftol_rel(self.rtol)
+            if self.initial_step is not None:
+                opt.set_initial_step(self.initial_step)
+            if self.maxeval is not None:
+                opt.set_maxeval(self.maxeval)
+            opt.set_min_objective(lambda x, grad: fun(x))
+            if bounds is not None:
+                opt.set_lower_bounds([b[0] for b in bounds])
+                opt.set_upper_bounds([b[1] for b in bounds])
+            x = opt.optimize(np.asarray(x0, dtype=np.float64))
+            return opt.last_optimum_value(), opt.get_numevals(), 0, np.asarray(x)
+        import scipy.optimize
+
+        solver = getattr(scipy.optimize, self.method)
+        kwargs = dict(self.kwargs)
+        if self.method == "minimize":
+            if bounds is not None:
+                kwargs["bounds"] = bounds
+            res = solver(fun=fun, x0=x0, **kwargs)
+        elif self.supports_bounds:
+            if bounds is None:
+                raise ValueError(f"Method {self.method!r} optimises within bounds: pass a trust region")
+            res = solver(func=fun, bounds=bounds, **kwargs)
+        else:  # basinhopping
+            kwargs["minimizer_kwargs"] = dict(kwargs["minimizer_kwargs"])
+            res = solver(func=fun, x0=x0, **kwargs)
+        return float(res.fun), int(res.nfev), int(getattr(res, "nit", 0) or 0), np.asarray(res.x, dtype=np.float64)
+
+
+def _optimization_plan(method, method_kwargs, initial_step, rtol, maxeval, mode):
+    """(device options | None, host optimiser | None, what the info message shows)."""
+    try:
+        nm, shown = _nelder_mead_options(method, method_kwargs, initial_step, maxeval)
+        return nm, None, dict(method_name="Nelder-Mead", type="local", package="scipy", supports_bounds=True, kwargs=shown)
+    except NotImplementedError:
+        host = _HostOptimizer((method or "minimize").lower(), method_kwargs, initial_step, rtol, maxeval, mode)
+        return None, host, dict(method_name=host.method_name, type=host.type, package=host.package,
+                                supports_bounds=host.supports_bounds, kwargs=host.shown_kwargs, host=host)
+
+
+def _host_solve(ctx, mode_code, host, x0, fixed, lower, upper):
+    """The host-driven counterpart of `Context.refine_solve`: same (n, starts, 3 + nvar) result."""
+    n, starts, nvar = x0.shape
+    res = np.empty((n, starts, 3 + nvar))
+    for i in range(n):
+        for s in range(starts):
+            fx = None if fixed is None else fixed[i, s][None]
+
+            def fun(x, _i=i, _fx=fx):
+                return float(ctx.refine_objective(mode_code, [_i], np.asarray(x, dtype=np.float64)[None], _fx)[0])
+
+            bounds = None if lower is None else list(zip(lower[i, s], upper[i, s]))
+            f, nfev, nit, x = host.run(fun, x0[i, s], bounds)
+            res[i, s, 0], res[i, s, 1], res[i, s, 2], res[i, s, 3:] = f, nfev, nit, x
+    return res
+
+
 def _bounds(mode, x0, trust_region):
     """`_RefinementSetup.get_bound_constraints` (:1178-1242)."""
     if trust_region is None:
@@ -180,12 +293,23 @@ def _bounds(mode, x0, trust_region):
     return np.fmax(x0 - trust_region, lower_abs), np.fmin(x0 + trust_region, upper_abs)
 
 
-def _info_message(mode, trust_region, shown_kwargs, n_pseudo):
+def _info_message(mode, trust_region, shown_kwargs, n_pseudo, plan=None):
     """`_RefinementSetup.get_info_message` (:1244-1286)."""
-    info = "Refinement information:\n  Method: Nelder-Mead (local) from SciPy"
-    tr_str = np.array_str(np.asarray(trust_region), precision=5)
-    info += "\n  Trust region (+/-): " + tr_str
-    info += f"\n  Keyword arguments passed to method: {shown_kwargs}"
+    plan = plan or dict(method_name="Nelder-Mead", type="local", package="scipy", supports_bounds=True)
+    package = {"scipy": "SciPy", "nlopt": "NLopt"}[plan["package"]]
+    info = f"Refinement information:\n  Method: {plan['method_name']} ({plan['type']}) from {package}"
+    if plan["supports_bounds"]:
+        tr_str = np.array_str(np.asarray(trust_region), precision=5)
+        info += "\n  Trust region (+/-): " + tr_str
+    if plan["package"] == "scipy":
+        info += f"\n  Keyword arguments passed to method: {shown_kwargs}"
+    else:
+        host = plan["host"]
+        info += f"\n  Relative tolerance: {host.rtol}"
+        if host.initial_step:
+            info += f"\n  Initial step(s): {host.initial_step}"
+        if host.maxeval:
+            info += f"\n  Max. function evaulations: {host.maxeval}"
     if n_pseudo > 0:
         info += f"\n  No. pseudo-symmetry operators: {n_pseudo}"
     return info
@@ -226,7 +350,8 @@ def refine(mode, patterns, rotations, detector, master_pattern, energy=None, nav
     """
     if mode not in MODES:
         raise ValueError(f"mode must be one of {sorted(MODES)}")
-    nm, shown = _nelder_mead_options(method, method_kwargs, initial_step, maxeval)
+    nm, host, plan = _optimization_plan(method, method_kwargs, initial_step, rtol, maxeval, mode)
+    shown = plan["kwargs"]
     master_pattern._is_suitable_for_projection(raise_if_not=True)
     patterns = np.asarray(patterns)
     if patterns.ndim < 2 or patterns.ndim > 4:
@@ -285,7 +410,7 @@ def refine(mode, patterns, rotations, detector, master_pattern, energy=None, nav
         x0, fixed = np.concatenate([euler_from_rotation(rot_starts), pc_starts], axis=2), None
     lower, upper = _bounds(mode, x0, trust_region)
     if verbose:
-        print(_info_message(mode, trust_region, shown, n_pseudo))
+        print(_info_message(mode, trust_region, shown, n_pseudo, plan))
         what = {"ori": "orientation(s)", "pc": "projection center(s)", "ori_pc": "orientation(s) and projection center(s)"}
         print(f"Refining {n} {what[mode]}:")
 
@@ -302,9 +427,13 @@ def refine(mode, patterns, rotations, detector, master_pattern, energy=None, nav
             ctx.set_master_pattern(*_master_pattern_data(master_pattern, energy))
             # rescale exactly when the patterns are float32 (_refinement.py:956)
             ctx.refine_set_patterns(pats[part], signal_mask, pats.dtype == np.float32, detector.detector_to_sample)
-            res = ctx.refine_solve(MODES[mode], x0[part], None if fixed is None else fixed[part],
-                                   None if lower is None else lower[part], None if upper is None else upper[part],
-                                   nm["xatol"], nm["fatol"], nm["maxiter"] or 0, nm["maxfev"] or 0)
+            if host is None:  # the whole simplex search on the device
+                res = ctx.refine_solve(MODES[mode], x0[part], None if fixed is None else fixed[part],
+                                       None if lower is None else lower[part], None if upper is None else upper[part],
+                                       nm["xatol"], nm["fatol"], nm["maxiter"] or 0, nm["maxfev"] or 0)
+            else:  # the reference's optimiser on the host, the objective on the device
+                res = _host_solve(ctx, MODES[mode], host, x0[part], None if fixed is None else fixed[part],
+                                  None if lower is None else lower[part], None if upper is None else upper[part])
         else:
             res = np.empty((0, starts, 3 + x0.shape[2]))
         if comm is not None and comm.world_size > 1:

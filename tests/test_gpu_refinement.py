@@ -318,6 +318,52 @@ def test_refine_pc_and_both_api(api_inputs, g, g115):
     assert np.all(res.scores > only.scores - 1e-4)
 
 
+def test_other_optimisers_run_on_the_host_with_the_device_objective(api_inputs, g, capsys):
+    """Every optimiser of the reference other than plain Nelder-Mead (indexing/_refinement/_solvers.py:179-207):
+    the SciPy call runs on the host as in the reference, the objective on the device.  Against the oracle's own
+    SciPy run of the same method from the same start (`ko.refine_solver`)."""
+    s, det, mp, rot0 = api_inputs
+    p = load_golden("projection.npz")
+    mpu, mpl = ko.refinement_master_pattern(p["mp_upper"], p["mp_lower"])
+    pats = g["patterns"].reshape(4, -1)
+    base = s.refine_orientation(rot0, det, mp, verbose=False)
+
+    def oracle(i, method_kwargs, bounds=None):
+        dc = ko.detector_direction_cosines((60, 60), g["pc0"][i])
+        return ko.refine_solver(pats[i], "ori", g["eu0"][i], mpu, mpl, False, bounds=bounds, method_kwargs=method_kwargs,
+                                direction_cosines=dc)
+
+    # a local SciPy method
+    res = s.refine_orientation(rot0, det, mp, method_kwargs=dict(method="Powell"))
+    out = capsys.readouterr().out
+    assert "Method: Powell (local) from SciPy" in out and "{'method': 'Powell'}" in out
+    for i in range(4):
+        want = oracle(i, dict(method="Powell"))
+        assert abs(res.scores[i] - want[0]) < 2e-4 and np.abs(res.euler[i] - want[2:5]).max() < 2e-3
+        assert abs(int(res.num_evals[i]) - want[1]) <= 0.25 * want[1]
+    assert np.all(res.scores > base.scores - 2e-3)
+    # with bounds
+    tr = np.deg2rad(2)
+    res = s.refine_orientation(rot0, det, mp, method_kwargs=dict(method="L-BFGS-B"), trust_region=[2, 2, 2], verbose=False)
+    for i in range(4):
+        bounds = np.column_stack([g["eu0"][i] - tr, g["eu0"][i] + tr])
+        want = oracle(i, dict(method="L-BFGS-B"), bounds=bounds)
+        # (finite-difference gradients with SciPy's 1e-8 step on an objective with 1e-7 of float32 noise: where the
+        # search ends is noise on both sides - here only: not worse than the oracle's run, and inside the bounds)
+        assert res.scores[i] > want[0] - 5e-3
+        assert np.all(res.euler[i] >= bounds[:, 0] - 1e-12) and np.all(res.euler[i] <= bounds[:, 1] + 1e-12)
+    # a global method inside the trust region, seeded: reaches the optimum the local searches find
+    res = s.refine_orientation(rot0, det, mp, method="differential_evolution", trust_region=[1, 1, 1], verbose=False,
+                               method_kwargs=dict(seed=1, maxiter=12, popsize=8, tol=1e-6))
+    assert np.all(res.scores > base.scores - 2e-3) and np.all(res.num_evals > 100)
+    with pytest.raises(ValueError, match="trust region"):
+        s.refine_orientation(rot0, det, mp, method="dual_annealing", verbose=False)
+    # the PC and the combined refinement go the same way
+    scores, new_det, num_evals = s.refine_projection_center(rot0, det, mp, method_kwargs=dict(method="Powell"), verbose=False)
+    ref_scores, ref_det, _ = s.refine_projection_center(rot0, det, mp, verbose=False)
+    assert np.allclose(scores, ref_scores, atol=2e-3) and np.allclose(new_det.pc, ref_det.pc, atol=5e-3)
+
+
 def test_float32_patterns_are_rescaled(api_inputs, g):
     """Patterns given as float32 go through the [-1, 1] rescale (_refinement.py:956); NCC is
     invariant to it up to rounding, so the refinement result is the same."""

@@ -136,3 +136,127 @@ def test_argument_validation():
         rf.refine("both", pats, rot, det, mp)
     with pytest.raises(NotImplementedError, match="compute=False"):
         ka.EBSD(pats).refine_orientation(rot, det, mp, compute=False)
+
+
+# ------------------------------------------------------------------ optimisers driven from the host
+class _QuadraticContext:
+    """Stands in for the device objective: f(x) = sum(w (x - c_i)^2) + 0.1 for pattern i."""
+
+    def __init__(self, centres, weights):
+        self.centres, self.weights, self.calls = np.asarray(centres, float), np.asarray(weights, float), 0
+
+    def refine_objective(self, mode, pattern_index, x, fixed=None):
+        self.calls += len(pattern_index)
+        x = np.asarray(x, float)
+        return np.array([np.sum(self.weights * (xx - self.centres[i]) ** 2) + 0.1 for i, xx in zip(pattern_index, x)])
+
+
+@pytest.mark.parametrize("method,kwargs", [
+    ("minimize", dict(method="Powell")),
+    ("minimize", dict(method="L-BFGS-B")),
+    ("minimize", dict(method="Nelder-Mead", options=dict(adaptive=True))),   # an option the device search lacks
+    ("differential_evolution", dict(seed=3, maxiter=15, tol=1e-8)),
+    ("dual_annealing", dict(seed=3, maxiter=40)),
+    ("shgo", dict()),
+    ("basinhopping", dict(seed=3, niter=3, minimizer_kwargs=dict(method="Powell"))),
+])
+def test_host_driven_optimisers_call_scipy_like_the_reference(method, kwargs):
+    """indexing/_refinement/_solvers.py:179-207: minimize(fun, x0, bounds=..., **kw), <global>(func, bounds=...,
+    **kw), basinhopping(func, x0, **kw) - same results as calling SciPy directly on the same objective."""
+    import scipy.optimize
+
+    centres = np.array([[0.3, -0.2, 0.5], [1.0, 0.4, -0.7]])
+    ctx = _QuadraticContext(centres, [1.0, 2.0, 0.5])
+    nm, host, plan = rf._optimization_plan(method, kwargs, None, 1e-4, None, "ori")
+    assert nm is None and host is not None and plan["package"] == "scipy"
+    x0 = np.zeros((2, 1, 3))
+    lower, upper = x0 - 2.0, x0 + 2.0
+    res = rf._host_solve(ctx, 0, host, x0, np.zeros((2, 1, 3)), lower, upper)
+    assert res.shape == (2, 1, 6) and ctx.calls > 0
+    for i in range(2):
+        fun = lambda x, i=i: float(np.sum(np.array([1.0, 2.0, 0.5]) * (np.asarray(x) - centres[i]) ** 2) + 0.1)  # noqa: E731
+        bounds = list(zip(lower[i, 0], upper[i, 0]))
+        solver = getattr(scipy.optimize, method)
+        if method == "minimize":
+            want = solver(fun, x0[i, 0], bounds=bounds, **kwargs)
+        elif method == "basinhopping":
+            want = solver(fun, x0[i, 0], **kwargs)
+        else:
+            want = solver(fun, bounds=bounds, **kwargs)
+        assert res[i, 0, 0] == want.fun and res[i, 0, 1] == want.nfev and np.array_equal(res[i, 0, 3:], want.x)
+        assert np.abs(res[i, 0, 3:] - centres[i]).max() < 2e-2
+
+
+def test_global_methods_need_a_trust_region_and_messages():
+    nm, host, plan = rf._optimization_plan("differential_evolution", None, None, 1e-4, None, "pc")
+    with pytest.raises(ValueError, match="trust region"):
+        rf._host_solve(_QuadraticContext([[0, 0, 0]], [1, 1, 1]), 1, host, np.zeros((1, 1, 3)), np.zeros((1, 1, 4)), None, None)
+    msg = rf._info_message("pc", [0.1, 0.1, 0.1], plan["kwargs"], 0, plan)
+    assert msg == ("Refinement information:\n  Method: differential_evolution (global) from SciPy\n"
+                   "  Trust region (+/-): [0.1 0.1 0.1]\n  Keyword arguments passed to method: {}")
+    nm, host, plan = rf._optimization_plan("basinhopping", None, None, 1e-4, None, "ori")
+    msg = rf._info_message("ori", None, plan["kwargs"], 0, plan)
+    assert "Method: basinhopping (global) from SciPy" in msg and "Trust region" not in msg
+    assert "minimizer_kwargs" in msg  # added like the reference does (_refinement.py:1132-1133)
+    nm, host, plan = rf._optimization_plan("minimize", dict(method="Powell"), None, 1e-4, None, "ori")
+    assert "Method: Powell (local) from SciPy" in rf._info_message("ori", [1, 1, 1], plan["kwargs"], 0, plan)
+    # the plain Nelder-Mead stays on the device
+    nm, host, plan = rf._optimization_plan(None, None, None, 1e-4, None, "ori")
+    assert host is None and nm["xatol"] == 1e-4
+
+
+def test_nlopt_is_driven_like_the_reference(monkeypatch):
+    """LN_NELDERMEAD (indexing/_refinement/_solvers.py:464-536, _refinement.py:1098-1124): NLopt is not installable
+    in the build image, so the calls are checked against a stand-in module that records them."""
+    import sys
+    import types
+
+    with pytest.raises(ImportError, match="nlopt"):
+        rf._optimization_plan("ln_neldermead", None, None, 1e-4, None, "ori")
+
+    log = []
+
+    class Opt:
+        def __init__(self, name, n):
+            log.append(("opt", name, n))
+            self.n, self.evals = n, 0
+
+        def set_ftol_rel(self, v): log.append(("ftol_rel", v))
+        def set_initial_step(self, v): log.append(("initial_step", list(v)))
+        def set_maxeval(self, v): log.append(("maxeval", v))
+        def set_lower_bounds(self, v): log.append(("lower", list(v)))
+        def set_upper_bounds(self, v): log.append(("upper", list(v)))
+        def set_min_objective(self, f): self.f = f
+
+        def optimize(self, x0):  # a few coordinate steps are enough to see the objective being called
+            x, best = np.array(x0, float), None
+            for _ in range(20):
+                for d in range(self.n):
+                    for step in (0.05, -0.05):
+                        y = x.copy()
+                        y[d] += step
+                        self.evals += 1
+                        fy = self.f(y, None)
+                        if best is None or fy < best:
+                            best, x = fy, y
+            self.best = best
+            return x
+
+        def last_optimum_value(self): return self.best
+        def get_numevals(self): return self.evals
+
+    monkeypatch.setitem(sys.modules, "nlopt", types.SimpleNamespace(opt=Opt))
+    nm, host, plan = rf._optimization_plan("LN_NELDERMEAD", None, [0.5, 0.01], 1e-3, 250, "ori_pc")
+    assert host.method_name == "LN_NELDERMEAD" and plan["package"] == "nlopt"
+    centres = np.array([[0.2, 0.1, -0.1, 0.4, 0.5, 0.6]])
+    ctx = _QuadraticContext(centres, np.ones(6))
+    x0 = np.zeros((1, 1, 6))
+    res = rf._host_solve(ctx, 2, host, x0, None, x0 - 1, x0 + 1)
+    assert ("opt", "LN_NELDERMEAD", 6) in log and ("ftol_rel", 1e-3) in log and ("maxeval", 250) in log
+    assert ("initial_step", [0.5, 0.5, 0.5, 0.01, 0.01, 0.01]) in log and ("lower", [-1.0] * 6) in log
+    assert res[0, 0, 1] == 240 and res[0, 0, 0] < 0.1 + np.sum(centres**2)
+    msg = rf._info_message("ori_pc", [1] * 6, plan["kwargs"], 1, plan)
+    assert "Method: LN_NELDERMEAD (local) from NLopt" in msg and "Relative tolerance: 0.001" in msg
+    assert "Initial step(s): [0.5, 0.5, 0.5, 0.01, 0.01, 0.01]" in msg and "Max. function evaulations: 250" in msg
+    with pytest.raises(ValueError, match="initial step"):
+        rf._optimization_plan("ln_neldermead", None, [1, 2, 3], 1e-4, None, "ori")
