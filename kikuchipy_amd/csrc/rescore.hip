@@ -47,12 +47,12 @@ constexpr int RESCORE_THREADS = 256;
 // One workgroup per experimental pattern; wave w rescores candidates w, w + 4, ...
 __global__ __launch_bounds__(RESCORE_THREADS) void rescore_kernel(RescoreLaunch a) {
   __shared__ double red[RESCORE_THREADS / 64];
-  __shared__ double xstat[2];
+  __shared__ double xstat[3];
   __shared__ float diff_red[RESCORE_THREADS / 64];
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t xrow = (size_t)(a.row_map ? a.row_map[m] : m) * a.npix;
   const bool centre = a.metric != KPDI_METRIC_NDP;
-  // ---- the experimental pattern: mean and sum of squares of the (centred) kept pixels
+  // ---- the experimental pattern: mean, then the sum and the sum of squares of the centred kept pixels
   double s = 0.0;
   if (centre)
     for (int i = tid; i < a.k; i += RESCORE_THREADS) s += raw_value(a.exp_raw, a.exp_dtype, xrow + (a.pix_map ? a.pix_map[i] : i));
@@ -61,21 +61,30 @@ __global__ __launch_bounds__(RESCORE_THREADS) void rescore_kernel(RescoreLaunch 
   __syncthreads();
   const double mx = centre ? ((red[0] + red[1]) + (red[2] + red[3])) / (double)a.k : 0.0;
   __syncthreads();
-  double q = 0.0;
+  double q = 0.0, r1 = 0.0;
   for (int i = tid; i < a.k; i += RESCORE_THREADS) {
     const double v = raw_value(a.exp_raw, a.exp_dtype, xrow + (a.pix_map ? a.pix_map[i] : i)) - mx;
     q += v * v;
+    r1 += v;
   }
   q = wave_sum_f64(q);
-  if (lane == 0) red[wave] = q;
-  __syncthreads();
-  if (tid == 0) {
-    xstat[0] = mx;
-    xstat[1] = (red[0] + red[1]) + (red[2] + red[3]);
+  r1 = wave_sum_f64(r1);
+  if (lane == 0) {
+    red[wave] = q;
+    diff_red[wave] = 0.f;
   }
   __syncthreads();
-  const double sxx = xstat[1];
-  // ---- candidates
+  if (tid == 0) xstat[1] = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  if (lane == 0) red[wave] = r1;
+  __syncthreads();
+  if (tid == 0) xstat[2] = (red[0] + red[1]) + (red[2] + red[3]);  // sum of the centred pixels: ~1e-13, not 0
+  __syncthreads();
+  const double sxx = xstat[1], sx_res = xstat[2];
+  // ---- candidates: ONE pass over a dictionary row.  With y0 = its first kept pixel (a shift that keeps the
+  // one-pass variance free of cancellation) and x' = x - mean(x):
+  //   sum (y - my)^2 = sum (y - y0)^2 - (sum (y - y0))^2 / K
+  //   sum x' (y - my) = sum x' (y - y0) - (my - y0) sum x'
   float worst = 0.f;
   for (int j = wave; j < a.n_cand; j += RESCORE_THREADS / 64) {
     const size_t ci = (size_t)m * a.cand_stride + a.cand_offset + j;
@@ -85,20 +94,21 @@ __global__ __launch_bounds__(RESCORE_THREADS) void rescore_kernel(RescoreLaunch 
     const int64_t local = (int64_t)idx - a.global_start;
     if (idx != INT_MAX && local >= 0 && local < a.n_chunk) {
       const size_t yrow = (size_t)local * a.npix;
-      double sy = 0.0;
-      if (centre)
-        for (int i = lane; i < a.k; i += 64) sy += raw_value(a.dict_raw, a.dict_dtype, yrow + (a.pix_map ? a.pix_map[i] : i));
-      const double my = centre ? wave_sum_f64(sy) / (double)a.k : 0.0;
-      double sxy = 0.0, syy = 0.0;
+      const double y0 = centre ? raw_value(a.dict_raw, a.dict_dtype, yrow + (a.pix_map ? a.pix_map[0] : 0)) : 0.0;
+      double s1 = 0.0, s2 = 0.0, sxy = 0.0;
       for (int i = lane; i < a.k; i += 64) {
         const int p = a.pix_map ? a.pix_map[i] : i;
         const double x = raw_value(a.exp_raw, a.exp_dtype, xrow + p) - mx;
-        const double y = raw_value(a.dict_raw, a.dict_dtype, yrow + p) - my;
+        const double y = raw_value(a.dict_raw, a.dict_dtype, yrow + p) - y0;
         sxy += x * y;
-        syy += y * y;
+        s1 += y;
+        s2 += y * y;
       }
       sxy = wave_sum_f64(sxy);
-      syy = wave_sum_f64(syy);
+      s1 = wave_sum_f64(s1);
+      s2 = wave_sum_f64(s2);
+      const double syy = centre ? s2 - s1 * s1 / (double)a.k : s2;
+      if (centre) sxy -= (s1 / (double)a.k) * sx_res;
       // a pattern without variance: the engine's f32 path prepares it as zeros (score 0); the reference
       // divides by zero (NaN) - out of contract
       score = (sxx > 0.0 && syy > 0.0) ? sxy / (sqrt(sxx) * sqrt(syy)) : 0.0;

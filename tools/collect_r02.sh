@@ -17,4 +17,12 @@ python bench.py --workload config5 --steps 3 --warmup 1 --no-cpu-baseline > $O/b
 python bench.py --workload config5 --steps 3 --warmup 1 --no-cpu-baseline --compute f16 > $O/bench_config5_1gpu_f16.json 2> $O/bench_config5_f16.err
 (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_config5_f16 -o b -- python $R/bench.py --workload config5 --steps 2 --warmup 1 --no-cpu-baseline --compute f16 --check-rows 0 > /dev/null 2>&1)
 (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_config4 -o b -- python $R/bench.py --workload config4 --steps 2 --warmup 1 --no-cpu-baseline --check-rows 0 > /dev/null 2>&1)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_peak.hip -o /tmp/mfma_peak > /dev/null 2>&1 && /tmp/mfma_peak > $O/mfma_peak.txt 2>&1
+python tools/f64_probe.py > $O/f64_probe.txt 2>&1
+for v in "" "-DKPDI16_NO_EPILOGUE"; do
+  t=ship; [ -n "$v" ] && t=noepi && bash tools/build_variant.sh noepi match16.hip $v > /dev/null 2>&1
+  lib=-; [ "$t" == "noepi" ] && lib=build/variants/libkpdi_noepi.so
+  bash tools/pmc_busy.sh $t $lib >> $O/match16_busy.txt 2>&1
+  bash tools/pmc_busy.sh ${t}_k14400 $lib --s 120 --n 62500 >> $O/match16_busy.txt 2>&1
+done
 ls -la $O
