@@ -58,7 +58,7 @@ def rounded_operand_topk(exp, dic, metric, keep_n, signal_mask=None, navigation_
     (130, 257, 20, 20, 8, 100, "ndp", True),       # K not a multiple of 64: zero-padded slab
     (260, 1000, 31, 33, 20, 333, "ncc", False),    # K = 1023, odd: scalar preparation path
     (40, 640, 60, 60, 33, 250, "ncc", True),       # keep_n > 32: multi-pass path; staged masked prep
-    (257, 900, 6, 37, 64, None, "ncc", True),      # second pass = the bounded 32-entry form (once spilled an accumulator)
+    (257, 900, 6, 37, 64, None, "ncc", False),     # second pass = the bounded 32-entry form (once spilled an accumulator)
     (130, 700, 12, 12, 96, 400, "ndp", False),     # three passes
     (21, 300, 120, 120, 7, 170, "ncc", False),     # workgroup-per-pattern preparation
     (21, 300, 96, 80, 7, None, "ndp", True),
