@@ -348,6 +348,62 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_masked_kernel(const T 
   }
 }
 
+// ---- the same for float32 patterns (dictionaries), rows brought in by LDS-DMA, double-buffered ---------------
+// prep_wave_masked_kernel is latency-bound: 69 KB of LDS per workgroup = 2 waves per SIMD, each of which waits for
+// its row, gathers, writes, and only then asks for the next row (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.77; 3.2 TB/s).
+// Here a wave's NEXT row is in flight (buffer_load ... lds, no registers involved) while it gathers, normalises and
+// stores the current one.  LDS: [k ints pixel map][4 waves x 2 x row], a row rounded up to whole 1 KB pieces
+// (reads past the row's end return zeros: the buffer descriptor is sized to the row).
+template <bool H16>
+__global__ __launch_bounds__(PREP_THREADS) void prep_wave_masked_dma_kernel(const float *raw, int npix, const int *row_map,
+                                                                            const int *pix_map, int k, int kpad,
+                                                                            int metric, int n_out, float *out, int split) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int *map = (int *)smem_raw;
+  const int map_words = (k + 3) & ~3;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row_words = (npix + 255) & ~255;
+  const int pieces = row_words / 256;
+  float *rows = (float *)smem_raw + map_words + (size_t)wv * 2 * row_words;
+  for (int c = threadIdx.x; c < map_words; c += PREP_THREADS) map[c] = c < k ? pix_map[c] : 0;
+  __syncthreads();
+  auto fetch = [&](int r, int buf) {
+    const int64_t src = row_map ? row_map[r] : r;
+    const float *p = raw + src * (int64_t)npix;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, npix * 4, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < WAVE_VALUES / 4; ++q)
+      if (q < pieces)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrc, (__attribute__((address_space(3))) void *)(rows + (size_t)buf * row_words + q * 256), 16, lane * 16,
+            q * 1024, 0, 0);
+  };
+  const int stride = gridDim.x * 4;
+  int r = blockIdx.x * 4 + wv, buf = 0;
+  if (r < n_out) fetch(r, 0);
+  for (; r < n_out; r += stride, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this row has landed (and the previous row's stores are out)
+    if (r + stride < n_out) fetch(r + stride, buf ^ 1);
+    const float *row = rows + (size_t)buf * row_words;
+    float v[WAVE_VALUES];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < WAVE_VALUES / 4; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      int4 px = make_int4(0, 0, 0, 0);
+      if (c < k) px = *reinterpret_cast<const int4 *>(map + c);
+      v[4 * i] = c < k ? row[px.x] : 0.f;
+      v[4 * i + 1] = c + 1 < k ? row[px.y] : 0.f;
+      v[4 * i + 2] = c + 2 < k ? row[px.z] : 0.f;
+      v[4 * i + 3] = c + 3 < k ? row[px.w] : 0.f;
+      s += (v[4 * i] + v[4 * i + 1]) + (v[4 * i + 2] + v[4 * i + 3]);
+    }
+    normalise_and_store_quads<64, WAVE_VALUES, H16>(v, s, lane, r, k, kpad, metric, out, split);
+    // the gathers of this row before the fetch that overwrites it (two iterations on): the s_waitcnt of the next
+    // iteration orders them - LDS reads have returned into `v` by then (their values were used above)
+  }
+}
+
 // ---- split-f16 form of a prepared matrix (KPDI_COMPUTE_F16X2), in place -------------------
 // One thread per (pattern row, 32-pixel slab): its eight 16-byte slots hold 32 floats
 // (slot q = pixels 4q..4q+3); they are rewritten as v * 2^12 = hi + lo with hi = f16(v * 2^12),
@@ -410,6 +466,9 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   const bool block_vec = block_path && a.pix_map == nullptr && (a.k % 4) == 0 && vec_ok;
   const bool block_masked = block_path && a.pix_map != nullptr;
   const size_t staged_lds = (size_t)(((a.k + 3) & ~3) + 4 * a.npix) * 4;
+  // float32 rows (dictionaries): LDS-DMA, double-buffered (prep_wave_masked_dma_kernel)
+  const size_t dma_lds = (size_t)(((a.k + 3) & ~3) + 8 * ((a.npix + 255) & ~255)) * 4;
+  const bool staged_dma = staged && a.dtype == KPDI_F32 && dma_lds <= 160 * 1024 && !getenv("KPDI_PREP_NO_DMA");
   dim3 block(PREP_THREADS);
   dim3 grid(wave_path ? (a.n_out + 3) / 4 : a.n_out);
   if (staged) grid = dim3(std::min((a.n_out + 3) / 4, 2048));
@@ -417,7 +476,15 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   if (vec4)                                                                                              \
     hipLaunchKernelGGL((prep_wave_kernel<T, 4, H>), grid, block, 0, s, (const T *)a.raw, a.npix,        \
                        a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form);               \
-  else if (staged) {                                                                                     \
+  else if (staged_dma) {                                                                                 \
+    auto kd = prep_wave_masked_dma_kernel<H>;                                                            \
+    if (dma_lds > 64 * 1024) {                                                                           \
+      hipError_t e = hipFuncSetAttribute((const void *)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds); \
+      if (e != hipSuccess) return e;                                                                     \
+    }                                                                                                    \
+    hipLaunchKernelGGL(kd, dim3(std::min((a.n_out + 3) / 4, 1024)), block, dma_lds, s, (const float *)a.raw, a.npix, \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form);               \
+  } else if (staged) {                                                                                   \
     if (staged_lds > 64 * 1024) {                                                                        \
       hipError_t e = hipFuncSetAttribute((const void *)prep_wave_masked_kernel<T, H>,                    \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)staged_lds);   \
