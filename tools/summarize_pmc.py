@@ -72,6 +72,17 @@ if match:
     mk = summary["kernels"][match]
     summary["match_kernel"] = match
     summary["match_traffic_bytes_per_launch"] = mk.get("fetch_bytes_per_launch", 0) + mk.get("write_bytes_per_launch", 0)
+# the match kernel launch by launch (kernel trace): the first launches of a process run at a clock that is still ramping
+trace_src = os.path.join(src, f"prof_{tag}", "stats", "bench_kernel_trace.csv")
+launch_ms = []
+if match and os.path.exists(trace_src):
+    rows = [r for r in csv.DictReader(open(trace_src)) if r["Kernel_Name"] == match]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    launch_ms = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+    summary["match_launch_ms"] = [round(v, 4) for v in launch_ms]
+    warm = 3 if len(launch_ms) > 6 else 2
+    summary["match_steady_ms"] = mean(launch_ms[warm:])
+    summary["match_steady_from_launch"] = warm
 json.dump(summary, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
 
 lines = [f"# rocprofv3 summary {tag}: `{command}` (tools/collect_profiles.sh; "
@@ -85,5 +96,9 @@ for name, k in summary["kernels"].items():
         "%.3f" % (k["write_bytes_per_launch"] / 1e9) if "write_bytes_per_launch" in k else "-",
         "%.3f" % k["mfma_busy_frac"] if "mfma_busy_frac" in k else "-",
         "%.2f" % k["clock_ghz_profiled"] if "clock_ghz_profiled" in k else "-"))
+if launch_ms:
+    lines += ["", "Match kernel launch by launch (ms, kernel trace): " + ", ".join("%.2f" % v for v in launch_ms),
+              "Mean of the launches after the first %d (the timed steps of the bench): **%.3f ms**; all %d launches: %.3f ms." % (
+                  summary["match_steady_from_launch"], summary["match_steady_ms"], len(launch_ms), mean(launch_ms))]
 open(os.path.join(out, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
