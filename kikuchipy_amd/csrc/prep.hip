@@ -460,7 +460,7 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   const int form = a.operand_form == 2 ? f16_form(a.f16_rows, a.f16_step) : a.operand_form;
   const bool vec_ok = (a.npix % 4) == 0 && ((uintptr_t)a.raw % (4 * dtype_size(a.dtype))) == 0;
   const bool vec4 = wave_path && a.pix_map == nullptr && (a.k % 4) == 0 && vec_ok;
-  const bool staged = wave_path && a.pix_map != nullptr && vec_ok && a.npix <= 64 * WAVE_VALUES;
+  const bool staged = wave_path && a.pix_map != nullptr && vec_ok && a.npix <= 64 * WAVE_VALUES && !getenv("KPDI_PREP_NO_STAGED");
   // larger detectors, still register-resident: one workgroup per pattern
   const bool block_path = !wave_path && span <= PREP_THREADS * WAVE_VALUES;
   const bool block_vec = block_path && a.pix_map == nullptr && (a.k % 4) == 0 && vec_ok;
