@@ -146,3 +146,26 @@ def test_single_rank_communicator_and_resident_refusal():
             c.sweep_held()
     with pytest.raises(ValueError, match="f64"):
         ka.ResidentDictionary(dic, "ncc", compute="f64")
+
+
+def test_recorded_preprocessing_then_float64():
+    """Recorded background removal runs (fused with the f32 preparation) before the screen; the rescoring kernel reads
+    the PROCESSED patterns, like the reference's float64 metric after `remove_*_background`."""
+    from kikuchipy_amd import _lib
+
+    rng = np.random.default_rng(8)
+    exp = rng.integers(0, 256, (70, 40, 40), dtype=np.uint8)
+    dic = rng.random((800, 40, 40), dtype=np.float32)
+    with _lib.Context(0) as c:
+        c.set_problem(40, 40, None, _lib.METRIC_NCC, 10, _lib.COMPUTE_F64)
+        c.set_experimental(exp)
+        c.remove_static_background(rng.integers(1, 256, (40, 40)).astype(np.float32), _lib.OP_SUBTRACT, False)
+        c.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
+        c.push_dictionary_chunk(dic[:500], 0)
+        c.push_dictionary_chunk(dic[500:], 500)
+        scores, idx = c.finalize(10)
+        processed = c.get_experimental()
+        assert c.counters()["uncertified_patterns"] == 0
+    assert not np.array_equal(processed, exp)
+    ref_s, ref_i = oracle64(processed, dic, "ncc", 10, n_per_iteration=500)
+    assert_exact(scores, idx, ref_s, ref_i)

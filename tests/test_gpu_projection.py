@@ -185,6 +185,26 @@ def test_generated_equals_pushed(ctx, g):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def test_generated_dictionary_in_float64_arithmetic(ctx, g):
+    """float64 arithmetic (KPDI_COMPUTE_F64) over a dictionary that is simulated on the device: the rescoring kernel
+    reads the simulated float32 patterns where they were generated."""
+    from kikuchipy_amd import _lib
+
+    ctx.set_master_pattern(g["mp_upper"], g["mp_lower"])
+    set_detector(ctx, DET60)
+    rot, exp = g["di_rot"][:700], g["di_exp"]
+    dic = ctx.project_patterns(rot, True, -1, 1)
+    ctx.set_problem(60, 60, None, _lib.METRIC_NCC, 20, _lib.COMPUTE_F64)
+    ctx.set_experimental(exp)
+    for start in (0, 300):
+        ctx.push_rotations_chunk(rot[start:start + 400 if start else 300], start, True, -1, 1)
+    scores, idx = ctx.finalize(20)
+    ref_s, ref_i = ko.dictionary_indexing(exp, dic, metric="ncc", keep_n=20, dtype=np.float64)
+    assert scores.dtype == np.float64 and np.abs(scores - ref_s).max() <= 1e-12 and np.array_equal(idx, ref_i)
+    assert ctx.counters()["uncertified_patterns"] == 0
+    ctx.set_problem(60, 60, None, _lib.METRIC_NCC, 20)  # the module's context goes back to float32 arithmetic
+
+
 def test_error_paths(g):
     from kikuchipy_amd import _lib
 
