@@ -359,7 +359,9 @@ def main():
             "parallelism": f"dictionary sharded over {world} GPU(s)" + (", RCCL all-gather merge" if world > 1 else ""),
         },
         "roofline": {
-            "kernel": "kpdi::match_topk_kernel<20,false,0> (f32 MFMA GEMM + fused top-k), rank 0" if a.compute == "f32"
+            "kernel": (("kpdi::match16_kernel<20,false,4,true> (exact-f32 MFMA GEMM, 256 x 256 tiles, fused top-k), rank 0"
+                        if cnt.get("match_form") == 3 else
+                        "kpdi::match_topk_kernel<20,false,0> (f32 MFMA GEMM + fused top-k), rank 0")) if a.compute == "f32"
             else ("kpdi::match16_kernel<20,false,8> (f16 MFMA, f32 accumulate; peak = dense f16 MFMA)" if a.compute == "f16"
                   else "kpdi::match_topk_kernel<20,false,1,4> (split-f16: 3 f16 MFMAs per product term, all counted)"),
             "bound": "mfma",

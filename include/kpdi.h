@@ -359,6 +359,9 @@ typedef struct kpdi_counters {
   double rescore_ms;             /* KPDI_COMPUTE_F64: float64 rescoring + merge kernels */
   int64_t rescore_extra_passes;  /* ... screening passes beyond the first keep_n + 12 candidates of a chunk */
   int64_t uncertified_patterns;  /* ... (pattern, chunk) pairs whose best-k could not be certified; 0 in practice */
+  int32_t match_form;            /* operand form of the last match launch: 0 match.hip f32, 1 split f16, 2 float16 (match16.hip),
+                                    3 f32 on match16.hip's one-wave-per-SIMD kernel (chosen per sweep, KPDI_F32_WIDE forces) */
+  int32_t reserved_;
 } kpdi_counters;
 int kpdi_set_profiling(kpdi_ctx *ctx, int on);
 int kpdi_get_counters(kpdi_ctx *ctx, kpdi_counters *out);

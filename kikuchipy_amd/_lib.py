@@ -59,6 +59,8 @@ class Counters(C.Structure):
         ("rescore_ms", C.c_double),
         ("rescore_extra_passes", C.c_int64),
         ("uncertified_patterns", C.c_int64),
+        ("match_form", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
     def as_dict(self):

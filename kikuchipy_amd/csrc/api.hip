@@ -171,6 +171,10 @@ struct kpdi_ctx {
   int metric = KPDI_METRIC_NCC;
   int compute = KPDI_COMPUTE_F32;
   int f16_waves = 8;  // variant of the float16 kernel (match16.hip), fixed per problem: KPDI_F16_WAVES = 8 | 4
+  // KPDI_COMPUTE_F32 on match16.hip's one-wave-per-SIMD kernel (256 x 256 tiles, lists out of the registers, exact f32
+  // MFMAs; operand form 3): fixed per problem, KPDI_F32_WIDE = 1 | 0
+  bool wide32 = false;
+  int wide_mode = -1;  // KPDI_F32_WIDE: 1 / 0 force the form, unset (-1): decided per sweep (decide_form)
   int keep_n = 0;
 
   // experimental
@@ -318,12 +322,19 @@ int prep_metric(const kpdi_ctx *c) {
   return c->metric == KPDI_METRIC_NDP && c->compute != KPDI_COMPUTE_F16 ? 2 : c->metric;
 }
 
+// the match kernel in use is match16.hip's (plane-major operand blocks, tiles of 256, lists in scratch)
+bool uses16(const kpdi_ctx *c) { return c->compute == KPDI_COMPUTE_F16 || c->wide32; }
+// operand form of the prepared matrices: 0 f32 tiled, 1 split f16, 2 float16, 3 f32 plane-major (kernels.h)
+int operand_form(const kpdi_ctx *c) { return c->wide32 ? 3 : c->compute; }
+
 // patterns per dictionary tile of the match kernel in use (the float16 form has its own kernel)
 int dict_tile(const kpdi_ctx *c) {
-  return c->compute == KPDI_COMPUTE_F16 ? kpdi::f16_geometry(c->f16_waves).dict_tile : kpdi::TILE_DICT;
+  return uses16(c) ? kpdi::f16_geometry(c->f16_waves).dict_tile : kpdi::TILE_DICT;
 }
 // lists per pattern and dictionary split the match kernel writes
-int lists_per_split(const kpdi_ctx *c) { return c->compute == KPDI_COMPUTE_F16 ? 4 : 2; }
+int lists_per_split(const kpdi_ctx *c) { return uses16(c) ? 4 : 2; }
+// entries ranked per pass when keep_n needs several (bounded) passes
+int pass_entries(const kpdi_ctx *c) { return c->wide32 ? 20 : kpdi::KMAX_LIMIT; }
 
 int use_device(kpdi_ctx *c) {
   HIPCHK(hipSetDevice(c->device));
@@ -387,7 +398,7 @@ int flush_preprocess(kpdi_ctx *c, bool with_prep, bool *prep_done) {
     a.k = c->k_kept;
     a.kpad = c->kpad;
     a.metric = prep_metric(c);
-    a.operand_form = c->compute;
+    a.operand_form = operand_form(c);
     a.f16_step = kpdi::f16_geometry(c->f16_waves).step;
     a.out = c->exp_x.as<float>();
   }
@@ -438,7 +449,7 @@ int prepare_experimental(kpdi_ctx *c) {
   p.kpad = c->kpad;
   p.n_out = c->m;
   p.metric = prep_metric(c);
-  p.operand_form = c->compute;
+  p.operand_form = operand_form(c);
   p.f16_rows = kpdi::F16_TILE;
   p.f16_step = kpdi::f16_geometry(c->f16_waves).step;
   p.out = c->exp_x.as<float>();
@@ -504,13 +515,13 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   const int row_blocks_all = c->m_pad / kpdi::TILE_EXP;
   int tail_tiles = 0;
   c->tail_nsplit = 0;
-  if (allow_tail && c->compute == KPDI_COMPUTE_F32 && bound_s == nullptr && row_blocks_all <= rows_per_launch &&
+  if (allow_tail && c->compute == KPDI_COMPUTE_F32 && !c->wide32 && bound_s == nullptr && row_blocks_all <= rows_per_launch &&
       !getenv("KPDI_NO_TAIL")) {
     const int rounds = n_tiles / nsplit, rem = n_tiles % nsplit;
     if (rounds >= 1 && rounds < 32 && rem > 0 && 4 * rem <= 3 * nsplit) tail_tiles = rem;
   }
   const int n_main = n_tiles - tail_tiles;
-  const bool f16 = c->compute == KPDI_COMPUTE_F16;
+  const bool f16 = uses16(c);
   const int lists_per_split = ::lists_per_split(c);
   const size_t part = (size_t)c->m_pad * lists_per_split * nsplit * list_len;
   HIPCHK(c->part_s.reserve(part * sizeof(float)));
@@ -529,7 +540,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   ml.part_idx = c->part_i.as<int>();
   ml.bound_score = bound_s;
   ml.bound_idx = bound_i;
-  ml.operand_form = c->compute;
+  ml.operand_form = operand_form(c);
   {
     // the published ranks are only comparable under one plan: (re)initialise when it changes
     int rank, grouped, used;
@@ -624,6 +635,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
     }
   }
   c->cnt.match_launches += 1;
+  c->cnt.match_form = operand_form(c);
   c->cnt.match_flops += 2.0 * (double)c->m * (double)n_chunk * (double)c->k_kept;
   c->cnt.match_grid = std::min(rows_per_launch, row_blocks) * nsplit;
   c->cnt.match_nsplit = nsplit;
@@ -649,7 +661,7 @@ int prepare_chunk(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chun
   p.kpad = c->kpad;
   p.n_out = (int)n_chunk;
   p.metric = prep_metric(c);
-  p.operand_form = c->compute;
+  p.operand_form = operand_form(c);
   p.f16_rows = kpdi::f16_geometry(c->f16_waves).dict_tile;
   p.f16_step = kpdi::f16_geometry(c->f16_waves).step;
   p.out = out;
@@ -658,6 +670,37 @@ int prepare_chunk(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chun
     HIPCHK(kpdi::launch_prep(p, c->stream));
   }
   return KPDI_OK;
+}
+
+// Which f32 match kernel serves this sweep.  match16.hip's one-wave-per-SIMD form (256 x 256 tiles, lists out of the
+// registers) does a unit of work 3 % faster than match.hip (128 x 256 tiles) but hands out whole 256-pattern tiles
+// statically, match.hip 128-pattern tiles with a dynamic tail of quarter tiles: the estimated makespans decide.  The two
+// kernels read different operand layouts (and row paddings), so the choice is made when the first chunk of a sweep
+// arrives - nothing prepared yet, no resident chunks - and stands until then again.  KPDI_F32_WIDE = 1 / 0 forces it.
+void decide_form(kpdi_ctx *c, int64_t n_chunk) {
+  if (c->compute != KPDI_COMPUTE_F32 || c->wide_mode >= 0) return;
+  if (c->exp_prepared || !c->held.empty()) return;
+  const int row_blocks = c->have_exp ? c->m_pad / kpdi::TILE_EXP : 16;
+  int rpl = 0;
+  // match.hip: whole rounds of 128-pattern tiles + (when few rounds) a quarter-tile tail launch
+  const int t128 = (int)((n_chunk + 127) / 128);
+  const int ns = choose_nsplit(c, row_blocks, t128, &rpl);
+  const int launches = (row_blocks + rpl - 1) / rpl;
+  double classic = (t128 + ns - 1) / ns;
+  if (launches == 1) {
+    const int rounds = t128 / ns, rem = t128 % ns;
+    if (rounds >= 1 && rounds < 32 && rem > 0 && 4 * rem <= 3 * ns) classic = rounds + ((4 * rem + ns - 1) / ns) * 0.25 + 0.25;
+  }
+  classic = launches * (classic + 0.25);  // + ~0.1 ms per launch
+  // match16.hip, float32 form: whole rounds of 256-pattern tiles, two 128-tile units each at 1 / 1.03 of the time
+  const int t256 = (int)((n_chunk + 255) / 256);
+  const int nsw = choose_nsplit(c, row_blocks, t256, &rpl);
+  const double wide = ((row_blocks + rpl - 1) / rpl) * (((t256 + nsw - 1) / nsw) * 2.0 / 1.03 + 0.25);
+  const bool w = wide < classic;
+  if (w == c->wide32) return;
+  c->wide32 = w;
+  c->kpad = kpdi::round_up(c->k_kept + (c->metric == KPDI_METRIC_NDP ? 1 : 0), w ? kpdi::F16_STEP / 2 : kpdi::TILE_K);
+  c->cnt.kpad = c->kpad;
 }
 
 int check_chunk_args(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_start) {
@@ -678,6 +721,7 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
   if (rc) return rc;
   if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
   if (c->m == 0) return KPDI_OK;
+  decide_form(c, n_chunk);
   HIPCHK(c->dict_y.reserve((size_t)kpdi::round_up(n_chunk, dict_tile(c)) * c->kpad * sizeof(float)));
   rc = prepare_chunk(c, d_patterns, dtype, n_chunk, c->dict_y.as<float>());
   if (rc) return rc;
@@ -726,7 +770,8 @@ int sweep_exact64(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_s
                   int n_tiles, int nsplit, int rows_per_launch) {
   const int k = c->keep_n;
   if ((int64_t)k + MARGIN64 > 4096) return fail(KPDI_EINVAL, "float64 arithmetic supports keep_n <= %d", 4096 - MARGIN64);
-  const int cap = kpdi::round_up(k + MARGIN64, kpdi::KMAX_LIMIT) + kpdi::KMAX_LIMIT * EXTRA64;
+  const int pass = pass_entries(c);
+  const int cap = kpdi::round_up(k + MARGIN64, pass) + pass * EXTRA64;
   const size_t n = (size_t)c->m * cap;
   HIPCHK(c->loc_s.reserve(n * sizeof(float)));
   HIPCHK(c->loc_i.reserve(n * sizeof(int)));
@@ -740,7 +785,7 @@ int sweep_exact64(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_s
   int64_t target = std::min<int64_t>((int64_t)k + MARGIN64, n_chunk);
   for (;;) {
     while (done < target) {
-      const int kp = (int)std::min<int64_t>(kpdi::KMAX_LIMIT, target - done);
+      const int kp = (int)std::min<int64_t>(done == 0 ? kpdi::KMAX_LIMIT : pass, target - done);
       int rc = local_pass(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, global_start, done, kp, cap);
       if (rc) return rc;
       ScopedTimer t(c, &c->ev_rescore);
@@ -792,7 +837,7 @@ int sweep_exact64(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_s
     HIPCHK(hipMemcpyAsync(&uncertified, cert + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (uncertified == 0 || done >= n_chunk || extra == EXTRA64) break;
-    target = std::min<int64_t>((int64_t)done + kpdi::KMAX_LIMIT, n_chunk);
+    target = std::min<int64_t>((int64_t)done + pass, n_chunk);
     ++extra;
     c->cnt.rescore_extra_passes += 1;
   }
@@ -869,10 +914,11 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
     HIPCHK(kpdi::launch_fill_topk(c->bound_s.as<float>(), c->bound_i.as<int>(), c->m_pad, c->stream));
     const int kk = (int)std::min<int64_t>(k, n_chunk);
     if (kk < k) HIPCHK(kpdi::launch_fill_topk(c->loc_s.as<float>(), c->loc_i.as<int>(), (int64_t)n, c->stream));
-    for (int done = 0; done < kk; done += kpdi::KMAX_LIMIT) {
-      rc = local_pass(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, global_start, done,
-                      std::min(kpdi::KMAX_LIMIT, kk - done), k);
+    for (int done = 0; done < kk;) {  // (the first pass is unbounded: up to 32 entries in every form)
+      const int kp = std::min(done == 0 ? kpdi::KMAX_LIMIT : pass_entries(c), kk - done);
+      rc = local_pass(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, global_start, done, kp, k);
       if (rc) return rc;
+      done += kp;
     }
     mg.src_scores[1] = c->loc_s.as<float>();
     mg.src_idx[1] = c->loc_i.as<int>();
@@ -1020,7 +1066,7 @@ std::vector<int64_t> upload_pieces(const kpdi_ctx *c, int64_t n_chunk, size_t ro
       if (swept < best - 1e-9) best = swept, piece = p;
     }
   }
-  if (c->compute == KPDI_COMPUTE_F16) piece = (piece + 1) / 2 * 2;  // whole 256-pattern tiles of match16.hip
+  if (uses16(c)) piece = (piece + 1) / 2 * 2;  // whole 256-pattern tiles of match16.hip
   std::vector<int64_t> out;
   for (int64_t left = n_chunk, per = piece * kpdi::TILE_DICT; left > 0; left -= per) out.push_back(std::min(per, left));
   return out;
@@ -1190,10 +1236,16 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   // the prepared layout of held chunks depends on shape, mask, metric and arithmetic
   int waves = 8;
   if (const char *e = getenv("KPDI_F16_WAVES")) waves = atoi(e) == 4 ? 4 : 8;
+  // the f32 kernel in use (match.hip / the one-wave form of match16.hip) is chosen when the first chunk of a sweep arrives
+  // (decide_form); until then - and whenever it cannot change any more - the previous choice stands
+  const int wide_mode = getenv("KPDI_F32_WIDE") ? (atoi(getenv("KPDI_F32_WIDE")) != 0) : -1;
+  bool wide32 = compute_dtype == KPDI_COMPUTE_F32 && (wide_mode == 1 || (wide_mode < 0 && c->have_problem && c->wide32));
   if (!c->have_problem || sy != c->sy || sx != c->sx || metric != c->metric || compute_dtype != c->compute ||
-      (signal_mask != nullptr) != c->have_sig_mask || keep != c->kept_pixels || waves != c->f16_waves)
+      (signal_mask != nullptr) != c->have_sig_mask || keep != c->kept_pixels || waves != c->f16_waves || wide32 != c->wide32)
     release_held(c);
   c->f16_waves = waves;
+  c->wide32 = wide32;
+  c->wide_mode = wide_mode;
   c->kept_pixels = keep;
   c->sy = sy;
   c->sx = sx;
@@ -1204,7 +1256,7 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   // (match16.hip).  `ndp` rows carry one extra column (prep.hip: centred evaluation), except in the float16 form
   c->kpad = compute_dtype == KPDI_COMPUTE_F16
                 ? kpdi::round_up(c->k_kept, kpdi::f16_geometry(c->f16_waves).step) / 2
-                : kpdi::round_up(c->k_kept + (metric == KPDI_METRIC_NDP ? 1 : 0), kpdi::TILE_K);
+                : kpdi::round_up(c->k_kept + (metric == KPDI_METRIC_NDP ? 1 : 0), wide32 ? kpdi::F16_STEP / 2 : kpdi::TILE_K);
   c->metric = metric;
   c->compute = compute_dtype;
   c->exact64 = exact64;
@@ -1388,6 +1440,7 @@ int kpdi_hold_dictionary_chunk(kpdi_ctx *c, const void *patterns, int dtype, int
   rc = use_device(c);
   if (rc) return rc;
   float *y = nullptr;
+  decide_form(c, n_chunk);
   rc = new_held_chunk(c, n_chunk, global_start, &y);
   if (rc) return rc;
   // pieces of whole tiles, so that every piece is prepared straight into its place
@@ -1415,6 +1468,7 @@ int kpdi_hold_dictionary_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtyp
   rc = use_device(c);
   if (rc) return rc;
   float *y = nullptr;
+  decide_form(c, n_chunk);
   rc = new_held_chunk(c, n_chunk, global_start, &y);
   if (rc) return rc;
   return prepare_chunk(c, d_patterns, dtype, n_chunk, y);
@@ -1662,6 +1716,7 @@ int kpdi_hold_rotations_chunk(kpdi_ctx *c, const double *rotations, int64_t n, i
   rc = project_to_device(c, rotations, n, rescale, out_min, out_max, KPDI_F32, c->dict_raw.p);
   if (rc) return rc;
   float *y = nullptr;
+  decide_form(c, n);
   rc = new_held_chunk(c, n, global_start, &y);
   if (rc) return rc;
   return prepare_chunk(c, c->dict_raw.p, KPDI_F32, n, y);

@@ -79,6 +79,12 @@ __device__ __forceinline__ void mfma16(f32x16 &c, const f32x4 &a, const f32x4 &b
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" KPDI16_MFMA_TAIL : "+v"(c) : "v"(a), "v"(b));
 }
 
+// float32 form: one v_mfma_f32_32x32x2_f32 per element j of the two 16-byte fragments (pixels j of lanes 0-31 and
+// 4 + j of lanes 32-63 of an 8-pixel plane) - exact f32 products, the arithmetic of match.hip
+__device__ __forceinline__ void mfma32(f32x16 &c, float a, float b) {
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
 // One of a wave's 1 KB LDS-DMA pieces of a stage (i < DPIECES: dictionary block, else experimental
 // block); piece q = wv + WAVES * i' of its block.  `gd` / `ge`: wave-uniform block addresses.
 template <int WAVES>
@@ -109,10 +115,10 @@ __device__ __forceinline__ T *chunk_base(T *base, int chunk) {
 // increasing dictionary index) into the lane's list: first a screen with plain compares (bit r of
 // `hot` = some lane of register r reaches the threshold), then only those registers go through the
 // loop with the scalar register index (match.hip: scan_tile, FORM = 2).
-template <int KMAX, bool BOUNDED>
+template <int KMAX, bool BOUNDED, bool F32 = false>
 __device__ __forceinline__ void scan16(f32x16 (&acc)[4], float (&best)[KMAX], int (&best_idx)[KMAX], float gthr,
                                        float ub, int ub_idx, int row0, int n_valid, int idx_base) {
-  constexpr float unscale = 0x1p-24f;  // operands are stored scaled by 2^12 each
+  constexpr float unscale = F32 ? 1.f : 0x1p-24f;  // float16 operands are stored scaled by 2^12 each
   float thr = fmaxf(gthr, next_up(best[KMAX - 1]));
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
@@ -151,8 +157,9 @@ __device__ __forceinline__ void scan16(f32x16 (&acc)[4], float (&best)[KMAX], in
 constexpr int CAND_CAP = KPDI16_CAP;  // a multiple of 16
 constexpr int CAND_CAP_PLAIN = 8;
 
-template <int KMAX, bool BOUNDED, int WAVES>
+template <int KMAX, bool BOUNDED, int WAVES, bool F32 = false>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArgs a, float *ls_scores, int *ls_idx) {
+  static_assert(!F32 || WAVES == 4, "the float32 form runs one wave per SIMD");
   typedef Geo<WAVES> G;
   constexpr int NCG = G::NCG;
   constexpr int BLOCK16 = G::DBLOCK, STAGE16 = G::STAGE, NSTAGE16 = G::NSTAGE, KSTEPS16 = G::KS;
@@ -319,6 +326,26 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
           }
           const int nk = ks == KSTEPS16 - 1 ? 0 : ks + 1;         // fragments read during this k-step
           const char *src = ks == KSTEPS16 - 1 ? ls_next : ls;    // ... of the next step for the last one
+          if (F32) {
+            // ---- float32 form: 64 MFMAs of 64 pipe cycles per k-step; behind every four of them one of the 8
+            // fragment reads of the next k-step, then (after the barrier) this wave's 6 LDS-DMA pieces
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+                for (int cg = 0; cg < NCG; ++cg) mfma32(acc[cg][rt], fa[ks][rt][j], fb[ks][cg][j]);
+                const int slot = 4 * j + rt;
+#ifndef KPDI16_NO_READS
+                if (slot < 4) fa[nk][slot] = KPDI_FA(src, slot, nk);
+                else if (slot < 8) fb[nk][slot - 4] = KPDI_FB(src, slot - 4, nk);
+#endif
+#ifndef KPDI16_NO_DMA
+                if (ks >= 1 && slot >= 8 && slot < 8 + 6) issue_piece16<WAVES>(gd, ge, ld_base, wv, (ks - 1) * 6 + slot - 8, goff);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+              }
+          } else
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt) {
 #pragma unroll
@@ -378,7 +405,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
           if (g[cg] == 12345.f) cnt[cg] = 1;
           continue;
 #endif
-          constexpr float unscale = 0x1p-24f;
+          constexpr float unscale = F32 ? 1.f : 0x1p-24f;
           // BOUNDED: the pass admits what ranks strictly after (ub, ubi); read here, not carried through the
           // MFMA loop in registers (there is none to spare: tools/check_mfma_loops.py)
           float ub_cg = INFINITY;
@@ -388,7 +415,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
             ubi_cg = a.bound_idx[m_lane + 32 * cg];
           }
           const float thr = fmaxf(g[cg], next_up(last[cg]));
-          const float thr_raw = thr * 0x1p24f;  // exact: the accumulators hold 2^24 * score
+          const float thr_raw = F32 ? thr : thr * 0x1p24f;  // exact: the float16 form's accumulators hold 2^24 * score
           float *bs = buf_s + cg * CAND_CAP * 64;
           int *bi = buf_i + cg * CAND_CAP * 64;
           unsigned *line = const_cast<unsigned *>(line0) + 32 * cg * BOUND_SLOTS;
@@ -456,7 +483,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
               }
             }
             cnt[cg] = 0;
-            scan16<KMAX, BOUNDED>(acc[cg], best, bidx, g[cg], ub_cg, ubi_cg, row0, n_valid, idx_base);
+            scan16<KMAX, BOUNDED, F32>(acc[cg], best, bidx, g[cg], ub_cg, ubi_cg, row0, n_valid, idx_base);
 #pragma unroll
             for (int q = 0; q < (KMAX + 15) / 16; ++q) {
               float *ps = chunk_base(hs, q);
@@ -556,11 +583,11 @@ size_t match16_scratch_bytes(int grid, int waves, int list_len) {
   return scratch16_entries(grid, waves, list_len) * (sizeof(float) + sizeof(int));
 }
 
-template <int KMAX, bool BOUNDED, int WAVES>
+template <int KMAX, bool BOUNDED, int WAVES, bool F32 = false>
 static hipError_t launch16_t(const MatchArgs &args, int grid, void *scratch, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)match16_kernel<KMAX, BOUNDED, WAVES>,
+    hipError_t e = hipFuncSetAttribute((const void *)match16_kernel<KMAX, BOUNDED, WAVES, F32>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Geo<WAVES>::LDS + 32);
     if (e != hipSuccess) return e;
     attr_set = true;
@@ -568,8 +595,8 @@ static hipError_t launch16_t(const MatchArgs &args, int grid, void *scratch, hip
   // scratch: scores of all lists, then their indices
   float *ls = (float *)scratch;
   int *li = (int *)(ls + scratch16_entries(grid, WAVES, KMAX));
-  hipLaunchKernelGGL((match16_kernel<KMAX, BOUNDED, WAVES>), dim3(grid), dim3(64 * WAVES), Geo<WAVES>::LDS + 32, s, args,
-                     ls, li);
+  hipLaunchKernelGGL((match16_kernel<KMAX, BOUNDED, WAVES, F32>), dim3(grid), dim3(64 * WAVES), Geo<WAVES>::LDS + 32, s,
+                     args, ls, li);
   return hipGetLastError();
 }
 
@@ -590,8 +617,27 @@ static hipError_t launch16_w(const MatchLaunch &a, const MatchArgs &g, void *scr
   }
 }
 
+// the float32 form (operand_form 3): exact f32 products on the one-wave-per-SIMD kernel
+static hipError_t launch16_f32(const MatchLaunch &a, const MatchArgs &g, void *scratch, hipStream_t s) {
+  const int grid = a.rows * a.nsplit;
+  const bool bounded = a.bound_score != nullptr;
+  switch (a.list_len) {
+    case 1:
+      return bounded ? launch16_t<1, true, 4, true>(g, grid, scratch, s) : launch16_t<1, false, 4, true>(g, grid, scratch, s);
+    case 8:
+      return bounded ? launch16_t<8, true, 4, true>(g, grid, scratch, s) : launch16_t<8, false, 4, true>(g, grid, scratch, s);
+    case 20:
+      return bounded ? launch16_t<20, true, 4, true>(g, grid, scratch, s) : launch16_t<20, false, 4, true>(g, grid, scratch, s);
+    case 32:
+      // (bounded passes of this form rank 20 entries at a time, api.hip: the bounded 32-entry instantiation does not
+      // fit its registers - tools/check_mfma_loops.py)
+      return bounded ? hipErrorInvalidValue : launch16_t<32, false, 4, true>(g, grid, scratch, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_match16(const MatchLaunch &a, int waves, void *list_scratch, hipStream_t s) {
-  if (a.operand_form != 2 || a.row_tiles != 4 || !list_scratch) return hipErrorInvalidValue;
+  if ((a.operand_form != 2 && a.operand_form != 3) || a.row_tiles != 4 || !list_scratch) return hipErrorInvalidValue;
   MatchArgs g;
   g.dict = a.dict;
   g.exp = a.exp;
@@ -615,6 +661,7 @@ hipError_t launch_match16(const MatchLaunch &a, int waves, void *list_scratch, h
   g.xcd_rows = a.xcd_rows;
   g.xcd_splits = a.xcd_splits;
   g.rows = a.rows;
+  if (a.operand_form == 3) return launch16_f32(a, g, list_scratch, s);
   return waves == 4 ? launch16_w<4>(a, g, list_scratch, s) : launch16_w<8>(a, g, list_scratch, s);
 }
 

@@ -82,6 +82,12 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const T *raw, int np
           (_Float16)((c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv * 4096.f : 0.f);
     return;
   }
+  if ((form & 0xff) == 3) {
+    for (int c = tid; c < kpad; c += PREP_THREADS)
+      *(float *)half_slot(out, r, 2 * c, kpad, form) =
+          (c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv : ((centred && c == k) ? cval : 0.f);
+    return;
+  }
   for (int c = tid; c < kpad; c += PREP_THREADS)
     out[prepared_offset(r, c, nslab)] =
         (c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv : ((centred && c == k) ? cval : 0.f);
@@ -114,6 +120,8 @@ __device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], flo
     const int c = lane + 64 * i;
     if ((form & 0xff) == 2) {
       if (c < 2 * kpad) *(_Float16 *)half_slot(out, r, c, kpad, form) = (_Float16)(v[i] * inv * 4096.f);
+    } else if ((form & 0xff) == 3) {
+      if (c < kpad) *(float *)half_slot(out, r, 2 * c, kpad, form) = (centred && c == k) ? cval : v[i] * inv;
     } else if (c < kpad) {
       out[prepared_offset(r, c, nslab)] = (centred && c == k) ? cval : v[i] * inv;
     }
@@ -292,6 +300,42 @@ __global__ __launch_bounds__(PREP16_THREADS) void prep16_block4_kernel(const T *
   }
 }
 
+// ---- plane-major forms (float16, wide float32), K % 4 == 0, no mask: four patterns per workgroup as whole lines ----
+// prep_wave_kernel<T, 4, true> stores 8 / 16 bytes per lane into 32-byte row segments (3-4.6 TB/s); here the four
+// waves stage their normalised rows in LDS (4 x kpad floats) and the workgroup writes 128-byte lines (write_lines4).
+template <typename T>
+__global__ __launch_bounds__(PREP_THREADS) void prep_wave_lines_kernel(const T *raw, int npix, const int *row_map, int k,
+                                                                       int kpad, int metric, int n_out, float *out, int form) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * 4, r = r0 + wv;
+  float *stage = (float *)smem_raw + (size_t)wv * kpad;
+  float v[WAVE_VALUES];
+  float s = 0.f;
+  if (r < n_out) {
+    const int64_t src = row_map ? row_map[r] : r;
+    const T *p = raw + src * (int64_t)npix;
+#pragma unroll
+    for (int i = 0; i < WAVE_VALUES / 4; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      Quad<T> q;
+      q.v[0] = q.v[1] = q.v[2] = q.v[3] = (T)0;
+      if (c < k) q = *reinterpret_cast<const Quad<T> *>(p + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[4 * i + e] = (float)q.v[e];
+        s += v[4 * i + e];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < WAVE_VALUES; ++i) v[i] = 0.f;  // rows beyond the chunk: zeros (their line is shared with valid rows)
+  }
+  normalise_and_store_quads<64, WAVE_VALUES, true>(v, s, lane, r, k, kpad, metric, out, form, nullptr, stage);
+  __syncthreads();
+  write_lines4(out, (const float *)smem_raw, kpad, r0, kpad, form, threadIdx.x);
+}
+
 // ---- one wave per pattern, signal mask, row staged in LDS -------------------------------
 // LDS: [k ints pixel map][4 waves x npix floats].  Workgroups are persistent over groups of
 // 4 patterns, so the pixel map is staged once per workgroup.
@@ -457,7 +501,7 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   const int span = std::max(cols, a.operand_form == 2 ? 2 * a.kpad : a.kpad);
   const bool wave_path = span <= 64 * WAVE_VALUES;
   // what the kernels are told: the float16 form carries its block geometry
-  const int form = a.operand_form == 2 ? f16_form(a.f16_rows, a.f16_step) : a.operand_form;
+  const int form = a.operand_form == 2 ? f16_form(a.f16_rows, a.f16_step) : (a.operand_form == 3 ? wide32_form() : a.operand_form);
   const bool vec_ok = (a.npix % 4) == 0 && ((uintptr_t)a.raw % (4 * dtype_size(a.dtype))) == 0;
   const bool vec4 = wave_path && a.pix_map == nullptr && (a.k % 4) == 0 && vec_ok;
   const bool staged = wave_path && a.pix_map != nullptr && vec_ok && a.npix <= 64 * WAVE_VALUES && !getenv("KPDI_PREP_NO_STAGED");
@@ -466,6 +510,7 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   const bool block_vec = block_path && a.pix_map == nullptr && (a.k % 4) == 0 && vec_ok;
   const bool block_masked = block_path && a.pix_map != nullptr;
   const size_t staged_lds = (size_t)(((a.k + 3) & ~3) + 4 * a.npix) * 4;
+  const size_t lines_lds = (size_t)4 * a.kpad * 4 * (getenv("KPDI_PREP_NO_LINES") ? 1000 : 1);  // prep_wave_lines_kernel
   // float32 rows (dictionaries): LDS-DMA, double-buffered (prep_wave_masked_dma_kernel)
   const size_t dma_lds = (size_t)(((a.k + 3) & ~3) + 8 * ((a.npix + 255) & ~255)) * 4;
   const bool staged_dma = staged && a.dtype == KPDI_F32 && dma_lds <= 160 * 1024 && !getenv("KPDI_PREP_NO_DMA");
@@ -473,7 +518,10 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   dim3 grid(wave_path ? (a.n_out + 3) / 4 : a.n_out);
   if (staged) grid = dim3(std::min((a.n_out + 3) / 4, 2048));
 #define KPDI_PREP_H(T, H)                                                                                \
-  if (vec4)                                                                                              \
+  if (H && vec4 && lines_lds <= 64 * 1024)                                                               \
+    hipLaunchKernelGGL((prep_wave_lines_kernel<T>), grid, block, lines_lds, s, (const T *)a.raw, a.npix, a.row_map, a.k, \
+                       a.kpad, a.metric, a.n_out, a.out, form);                                          \
+  else if (vec4)                                                                                       \
     hipLaunchKernelGGL((prep_wave_kernel<T, 4, H>), grid, block, 0, s, (const T *)a.raw, a.npix,        \
                        a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form);               \
   else if (staged_dma) {                                                                                 \
@@ -514,7 +562,7 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
     }                                                                                                    \
     hipLaunchKernelGGL(k16, dim3((a.n_out + 3) / 4), dim3(PREP16_THREADS), lds16, s, (const T *)a.raw, a.npix, \
                        a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form);               \
-  } else if (a.operand_form == 2) {   \
+  } else if (a.operand_form >= 2) {   \
     KPDI_PREP_H(T, true)              \
   } else {                            \
     KPDI_PREP_H(T, false)             \

@@ -48,6 +48,10 @@ struct alignas(sizeof(T) * 4) Quad {
 __host__ __device__ inline int f16_form(int tile_rows, int step) {
   return 2 | ((tile_rows == 128 ? 7 : 8) << 8) | (step << 16);
 }
+// Form 3 = the same plane-major blocks holding FLOAT32 values (the f32 form of match16.hip: tiles of 256 patterns,
+// steps of 24 pixels, a row's 32 bytes of a plane = 8 pixels): byte for byte the float16 layout with every float32
+// in the place of two float16, so pixel c lives where float16 index 2 c would (half_slot(out, r, 2 c, kpad, form)).
+__host__ __device__ inline int wide32_form() { return 3 | (8 << 8) | (F16_STEP << 16); }
 __device__ __forceinline__ char *half_slot(float *out, int r, int c, int kpad, int form) {
   const int lr = (form >> 8) & 0xff, bk = (form >> 16) & 0xff;
   // c / bk as ONE v_mul_hi_u32 (exact for c < 10^7): a runtime divisor costs ~25 instructions per stored slot,
@@ -77,10 +81,12 @@ __device__ __forceinline__ float group_sum(float v, float *red) {
 // H16: the kernel was instantiated FOR the float16 form (split & 0xff == 2) / for the other two forms: with one
 // body for all three, the float16 stores' address arithmetic - unrolled 16 times - raised the f32 kernels
 // from 170-204 to 256 registers and the masked f32 preparation from 0.79 to 1.33 ms.
+// `stage` (plane-major forms only): the row goes to this LDS buffer (kpad floats: logical order, no swizzle) instead of
+// global memory; write_lines4() then writes four consecutive rows as whole 128-byte lines.
 template <int NT = 64, int NV = WAVE_VALUES, bool H16 = false>
 __device__ __forceinline__ void normalise_and_store_quads(float (&v)[NV], float s, int lane, int r, int k,
                                                           int kpad, int metric, float *out, int split,
-                                                          float *red = nullptr) {
+                                                          float *red = nullptr, float *stage = nullptr) {
   const int nslab = kpad / TILE_K;
   float mean = 0.f;
   if (metric != KPDI_METRIC_NDP) mean = group_sum<NT>(s, red) / (float)k;
@@ -103,7 +109,7 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[NV], float 
 #pragma unroll
   for (int i = 0; i < NV / 4; ++i) {
     const int c = 4 * (lane + NT * i);
-    if (c < (H16 ? 2 * kpad : kpad)) {
+    if (c < ((H16 && (split & 0xff) == 2) ? 2 * kpad : kpad)) {
       float4 w;
       w.x = (centred && c == k) ? cval : v[4 * i] * inv;
       w.y = (centred && c + 1 == k) ? cval : v[4 * i + 1] * inv;
@@ -111,6 +117,11 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[NV], float 
       w.w = (centred && c + 3 == k) ? cval : v[4 * i + 3] * inv;
       if (!H16 && !split) {
         *reinterpret_cast<float4 *>(out + prepared_offset(r, c, nslab)) = w;
+      } else if (H16 && (split & 0xff) == 3) {
+        if (stage)
+          *reinterpret_cast<float4 *>(stage + c) = w;
+        else
+          *reinterpret_cast<float4 *>(half_slot(out, r, 2 * c, kpad, split)) = w;  // half of a row's 32 bytes of a plane
       } else if (H16) {
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         h4 h;
@@ -118,7 +129,10 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[NV], float 
         h[1] = (_Float16)(w.y * 4096.f);
         h[2] = (_Float16)(w.z * 4096.f);
         h[3] = (_Float16)(w.w * 4096.f);
-        *reinterpret_cast<h4 *>(half_slot(out, r, c, kpad, split)) = h;  // half of a slot: 8 bytes
+        if (stage)
+          *reinterpret_cast<h4 *>((_Float16 *)stage + c) = h;
+        else
+          *reinterpret_cast<h4 *>(half_slot(out, r, c, kpad, split)) = h;  // half of a slot: 8 bytes
       } else {
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         const float x[4] = {w.x * 4096.f, w.y * 4096.f, w.z * 4096.f, w.w * 4096.f};
@@ -139,5 +153,28 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[NV], float 
   }
 }
 
+
+// Four consecutive rows r0 .. r0 + 3 (r0 % 4 == 0) of a plane-major form, staged in LDS as rows of `row_floats` floats
+// (kpad * 4 bytes of payload each, logical order), written by 256 threads as whole 128-byte lines: a plane's 32 bytes of
+// the four rows are contiguous, the two 16-byte halves of a row swapped when its bit 3 is set - the same for all four.
+__device__ __forceinline__ void write_lines4(float *out, const float *stage, int row_floats, int r0, int kpad, int form,
+                                             int tid) {
+  const int lr = (form >> 8) & 0xff, bk = (form >> 16) & 0xff;
+  const unsigned magic = bk == 48 ? 89478486u : 134217728u;
+  const int planes = kpad / 8;                       // 32 bytes per row and plane
+  const int planes_per_step = bk / 16;
+  const int nsteps = (int)__umulhi(2u * (unsigned)kpad, magic);
+  const int row0 = r0 & ((1 << lr) - 1);
+  const int swz = (row0 >> 3) & 1;
+  const int j = tid & 7, row = j >> 1, half = j & 1;
+  for (int P = tid >> 3; P < planes; P += 32) {
+    const int step = (int)__umulhi((unsigned)(16 * P), magic);
+    const int pl = P - step * planes_per_step;
+    const size_t block = (size_t)(r0 >> lr) * nsteps + step;
+    char *line = (char *)out + ((block * bk) << (lr + 1)) + (((size_t)pl << lr) + row0) * 32;
+    const float4 q = *reinterpret_cast<const float4 *>(stage + (size_t)row * row_floats + 8 * P + 4 * (half ^ swz));
+    *reinterpret_cast<float4 *>(line + 32 * row + 16 * half) = q;
+  }
+}
 
 }  // namespace kpdi

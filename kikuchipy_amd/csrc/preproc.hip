@@ -361,7 +361,7 @@ static hipError_t launch_pre_t(const PreLaunch &l, const PreArgs &a, bool *prep_
     const size_t npix4 = ((size_t)l.sy * l.sx + 3) & ~(size_t)3;
     const size_t lds = npix4 * 8;
     const bool small = !prep || std::max(cols, cols_pad) <= PP_THREADS * 16;
-    const bool h16 = prep && l.operand_form == 2;
+    const bool h16 = prep && l.operand_form >= 2;
     auto kernel = small ? (h16 ? preproc_fused_kernel<T, 16, true> : preproc_fused_kernel<T, 16, false>)
                         : (h16 ? preproc_fused_kernel<T, WAVE_VALUES, true> : preproc_fused_kernel<T, WAVE_VALUES, false>);
     if (lds > 64 * 1024) {
@@ -417,7 +417,7 @@ hipError_t launch_preprocess(const PreLaunch &l, bool *prep_done, hipStream_t s)
   a.k = l.k;
   a.kpad = l.kpad;
   a.metric = l.metric;
-  a.form = l.operand_form == 2 ? f16_form(F16_TILE, l.f16_step) : l.operand_form;
+  a.form = l.operand_form == 2 ? f16_form(F16_TILE, l.f16_step) : (l.operand_form == 3 ? wide32_form() : l.operand_form);
   a.out = l.out;
   a.scratch = l.scratch;
   switch (l.dtype) {

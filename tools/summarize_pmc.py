@@ -66,8 +66,13 @@ for name, row in stats.items():
         k["clock_ghz_profiled"] = (k["GRBM_GUI_ACTIVE"] / 8) / (k["avg_ms"] * 1e-3) / 1e9
     summary["kernels"][name] = k
 
-match = next((n for n in summary["kernels"] if "match_topk_kernel<20, false, 0, 4>" in n), None) or \
-    next((n for n in summary["kernels"] if "match_topk_kernel" in n), None)
+def busiest(pattern):
+    hits = [n for n in summary["kernels"] if pattern in n]
+    return max(hits, key=lambda n: summary["kernels"][n]["percentage"]) if hits else None
+
+
+match = busiest("match16_kernel<20, false, 4, true>") or busiest("match_topk_kernel<20, false, 0, 4>") or \
+    busiest("match_topk_kernel") or busiest("match16_kernel")
 if match:
     mk = summary["kernels"][match]
     summary["match_kernel"] = match
