@@ -510,6 +510,7 @@ void plan_xcd_grid(int rows, int nsplit, int tile_dict, int *xr, int *xs) {
 // whole tiles would leave most workgroups idle during the last round (makespan 7 tile-times for 6.1 of
 // work).  The last n_tiles % nsplit tiles are then handed out as QUARTER tiles by a second launch of the
 // kernel's 32-row form, whose lists join the merge as a third source.
+double wide_tail_plan(int n_tiles, int nsplit, int *shift);
 int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int nsplit, int rows_per_launch,
               int list_len, int64_t global_start, const float *bound_s, const int *bound_i, bool allow_tail = false) {
   const int row_blocks_all = c->m_pad / kpdi::TILE_EXP;
@@ -541,6 +542,10 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   ml.bound_score = bound_s;
   ml.bound_idx = bound_i;
   ml.operand_form = operand_form(c);
+  if (c->wide32) {
+    (void)wide_tail_plan(n_main, nsplit, &ml.tail_shift);
+    ml.tail_first = n_main - n_main % nsplit;
+  }
   {
     // the published ranks are only comparable under one plan: (re)initialise when it changes
     int rank, grouped, used;
@@ -677,6 +682,7 @@ int prepare_chunk(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chun
 // statically, match.hip 128-pattern tiles with a dynamic tail of quarter tiles: the estimated makespans decide.  The two
 // kernels read different operand layouts (and row paddings), so the choice is made when the first chunk of a sweep
 // arrives - nothing prepared yet, no resident chunks - and stands until then again.  KPDI_F32_WIDE = 1 / 0 forces it.
+double wide_tail_plan(int n_tiles, int nsplit, int *shift);
 void decide_form(kpdi_ctx *c, int64_t n_chunk) {
   if (c->compute != KPDI_COMPUTE_F32 || c->wide_mode >= 0) return;
   if (c->exp_prepared || !c->held.empty()) return;
@@ -695,12 +701,30 @@ void decide_form(kpdi_ctx *c, int64_t n_chunk) {
   // match16.hip, float32 form: whole rounds of 256-pattern tiles, two 128-tile units each at 1 / 1.03 of the time
   const int t256 = (int)((n_chunk + 255) / 256);
   const int nsw = choose_nsplit(c, row_blocks, t256, &rpl);
-  const double wide = ((row_blocks + rpl - 1) / rpl) * (((t256 + nsw - 1) / nsw) * 2.0 / 1.03 + 0.25);
+  int shift = 0;
+  const double wide = ((row_blocks + rpl - 1) / rpl) * ((t256 / nsw + wide_tail_plan(t256, nsw, &shift)) * 2.0 / 1.03 + 0.25);
   const bool w = wide < classic;
   if (w == c->wide32) return;
   c->wide32 = w;
   c->kpad = kpdi::round_up(c->k_kept + (c->metric == KPDI_METRIC_NDP ? 1 : 0), w ? kpdi::F16_STEP / 2 : kpdi::TILE_K);
   c->cnt.kpad = c->kpad;
+}
+
+// match16.hip, float32 form: how the last n_tiles % nsplit tiles of a launch are handed out - as whole tiles (one more
+// round, shift 0) or as halves / quarters of a tile (a half / a quarter of a round each, at ~1.1 / 1.25 of the time per
+// row because the experimental fragments are reused by fewer row groups).  Returns the cost of that last round in
+// tile-times.
+double wide_tail_plan(int n_tiles, int nsplit, int *shift) {
+  *shift = 0;
+  const int left = n_tiles % nsplit;
+  if (left == 0) return 0.0;
+  double best = 1.0;
+  if (!getenv("KPDI_NO_TAIL"))
+    for (int sh = 1; sh <= 2; ++sh) {
+      const double cost = (double)(((left << sh) + nsplit - 1) / nsplit) / (1 << sh) * (sh == 1 ? 1.1 : 1.25);
+      if (cost < best - 1e-9) best = cost, *shift = sh;
+    }
+  return best;
 }
 
 int check_chunk_args(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_start) {

@@ -73,6 +73,7 @@ struct MatchLaunch {
   int operand_form;    // 0 = f32, 1 = split-f16 (KPDI_COMPUTE_F16X2), 2 = f16 (KPDI_COMPUTE_F16), see match.hip
   int row_tiles = 4;   // 4: units of work = 128-pattern tiles; 1: the tail form - 32-pattern units (f32 only)
   int row_base = 0;    // tail form: dictionary row (of this chunk) of unit 0, a multiple of 32; `n_tiles` counts units
+  int tail_first = 0, tail_shift = 0;  // float32 form of match16.hip: partial units for the tiles from tail_first on
 };
 constexpr unsigned THRESHOLD_NONE = 0x007fffffu;  // key of -inf
 constexpr int BOUND_SLOTS = 32;

@@ -496,6 +496,8 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   g.tile_ctr = a.tile_ctr;
   g.tile_groups = 1;
   g.fixed_draws = a.fixed_draws < 3 ? 3 : a.fixed_draws;
+  g.tail_first = a.n_tiles;
+  g.tail_shift = 0;
   g.xcd_rows = a.xcd_rows;
   g.xcd_splits = a.xcd_splits;
   g.rows = a.rows;

@@ -117,11 +117,12 @@ __device__ __forceinline__ T *chunk_base(T *base, int chunk) {
 // loop with the scalar register index (match.hip: scan_tile, FORM = 2).
 template <int KMAX, bool BOUNDED, bool F32 = false>
 __device__ __forceinline__ void scan16(f32x16 (&acc)[4], float (&best)[KMAX], int (&best_idx)[KMAX], float gthr,
-                                       float ub, int ub_idx, int row0, int n_valid, int idx_base) {
+                                       float ub, int ub_idx, int row0, int n_valid, int idx_base, int rt_n = 4) {
   constexpr float unscale = F32 ? 1.f : 0x1p-24f;  // float16 operands are stored scaled by 2^12 each
   float thr = fmaxf(gthr, next_up(best[KMAX - 1]));
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
+    if (F32 && rt >= rt_n) continue;  // a partial unit of the float32 form's tail
     unsigned hot = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -182,7 +183,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
   // LDS -> MFMA fragments: lane l reads row (l & 31) of a 32-row group in plane ks: the 16-byte half
   // (l >> 5) of the row's 32 bytes, halves swapped for rows with bit 3 set (prep_device.h: half_slot)
   const unsigned half_off = (unsigned)((((lane >> 5) ^ (lane >> 3)) & 1) * 16);
-  const unsigned fa_off = (unsigned)((wr * 128 + (lane & 31)) * 32) + half_off;
+  // (float32 form: the rows of this wave within the tile change with the unit - fa_base below)
+  const unsigned fa_lane = (unsigned)((lane & 31) * 32) + half_off;
+  unsigned fa_off = (unsigned)(wr * 128 * 32) + fa_lane;
   const unsigned fb_off = (unsigned)(BLOCK16 + (wc * G::WCOLS + (lane & 31)) * 32) + half_off;
 #define KPDI_FA(base, rt, ks) (*(const f32x4 *)((base) + fa_off + (rt) * 1024 + (ks) * (G::DT * 32)))
 #define KPDI_FB(base, cg, ks) (*(const f32x4 *)((base) + fb_off + (cg) * 1024 + (ks) * (F16_TILE * 32)))
@@ -243,14 +246,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
 #else
 #define KPDI16_ABLATE_ADDR
 #endif
+  // Units of work.  Whole tiles everywhere except in the float32 form's tail: the tiles from a.tail_first on are cut
+  // into units of 256 >> tail_shift dictionary rows (unit u >= tail_first: tile tail_first + ((u - tail_first) >>
+  // tail_shift), rows from ((u - tail_first) & (2^tail_shift - 1)) * (256 >> tail_shift)), in which a wave runs
+  // 4 >> tail_shift of its four 32-row groups: the last round costs a half or a quarter of a tile-time.
+  const int tail_first = F32 ? a.tail_first : n_tiles, tail_shift = F32 ? a.tail_shift : 0;
+  const int n_units = tail_first + ((n_tiles - tail_first) << tail_shift);
+#define KPDI16_UNIT_TILE(u) ((u) < tail_first ? (u) : tail_first + (((u) - tail_first) >> tail_shift))
+#define KPDI16_UNIT_ROW(u) ((u) < tail_first ? 0 : ((((u) - tail_first) & ((1 << tail_shift) - 1)) * (F16_TILE >> tail_shift)))
+#define KPDI16_UNIT_RT(u) ((u) < tail_first ? 4 : (4 >> tail_shift))
   int t0 = sp, t1 = sp + a.nsplit, t2 = sp + 2 * a.nsplit;
-  if (t0 < n_tiles) {
+  if (t0 < n_units) {
     const int last_tile = n_tiles - 1;
     int ld_pos = 0, ld_step = 0, ld_stage = 0;
     const char *gd = nullptr, *ge = nullptr;
 #define KPDI16_CURSOR_SET()                                                          \
   {                                                                                  \
     int t_ = ld_pos == 0 ? t0 : (ld_pos == 1 ? t1 : t2);                             \
+    t_ = KPDI16_UNIT_TILE(t_);                                                       \
     t_ = t_ < last_tile ? t_ : last_tile; /* past the end: harmless re-load */       \
     gd = dict_base + (size_t)t_ * tile_bytes + (size_t)ld_step * G::DBLOCK;          \
     ge = exp_base + (size_t)ld_step * G::EBLOCK;                                     \
@@ -276,6 +289,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // rows of this wave in a unit: 32 * rt_n consecutive rows from unit row + wr * 32 * rt_n
+    auto fa_base = [&](int u) { return (unsigned)((KPDI16_UNIT_ROW(u) + wr * 32 * KPDI16_UNIT_RT(u)) * 32) + fa_lane; };
+    if (F32) fa_off = fa_base(t0);
     // fragments of the three k-steps of a step, each in its own registers (static indices)
     f32x4 fa[KSTEPS16][4], fb[KSTEPS16][NCG];
 #pragma unroll
@@ -286,7 +302,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
     int stage = 0;
     int tiles_done = 0, refresh_at = 0;
 #pragma clang loop unroll(disable)
-    for (;;) {  // dictionary tiles
+    for (;;) {  // dictionary tiles (units)
+      const int rt_n = F32 ? KPDI16_UNIT_RT(t0) : 4;                        // row groups of this wave in this unit
       f32x16 acc[NCG][4];  // [column group][32-row group]
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg)
@@ -326,6 +343,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
           }
           const int nk = ks == KSTEPS16 - 1 ? 0 : ks + 1;         // fragments read during this k-step
           const char *src = ks == KSTEPS16 - 1 ? ls_next : ls;    // ... of the next step for the last one
+          if (F32 && ks == KSTEPS16 - 1 && step == nsteps - 1) fa_off = fa_base(t1);  // those are the next unit's rows
           if (F32) {
             // ---- float32 form: 64 MFMAs of 64 pipe cycles per k-step; behind every four of them one of the 8
             // fragment reads of the next k-step, then (after the barrier) this wave's 6 LDS-DMA pieces
@@ -333,8 +351,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
             for (int j = 0; j < 4; ++j)
 #pragma unroll
               for (int rt = 0; rt < 4; ++rt) {
+                if (rt < rt_n) {  // (a partial unit of the tail runs 2 or 1 of its row groups; the schedule stays)
 #pragma unroll
-                for (int cg = 0; cg < NCG; ++cg) mfma32(acc[cg][rt], fa[ks][rt][j], fb[ks][cg][j]);
+                  for (int cg = 0; cg < NCG; ++cg) mfma32(acc[cg][rt], fa[ks][rt][j], fb[ks][cg][j]);
+                }
                 const int slot = 4 * j + rt;
 #ifndef KPDI16_NO_READS
                 if (slot < 4) fa[nk][slot] = KPDI_FA(src, slot, nk);
@@ -395,7 +415,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
         // itself is only loaded, updated and stored when a buffer is full (the first tiles of a launch,
         // rarely afterwards) and at the end.  The waves of a workgroup run in lockstep (one barrier per
         // step), so every cycle spent here is lost on the matrix pipe: a list update per tile cost 23 %.
-        const int row0 = t0 * G::DT + wr * 128 + 4 * (lane >> 5);
+        const int row0 = F32 ? KPDI16_UNIT_TILE(t0) * G::DT + KPDI16_UNIT_ROW(t0) + wr * 32 * rt_n + 4 * (lane >> 5)
+                             : t0 * G::DT + wr * 128 + 4 * (lane >> 5);
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) {
 #ifdef KPDI16_NO_EPILOGUE  // (the MFMAs are asm volatile: they stay)
@@ -424,6 +445,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
           float mx = -INFINITY;
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt) {
+            if (F32 && rt >= rt_n) continue;
             float m = acc[cg][rt][0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[cg][rt][r]);
@@ -483,7 +505,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
               }
             }
             cnt[cg] = 0;
-            scan16<KMAX, BOUNDED, F32>(acc[cg], best, bidx, g[cg], ub_cg, ubi_cg, row0, n_valid, idx_base);
+            scan16<KMAX, BOUNDED, F32>(acc[cg], best, bidx, g[cg], ub_cg, ubi_cg, row0, n_valid, idx_base, rt_n);
 #pragma unroll
             for (int q = 0; q < (KMAX + 15) / 16; ++q) {
               float *ps = chunk_base(hs, q);
@@ -509,7 +531,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
         t1 = t2;
         t2 += a.nsplit;
         --ld_pos;
-        if (t0 >= n_tiles) break;
+        if (t0 >= n_units) break;
       }
     }
   }
@@ -658,6 +680,8 @@ hipError_t launch_match16(const MatchLaunch &a, int waves, void *list_scratch, h
   g.tile_ctr = a.tile_ctr;
   g.tile_groups = 1;
   g.fixed_draws = 1 << 30;
+  g.tail_first = a.operand_form == 3 && a.tail_shift > 0 ? a.tail_first : a.n_tiles;
+  g.tail_shift = a.operand_form == 3 ? a.tail_shift : 0;
   g.xcd_rows = a.xcd_rows;
   g.xcd_splits = a.xcd_splits;
   g.rows = a.rows;

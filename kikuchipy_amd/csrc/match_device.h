@@ -28,6 +28,9 @@ struct MatchArgs {
   // from the row block's counter.  xcd_rows x xcd_splits = 8 arranges the 8 XCDs as a grid over the launch's
   // (row block, split) workgroups (block_rb_sp below); xcd_rows = 0: block b -> (b / nsplit, b % nsplit).
   int fixed_draws, xcd_rows, xcd_splits, rows;
+  // match16.hip, float32 form: the tiles [tail_first, n_tiles) are handed out as units of 256 >> tail_shift rows
+  // (tail_shift = 1, 2; 0 = whole tiles only): the last round of a launch then costs a half / a quarter of a tile-time
+  int tail_first, tail_shift;
   unsigned *gthr;      // [m_pad][BOUND_SLOTS] published list ranks (monotone keys), see shared_bound()
   int bound_rank;      // which entry (1-based) of its list a workgroup lane publishes
   int bound_grouped;   // 1: all 32 slots are in use and bound_rank == 1 (grouped form)
