@@ -702,7 +702,9 @@ void decide_form(kpdi_ctx *c, int64_t n_chunk) {
   const int t256 = (int)((n_chunk + 255) / 256);
   const int nsw = choose_nsplit(c, row_blocks, t256, &rpl);
   int shift = 0;
-  const double wide = ((row_blocks + rpl - 1) / rpl) * ((t256 / nsw + wide_tail_plan(t256, nsw, &shift)) * 2.0 / 1.03 + 0.25);
+  // (its launch costs more: the first tile's 64 candidates per lane go to the buffers, the lists are built at the end -
+  // 0.27 ms against 0.1 ms, measured on one rank's share of configs[1] at N = 8)
+  const double wide = ((row_blocks + rpl - 1) / rpl) * ((t256 / nsw + wide_tail_plan(t256, nsw, &shift)) * 2.0 / 1.03 + 0.65);
   const bool w = wide < classic;
   if (w == c->wide32) return;
   c->wide32 = w;
