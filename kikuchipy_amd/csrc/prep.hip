@@ -300,6 +300,103 @@ __global__ __launch_bounds__(PREP16_THREADS) void prep16_block4_kernel(const T *
   }
 }
 
+// ---- the same for the float32 plane-major form (form 3): a row of 16 384 float32 does not fit LDS four times, so the
+// normalised rows (in registers) are staged and written HALF a row at a time (4 x kpad / 2 floats of LDS).
+template <typename T, bool MASKED>
+__global__ __launch_bounds__(PREP16_THREADS) void prep32_block4_kernel(const T *raw, int npix, const int *row_map,
+                                                                       const int *pix_map, int k, int kpad,
+                                                                       int metric, int n_out, float *out, int form) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ float red[PREP16_THREADS / 64];
+  const int tid = threadIdx.x, g = tid >> 8, t = tid & 255, wave = tid >> 6;
+  const int r = blockIdx.x * 4 + g;
+  const bool live = r < n_out;
+  float v[WAVE_VALUES];
+  float s = 0.f;
+  if (live) {
+    const int64_t src = row_map ? row_map[r] : r;
+    const T *p = raw + src * (int64_t)npix;
+#pragma unroll
+    for (int i = 0; i < WAVE_VALUES / 4; ++i) {
+      const int c = 4 * (t + 256 * i);
+      if (!MASKED) {
+        Quad<T> q;
+        q.v[0] = q.v[1] = q.v[2] = q.v[3] = (T)0;
+        if (c < k) q = *reinterpret_cast<const Quad<T> *>(p + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * i + e] = (float)q.v[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * i + e] = c + e < k ? (float)p[pix_map[c + e]] : 0.f;
+      }
+      s += (v[4 * i] + v[4 * i + 1]) + (v[4 * i + 2] + v[4 * i + 3]);
+    }
+  }
+  auto group_total = [&](float x) {
+    x = wave_sum(x);
+    __syncthreads();
+    if ((tid & 63) == 0) red[wave] = x;
+    __syncthreads();
+    return (red[4 * g] + red[4 * g + 1]) + (red[4 * g + 2] + red[4 * g + 3]);
+  };
+  float mean = 0.f;
+  if (metric != KPDI_METRIC_NDP) mean = group_total(s) / (float)k;
+  float q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < WAVE_VALUES; ++i) {
+    const int c = 4 * (t + 256 * (i / 4)) + (i & 3);
+    if (c < k) {
+      v[i] -= mean;
+      q2 += v[i] * v[i];
+    } else {
+      v[i] = 0.f;
+    }
+  }
+  q2 = group_total(q2);
+  const bool centred = metric == NORM_NDP_CENTRED;
+  const float norm = sqrtf(centred ? q2 + (float)k * mean * mean : q2);
+  const float inv = norm > 0.f ? 1.f / norm : 0.f;
+  const float cval = sqrtf((float)k) * mean * inv;
+  // two passes over the row: planes [0, half_planes) and the rest
+  const int planes = kpad / 8, half_planes = (planes + 1) / 2;
+  const int row_floats = 8 * half_planes + 4;  // + 16 bytes: the four rows start in different banks
+  float *stage = (float *)smem_raw + (size_t)g * row_floats;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int c_first = pass * 8 * half_planes;
+    const int c_last = pass == 0 ? 8 * half_planes : kpad;
+    if (pass) __syncthreads();  // the first half has been written out
+#pragma unroll
+    for (int i = 0; i < WAVE_VALUES / 4; ++i) {
+      const int c = 4 * (t + 256 * i);
+      if (c >= c_first && c < c_last) {
+        float4 w;
+        w.x = (centred && c == k) ? cval : v[4 * i] * inv;
+        w.y = (centred && c + 1 == k) ? cval : v[4 * i + 1] * inv;
+        w.z = (centred && c + 2 == k) ? cval : v[4 * i + 2] * inv;
+        w.w = (centred && c + 3 == k) ? cval : v[4 * i + 3] * inv;
+        *reinterpret_cast<float4 *>(stage + (c - c_first)) = w;
+      }
+    }
+    __syncthreads();
+    // write-out as in write_lines4, 1024 threads: 8 threads per 128-byte line
+    const int lr = (form >> 8) & 0xff, bk = (form >> 16) & 0xff;
+    const unsigned magic = bk == 48 ? 89478486u : 134217728u;
+    const int nsteps = (int)__umulhi(2u * (unsigned)kpad, magic);
+    const int r0 = blockIdx.x * 4, row0 = r0 & ((1 << lr) - 1), swz = (row0 >> 3) & 1;
+    const int j = tid & 7, row = j >> 1, half = j & 1;
+    const int p_first = c_first / 8, p_last = c_last / 8;
+    for (int P = p_first + (tid >> 3); P < p_last; P += PREP16_THREADS / 8) {
+      const int step = (int)__umulhi((unsigned)(16 * P), magic);
+      const int pl = P - step * (bk / 16);
+      const size_t block = (size_t)(r0 >> lr) * nsteps + step;
+      char *line = (char *)out + ((block * bk) << (lr + 1)) + (((size_t)pl << lr) + row0) * 32;
+      const float4 q = *reinterpret_cast<const float4 *>((const float *)smem_raw + (size_t)row * row_floats +
+                                                         8 * (P - p_first) + 4 * (half ^ swz));
+      *reinterpret_cast<float4 *>(line + 32 * row + 16 * half) = q;
+    }
+  }
+}
+
 // ---- plane-major forms (float16, wide float32), K % 4 == 0, no mask: four patterns per workgroup as whole lines ----
 // prep_wave_kernel<T, 4, true> stores 8 / 16 bytes per lane into 32-byte row segments (3-4.6 TB/s); here the four
 // waves stage their normalised rows in LDS (4 x kpad floats) and the workgroup writes 128-byte lines (write_lines4).
@@ -553,7 +650,16 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
     hipLaunchKernelGGL((prep_kernel<T>), grid, block, 0, s, (const T *)a.raw, a.npix, a.row_map,        \
                        a.pix_map, a.k, a.kpad, a.metric, a.out, H ? form : 0);
 #define KPDI_PREP(T)                  \
-  if (a.operand_form == 2 && (block_vec || block_masked)) {                                              \
+  if (a.operand_form == 3 && (block_vec || block_masked)) {                                              \
+    const size_t lds32 = (size_t)4 * (8 * ((a.kpad / 8 + 1) / 2) + 4) * 4;                               \
+    auto k32 = block_masked ? prep32_block4_kernel<T, true> : prep32_block4_kernel<T, false>;            \
+    if (lds32 > 64 * 1024) {                                                                             \
+      hipError_t e = hipFuncSetAttribute((const void *)k32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32); \
+      if (e != hipSuccess) return e;                                                                     \
+    }                                                                                                    \
+    hipLaunchKernelGGL(k32, dim3((a.n_out + 3) / 4), dim3(PREP16_THREADS), lds32, s, (const T *)a.raw, a.npix, \
+                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form);               \
+  } else if (a.operand_form == 2 && (block_vec || block_masked)) {                                       \
     const size_t lds16 = (size_t)4 * (2 * a.kpad + 8) * 2;                                               \
     auto k16 = block_masked ? prep16_block4_kernel<T, true> : prep16_block4_kernel<T, false>;            \
     if (lds16 > 64 * 1024) {                                                                             \
