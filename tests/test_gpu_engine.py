@@ -313,3 +313,41 @@ def test_large_experimental_set_takes_several_launches(k, metric):
     rs, ri = ko.dictionary_indexing(exp[rows], dic, metric=metric, keep_n=k)
     pos = np.searchsorted(np.flatnonzero(~nav), rows)
     ko.assert_topk_parity(s[pos], i[pos], rs, ri, atol=ATOL)
+
+
+def test_the_two_f32_kernels_agree_and_are_chosen_by_size(monkeypatch):
+    """KPDI_COMPUTE_F32 runs on match.hip (128 x 256 tiles, lists in registers) or on the one-wave form of match16.hip
+    (256 x 256 tiles, lists in scratch, partial units at the end of a launch): the same exact-f32 products in the same
+    order - identical scores and indices - and the choice follows the estimated makespan (api.hip: decide_form)."""
+    from kikuchipy_amd import _lib
+
+    rng = np.random.default_rng(17)
+    exp = rng.integers(0, 256, (600, 24, 24), dtype=np.uint8)
+    dic = rng.random((4700, 24, 24), dtype=np.float32)   # 19 tiles of 256: whole tiles + partial units
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("KPDI_F32_WIDE", mode)
+        with _lib.Context(0) as c:
+            for metric in (_lib.METRIC_NCC, _lib.METRIC_NDP):
+                c.set_problem(24, 24, None, metric, 20)
+                c.set_experimental(exp)
+                c.push_dictionary_chunk(dic[:3000], 0)
+                c.push_dictionary_chunk(dic[3000:], 3000)
+                out[mode, metric] = c.finalize(20)
+                assert c.counters()["match_form"] == (3 if mode == "1" else 0)
+    for metric in (_lib.METRIC_NCC, _lib.METRIC_NDP):
+        assert np.array_equal(out["0", metric][0], out["1", metric][0])
+        assert np.array_equal(out["0", metric][1], out["1", metric][1])
+    monkeypatch.delenv("KPDI_F32_WIDE")
+    big = rng.random((100000, 8, 8), dtype=np.float32)
+    with _lib.Context(0) as c:
+        c.set_problem(8, 8, None, _lib.METRIC_NCC, 20)
+        c.set_experimental(rng.integers(0, 256, (4096, 8, 8), dtype=np.uint8))
+        d = c.dev_alloc(big.nbytes)
+        c.h2d(d, big)
+        c.push_dictionary_chunk_dev(d, np.float32, 100000, 0)   # 391 tiles of 256 over 16 splits: the one-wave kernel
+        assert c.counters()["match_form"] == 3
+        c.set_experimental(rng.integers(0, 256, (4096, 8, 8), dtype=np.uint8))
+        c.push_dictionary_chunk_dev(d, np.float32, 12500, 0)    # one rank's share at N = 8: match.hip + quarter-tile tail
+        assert c.counters()["match_form"] == 0
+        c.dev_free(d)
