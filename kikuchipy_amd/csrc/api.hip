@@ -542,7 +542,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   ml.bound_score = bound_s;
   ml.bound_idx = bound_i;
   ml.operand_form = operand_form(c);
-  if (c->wide32) {
+  if (c->wide32) {  // (float32 form only: the same guards in the float16 schedule cost its 32-cycle MFMAs 10 %)
     (void)wide_tail_plan(n_main, nsplit, &ml.tail_shift);
     ml.tail_first = n_main - n_main % nsplit;
   }
