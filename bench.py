@@ -1,8 +1,9 @@
 """bench.py - dictionary-indexing throughput on N MI355X (one process per GPU).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 --steps 20 --warmup 3            # spawns its own 8 ranks (one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3   # or under a launcher
 
 Workload = BASELINE.json configs[1]: 4096 synthetic experimental patterns
 (60x60, uint8) against a 100 000-pattern synthetic dictionary (float32), `ncc`,
@@ -17,14 +18,22 @@ best-k scores/indices copied to the host.  With N ranks the SAME job is sharded
 over the dictionary axis (strong scaling); value = patterns indexed per second
 by the whole job.
 
-Prints ONE JSON line on rank 0.  torch is only imported for N > 1 (rendezvous,
-barrier and max-over-ranks through gloo); the data path is libkpdi + RCCL.
+Prints ONE JSON line on rank 0.  No PyTorch: rendezvous, barrier and the
+max-over-ranks of the timing go over kikuchipy_amd.parallel.SocketGroup (plain
+TCP on the loopback interface, reading RANK / WORLD_SIZE / MASTER_ADDR /
+MASTER_PORT as a launcher exports them); the data path is libkpdi + RCCL.  For
+N > 1 rank 0 checks the MERGED result against the C oracle exactly as for
+N = 1, and every rank's result must be bit-identical to rank 0's.
 """
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -206,7 +215,52 @@ def cpu_baseline(w, exp, dic, bg, mask, n_sample):
     }
 
 
-def main():
+def spawn_ranks(n_ranks, argv, script=None):
+    """`python bench.py --gpus N` as typed (no launcher): one child process per GPU with the
+    environment a launcher would export; rank 0's stdout (the JSON line) is relayed, everything
+    else goes to stderr.  Returns the exit code (the first failing rank's; the others are stopped)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    job = f"kpdi-bench-{os.getpid()}-{time.time_ns()}"
+    script = script or os.path.abspath(__file__)
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), KPDI_JOB_ID=job)
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    line = []
+    reader = threading.Thread(target=lambda: line.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    live = set(range(n_ranks))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+        time.sleep(0.05)
+    for r in live:  # a rank failed: stop exactly the processes started here
+        procs[r].terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    reader.join(timeout=10)
+    if rc == 0 and line and line[0]:
+        sys.stdout.buffer.write(line[0])
+        sys.stdout.flush()
+    return rc
+
+
+def main(argv=None, context_factory=None):
+    """`context_factory(device) -> engine context` replaces `kikuchipy_amd._lib.Context` in the CPU
+    rehearsal of the multi-rank control flow (tests/_bench_worker.py); never set otherwise."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -226,7 +280,11 @@ def main():
     ap.add_argument("--compute", default="f32", choices=["f32", "f16x2", "f16"],
                     help="arithmetic of the match kernel; f16x2 / f16 are the opt-in float16 modes (never the default; "
                          "f16 is reduced precision)")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
+
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return spawn_ranks(a.gpus, sys.argv[1:] if argv is None else argv,
+                           script=os.environ.get("KPDI_BENCH_SCRIPT"))
 
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line
     # version banner through C stdio when a communicator is created, flushed at exit): keep the real
@@ -238,22 +296,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("--gpus > 1 must be launched through `python -m torch.distributed.run` (one rank per GPU)")
-        a.gpus = world
-    dist = None
+    a.gpus = world  # under a launcher the launcher's world size is what runs
     if world > 1:
         # one node: RCCL's bootstrap can always use the loopback interface (the container's
         # hostname may not resolve), and the host driver only supports dmabuf IPC
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        from kikuchipy_amd.parallel import init_process_group
-
-        dist = init_process_group("gloo")
 
     from kikuchipy_amd import _lib
     from kikuchipy_amd.parallel import Communicator, shard_range
+
+    comm = Communicator(rank, world)  # world > 1: TCP rendezvous on MASTER_ADDR:MASTER_PORT (no torch)
+    make_context = context_factory or _lib.Context
+    # KPDI_BENCH_SHARE_GPU=1: ranks beyond the visible GPUs share them (rehearsals on a 1-GPU box)
+    device = local_rank
+    if os.environ.get("KPDI_BENCH_SHARE_GPU") and context_factory is None:
+        device = local_rank % max(_lib.device_count(), 1)
 
     w = WORKLOADS[a.workload]
     large = a.workload in ("config4", "config5")
@@ -268,8 +326,9 @@ def main():
     lo, hi = shard_range(w["n"], rank, world)
     n_local = hi - lo
 
-    ctx = _lib.Context(local_rank)
-    comm = Communicator(rank, world)
+    if os.environ.get("KPDI_BENCH_FAIL_RANK") == str(rank):  # tests: a rank that dies must fail the whole run
+        sys.exit(3)
+    ctx = make_context(device)
     comm.attach(ctx)
     metric = {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[w["metric"]]
     compute = {"f32": _lib.COMPUTE_F32, "f16x2": _lib.COMPUTE_F16X2, "f16": _lib.COMPUTE_F16}[a.compute]
@@ -293,34 +352,35 @@ def main():
         ctx.push_dictionary_chunk_dev(d_dic, np.float32, n_local, lo)
         return ctx.finalize(w["keep_n"])
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
     for _ in range(a.warmup):
         step()
     ctx.set_profiling(True)
     ctx.reset_counters()
-    barrier()
+    comm.barrier()
     ctx.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         scores, indices = step()
     ctx.synchronize()
-    barrier()
+    comm.barrier()
     elapsed = time.perf_counter() - t0
     cnt = ctx.counters()
     ctx.set_profiling(False)
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    per_rank = None
+    if world > 1:
+        elapsed = comm.all_reduce_max(elapsed)
+        digest = hashlib.sha256(np.ascontiguousarray(scores).tobytes() + np.ascontiguousarray(indices).tobytes()).hexdigest()
+        per_rank = comm.all_gather({
+            "rank": rank, "device": device, "shard": [int(lo), int(hi)], "result_sha256": digest,
+            "match_ms": cnt["match_ms"], "match_launches": int(cnt["match_launches"]), "match_flops": cnt["match_flops"],
+            "prep_ms": cnt["prep_ms"], "merge_ms": cnt["merge_ms"], "comm_ms": cnt.get("comm_ms", 0.0),
+            "fixed_ms": cnt.get("fixed_ms", 0.0), "comm_ranks": int(cnt.get("comm_ranks", 0)),
+            "match_form": int(cnt.get("match_form", 0))})
+    comm.close()
 
     if rank != 0:
         ctx.close()
-        return
+        return 0
 
     ms_per_step = elapsed / a.steps * 1e3
     value = w["m"] * a.steps / elapsed
@@ -380,6 +440,7 @@ def main():
             "prep_ms_per_step": round(cnt["prep_ms"] / a.steps, 4),
             "preproc_ms_per_step": round(cnt["preproc_ms"] / a.steps, 4),
             "merge_ms_per_step": round(cnt["merge_ms"] / a.steps, 4),
+            "fixed_ms_per_step": round(cnt.get("fixed_ms", 0.0) / a.steps, 4),
             "best_score_mean": float(scores[:, 0].mean()),
         },
     }
@@ -404,8 +465,34 @@ def main():
 
     # ---- the result of the timed run is checked before anything is printed
     n_check = a.check_rows if a.check_rows is not None else (32 if large else 64)
-    if world == 1 and n_check > 0:
+    if n_check > 0:  # N > 1: the MERGED result (all shards, after the RCCL all-gather) is what rank 0 holds
         out["check"] = check_result(w, exp, dic, bg, mask, scores, indices, n_check, large, a.compute)
+    if per_rank is not None:
+        # every rank must end with the bit-identical global result (total order of the merge)
+        same = all(p["result_sha256"] == per_rank[0]["result_sha256"] for p in per_rank)
+        assert same, f"ranks disagree on the merged result: {[p['result_sha256'][:12] for p in per_rank]}"
+        ranks_in_comm = sorted({p["comm_ranks"] for p in per_rank})
+        assert ranks_in_comm == [world], f"RCCL communicator sizes {ranks_in_comm}, expected {world} on every rank"
+        avg = [p["match_ms"] / max(p["match_launches"], 1) for p in per_rank]
+        tf = [p["match_flops"] / max(p["match_launches"], 1) / (m * 1e-3) / 1e12 if m > 0 else 0.0 for p, m in zip(per_rank, avg)]
+        slow = int(np.argmax(avg))
+        out["roofline"]["max_over_ranks"] = {
+            "rank": slow, "avg_launch_ms": round(avg[slow], 4), "achieved": round(tf[slow] * mfma_per_term, 2),
+            "frac": round(tf[slow] * mfma_per_term / peak_tflops, 4)}
+        out["multi_gpu"] = {
+            "rccl_ranks": world,  # ncclCommCount of every rank's communicator (asserted above)
+            "identical_result_on_every_rank": same,
+            "allgather_ms_per_step": round(max(p["comm_ms"] for p in per_rank) / a.steps, 4),
+            "allgather_ms_per_step_min_over_ranks": round(min(p["comm_ms"] for p in per_rank) / a.steps, 4),
+            "per_rank": [{"rank": p["rank"], "device": p["device"], "shard": p["shard"],
+                          "match_ms_per_step": round(p["match_ms"] / a.steps, 4),
+                          "prep_ms_per_step": round(p["prep_ms"] / a.steps, 4),
+                          "merge_ms_per_step": round(p["merge_ms"] / a.steps, 4),
+                          "fixed_ms_per_step": round(p["fixed_ms"] / a.steps, 4),
+                          "allgather_ms_per_step": round(p["comm_ms"] / a.steps, 4),
+                          "match_form": p["match_form"]} for p in per_rank],
+            "control_plane": "kikuchipy_amd.parallel.SocketGroup (TCP, loopback); data path: ncclAllGather inside kpdi_finalize",
+        }
 
     # ---- configs[2] inside the default run: circular signal mask (K = 2819) + static and dynamic
     # background removal fused with the preparation of the patterns (ONE pre-kernel), then the match
@@ -413,7 +500,7 @@ def main():
         try:
             w3 = WORKLOADS["config3"]
             mask3 = circular_mask(w3["sy"], w3["sx"])
-            c3 = _lib.Context(local_rank)
+            c3 = _lib.Context(device)
             c3.set_problem(w3["sy"], w3["sx"], mask3, metric, w3["keep_n"], compute)
             c3.set_profiling(True)
             reps = max(3, min(a.steps, 10))
@@ -512,7 +599,7 @@ def main():
         try:
             # informational: the same sweep with the OPT-IN float16 arithmetics of the match kernel.
             # Never `value`: the headline stays the exact-f32 GEMM north_star names.
-            c16 = _lib.Context(local_rank)
+            c16 = _lib.Context(device)
             c16.set_problem(w["sy"], w["sx"], mask, metric, w["keep_n"], getattr(_lib, mode))
             c16.set_profiling(True)
             for r in range(4):
@@ -549,7 +636,7 @@ def main():
         try:
             # informational: float64 arithmetic (the reference's dtype=float64) - the f32 sweep as the screen,
             # float64 rescoring of keep_n + 12 candidates per pattern from the raw patterns (csrc/rescore.hip).
-            c64 = _lib.Context(local_rank)
+            c64 = _lib.Context(device)
             c64.set_problem(w["sy"], w["sx"], mask, metric, w["keep_n"], _lib.COMPUTE_F64)
             c64.set_profiling(True)
             for r in range(4):
@@ -668,7 +755,7 @@ def main():
         except Exception as err:  # an informational leg must not cost the bench line
             out["extra"]["refinement_error"] = f"{type(err).__name__}: {err}"
 
-    if world == 1 and not a.no_cpu_baseline:
+    if not a.no_cpu_baseline:  # rank 0 only, whatever N (the other ranks have left)
         try:
             # bounded: ~10 s of CPU work on this host (20 000 dictionary patterns of configs[1] take ~4.5 s on 8
             # cores with either variant), whatever the workload; never more than the dictionary
@@ -685,7 +772,8 @@ def main():
                                    "error": f"{type(err).__name__}: {err}"}
     ctx.close()
     os.write(json_fd, (json.dumps(out) + "\n").encode())
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -361,7 +361,10 @@ typedef struct kpdi_counters {
   int64_t uncertified_patterns;  /* ... (pattern, chunk) pairs whose best-k could not be certified; 0 in practice */
   int32_t match_form;            /* operand form of the last match launch: 0 match.hip f32, 1 split f16, 2 float16 (match16.hip),
                                     3 f32 on match16.hip's one-wave-per-SIMD kernel (chosen per sweep, KPDI_F32_WIDE forces) */
-  int32_t reserved_;
+  int32_t comm_ranks;            /* ranks of the RCCL communicator (ncclCommCount), 0 = none attached */
+  double comm_ms;                /* RCCL all-gather of the per-rank best-k lists inside kpdi_finalize (incl. waiting for the
+                                    slowest rank to arrive) */
+  double fixed_ms;               /* per-sweep bookkeeping kernels around the match: list / bound / counter initialisation */
 } kpdi_counters;
 int kpdi_set_profiling(kpdi_ctx *ctx, int on);
 int kpdi_get_counters(kpdi_ctx *ctx, kpdi_counters *out);

@@ -60,7 +60,9 @@ class Counters(C.Structure):
         ("rescore_extra_passes", C.c_int64),
         ("uncertified_patterns", C.c_int64),
         ("match_form", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("comm_ranks", C.c_int32),
+        ("comm_ms", C.c_double),
+        ("fixed_ms", C.c_double),
     ]
 
     def as_dict(self):

@@ -98,6 +98,7 @@ struct Rccl {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
   std::string why;  // why the last load() failed
   bool load() {
     if (lib) return true;
@@ -129,6 +130,7 @@ struct Rccl {
     KPDI_SYM(GroupStart, "ncclGroupStart")
     KPDI_SYM(GroupEnd, "ncclGroupEnd")
     KPDI_SYM(GetErrorString, "ncclGetErrorString")
+    KPDI_SYM(CommCount, "ncclCommCount")
 #undef KPDI_SYM
     GetUniqueId = t.GetUniqueId;
     CommInitRank = t.CommInitRank;
@@ -137,6 +139,7 @@ struct Rccl {
     GroupStart = t.GroupStart;
     GroupEnd = t.GroupEnd;
     GetErrorString = t.GetErrorString;
+    CommCount = t.CommCount;
     lib = h;
     return true;
   }
@@ -256,7 +259,7 @@ struct kpdi_ctx {
 
   // measurement
   bool profiling = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_match, ev_prep, ev_merge, ev_proj, ev_pre, ev_rescore;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_match, ev_prep, ev_merge, ev_proj, ev_pre, ev_rescore, ev_comm, ev_fixed;
   std::vector<hipEvent_t> ev_pool;
   kpdi_counters cnt{};
 
@@ -2031,11 +2034,15 @@ int finalize64(kpdi_ctx *c, double *scores64, float *scores32, int64_t *indices_
     HIPCHK(c->gather64_i.reserve(n * c->nranks * sizeof(int)));
     HIPCHK(c->final64_s.reserve(n * sizeof(double)));
     HIPCHK(c->final64_i.reserve(n * sizeof(int)));
-    ncclResult_t r = g_rccl.GroupStart();
-    if (r == ncclSuccess) r = g_rccl.AllGather(d_s, c->gather64_s.p, n, ncclFloat64, c->comm, c->stream);
-    if (r == ncclSuccess) r = g_rccl.AllGather(d_i, c->gather64_i.p, n, ncclInt32, c->comm, c->stream);
-    ncclResult_t r2 = g_rccl.GroupEnd();
-    if (r == ncclSuccess) r = r2;
+    ncclResult_t r;
+    {
+      ScopedTimer t(c, &c->ev_comm);
+      r = g_rccl.GroupStart();
+      if (r == ncclSuccess) r = g_rccl.AllGather(d_s, c->gather64_s.p, n, ncclFloat64, c->comm, c->stream);
+      if (r == ncclSuccess) r = g_rccl.AllGather(d_i, c->gather64_i.p, n, ncclInt32, c->comm, c->stream);
+      ncclResult_t r2 = g_rccl.GroupEnd();
+      if (r == ncclSuccess) r = r2;
+    }
     if (r != ncclSuccess) return fail(KPDI_ECOMM, "RCCL all-gather failed: %s", g_rccl.GetErrorString(r));
     kpdi::Merge64Launch g{};
     g.m = c->m;
@@ -2102,11 +2109,15 @@ int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
   if (c->comm) {  // also with one rank: keeps the RCCL path testable on a single GPU
     HIPCHK(c->gather_s.reserve(n * c->nranks * sizeof(float)));
     HIPCHK(c->gather_i.reserve(n * c->nranks * sizeof(int)));
-    ncclResult_t r = g_rccl.GroupStart();
-    if (r == ncclSuccess) r = g_rccl.AllGather(d_s, c->gather_s.p, n, ncclFloat32, c->comm, c->stream);
-    if (r == ncclSuccess) r = g_rccl.AllGather(d_i, c->gather_i.p, n, ncclInt32, c->comm, c->stream);
-    ncclResult_t r2 = g_rccl.GroupEnd();
-    if (r == ncclSuccess) r = r2;
+    ncclResult_t r;
+    {
+      ScopedTimer t(c, &c->ev_comm);
+      r = g_rccl.GroupStart();
+      if (r == ncclSuccess) r = g_rccl.AllGather(d_s, c->gather_s.p, n, ncclFloat32, c->comm, c->stream);
+      if (r == ncclSuccess) r = g_rccl.AllGather(d_i, c->gather_i.p, n, ncclInt32, c->comm, c->stream);
+      ncclResult_t r2 = g_rccl.GroupEnd();
+      if (r == ncclSuccess) r = r2;
+    }
     if (r != ncclSuccess) return fail(KPDI_ECOMM, "RCCL all-gather failed: %s", g_rccl.GetErrorString(r));
     const int nxt = c->run_cur ^ 1;
     kpdi::MergeLaunch mg{};
@@ -2173,7 +2184,10 @@ int kpdi_comm_init(kpdi_ctx *c, int rank, int nranks, const uint8_t *id) {
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof uid);
   ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, uid, rank);
-  if (r != ncclSuccess) return fail(KPDI_ECOMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r));
+  if (r != ncclSuccess) {
+    c->comm = nullptr;
+    return fail(KPDI_ECOMM, "ncclCommInitRank(rank %d of %d, device %d): %s", rank, nranks, c->device, g_rccl.GetErrorString(r));
+  }
   c->rank = rank;
   c->nranks = nranks;
   return KPDI_OK;
@@ -2237,6 +2251,15 @@ int kpdi_get_counters(kpdi_ctx *c, kpdi_counters *out) {
   if (rc) return rc;
   rc = drain_events(c, c->ev_rescore, &c->cnt.rescore_ms);
   if (rc) return rc;
+  rc = drain_events(c, c->ev_comm, &c->cnt.comm_ms);
+  if (rc) return rc;
+  rc = drain_events(c, c->ev_fixed, &c->cnt.fixed_ms);
+  if (rc) return rc;
+  c->cnt.comm_ranks = 0;
+  if (c->comm) {
+    int count = 0;
+    if (g_rccl.CommCount(c->comm, &count) == ncclSuccess) c->cnt.comm_ranks = count;
+  }
   *out = c->cnt;
   return KPDI_OK;
 }

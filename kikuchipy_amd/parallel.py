@@ -15,12 +15,25 @@ Refinement shards the other way: every rank refines a contiguous block of the
 map's patterns (they are independent), and the per-pattern results (9 doubles)
 are concatenated over the control plane (`Communicator.all_gather_rows`).
 
-Control plane (rank discovery, the 128-byte RCCL unique id, barriers) goes
-through `torch.distributed` (gloo), which is what `torchrun` sets up; the data
-path never touches torch.
+Control plane (rank discovery, the 128-byte RCCL unique id, barriers, the
+max-over-ranks of a timing): `SocketGroup`, ~150 lines of plain TCP over the
+loopback interface - no PyTorch anywhere in this package.  It reads the same
+environment a launcher like `python -m torch.distributed.run` exports
+(RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), so the driver's command line
+works unchanged; `Communicator(..., broadcast_bytes=, barrier=, all_gather=)`
+accepts any other transport as three callables (tests/_gloo_worker.py passes
+`torch.distributed` ones).
 """
 
+import hashlib
+import io
+import json
 import os
+import socket
+import struct
+import time
+
+import numpy as np
 
 
 def shard_range(n_total, rank, world_size):
@@ -32,26 +45,254 @@ def shard_range(n_total, rank, world_size):
     return start, start + base + (1 if rank < rem else 0)
 
 
-class Communicator:
-    """Rank/world bookkeeping + creation of the RCCL communicator inside a
-    libkpdi context.  `broadcast_bytes(payload_or_None, src) -> bytes` moves the
-    unique id from rank 0 to everybody (default: torch.distributed)."""
+# ---------------------------------------------------------------------------------------------
+# wire format: no pickle (a socket is not a trusted source of code) - JSON for plain values,
+# the .npy format (allow_pickle=False) for arrays, a tagged list for tuples / lists of those
+# ---------------------------------------------------------------------------------------------
+def _encode(obj):
+    if obj is None:
+        return b"N"
+    if isinstance(obj, (bytes, bytearray, memoryview)):
+        return b"B" + bytes(obj)
+    if isinstance(obj, np.ndarray):
+        buf = io.BytesIO()
+        np.lib.format.write_array(buf, np.ascontiguousarray(obj), allow_pickle=False)
+        return b"A" + buf.getvalue()
+    if isinstance(obj, (tuple, list)):
+        parts = [_encode(o) for o in obj]
+        head = struct.pack("<cI", b"T" if isinstance(obj, tuple) else b"L", len(parts))
+        return head + b"".join(struct.pack("<Q", len(p)) + p for p in parts)
+    if isinstance(obj, np.generic):
+        obj = obj.item()
+    return b"J" + json.dumps(obj).encode()
 
-    def __init__(self, rank, world_size, broadcast_bytes=None, barrier=None, all_gather=None):
+
+def _decode(data):
+    tag, body = data[:1], data[1:]
+    if tag == b"N":
+        return None
+    if tag == b"B":
+        return bytes(body)
+    if tag == b"A":
+        return np.lib.format.read_array(io.BytesIO(body), allow_pickle=False)
+    if tag in (b"T", b"L"):
+        (n,) = struct.unpack("<I", body[:4])
+        out, at = [], 4
+        for _ in range(n):
+            (ln,) = struct.unpack("<Q", body[at:at + 8])
+            out.append(_decode(body[at + 8:at + 8 + ln]))
+            at += 8 + ln
+        return tuple(out) if tag == b"T" else out
+    if tag == b"J":
+        return json.loads(body.decode())
+    raise ValueError(f"unknown message tag {tag!r}")
+
+
+def _send_msg(sock, payload):
+    sock.sendall(struct.pack("<Q", len(payload)) + payload)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(min(n - len(buf), 1 << 20))
+        if not chunk:
+            raise ConnectionError("control-plane peer closed the connection (did another rank fail?)")
+        buf += chunk
+    return bytes(buf)
+
+
+def _recv_msg(sock):
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+_MAGIC = b"KPDI-RDV1"
+_PORT_CANDIDATES = 32
+
+
+def _job_token(world_size):
+    """What tells this job's rendezvous from a stale / foreign one on a neighbouring port: the
+    launcher's run id when it exports one (torchrun: TORCHELASTIC_RUN_ID; bench.py's own spawner:
+    KPDI_JOB_ID) and the world size."""
+    run = os.environ.get("KPDI_JOB_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or "none"
+    return hashlib.sha256(f"{run}/{int(world_size)}".encode()).digest()[:16]
+
+
+class SocketGroup:
+    """The ranks of one job as a TCP star around rank 0.
+
+    Rendezvous: rank 0 listens on MASTER_ADDR at the first free port of MASTER_PORT,
+    MASTER_PORT + 1, ... (under `torch.distributed.run` MASTER_PORT itself is taken by the
+    launcher's own store, so the first candidate is usually busy) and GREETS every connection with
+    a magic string + the job token; the other ranks walk the same candidates and only talk to a
+    server that greeted them correctly - they never write to a foreign server.  Every collective
+    goes through rank 0 (world sizes are <= 8 and the payloads are a 128-byte id, a timing, or a few
+    result rows: latency of tens of microseconds on loopback, irrelevant next to a sweep)."""
+
+    def __init__(self, rank, world_size, master_addr=None, master_port=None, timeout=120.0):
+        self.rank, self.world_size = int(rank), int(world_size)
+        if not 0 <= self.rank < self.world_size:
+            raise ValueError(f"bad rank {rank} / world size {world_size}")
+        self.timeout = float(timeout)
+        self._peers = {}  # rank 0: rank -> socket
+        self._up = None   # other ranks: socket to rank 0
+        self._server = None
+        if self.world_size == 1:
+            return
+        addr = master_addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(master_port or os.environ.get("MASTER_PORT", "29500"))
+        token = _job_token(self.world_size)
+        if self.rank == 0:
+            self._listen(addr, port, token)
+        else:
+            self._connect(addr, port, token)
+
+    @classmethod
+    def from_env(cls, timeout=120.0):
+        """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as exported by `python -m
+        torch.distributed.run` or by `bench.py --gpus N`'s own spawner."""
+        return cls(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), timeout=timeout)
+
+    # -- rendezvous
+    def _listen(self, addr, port, token):
+        srv, err = None, None
+        for cand in range(port, port + _PORT_CANDIDATES):
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            try:
+                s.bind((addr, cand))
+                s.listen(self.world_size)
+                srv = s
+                break
+            except OSError as e:  # busy (the launcher's store, a previous job): next candidate
+                err = e
+                s.close()
+        if srv is None:
+            raise ConnectionError(f"rank 0 found no free rendezvous port in {port}..{port + _PORT_CANDIDATES - 1}: {err}")
+        self._server = srv
+        self.port = srv.getsockname()[1]
+        deadline = time.monotonic() + self.timeout
+        while len(self._peers) < self.world_size - 1:
+            srv.settimeout(max(0.05, deadline - time.monotonic()))
+            try:
+                conn, _ = srv.accept()
+            except socket.timeout:
+                missing = sorted(set(range(1, self.world_size)) - set(self._peers))
+                raise TimeoutError(f"rendezvous: ranks {missing} did not join within {self.timeout:.0f} s") from None
+            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            conn.settimeout(5.0)
+            try:
+                conn.sendall(_MAGIC + token)
+                peer, world = struct.unpack("<ii", _recv_exact(conn, 8))
+            except (OSError, ConnectionError):
+                conn.close()  # a port scanner, a rank of another job that read the token and left
+                continue
+            if world != self.world_size or not 0 < peer < world or peer in self._peers:
+                conn.close()
+                continue
+            conn.settimeout(self.timeout)
+            self._peers[peer] = conn
+
+    def _connect(self, addr, port, token):
+        deadline = time.monotonic() + self.timeout
+        want = _MAGIC + token
+        while True:
+            for cand in range(port, port + _PORT_CANDIDATES):
+                s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                s.settimeout(1.0)
+                try:
+                    s.connect((addr, cand))
+                    # only OUR rank 0 speaks first; a foreign server stays silent -> timeout -> next
+                    s.settimeout(0.5)
+                    if _recv_exact(s, len(want)) == want:
+                        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        s.settimeout(self.timeout)
+                        s.sendall(struct.pack("<ii", self.rank, self.world_size))
+                        self._up, self.port = s, cand
+                        return
+                except (OSError, ConnectionError):
+                    pass
+                s.close()
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"rank {self.rank}: no rendezvous server of this job on {addr}:{port}.."
+                                   f"{port + _PORT_CANDIDATES - 1} within {self.timeout:.0f} s")
+            time.sleep(0.05)
+
+    # -- collectives (every rank must call them in the same order)
+    def all_gather(self, obj):
+        """[rank 0's obj, rank 1's obj, ...] on every rank."""
+        if self.world_size == 1:
+            return [obj]
+        mine = _encode(obj)
+        if self.rank == 0:
+            parts = [mine] + [_recv_msg(self._peers[r]) for r in range(1, self.world_size)]
+            blob = _encode(parts)
+            for r in range(1, self.world_size):
+                _send_msg(self._peers[r], blob)
+        else:
+            _send_msg(self._up, mine)
+            parts = _decode(_recv_msg(self._up))
+        return [_decode(p) for p in parts]
+
+    def broadcast_bytes(self, payload, src=0):
+        """`payload` of rank `src` on every rank."""
+        if self.world_size == 1:
+            return payload
+        return self.all_gather(payload if self.rank == src else None)[src]
+
+    def barrier(self):
+        self.all_gather(None)
+
+    def all_reduce_max(self, value):
+        return max(float(v) for v in self.all_gather(float(value)))
+
+    def close(self):
+        for s in list(self._peers.values()) + [self._up, self._server]:
+            if s is not None:
+                try:
+                    s.close()
+                except OSError:
+                    pass
+        self._peers, self._up, self._server = {}, None, None
+
+    def __del__(self):
+        self.close()
+
+
+class Communicator:
+    """Rank/world bookkeeping + creation of the RCCL communicator inside a libkpdi context.
+    Transport of the control plane: a `SocketGroup` (default: from the environment), or three
+    callables - `broadcast_bytes(payload_or_None, src) -> bytes`, `barrier()`,
+    `all_gather(obj) -> list` - of whatever the caller already runs (MPI, torch.distributed)."""
+
+    def __init__(self, rank, world_size, broadcast_bytes=None, barrier=None, all_gather=None, group=None):
         self.rank = int(rank)
         self.world_size = int(world_size)
-        self._broadcast = broadcast_bytes or _torch_broadcast_bytes
-        self._barrier = barrier or _torch_barrier
-        self._all_gather = all_gather or _torch_all_gather
+        self.group = group
+        if self.world_size > 1 and group is None and not (broadcast_bytes and barrier and all_gather):
+            self.group = group = SocketGroup(self.rank, self.world_size)
+        self._broadcast = broadcast_bytes or (group.broadcast_bytes if group else None)
+        self._barrier = barrier or (group.barrier if group else None)
+        self._all_gather = all_gather or (group.all_gather if group else None)
 
     @classmethod
     def from_env(cls):
-        """RANK / WORLD_SIZE as exported by `python -m torch.distributed.run`."""
+        """RANK / WORLD_SIZE (+ MASTER_ADDR / MASTER_PORT for the rendezvous) as exported by
+        `python -m torch.distributed.run` or `bench.py --gpus N`."""
         return cls(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
     def barrier(self):
         if self.world_size > 1:
             self._barrier()
+
+    def all_gather(self, obj):
+        """One object per rank (rank order) on every rank, over the control plane."""
+        if self.world_size == 1:
+            return [obj]
+        return list(self._all_gather(obj))
+
+    def all_reduce_max(self, value):
+        return max(float(v) for v in self.all_gather(float(value)))
 
     def exchange_unique_id(self, make_id):
         """Rank 0 creates the id with `make_id()`; every rank returns it."""
@@ -65,7 +306,7 @@ class Communicator:
         per-pattern results (refinement: a few doubles per pattern) over the control plane."""
         if self.world_size == 1:
             return array
-        return _concat(self._all_gather(array))
+        return np.concatenate([np.asarray(b) for b in self._all_gather(array)], axis=0)
 
     def attach(self, ctx):
         """Create the RCCL communicator of `ctx` once (collective call: every rank must attach
@@ -78,39 +319,6 @@ class Communicator:
         ctx.comm_init(self.rank, self.world_size, uid)
         ctx._comm = self
 
-
-def init_process_group(backend="gloo"):
-    """Join the job `torchrun` started (MASTER_ADDR/PORT, RANK, WORLD_SIZE)."""
-    import torch.distributed as dist
-
-    if not dist.is_initialized():
-        dist.init_process_group(backend=backend)
-    return dist
-
-
-def _torch_broadcast_bytes(payload, src):
-    import torch.distributed as dist
-
-    box = [payload]
-    dist.broadcast_object_list(box, src=src)
-    return box[0]
-
-
-def _torch_barrier():
-    import torch.distributed as dist
-
-    dist.barrier()
-
-
-def _torch_all_gather(obj):
-    import torch.distributed as dist
-
-    box = [None] * dist.get_world_size()
-    dist.all_gather_object(box, obj)
-    return box
-
-
-def _concat(blocks):
-    import numpy as np
-
-    return np.concatenate([np.asarray(b) for b in blocks], axis=0)
+    def close(self):
+        if self.group is not None:
+            self.group.close()

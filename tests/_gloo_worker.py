@@ -1,5 +1,6 @@
-"""Worker of tests/test_distributed_gloo.py: launched by torch.distributed.run
-with 2 ranks on CPU (gloo).  Exercises the N>1 host path: rendezvous, unique-id
+"""Worker of tests/test_distributed_gloo.py: 2 ranks on CPU, once over torch.distributed (gloo,
+launched by torch.distributed.run - the optional transport) and once over the product's own TCP
+control plane (KPDI_TEST_TRANSPORT=socket, launched as two plain processes).  Exercises the N>1 host path: rendezvous, unique-id
 exchange, dictionary sharding, and that merging per-shard best-k lists with
 the (score desc, index asc) rule reproduces the global result.  The GPU data
 path (RCCL all-gather + merge kernel) implements the same merge; here the CPU
@@ -12,12 +13,35 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from kikuchipy_amd.parallel import Communicator, init_process_group, shard_range  # noqa: E402
+from kikuchipy_amd.parallel import Communicator, shard_range  # noqa: E402
 from oracle import kpdi_oracle as ko  # noqa: E402
 
-dist = init_process_group("gloo")
-comm = Communicator.from_env()
-assert comm.world_size == dist.get_world_size() == 2 and comm.rank == dist.get_rank()
+TRANSPORT = os.environ.get("KPDI_TEST_TRANSPORT", "gloo")
+if TRANSPORT == "gloo":
+    # the optional transport: torch.distributed (gloo) handed to Communicator as three callables
+    import torch.distributed as dist  # (test only: the product's control plane is torch-free)
+
+    dist.init_process_group(backend="gloo")
+
+    def _bcast(payload, src):
+        box = [payload]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    def _gather(obj):
+        box = [None] * dist.get_world_size()
+        dist.all_gather_object(box, obj)
+        return box
+
+    comm = Communicator(int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), broadcast_bytes=_bcast,
+                        barrier=dist.barrier, all_gather=_gather)
+    assert comm.group is None, "callables were given: no socket rendezvous must be attempted"
+    assert comm.world_size == dist.get_world_size() == 2 and comm.rank == dist.get_rank()
+else:
+    # the default transport: kikuchipy_amd.parallel.SocketGroup (plain TCP), no torch in the process
+    comm = Communicator.from_env()
+    assert comm.group is not None and comm.world_size == 2
+    assert "torch" not in sys.modules
 
 # 1. unique-id exchange: rank 0's payload reaches everybody
 uid = comm.exchange_unique_id(lambda: bytes(range(128)))
@@ -33,8 +57,7 @@ k = 6
 lo, hi = shard_range(len(dic), comm.rank, comm.world_size)
 s_loc, i_loc = ko.dictionary_indexing(exp, dic[lo:hi], metric="ncc", keep_n=k, n_per_iteration=97)
 i_loc = i_loc + lo
-gathered = [None, None]
-dist.all_gather_object(gathered, (s_loc, i_loc))
+gathered = comm.all_gather((s_loc, i_loc))
 scores = np.full((len(exp), k), -np.inf, dtype=np.float32)
 idx = np.full((len(exp), k), np.iinfo(np.int64).max, dtype=np.int64)
 for s_r, i_r in gathered:
@@ -57,63 +80,8 @@ import kikuchipy_amd as ka  # noqa: E402
 from kikuchipy_amd.indexing.similarity_metrics import NormalizedCrossCorrelationMetric, NormalizedDotProductMetric  # noqa: E402
 
 
-class OracleEngineContext:
-    live = 0
-
-    def __init__(self):
-        self.comm = None
-        self.pushed = []
-        OracleEngineContext.live += 1
-
-    def __del__(self):
-        OracleEngineContext.live -= 1
-
-    def set_problem(self, sy, sx, signal_mask, metric, keep_n, compute):
-        self.sig, self.mask, self.metric, self.keep_n = (sy, sx), signal_mask, {0: "ncc", 1: "ndp"}[metric], keep_n
-        self.scores = None
-
-    def set_keep_n(self, keep_n):
-        self.keep_n = keep_n
-        self.scores = None
-
-    def set_experimental(self, patterns, navigation_mask=None):
-        nav = None if navigation_mask is None else np.asarray(navigation_mask, dtype=bool).ravel()
-        self.exp = patterns if nav is None else patterns[~nav]
-        self.scores = None
-
-    @property
-    def n_experimental(self):
-        return len(self.exp)
-
-    @staticmethod
-    def comm_unique_id():
-        return bytes(range(128))
-
-    def comm_init(self, rank, nranks, uid):
-        assert uid == bytes(range(128)) and nranks == 2
-        self.comm = (rank, nranks)
-
-    def push_dictionary_chunk(self, patterns, global_start):
-        self.pushed.append((global_start, len(patterns)))
-        k = min(self.keep_n, len(patterns))
-        s, i = ko.dictionary_indexing(self.exp, patterns, metric=self.metric, keep_n=k, signal_mask=self.mask)
-        if self.scores is None:
-            self.scores = np.full((len(self.exp), self.keep_n), -np.inf, dtype=np.float32)
-            self.idx = np.full((len(self.exp), self.keep_n), np.iinfo(np.int64).max, dtype=np.int64)
-        self.scores, self.idx = ko.merge_topk(self.scores, self.idx, s, i + global_start, self.keep_n)
-
-    def finalize(self, keep_n):
-        assert keep_n == self.keep_n
-        if self.comm is None:
-            return self.scores, self.idx
-        box = [None, None]
-        dist.all_gather_object(box, (self.scores, self.idx))
-        s = np.full_like(self.scores, -np.inf)
-        i = np.full_like(self.idx, np.iinfo(np.int64).max)
-        for s_r, i_r in box:
-            s, i = ko.merge_topk(s, i, s_r, i_r, keep_n)
-        return s, i
-
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _standin_engine import StandInContext as OracleEngineContext  # noqa: E402
 
 exp4 = exp.reshape(3, 7, 12, 12)
 nav = np.zeros((3, 7), dtype=bool)
@@ -190,6 +158,11 @@ assert np.array_equal(res.num_evals, one.num_evals)
 lo5, hi5 = shard_range(5, comm.rank, 2)
 assert (lo5, hi5) == ((0, 3) if comm.rank == 0 else (3, 5))
 comm.barrier()
+assert comm.all_reduce_max(1.5 + comm.rank) == 2.5
+if TRANSPORT != "gloo":
+    assert "torch" not in sys.modules, "the product pulled torch in"
 if comm.rank == 0:
-    print("GLOO_WORKER_OK")
-dist.destroy_process_group()
+    print("GLOO_WORKER_OK" if TRANSPORT == "gloo" else "SOCKET_WORKER_OK")
+comm.close()
+if TRANSPORT == "gloo":
+    dist.destroy_process_group()

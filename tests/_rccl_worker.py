@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_multigpu.py: launched by torch.distributed.run with one rank per GPU.
+"""Worker of tests/test_gpu_multigpu.py: launched with one rank per GPU (RANK / WORLD_SIZE / MASTER_* in the environment).
 The REAL N > 1 path: every rank matches its dictionary shard on its own MI355X,
 `kpdi_finalize` all-gathers the per-rank best-k lists with RCCL over xGMI and merges them; the
 result of every rank must equal the oracle's single-process result.  Called twice (a new engine
@@ -14,12 +14,14 @@ os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import kikuchipy_amd as ka  # noqa: E402
-from kikuchipy_amd.parallel import Communicator, init_process_group  # noqa: E402
+from kikuchipy_amd import _lib  # noqa: E402
+from kikuchipy_amd.parallel import Communicator  # noqa: E402
 from oracle import kpdi_oracle as ko  # noqa: E402
 
-dist = init_process_group("gloo")
-comm = Communicator.from_env()
+comm = Communicator.from_env()  # TCP rendezvous on MASTER_ADDR:MASTER_PORT (no torch)
 device = int(os.environ.get("LOCAL_RANK", "0"))
+if os.environ.get("KPDI_BENCH_SHARE_GPU"):  # more ranks than GPUs (only to see what RCCL says about it)
+    device %= max(_lib.device_count(), 1)
 rng = np.random.default_rng(11)
 exp = rng.integers(0, 256, (6, 50, 60, 60)).astype(np.uint8)
 dic = rng.random((5003, 60, 60)).astype(np.float32)
@@ -36,10 +38,9 @@ for kw in (dict(metric="ncc", n_per_iteration=1300), dict(metric="ncc", n_per_it
         s, i = s[~nav.ravel()], i[~nav.ravel()]
     ko.assert_topk_parity(s, i, rs, ri, atol=1e-5)
     # every rank holds the identical result
-    box = [None] * comm.world_size
-    dist.all_gather_object(box, (res.scores, res.simulation_indices))
+    box = comm.all_gather((res.scores, res.simulation_indices))
     assert all(np.array_equal(b[0], box[0][0]) and np.array_equal(b[1], box[0][1]) for b in box)
 comm.barrier()
 if comm.rank == 0:
     print("RCCL_WORKER_OK", comm.world_size)
-dist.destroy_process_group()
+comm.close()

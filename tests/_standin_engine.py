@@ -1,0 +1,162 @@
+"""A stand-in for `kikuchipy_amd._lib.Context` on machines without a GPU (test infrastructure).
+
+It lets the REAL multi-rank host code - `kikuchipy_amd.dictionary_indexing(..., comm=)`, `bench.py`'s
+main() with its spawner, barriers, max-over-ranks timing, result check and JSON line - run under
+two ranks on CPU.  The oracle computes every pushed chunk; `finalize` does what kpdi_finalize does
+with RCCL - all-gather of the per-rank best-k lists + the (score desc, index asc) merge - over the
+communicator's control plane.  Like the real context it only gathers when `comm_init` reached it:
+a context that missed it returns its own shard's lists and every comparison with the global result
+fails (the id()-reuse bug of round 1).  "Device memory" is a dict of byte buffers addressed by
+integers, so pointer arithmetic on the host side (`d + offset`) behaves as with HBM pointers."""
+import time
+
+import numpy as np
+
+from oracle import kpdi_oracle as ko
+
+DTYPES = {0: np.uint8, 1: np.uint16, 2: np.float32, 3: np.float64, 8: np.float16}
+
+
+class StandInContext:
+    live = 0
+    _next_base = 1 << 40
+
+    def __init__(self, device=0):
+        self.device = device
+        self.comm = None
+        self._comm = None  # set by Communicator.attach, as on the real context
+        self.pushed = []
+        self.mem = {}
+        self.scores = None
+        self.pre = []
+        self.t = dict(match_ms=0.0, match_launches=0, match_flops=0.0, prep_ms=0.0, merge_ms=0.0, comm_ms=0.0,
+                      fixed_ms=0.0, preproc_ms=0.0, preproc_launches=0)
+        StandInContext.live += 1
+
+    def __del__(self):
+        StandInContext.live -= 1
+
+    # -- problem / patterns
+    def set_problem(self, sy, sx, signal_mask, metric, keep_n, compute=0):
+        self.sig, self.metric, self.keep_n = (sy, sx), {0: "ncc", 1: "ndp"}[metric], keep_n
+        self.mask = None if signal_mask is None else np.asarray(signal_mask, dtype=bool).reshape(sy, sx)
+        self.scores = None
+
+    def set_keep_n(self, keep_n):
+        self.keep_n = keep_n
+        self.scores = None
+
+    def set_experimental(self, patterns, navigation_mask=None):
+        nav = None if navigation_mask is None else np.asarray(navigation_mask, dtype=bool).ravel()
+        self.exp = patterns if nav is None else patterns[~nav]
+        self.scores = None
+        self.pre = []
+
+    def set_experimental_dev(self, d_ptr, dtype, m_all, navigation_mask=None):
+        sy, sx = self.sig
+        self.set_experimental(self._read(d_ptr, dtype, (m_all, sy, sx)), navigation_mask)
+
+    @property
+    def n_experimental(self):
+        return len(self.exp)
+
+    def remove_static_background(self, bg, operation=0, scale_bg=False):
+        self.pre.append(lambda e: ko.remove_static_background(e, np.asarray(bg).astype(e.dtype), "subtract" if operation == 0 else "divide",
+                                                              bool(scale_bg)))
+
+    def remove_dynamic_background(self, operation=0, filter_domain=0, std=0.0, truncate=4.0):
+        self.pre.append(lambda e: ko.remove_dynamic_background(e, "subtract" if operation == 0 else "divide",
+                                                               "frequency" if filter_domain == 0 else "spatial",
+                                                               std or None, truncate))
+
+    # -- sweep
+    def push_dictionary_chunk(self, patterns, global_start):
+        if self.pre:
+            for f in self.pre:
+                self.exp = f(self.exp)
+            self.pre = []
+        self.pushed.append((global_start, len(patterns)))
+        k = min(self.keep_n, len(patterns))
+        t0 = time.perf_counter()
+        s, i = ko.dictionary_indexing(self.exp, patterns, metric=self.metric, keep_n=k, signal_mask=self.mask)
+        self.t["match_ms"] += (time.perf_counter() - t0) * 1e3
+        self.t["match_launches"] += 1
+        kept = int(np.prod(self.sig)) if self.mask is None else int(np.count_nonzero(~self.mask))
+        self.t["match_flops"] += 2.0 * len(self.exp) * len(patterns) * kept
+        if self.scores is None:
+            self.scores = np.full((len(self.exp), self.keep_n), -np.inf, dtype=np.float32)
+            self.idx = np.full((len(self.exp), self.keep_n), np.iinfo(np.int64).max, dtype=np.int64)
+        self.scores, self.idx = ko.merge_topk(self.scores, self.idx, s, i + global_start, self.keep_n)
+
+    def push_dictionary_chunk_dev(self, d_ptr, dtype, n_chunk, global_start):
+        sy, sx = self.sig
+        self.push_dictionary_chunk(self._read(d_ptr, dtype, (n_chunk, sy, sx)), global_start)
+
+    def finalize(self, keep_n=None):
+        assert keep_n is None or keep_n == self.keep_n
+        if self.scores is None:  # a rank that pushed nothing contributes empty lists
+            self.scores = np.full((len(self.exp), self.keep_n), -np.inf, dtype=np.float32)
+            self.idx = np.full((len(self.exp), self.keep_n), np.iinfo(np.int64).max, dtype=np.int64)
+        if self.comm is None:
+            return self.scores, self.idx
+        t0 = time.perf_counter()
+        box = self._comm.all_gather((self.scores, self.idx))
+        self.t["comm_ms"] += (time.perf_counter() - t0) * 1e3
+        s = np.full_like(self.scores, -np.inf)
+        i = np.full_like(self.idx, np.iinfo(np.int64).max)
+        for s_r, i_r in box:
+            s, i = ko.merge_topk(s, i, np.asarray(s_r), np.asarray(i_r), self.keep_n)
+        return s, i
+
+    # -- multi-rank
+    @staticmethod
+    def comm_unique_id():
+        return bytes(range(128))
+
+    def comm_init(self, rank, nranks, uid):
+        assert uid == bytes(range(128)), "the unique id did not travel from rank 0"
+        self.comm = (rank, nranks)
+
+    # -- "device memory"
+    def dev_alloc(self, nbytes):
+        base = StandInContext._next_base
+        StandInContext._next_base += (int(nbytes) + (1 << 20)) & ~0xFFF
+        self.mem[base] = bytearray(int(nbytes))
+        return base
+
+    def _find(self, ptr):
+        for base, buf in self.mem.items():
+            if base <= ptr < base + max(len(buf), 1):
+                return buf, ptr - base
+        raise KeyError(f"pointer {ptr:#x} is not inside an allocation")
+
+    def h2d(self, d_ptr, array):
+        a = np.ascontiguousarray(array)
+        buf, off = self._find(d_ptr)
+        assert off + a.nbytes <= len(buf), "h2d beyond the allocation"
+        buf[off:off + a.nbytes] = a.tobytes()
+
+    def _read(self, d_ptr, dtype, shape):
+        buf, off = self._find(d_ptr)
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        assert off + n <= len(buf), "read beyond the allocation"
+        return np.frombuffer(bytes(buf[off:off + n]), dtype=dtype).reshape(shape)
+
+    # -- measurement
+    def synchronize(self):
+        pass
+
+    def set_profiling(self, on=True):
+        pass
+
+    def reset_counters(self):
+        for k in self.t:
+            self.t[k] = 0 if isinstance(self.t[k], int) else 0.0
+
+    def counters(self):
+        kept = int(np.prod(self.sig)) if self.mask is None else int(np.count_nonzero(~self.mask))
+        return dict(self.t, k_kept=kept, kpad=kept, match_grid=0, match_nsplit=0, match_form=-1,
+                    comm_ranks=self.comm[1] if self.comm else 0)
+
+    def close(self):
+        self.mem = {}

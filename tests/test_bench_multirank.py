@@ -1,0 +1,79 @@
+"""`bench.py --gpus N` under two ranks on CPU: the driver's command shapes, rehearsed.
+
+The engine is the stand-in of tests/_standin_engine.py (no GPU here); everything else is bench.py's
+own code: its spawner (`python bench.py --gpus 2` as typed), the launcher form (`python -m
+torch.distributed.run ... bench.py --gpus 2`), the TCP control plane of kikuchipy_amd.parallel, the
+dictionary shards, the check of the merged result against the C oracle, cpu_baseline, the JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+from test_distributed_gloo import free_port
+
+WORKER = os.path.join(ROOT, "tests", "_bench_worker.py")
+
+
+def run(cmd, extra_env=None):
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout  # the contract: ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def check_line(out, workload_key, n_gpus=2):
+    assert out["n_gpus"] == n_gpus and out["value"] > 0 and out["unit"] == "patterns/s"
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "strong"
+    assert workload_key in out["config"]["workload"]
+    assert out["check"]["rows"] == 8  # rank 0 checked the MERGED result against the C oracle
+    mg = out["multi_gpu"]
+    assert mg["rccl_ranks"] == n_gpus and mg["identical_result_on_every_rank"]
+    shards = [p["shard"] for p in mg["per_rank"]]
+    assert shards[0][0] == 0 and shards[-1][1] == out["config"]["dictionary_patterns"]
+    assert all(a[1] == b[0] for a, b in zip(shards, shards[1:]))
+    assert out["roofline"]["max_over_ranks"]["avg_launch_ms"] >= out["roofline"]["avg_launch_ms"] - 1e-9
+
+
+@pytest.mark.parametrize("workload,key,extra", [
+    ("config2", "configs[1]", ["--cpu-sample", "200"]),
+    ("config4", "configs[3]", ["--no-cpu-baseline"]),
+    ("config5", "configs[4]", ["--no-cpu-baseline", "--compute", "f16"]),
+])
+def test_bench_spawns_its_own_ranks(workload, key, extra):
+    out = run([sys.executable, WORKER, "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload,
+               "--check-rows", "8"] + extra)
+    check_line(out, key)
+    if workload == "config2":
+        cb = out["cpu_baseline"]
+        assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port"
+    else:
+        assert out["check"]["planted_found"] == 16
+
+
+def test_bench_under_the_launcher():
+    """The driver's form.  Under torch.distributed.run MASTER_PORT belongs to the launcher's own
+    store: the control plane must find its own port next to it."""
+    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(free_port()), WORKER, "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--workload", "config3", "--check-rows", "8", "--no-cpu-baseline"])
+    check_line(out, "configs[2]")
+
+
+def test_a_failing_rank_fails_the_run():
+    env = dict(os.environ, KPDI_BENCH_FAIL_RANK="1")
+    p = subprocess.run([sys.executable, WORKER, "--gpus", "2", "--steps", "1", "--warmup", "0", "--check-rows", "4",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and not p.stdout.strip()
+
+
+def test_bench_imports_no_torch():
+    text = open(os.path.join(ROOT, "bench.py")).read()
+    assert "import torch" not in text and "from torch" not in text

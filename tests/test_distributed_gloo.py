@@ -1,4 +1,5 @@
-"""world_size-2 test of the multi-rank host path on CPU (gloo backend)."""
+"""world_size-2 tests of the multi-rank host path on CPU: torch.distributed (gloo) as the optional
+transport, and the product's own torch-free TCP control plane (kikuchipy_amd.parallel.SocketGroup)."""
 import os
 import socket
 import subprocess
@@ -22,3 +23,87 @@ def test_two_ranks_gloo():
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "GLOO_WORKER_OK" in p.stdout
+
+
+def launch_plain(script, n_ranks, extra_env=None, args=()):
+    """One plain process per rank with the environment a launcher would export (no torch anywhere)."""
+    port = free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), KPDI_JOB_ID=f"test-{os.getpid()}-{port}", OMP_NUM_THREADS="1")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, script, *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-3000:] + se[-3000:]
+    return outs[0][0]
+
+
+def test_two_ranks_plain_sockets():
+    out = launch_plain(os.path.join(ROOT, "tests", "_gloo_worker.py"), 2, {"KPDI_TEST_TRANSPORT": "socket"})
+    assert "SOCKET_WORKER_OK" in out
+
+
+def test_socket_group_wire_format_and_port_walk():
+    """No pickle on the wire; a busy MASTER_PORT (the launcher's own store) is stepped over; a
+    foreign, silent server on a candidate port is never written to."""
+    import socket
+    import threading
+
+    import numpy as np
+
+    from kikuchipy_amd import parallel
+
+    for obj in (None, b"\x00\x01", 3, 2.5, "id", [1, "a", None], (np.arange(6, dtype=np.float32).reshape(2, 3), 7),
+                {"a": [1, 2]}, np.float64(1.5)):
+        back = parallel._decode(parallel._encode(obj))
+        if isinstance(obj, tuple):
+            assert isinstance(back, tuple) and np.array_equal(back[0], obj[0]) and back[1] == obj[1]
+        else:
+            assert back == obj
+    try:
+        parallel._encode(object())
+    except TypeError:
+        pass
+    else:
+        raise AssertionError("arbitrary objects must not be serialisable")
+
+    busy = socket.socket()
+    busy.bind(("127.0.0.1", 0))
+    busy.listen(8)  # silent: accepts (kernel backlog) but never greets - like torchrun's TCPStore
+    port = busy.getsockname()[1]
+    received = []
+    os.environ["KPDI_JOB_ID"] = "wire-test"
+    res = [None, None]
+
+    def rank(r):
+        g = parallel.SocketGroup(r, 2, "127.0.0.1", port, timeout=30)
+        res[r] = (g.port, g.all_gather(np.full(3, r)), g.broadcast_bytes(b"uid" if r == 0 else None, 0),
+                  g.all_reduce_max(10 + r))
+        g.barrier()
+        g.close()
+
+    threads = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    [t.start() for t in threads]
+    [t.join(60) for t in threads]
+    busy.settimeout(0.2)
+    try:
+        while True:
+            conn, _ = busy.accept()
+            conn.settimeout(0.2)
+            try:
+                received.append(conn.recv(64))
+            except OSError:
+                received.append(b"")
+            conn.close()
+    except OSError:
+        pass
+    busy.close()
+    del os.environ["KPDI_JOB_ID"]
+    assert res[0] is not None and res[1] is not None
+    assert res[0][0] == res[1][0] != port  # both ended on the same port next to the busy one
+    for r in range(2):
+        assert [list(a) for a in res[r][1]] == [[0, 0, 0], [1, 1, 1]] and res[r][2] == b"uid" and res[r][3] == 11.0
+    assert all(b == b"" for b in received), received  # nothing was ever sent to the foreign server

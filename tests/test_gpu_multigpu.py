@@ -9,7 +9,7 @@ import sys
 import pytest
 
 from conftest import ROOT
-from test_distributed_gloo import free_port
+from test_distributed_gloo import launch_plain
 
 pytestmark = pytest.mark.gpu
 
@@ -21,11 +21,21 @@ def test_sharded_dictionary_indexing_over_rccl():
     if n < 2:
         pytest.skip(f"{n} GPU visible: the multi-rank RCCL run needs at least 2")
     ranks = min(n, 8)
-    env = dict(os.environ)
-    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(ROOT, "tests", "_rccl_worker.py")]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    out = launch_plain(os.path.join(ROOT, "tests", "_rccl_worker.py"), ranks, {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert f"RCCL_WORKER_OK {ranks}" in out
+
+
+def test_bench_runs_sharded_over_rccl():
+    """`python bench.py --gpus N` as the driver types it, on every visible GPU (>= 2)."""
+    import json
+
+    from kikuchipy_amd import _lib
+
+    n = min(_lib.device_count(), 8)
+    if n < 2:
+        pytest.skip(f"{n} GPU visible: the multi-rank bench needs at least 2")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
-    assert f"RCCL_WORKER_OK {ranks}" in p.stdout
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == n and out["multi_gpu"]["rccl_ranks"] == n and out["check"]["rows"] == 64

@@ -26,5 +26,11 @@ def test_product_never_imports_torch_or_reference():
     for p in product_files():
         text = open(p).read()
         assert not pat.search(text), p
-        if not p.endswith("parallel.py"):  # control plane only (rendezvous/barrier)
-            assert not re.search(r"^\s*(from|import)\s+torch\b", text, re.M), p
+        # no PyTorch anywhere in the product - the control plane (parallel.py) is plain TCP
+        assert not re.search(r"^\s*(from|import)\s+torch\b", text, re.M), p
+
+
+def test_bench_and_entry_never_import_torch():
+    for name in ("bench.py", "__graft_entry__.py"):
+        text = open(os.path.join(ROOT, name)).read()
+        assert not re.search(r"^\s*(from|import)\s+torch\b", text, re.M), name
