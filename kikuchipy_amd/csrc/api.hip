@@ -171,6 +171,10 @@ struct kpdi_ctx {
   int k_kept = 0, kpad = 0;
   bool have_sig_mask = false;
   DevBuf pix_map;  // int[k_kept]
+  // signal mask as gather descriptors, one per 4 kept pixels (prep.hip: prep_wave_gather_kernel), when every such
+  // quad lies in at most two runs of consecutive detector pixels (a circular mask: one run per detector row)
+  DevBuf quad_desc;
+  bool have_quad_desc = false;
   int metric = KPDI_METRIC_NCC;
   int compute = KPDI_COMPUTE_F32;
   int f16_waves = 8;  // variant of the float16 kernel (match16.hip), fixed per problem: KPDI_F16_WAVES = 8 | 4
@@ -214,6 +218,17 @@ struct kpdi_ctx {
   DevBuf run_s[2], run_i[2];   // running best-k ping-pong
   int run_cur = 0;
   bool run_valid = false;
+  bool run_empty = true;          // no chunk merged yet: the running lists hold nothing (and are not initialised)
+  kpdi::FillSegments fills;       // small initialisations queued for ONE launch (queue_fill / flush_fills)
+  const float *tail_queued = nullptr;  // prepared chunk whose partial last tile is already queued for zeroing
+  // the match launch's bookkeeping (bound / counters) queued ahead of the preparation kernels by push_chunk_dev
+  struct MatchSetup {
+    bool valid = false;
+    int n_chunk = 0, n_tiles = 0, nsplit = 0, rows_per_launch = 0, list_len = 0;
+  } presetup;
+  struct MatchPlan {
+    int tail_tiles = 0, n_main = 0, fixed_draws = 3, bound_rank = 1, bound_grouped = 0, tail_units = 0, tail_nsplit = 0;
+  } preplan;
   bool final_valid = false;       // `final_idx` points at the lists kpdi_finalize handed out last
   const int *final_idx = nullptr;
   DevBuf osm_idx, osm_out;
@@ -306,6 +321,35 @@ int drain_events(kpdi_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> &li
   }
   list.clear();
   return KPDI_OK;
+}
+
+// ---- queued initialisations: one launch (kernels.h: FillSegments) instead of one per buffer
+int flush_fills(kpdi_ctx *c) {
+  if (c->fills.n == 0) return KPDI_OK;
+  {
+    ScopedTimer t(c, &c->ev_fixed);
+    HIPCHK(kpdi::launch_fill_segments(c->fills, c->stream));
+  }
+  c->fills.n = 0;
+  return KPDI_OK;
+}
+int queue_fill(kpdi_ctx *c, void *p, size_t words, unsigned value, int bound_used = -1) {
+  if (words == 0) return KPDI_OK;
+  if (c->fills.n == kpdi::FILL_SEGMENTS) {
+    int rc = flush_fills(c);
+    if (rc) return rc;
+  }
+  const int i = c->fills.n++;
+  c->fills.p[i] = (unsigned *)p;
+  c->fills.words[i] = words;
+  c->fills.value[i] = value;
+  c->fills.bound_used[i] = bound_used;
+  return KPDI_OK;
+}
+constexpr unsigned BITS_NEG_INF = 0xff800000u, BITS_INT_MAX = 0x7fffffffu;
+int queue_fill_topk(kpdi_ctx *c, float *scores, int *idx, size_t n) {
+  int rc = queue_fill(c, scores, n, BITS_NEG_INF);
+  return rc ? rc : queue_fill(c, idx, n, BITS_INT_MAX);
 }
 
 void dtype_range(int dtype, float *omin, float *omax) {
@@ -431,9 +475,14 @@ int prepare_experimental(kpdi_ctx *c) {
     // the preparation kernels write every column of every valid row; only the rows beyond m need zeros
     // (from the start of the 128-pattern tile m falls into: a tile's rows are interleaved)
     const size_t first = (size_t)(c->m / kpdi::TILE_DICT) * kpdi::TILE_DICT;
-    if (first < (size_t)c->m_pad)
-      HIPCHK(hipMemsetAsync(c->exp_x.as<float>() + first * c->kpad, 0, ((size_t)c->m_pad - first) * c->kpad * sizeof(float),
-                            c->stream));
+    if (first < (size_t)c->m_pad) {
+      int rc = queue_fill(c, c->exp_x.as<float>() + first * c->kpad, ((size_t)c->m_pad - first) * c->kpad, 0u);
+      if (rc) return rc;
+    }
+  }
+  {
+    int rc = flush_fills(c);  // (with whatever push_chunk_dev queued ahead: one launch)
+    if (rc) return rc;
   }
   bool fused = false;
   int rc = flush_preprocess(c, true, &fused);
@@ -448,6 +497,7 @@ int prepare_experimental(kpdi_ctx *c) {
   p.npix = c->npix;
   p.row_map = c->have_nav_mask ? c->row_map.as<int>() : nullptr;
   p.pix_map = c->have_sig_mask ? c->pix_map.as<int>() : nullptr;
+  p.quad_desc = c->have_sig_mask && c->have_quad_desc ? c->quad_desc.as<unsigned>() : nullptr;
   p.k = c->k_kept;
   p.kpad = c->kpad;
   p.n_out = c->m;
@@ -472,7 +522,7 @@ int ensure_running(kpdi_ctx *c) {
     HIPCHK(c->run_i[j].reserve(std::max<size_t>(n, 1) * sizeof(int)));
   }
   c->run_cur = 0;
-  HIPCHK(kpdi::launch_fill_topk(c->run_s[0].as<float>(), c->run_i[0].as<int>(), (int64_t)n, c->stream));
+  c->run_empty = true;  // the first merge of the sweep takes the partial lists alone; nothing to initialise
   if (c->exact64) {
     HIPCHK(c->run64_s.reserve(std::max<size_t>(n, 1) * sizeof(double)));
     HIPCHK(c->run64_i.reserve(std::max<size_t>(n, 1) * sizeof(int)));
@@ -514,17 +564,74 @@ void plan_xcd_grid(int rows, int nsplit, int tile_dict, int *xr, int *xs) {
 // work).  The last n_tiles % nsplit tiles are then handed out as QUARTER tiles by a second launch of the
 // kernel's 32-row form, whose lists join the merge as a third source.
 double wide_tail_plan(int n_tiles, int nsplit, int *shift);
-int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int nsplit, int rows_per_launch,
-              int list_len, int64_t global_start, const float *bound_s, const int *bound_i, bool allow_tail = false) {
-  const int row_blocks_all = c->m_pad / kpdi::TILE_EXP;
-  int tail_tiles = 0;
-  c->tail_nsplit = 0;
-  if (allow_tail && c->compute == KPDI_COMPUTE_F32 && !c->wide32 && bound_s == nullptr && row_blocks_all <= rows_per_launch &&
+// What a match launch needs initialised before it starts - the shared bound (when its plan changes), the tile counters of
+// the main and the tail launch - is QUEUED here (queue_fill), so that it shares one launch with whatever else the sweep
+// initialises; the plan itself is returned for run_match.
+typedef kpdi_ctx::MatchPlan MatchPlan;
+int match_setup(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int rows_per_launch, int list_len, bool bounded,
+                bool allow_tail, MatchPlan *pl) {
+  const int row_blocks = c->m_pad / kpdi::TILE_EXP;
+  *pl = MatchPlan{};
+  if (allow_tail && c->compute == KPDI_COMPUTE_F32 && !c->wide32 && !bounded && row_blocks <= rows_per_launch &&
       !getenv("KPDI_NO_TAIL")) {
     const int rounds = n_tiles / nsplit, rem = n_tiles % nsplit;
-    if (rounds >= 1 && rounds < 32 && rem > 0 && 4 * rem <= 3 * nsplit) tail_tiles = rem;
+    if (rounds >= 1 && rounds < 32 && rem > 0 && 4 * rem <= 3 * nsplit) pl->tail_tiles = rem;
   }
-  const int n_main = n_tiles - tail_tiles;
+  pl->n_main = n_tiles - pl->tail_tiles;
+  {
+    // the published ranks are only comparable under one plan: (re)initialise when it changes
+    int used;
+    kpdi::bound_plan(lists_per_split(c) * nsplit, list_len, &pl->bound_rank, &pl->bound_grouped, &used);
+    const int key = (pl->bound_rank << 8) | (pl->bound_grouped << 7) | used;
+    if (key != c->bound_key || bounded) {
+      HIPCHK(c->gthr.reserve((size_t)c->m_pad * kpdi::BOUND_SLOTS * sizeof(unsigned)));
+      int rc = queue_fill(c, c->gthr.p, (size_t)c->m_pad * kpdi::BOUND_SLOTS, 0u, used);
+      if (rc) return rc;
+      c->bound_key = bounded ? -1 : key;  // bounded passes always start from scratch
+    }
+  }
+  // Tile hand-out (match.hip): a workgroup's first `fixed_draws` tiles are fixed (sp, sp + nsplit, ...) so that
+  // the workgroups sharing an XCD stream the same operands at the same pace (the XCD's L2 then serves them:
+  // 26 -> ~12 GB crossing the fabric per config-2 launch); the last ~20 % are drawn from the row block's counter,
+  // which evens out the speeds at the end (all tiles fixed left CUs idle for the last ~10 % of the launch).
+  // KPDI_FIXED_FRAC overrides the fixed share.
+  {
+    double frac = 0.8;
+    if (const char *e = getenv("KPDI_FIXED_FRAC")) frac = atof(e);
+    const int per_wg = pl->n_main / nsplit;
+    pl->fixed_draws = (pl->tail_tiles > 0 || pl->n_main % nsplit == 0) && frac > 0 ? per_wg + 1 : std::max(3, (int)(frac * per_wg));
+  }
+  const size_t ctr_words = (size_t)row_blocks;
+  HIPCHK(c->tile_ctr.reserve(2 * ctr_words * sizeof(unsigned)));  // second half: the tail launch
+  int rc = queue_fill(c, c->tile_ctr.p, ctr_words, (unsigned)pl->fixed_draws * (unsigned)nsplit);
+  if (rc) return rc;
+  if (pl->tail_tiles > 0) {
+    pl->tail_units = (std::min(n_chunk, n_tiles * kpdi::TILE_DICT) - pl->n_main * kpdi::TILE_DICT + 31) / 32;
+    pl->tail_nsplit = std::min(nsplit, pl->tail_units);
+    rc = queue_fill(c, c->tile_ctr.as<unsigned>() + ctr_words, ctr_words, 3u * (unsigned)pl->tail_nsplit);
+    if (rc) return rc;
+  }
+  return KPDI_OK;
+}
+
+int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int nsplit, int rows_per_launch,
+              int list_len, int64_t global_start, const float *bound_s, const int *bound_i, bool allow_tail = false) {
+  c->tail_nsplit = 0;
+  MatchPlan pl;
+  const kpdi_ctx::MatchSetup &ps = c->presetup;
+  if (ps.valid && ps.n_chunk == n_chunk && ps.n_tiles == n_tiles && ps.nsplit == nsplit && ps.rows_per_launch == rows_per_launch &&
+      ps.list_len == list_len && bound_s == nullptr && allow_tail) {
+    pl = c->preplan;  // queued (and flushed with the preparation's own initialisations) by push_chunk_dev
+  } else {
+    int rc = match_setup(c, n_chunk, n_tiles, nsplit, rows_per_launch, list_len, bound_s != nullptr, allow_tail, &pl);
+    if (rc) return rc;
+  }
+  c->presetup.valid = false;
+  {
+    int rc = flush_fills(c);
+    if (rc) return rc;
+  }
+  const int tail_tiles = pl.tail_tiles, n_main = pl.n_main;
   const bool f16 = uses16(c);
   const int lists_per_split = ::lists_per_split(c);
   const size_t part = (size_t)c->m_pad * lists_per_split * nsplit * list_len;
@@ -549,36 +656,12 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
     (void)wide_tail_plan(n_main, nsplit, &ml.tail_shift);
     ml.tail_first = n_main - n_main % nsplit;
   }
-  {
-    // the published ranks are only comparable under one plan: (re)initialise when it changes
-    int rank, grouped, used;
-    kpdi::bound_plan(lists_per_split * nsplit, list_len, &rank, &grouped, &used);
-    const int key = (rank << 8) | (grouped << 7) | used;
-    if (key != c->bound_key || bound_s != nullptr) {
-      HIPCHK(c->gthr.reserve((size_t)c->m_pad * kpdi::BOUND_SLOTS * sizeof(unsigned)));
-      HIPCHK(kpdi::launch_init_bound(c->gthr.as<unsigned>(), c->m_pad, used, c->stream));
-      c->bound_key = bound_s != nullptr ? -1 : key;  // bounded passes always start from scratch
-    }
-    ml.bound_rank = rank;
-    ml.bound_grouped = grouped;
-  }
+  ml.bound_rank = pl.bound_rank;
+  ml.bound_grouped = pl.bound_grouped;
   ml.gthr = c->gthr.as<unsigned>();
-  // Tile hand-out (match.hip): a workgroup's first `fixed_draws` tiles are fixed (sp, sp + nsplit, ...) so that
-  // the workgroups sharing an XCD stream the same operands at the same pace (the XCD's L2 then serves them:
-  // 26 -> ~12 GB crossing the fabric per config-2 launch); the last ~20 % are drawn from the row block's counter,
-  // which evens out the speeds at the end (all tiles fixed left CUs idle for the last ~10 % of the launch).
-  // KPDI_FIXED_FRAC overrides the fixed share.
   ml.tile_groups = 1;
-  {
-    double frac = 0.8;
-    if (const char *e = getenv("KPDI_FIXED_FRAC")) frac = atof(e);
-    const int per_wg = n_main / nsplit;
-    ml.fixed_draws = (tail_tiles > 0 || n_main % nsplit == 0) && frac > 0 ? per_wg + 1 : std::max(3, (int)(frac * per_wg));
-  }
+  ml.fixed_draws = pl.fixed_draws;
   const size_t ctr_bytes = (size_t)(c->m_pad / kpdi::TILE_EXP) * sizeof(unsigned);
-  HIPCHK(c->tile_ctr.reserve(2 * ctr_bytes));  // second half: the tail launch
-  HIPCHK(kpdi::launch_fill_u32(c->tile_ctr.as<unsigned>(), (unsigned)ml.fixed_draws * (unsigned)nsplit,
-                               (int64_t)(ctr_bytes / sizeof(unsigned)), c->stream));
   ml.tile_ctr = c->tile_ctr.as<unsigned>();
   const int row_blocks = c->m_pad / kpdi::TILE_EXP;
   {
@@ -586,7 +669,8 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
     // several launches (large experimental sets) alternate between two streams: the workgroups
     // of launch j+1 start on the CUs that launch j's tail leaves idle
     const bool two = row_blocks > rows_per_launch && !getenv("KPDI_ONE_STREAM");
-    if (two) {
+    const bool tail2 = tail_tiles > 0 && !getenv("KPDI_TAIL_SERIAL");  // the tail launch runs on the second stream
+    if (two || tail2) {
       if (!c->stream2) {
         HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -619,8 +703,8 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
     if (tail_tiles > 0) {
       // 32-row units over the rows [n_main * 128, n_chunk): the same shared bound (a slot then holds the
       // larger of a main list's and a tail list's published entry - still backed by that many candidates)
-      const int units = (std::min(n_chunk, n_tiles * kpdi::TILE_DICT) - n_main * kpdi::TILE_DICT + 31) / 32;
-      const int ns_t = std::min(nsplit, units);
+      const int units = pl.tail_units;
+      const int ns_t = pl.tail_nsplit;
       const size_t part_t = (size_t)c->m_pad * 2 * ns_t * list_len;
       HIPCHK(c->tail_s.reserve(part_t * sizeof(float)));
       HIPCHK(c->tail_i.reserve(part_t * sizeof(int)));
@@ -634,11 +718,22 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
       tl.xcd_rows = tl.xcd_splits = 0;
       tl.part_scores = c->tail_s.as<float>();
       tl.part_idx = c->tail_i.as<int>();
-      tl.tile_ctr = c->tile_ctr.as<unsigned>() + ctr_bytes / sizeof(unsigned);
-      HIPCHK(kpdi::launch_fill_u32(tl.tile_ctr, 3u * (unsigned)ns_t, (int64_t)row_blocks, c->stream));
+      tl.tile_ctr = c->tile_ctr.as<unsigned>() + ctr_bytes / sizeof(unsigned);  // (initialised with the main launch's)
       tl.row_first = 0;
       tl.rows = row_blocks;
-      HIPCHK(kpdi::launch_match(tl, c->stream));
+      // The tail launch does not depend on the main launch (lists of its own, counters of its own, the shared bound is a
+      // filter that is valid however stale): on the second stream its workgroups start on the CUs the main launch's
+      // workgroups free one by one, instead of after the main launch has drained and a new one has ramped up.
+      // KPDI_TAIL_SERIAL=1 keeps it behind the main launch on the same stream.
+      static const bool serial = getenv("KPDI_TAIL_SERIAL") != nullptr;
+      if (serial) {
+        HIPCHK(kpdi::launch_match(tl, c->stream));
+      } else {
+        HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));  // recorded in front of the main launch (below)
+        HIPCHK(kpdi::launch_match(tl, c->stream2));
+        HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+      }
       c->tail_nsplit = ns_t;
     }
   }
@@ -656,15 +751,22 @@ int prepare_chunk(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chun
   const int tile = dict_tile(c);
   const int n_pad = kpdi::round_up(n_chunk, tile);
   const int n_tiles = n_pad / tile;
-  if (n_pad > n_chunk)  // rows of the last tile are interleaved: clear the whole tile
-    HIPCHK(hipMemsetAsync(out + (size_t)(n_tiles - 1) * tile * c->kpad, 0, (size_t)tile * c->kpad * sizeof(float),
-                          c->stream));
+  if (n_pad > n_chunk && c->tail_queued != out) {  // rows of the last tile are interleaved: clear the whole tile
+    int rc = queue_fill(c, out + (size_t)(n_tiles - 1) * tile * c->kpad, (size_t)tile * c->kpad, 0u);
+    if (rc) return rc;
+  }
+  c->tail_queued = nullptr;
+  {
+    int rc = flush_fills(c);
+    if (rc) return rc;
+  }
   kpdi::PrepLaunch p;
   p.raw = d_patterns;
   p.dtype = dtype;
   p.npix = c->npix;
   p.row_map = nullptr;
   p.pix_map = c->have_sig_mask ? c->pix_map.as<int>() : nullptr;
+  p.quad_desc = c->have_sig_mask && c->have_quad_desc ? c->quad_desc.as<unsigned>() : nullptr;
   p.k = c->k_kept;
   p.kpad = c->kpad;
   p.n_out = (int)n_chunk;
@@ -751,7 +853,34 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
   if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
   if (c->m == 0) return KPDI_OK;
   decide_form(c, n_chunk);
-  HIPCHK(c->dict_y.reserve((size_t)kpdi::round_up(n_chunk, dict_tile(c)) * c->kpad * sizeof(float)));
+  const int tile = dict_tile(c);
+  const int n_pad = kpdi::round_up(n_chunk, tile);
+  HIPCHK(c->dict_y.reserve((size_t)n_pad * c->kpad * sizeof(float)));
+  // Everything the step initialises - the shared bound and the tile counters of the match launch, the zero rows behind a
+  // partial last tile of this chunk and of the experimental matrix - is queued BEFORE the first preparation kernel and
+  // goes out as ONE launch (one rank's share of a sharded job is a 3 ms step: five small launches were 2 % of it).
+  if (!c->exact64 && c->keep_n <= kpdi::KMAX_LIMIT) {
+    rc = ensure_running(c);
+    if (rc) return rc;
+    kpdi_ctx::MatchSetup &ps = c->presetup;
+    ps.n_chunk = (int)n_chunk;
+    ps.n_tiles = n_pad / tile;
+    const int row_blocks = c->m_pad / kpdi::TILE_EXP;
+    ps.rows_per_launch = row_blocks;
+    ps.nsplit = choose_nsplit(c, row_blocks, ps.n_tiles, &ps.rows_per_launch);
+    ps.list_len = kpdi::match_list_len(c->keep_n);
+    rc = match_setup(c, ps.n_chunk, ps.n_tiles, ps.nsplit, ps.rows_per_launch, ps.list_len, false, true, &c->preplan);
+    if (rc) return rc;
+    ps.valid = true;
+    if (n_pad > n_chunk) {
+      float *out = c->dict_y.as<float>();
+      rc = queue_fill(c, out + (size_t)(ps.n_tiles - 1) * tile * c->kpad, (size_t)tile * c->kpad, 0u);
+      if (rc) return rc;
+      c->tail_queued = out;
+    }
+  }
+  rc = prepare_experimental(c);  // (flushes the queue in front of its kernel)
+  if (rc) return rc;
   rc = prepare_chunk(c, d_patterns, dtype, n_chunk, c->dict_y.as<float>());
   if (rc) return rc;
   return sweep_prepared(c, c->dict_y.as<float>(), n_chunk, global_start, d_patterns, dtype);
@@ -903,35 +1032,41 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
   mg.out_stride = k;
   mg.out_offset = 0;
   mg.k = k;
-  // source 0: the running best-k
-  mg.src_scores[0] = c->run_s[cur].as<float>();
-  mg.src_idx[0] = c->run_i[cur].as<int>();
-  mg.src_lists[0] = 1;
-  mg.src_len[0] = k;
-  mg.src_row_stride[0] = k;
-  mg.src_list_stride[0] = k;
+  // first source: the running best-k - unless this is the first chunk of the sweep (nothing to merge with, and
+  // nothing was initialised: ensure_running)
+  int ns = 0;
+  if (!c->run_empty) {
+    mg.src_scores[ns] = c->run_s[cur].as<float>();
+    mg.src_idx[ns] = c->run_i[cur].as<int>();
+    mg.src_lists[ns] = 1;
+    mg.src_len[ns] = k;
+    mg.src_row_stride[ns] = k;
+    mg.src_list_stride[ns] = k;
+    ++ns;
+  }
 
   if (k <= kpdi::KMAX_LIMIT) {
     const int len = kpdi::match_list_len(k);
     rc = run_match(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, len, global_start, nullptr, nullptr, true);
     if (rc) return rc;
-    mg.src_scores[1] = c->part_s.as<float>();
-    mg.src_idx[1] = c->part_i.as<int>();
+    mg.src_scores[ns] = c->part_s.as<float>();
+    mg.src_idx[ns] = c->part_i.as<int>();
     const int lps = lists_per_split(c);
-    mg.src_lists[1] = lps * nsplit;
-    mg.src_len[1] = len;
-    mg.src_row_stride[1] = lps * nsplit * len;
-    mg.src_list_stride[1] = len;
-    mg.n_src = 2;
+    mg.src_lists[ns] = lps * nsplit;
+    mg.src_len[ns] = len;
+    mg.src_row_stride[ns] = lps * nsplit * len;
+    mg.src_list_stride[ns] = len;
+    ++ns;
     if (c->tail_nsplit > 0) {
-      mg.src_scores[2] = c->tail_s.as<float>();
-      mg.src_idx[2] = c->tail_i.as<int>();
-      mg.src_lists[2] = 2 * c->tail_nsplit;
-      mg.src_len[2] = len;
-      mg.src_row_stride[2] = 2 * c->tail_nsplit * len;
-      mg.src_list_stride[2] = len;
-      mg.n_src = 3;
+      mg.src_scores[ns] = c->tail_s.as<float>();
+      mg.src_idx[ns] = c->tail_i.as<int>();
+      mg.src_lists[ns] = 2 * c->tail_nsplit;
+      mg.src_len[ns] = len;
+      mg.src_row_stride[ns] = 2 * c->tail_nsplit * len;
+      mg.src_list_stride[ns] = len;
+      ++ns;
     }
+    mg.n_src = ns;
   } else {
     // keep_n > 32: passes of 32 ranks; pass p only admits candidates ranked
     // strictly after the last entry of pass p-1
@@ -949,19 +1084,20 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
       if (rc) return rc;
       done += kp;
     }
-    mg.src_scores[1] = c->loc_s.as<float>();
-    mg.src_idx[1] = c->loc_i.as<int>();
-    mg.src_lists[1] = 1;
-    mg.src_len[1] = k;
-    mg.src_row_stride[1] = k;
-    mg.src_list_stride[1] = k;
-    mg.n_src = 2;
+    mg.src_scores[ns] = c->loc_s.as<float>();
+    mg.src_idx[ns] = c->loc_i.as<int>();
+    mg.src_lists[ns] = 1;
+    mg.src_len[ns] = k;
+    mg.src_row_stride[ns] = k;
+    mg.src_list_stride[ns] = k;
+    mg.n_src = ns + 1;
   }
   {
     ScopedTimer t(c, &c->ev_merge);
     HIPCHK(kpdi::launch_merge(mg, c->stream));
   }
   c->run_cur = nxt;
+  c->run_empty = false;
   return KPDI_OK;
 }
 
@@ -1192,7 +1328,7 @@ int kpdi_destroy(kpdi_ctx *c) {
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   release_held(c);
   c->pin_out.release();
-  for (DevBuf *b : {&c->pix_map, &c->exp_raw, &c->row_map, &c->exp_x, &c->dict_raw, &c->dict_y, &c->part_s,
+  for (DevBuf *b : {&c->pix_map, &c->quad_desc, &c->exp_raw, &c->row_map, &c->exp_x, &c->dict_raw, &c->dict_y, &c->part_s,
                     &c->part_i, &c->tail_s, &c->tail_i, &c->list16, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
                     &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps, &c->inv_map, &c->pre_scratch,
                     &c->mp_packed, &c->dcos, &c->rot, &c->proj_out,
@@ -1254,7 +1390,15 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
     if (keep.empty()) return fail(KPDI_EINVAL, "the signal mask excludes every pixel");
     HIPCHK(c->pix_map.reserve(keep.size() * sizeof(int)));
     HIPCHK(hipMemcpyAsync(c->pix_map.p, keep.data(), keep.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    std::vector<unsigned> desc;
+    c->have_quad_desc = kpdi::gather_descriptors(keep.data(), (int)keep.size(), npix, &desc);
+    if (c->have_quad_desc) {
+      HIPCHK(c->quad_desc.reserve(desc.size() * sizeof(unsigned)));
+      HIPCHK(hipMemcpyAsync(c->quad_desc.p, desc.data(), desc.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
+  } else {
+    c->have_quad_desc = false;
   }
   if ((c->pend.st || c->pend.dy) && c->have_exp && (sy != c->sy || sx != c->sx)) {
     bool dummy = false;  // recorded background-removal steps belong to the old detector shape
@@ -2102,6 +2246,13 @@ int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
   rc = ensure_running(c);  // a rank that pushed nothing contributes empty lists
   if (rc) return rc;
   if (c->exact64) return finalize64(c, nullptr, scores_out, indices_out);
+  if (c->run_empty) {
+    const size_t n0 = (size_t)c->m * c->keep_n;
+    rc = queue_fill_topk(c, c->run_s[c->run_cur].as<float>(), c->run_i[c->run_cur].as<int>(), n0);
+    if (!rc) rc = flush_fills(c);
+    if (rc) return rc;
+    c->run_empty = false;
+  }
   const int k = c->keep_n;
   const size_t n = (size_t)c->m * k;
   const float *d_s = c->run_s[c->run_cur].as<float>();

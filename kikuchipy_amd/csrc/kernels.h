@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace kpdi {
 
 // ---- tile geometry of the match kernel (match.hip) -------------------------
@@ -105,6 +107,7 @@ struct PrepLaunch {
   int npix;            // sy*sx
   const int *row_map;  // [n_out] source row per output row, or nullptr (identity)
   const int *pix_map;  // [k] kept pixel indices, or nullptr (all pixels)
+  const unsigned *quad_desc = nullptr;  // [ceil(k / 4)] gather_descriptors() of pix_map, or nullptr
   int k;               // kept pixels
   int kpad;
   int n_out;           // rows to produce
@@ -115,6 +118,11 @@ struct PrepLaunch {
   int f16_rows = F16_TILE, f16_step = F16_STEP;  // float16 form: patterns per tile / pixels per step of the layout
 };
 hipError_t launch_prep(const PrepLaunch &a, hipStream_t s);
+// host: the signal mask's pixel map as one descriptor per 4 kept pixels for the gather kernels of prep.hip - the quad's
+// pixels as (up to) two runs of consecutive detector pixels: bits 0-11 = detector pixel of element 0, bits 12-23 =
+// detector pixel of element j MINUS j (so that element e >= j is the e-th float behind it), bits 24-26 = j (4: one run).
+// Returns false when some quad needs more than two runs or npix > 4096 (descriptors unusable).
+bool gather_descriptors(const int *pix_map, int k, int npix, std::vector<unsigned> *out);
 // in place: prepared f32 rows [0, n_rows_pad) x kpad -> split-f16 form (KPDI_COMPUTE_F16X2): every
 // 128-byte row-slab (32 pixels) becomes 4 slots of high halves + 4 slots of low halves of
 // 2^12 * value, eight f16 pixels per 16-byte slot; n_rows_pad multiple of 128
@@ -140,6 +148,18 @@ struct MergeLaunch {
 hipError_t launch_merge(const MergeLaunch &a, hipStream_t s);
 hipError_t launch_fill_topk(float *scores, int *idx, int64_t n, hipStream_t s);
 hipError_t launch_fill_u32(unsigned *p, unsigned value, int64_t n, hipStream_t s);
+// ONE launch for all the small initialisations in front of a sweep (running lists, shared bound, tile counters, the zero
+// rows behind a partial tile): up to FILL_SEGMENTS word ranges, each filled with a constant, or (bound_used >= 0) with
+// the shared bound's pattern - slot (i % BOUND_SLOTS) < bound_used ? key(-inf) : key(+inf)
+constexpr int FILL_SEGMENTS = 8;
+struct FillSegments {
+  unsigned *p[FILL_SEGMENTS];
+  unsigned long long words[FILL_SEGMENTS];
+  unsigned value[FILL_SEGMENTS];
+  int bound_used[FILL_SEGMENTS];
+  int n = 0;
+};
+hipError_t launch_fill_segments(const FillSegments &f, hipStream_t s);
 hipError_t launch_last_column(const float *scores, const int *idx, int m, int stride, int col,
                               float *bound_score, int *bound_idx, hipStream_t s);
 

@@ -15,6 +15,7 @@
 // (merge_block_kernel: few experimental patterns -> many lists each); more are re-read from
 // L2 every round (merge_kernel).
 // Latency-bound and tiny next to the match kernel.
+#include <algorithm>
 #include "kernels.h"
 #include <limits.h>
 #include <math.h>
@@ -253,6 +254,35 @@ __global__ void fill_u32_kernel(unsigned *p, unsigned value, int64_t n) {
 hipError_t launch_fill_u32(unsigned *p, unsigned value, int64_t n, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, value, n);
+  return hipGetLastError();
+}
+
+// see kernels.h: FillSegments.  blockIdx.y = segment; 16-byte stores when the range allows them.
+__global__ __launch_bounds__(256) void fill_segments_kernel(FillSegments f) {
+  const int seg = blockIdx.y;
+  unsigned *p = f.p[seg];
+  const unsigned long long n = f.words[seg];
+  const unsigned value = f.value[seg];
+  const int used = f.bound_used[seg];
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+  unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  if (used < 0 && (((uintptr_t)p | (uintptr_t)(n * 4)) & 15) == 0) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = {value, value, value, value};
+    for (; i < n / 4; i += stride) ((u32x4 *)p)[i] = v;
+    return;
+  }
+  for (; i < n; i += stride)
+    p[i] = used < 0 ? value : ((int)(i & (BOUND_SLOTS - 1)) < used ? THRESHOLD_NONE : 0xffffffffu);
+}
+
+hipError_t launch_fill_segments(const FillSegments &f, hipStream_t s) {
+  if (f.n <= 0) return hipSuccess;
+  unsigned long long most = 0;
+  for (int i = 0; i < f.n; ++i) most = std::max(most, f.words[i]);
+  if (most == 0) return hipSuccess;
+  const unsigned gx = (unsigned)std::min<unsigned long long>((most + 1023) / 1024, 1024);
+  hipLaunchKernelGGL(fill_segments_kernel, dim3(gx, (unsigned)f.n), dim3(256), 0, s, f);
   return hipGetLastError();
 }
 

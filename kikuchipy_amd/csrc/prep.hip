@@ -37,6 +37,7 @@
 #include "prep_device.h"
 
 #include <algorithm>
+#include <cstring>
 
 namespace kpdi {
 
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, i
       const int c = 4 * (lane + 64 * i);
       Quad<T> q;
       q.v[0] = q.v[1] = q.v[2] = q.v[3] = (T)0;
-      if (c < k) q = *reinterpret_cast<const Quad<T> *>(p + c);
+      if (c < k) q = load_quad(p + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v[4 * i + e] = (float)q.v[e];
@@ -172,13 +173,23 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_kernel(const T *raw, i
 // The same register-resident scheme with 256 threads x 64 values: every pixel is read once
 // (vector loads when there is no signal mask, else a gather through the pixel map - the row
 // is then served by L2 after its first touch) and stored once as whole 16-byte slots.
+//
+// Plane-major forms (H16): a pattern owns 32 bytes of every 128-byte line it touches, the other three quarters belong
+// to its three neighbours in the tile.  `n_affine` > 0 makes those four workgroups neighbours in TIME and PLACE: block b
+// runs on XCD b % 8 (observed, used for speed only), so pattern 4 g + j goes to block ((g / 8) * 4 + j) * 8 + g % 8 -
+// the four quarters of a line then meet in ONE XCD's L2 within microseconds and leave it as a whole line.
 template <typename T, bool MASKED, bool H16>
 __global__ __launch_bounds__(PREP_THREADS) void prep_block_kernel(const T *raw, int npix, const int *row_map,
                                                                   const int *pix_map, int k, int kpad,
-                                                                  int metric, float *out, int split) {
+                                                                  int metric, float *out, int split, int n_affine) {
   __shared__ float red[PREP_THREADS / 64];
   const int tid = threadIdx.x;
-  const int r = blockIdx.x;
+  int r = blockIdx.x;
+  if (H16 && n_affine > 0) {
+    const int x = r & 7, q = r >> 3;
+    r = 4 * ((q >> 2) * 8 + x) + (q & 3);
+    if (r >= n_affine) return;
+  }
   const int64_t src = row_map ? row_map[r] : r;
   const T *p = raw + src * (int64_t)npix;
   float v[WAVE_VALUES];
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_block_kernel(const T *raw, 
     if (!MASKED) {
       Quad<T> q;
       q.v[0] = q.v[1] = q.v[2] = q.v[3] = (T)0;
-      if (c < k) q = *reinterpret_cast<const Quad<T> *>(p + c);
+      if (c < k) q = load_quad(p + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[4 * i + e] = (float)q.v[e];
     } else {
@@ -209,16 +220,30 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_block_kernel(const T *raw, 
 // in registers (as prep_block_kernel), the float16 rows are staged in LDS, and the workgroup writes them out
 // as whole lines.  LDS: 4 x (2 * kpad + 8) float16.
 constexpr int PREP16_THREADS = 1024;
-template <typename T, bool MASKED>
-__global__ __launch_bounds__(PREP16_THREADS) void prep16_block4_kernel(const T *raw, int npix, const int *row_map,
-                                                                       const int *pix_map, int k, int kpad,
-                                                                       int metric, int n_out, float *out, int form) {
+// NP = patterns per workgroup.  4 (1024 threads): whole 128-byte lines, but 64 values per thread x 1024 threads is all of
+// a CU's registers - ONE workgroup per CU, whose load, reduce and store phases nothing overlaps (3.7 TB/s on configs[4]).
+// 2 (512 threads): two workgroups per CU in different phases; a plane's 64 bytes of the two rows are one aligned half
+// line = one HBM burst, and the workgroup holding the other half runs on the same XCD at the same time (`affine`: block b
+// runs on XCD b % 8, so pair 2 G + j of row group G goes to block ((G / 8) * 2 + j) * 8 + G % 8), i.e. the halves meet in
+// that XCD's L2.
+template <typename T, bool MASKED, int NP>
+__global__ __launch_bounds__(256 * NP) void prep16_block4_kernel(const T *raw, int npix, const int *row_map,
+                                                                 const int *pix_map, int k, int kpad,
+                                                                 int metric, int n_out, float *out, int form) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  __shared__ float red[PREP16_THREADS / 64];
+  __shared__ float red[4 * NP];
+  constexpr int THREADS = 256 * NP;
   const int tid = threadIdx.x, g = tid >> 8, t = tid & 255, wave = tid >> 6;
-  const int r = blockIdx.x * 4 + g;
+  int unit = blockIdx.x;  // group of NP consecutive patterns
+  if (NP == 2) {
+    const int x = unit & 7, q = unit >> 3;
+    unit = 2 * ((q >> 1) * 8 + x) + (q & 1);
+  }
+  const int r0 = unit * NP;
+  if (r0 >= n_out) return;  // (whole workgroup)
+  const int r = r0 + g;
   const bool live = r < n_out;
-  const int row_halves = 2 * kpad + 8;  // + 16 bytes: the four rows start in different banks
+  const int row_halves = 2 * kpad + 8;  // + 16 bytes: the rows start in different banks
   _Float16 *stage = (_Float16 *)smem_raw + (size_t)g * row_halves;
   float v[WAVE_VALUES];
   float s = 0.f;
@@ -231,7 +256,7 @@ __global__ __launch_bounds__(PREP16_THREADS) void prep16_block4_kernel(const T *
       if (!MASKED) {
         Quad<T> q;
         q.v[0] = q.v[1] = q.v[2] = q.v[3] = (T)0;
-        if (c < k) q = *reinterpret_cast<const Quad<T> *>(p + c);
+        if (c < k) q = load_quad(p + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[4 * i + e] = (float)q.v[e];
       } else {
@@ -277,26 +302,24 @@ __global__ __launch_bounds__(PREP16_THREADS) void prep16_block4_kernel(const T *
     }
   }
   __syncthreads();
-  // ---- write-out: plane P of the four rows = one 128-byte line (rows 4b .. 4b+3 of a tile, 32 bytes each, the two
-  // 16-byte halves of a row swapped when its bit 3 is set - the same for all four); 16 threads per line, 8 bytes each
+  // ---- write-out: plane P of the NP rows = NP x 32 contiguous bytes (rows r0 .. of a tile, 32 bytes each, the two
+  // 16-byte halves of a row swapped when its bit 3 is set - the same for all of them); 4 threads per row, 8 bytes each
   const int lr = (form >> 8) & 0xff, bk = (form >> 16) & 0xff;
   const unsigned magic = bk == 48 ? 89478486u : 134217728u;
   const int nsteps = (int)__umulhi(2u * (unsigned)kpad, magic);
-  const int r0 = blockIdx.x * 4;
   const int row0 = r0 & ((1 << lr) - 1);
   const int swz = (row0 >> 3) & 1;
   const int planes = (2 * kpad) / 16, planes_per_step = bk / 16;
-  const int j = tid & 15, row = j >> 2, piece = j & 3;  // piece: 8 bytes = 4 pixels of the row's 32 bytes
+  const int j = tid & (4 * NP - 1), row = j >> 2, piece = j & 3;  // piece: 8 bytes = 4 pixels of the row's 32 bytes
   const int px = (((piece >> 1) ^ swz) << 3) + ((piece & 1) << 2);
-  for (int P = tid >> 4; P < planes; P += PREP16_THREADS / 16) {
+  for (int P = tid / (4 * NP); P < planes; P += THREADS / (4 * NP)) {
     const int step = (int)__umulhi((unsigned)(16 * P), magic);
     const int pl = P - step * planes_per_step;
     const size_t block = (size_t)(r0 >> lr) * nsteps + step;
     char *line = (char *)out + ((block * bk) << (lr + 1)) + (((size_t)pl << lr) + row0) * 32;
-    if (r0 + row < n_out || true) {  // rows beyond n_out hold zeros (their group staged zeros): keeps the line whole
-      const _Float16 *srcp = (const _Float16 *)smem_raw + (size_t)row * row_halves + 16 * P + px;
-      *reinterpret_cast<h4 *>(line + 32 * row + 8 * piece) = *reinterpret_cast<const h4 *>(srcp);
-    }
+    // rows beyond n_out hold zeros (their group staged zeros): keeps the line whole
+    const _Float16 *srcp = (const _Float16 *)smem_raw + (size_t)row * row_halves + 16 * P + px;
+    store_out(reinterpret_cast<h4 *>(line + 32 * row + 8 * piece), *reinterpret_cast<const h4 *>(srcp));
   }
 }
 
@@ -322,7 +345,7 @@ __global__ __launch_bounds__(PREP16_THREADS) void prep32_block4_kernel(const T *
       if (!MASKED) {
         Quad<T> q;
         q.v[0] = q.v[1] = q.v[2] = q.v[3] = (T)0;
-        if (c < k) q = *reinterpret_cast<const Quad<T> *>(p + c);
+        if (c < k) q = load_quad(p + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[4 * i + e] = (float)q.v[e];
       } else {
@@ -417,7 +440,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_lines_kernel(const T *
       const int c = 4 * (lane + 64 * i);
       Quad<T> q;
       q.v[0] = q.v[1] = q.v[2] = q.v[3] = (T)0;
-      if (c < k) q = *reinterpret_cast<const Quad<T> *>(p + c);
+      if (c < k) q = load_quad(p + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v[4 * i + e] = (float)q.v[e];
@@ -458,7 +481,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_masked_kernel(const T 
       for (int i = 0; i < WAVE_VALUES / 4; ++i) {
         const int c = 4 * (lane + 64 * i);
         if (c < npix) {
-          const Quad<T> q = *reinterpret_cast<const Quad<T> *>(p + c);
+          const Quad<T> q = load_quad(p + c);
           float4 w;
           w.x = (float)q.v[0];
           w.y = (float)q.v[1];
@@ -545,6 +568,85 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_wave_masked_dma_kernel(cons
   }
 }
 
+// ---- signal mask, float32 rows: the kept pixels gathered STRAIGHT from global memory ------------------------------
+// A signal mask keeps runs of consecutive detector pixels (a circular mask: one run per detector row), so four
+// consecutive KEPT pixels are almost always four consecutive floats of the raw row, and never more than two such
+// runs when gather_descriptors() says so.  A lane's quad is then two unaligned 16-byte buffer loads - element e
+// comes from the first while e < j, from the second (which starts j floats before the second run) after - instead
+// of a staged copy of the whole row in LDS: no LDS for the input, no barrier, no wait for the acknowledgement of the
+// previous row's stores, and the workgroup's LDS budget goes to writing whole 128-byte lines (write_lines4).
+// Reads past the row's end return zero (the buffer descriptor is sized to the row); they are never selected.
+bool gather_descriptors(const int *pix_map, int k, int npix, std::vector<unsigned> *out) {
+  out->clear();
+  if (npix > 4096 || k <= 0) return false;
+  for (int q = 0; 4 * q < k; ++q) {
+    const int n = std::min(4, k - 4 * q);
+    const int *p = pix_map + 4 * q;
+    int j = n;  // first element that does not continue the run of element 0
+    for (int e = 1; e < n; ++e)
+      if (p[e] != p[0] + e) {
+        j = e;
+        break;
+      }
+    for (int e = j + 1; e < n; ++e)
+      if (p[e] != p[j] + (e - j)) return false;  // a third run
+    const int off2 = j < n ? p[j] - j : p[0];      // >= 0: pix_map ascends, so p[j] > p[j - 1] >= j - 1
+    if (off2 < 0) return false;
+    out->push_back((unsigned)p[0] | ((unsigned)off2 << 12) | ((unsigned)(j < n ? j : 4) << 24));
+  }
+  return true;
+}
+
+template <bool LINES>
+__global__ __launch_bounds__(PREP_THREADS) void prep_wave_gather_kernel(const float *raw, int npix, const int *row_map,
+                                                                        const unsigned *quad_desc, int k, int kpad,
+                                                                        int metric, int n_out, float *out, int form) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * 4, r = r0 + wv;
+  float *stage = LINES ? (float *)smem_raw + (size_t)wv * kpad : nullptr;
+  float v[WAVE_VALUES];
+  float s = 0.f;
+  if (r < n_out) {
+    const int64_t src = row_map ? row_map[r] : r;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(raw + src * (int64_t)npix), 0, npix * 4, 0x00020000);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned d[WAVE_VALUES / 4];
+#pragma unroll
+    for (int i = 0; i < WAVE_VALUES / 4; ++i) d[i] = 4 * (lane + 64 * i) < k ? quad_desc[lane + 64 * i] : 0u;
+    u32x4 a[WAVE_VALUES / 4], b[WAVE_VALUES / 4];
+#pragma unroll
+    for (int i = 0; i < WAVE_VALUES / 4; ++i) {  // every load in flight before the first use
+      if (4 * 64 * i < k) {                      // (wave-uniform)
+        a[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((d[i] & 0xfffu) * 4u), 0, KPDI_PREP_NT ? 2 : 0);
+        b[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((d[i] >> 12) & 0xfffu) * 4u), 0, KPDI_PREP_NT ? 2 : 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WAVE_VALUES / 4; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      const int j = (int)(d[i] >> 24);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = 0.f;
+        if (4 * 64 * i < k) x = __uint_as_float(e < j ? a[i][e] : b[i][e]);
+        v[4 * i + e] = c + e < k ? x : 0.f;
+      }
+      s += (v[4 * i] + v[4 * i + 1]) + (v[4 * i + 2] + v[4 * i + 3]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < WAVE_VALUES; ++i) v[i] = 0.f;  // rows beyond the chunk: zeros (their line is shared with valid rows)
+  }
+  if (LINES) {
+    normalise_and_store_quads<64, WAVE_VALUES, true>(v, s, lane, r, k, kpad, metric, out, form, nullptr, stage);
+    __syncthreads();
+    write_lines4(out, (const float *)smem_raw, kpad, r0, kpad, form, threadIdx.x);
+  } else if (r < n_out) {
+    normalise_and_store_quads<64, WAVE_VALUES, false>(v, s, lane, r, k, kpad, metric, out, form);
+  }
+}
+
 // ---- split-f16 form of a prepared matrix (KPDI_COMPUTE_F16X2), in place -------------------
 // One thread per (pattern row, 32-pixel slab): its eight 16-byte slots hold 32 floats
 // (slot q = pixels 4q..4q+3); they are rewritten as v * 2^12 = hi + lo with hi = f16(v * 2^12),
@@ -611,9 +713,16 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   // float32 rows (dictionaries): LDS-DMA, double-buffered (prep_wave_masked_dma_kernel)
   const size_t dma_lds = (size_t)(((a.k + 3) & ~3) + 8 * ((a.npix + 255) & ~255)) * 4;
   const bool staged_dma = staged && a.dtype == KPDI_F32 && dma_lds <= 160 * 1024 && !getenv("KPDI_PREP_NO_DMA");
+  // float32 rows whose mask is a set of runs: gathered straight from global memory (prep_wave_gather_kernel); the
+  // plane-major forms (2: float16, 3: wide float32) are written as whole lines through LDS, forms 0 / 1 as 16-byte slots
+  const bool gather = wave_path && a.pix_map != nullptr && a.quad_desc != nullptr && a.dtype == KPDI_F32 &&
+                      ((uintptr_t)a.raw % 4) == 0 && (a.operand_form < 2 || lines_lds <= 64 * 1024) &&
+                      !getenv("KPDI_PREP_NO_GATHER");
+  static const bool prep16_affine = getenv("KPDI_PREP16") && !strcmp(getenv("KPDI_PREP16"), "block");
+  static const int prep16_np = getenv("KPDI_PREP16") && !strcmp(getenv("KPDI_PREP16"), "block4") ? 4 : 2;
   dim3 block(PREP_THREADS);
   dim3 grid(wave_path ? (a.n_out + 3) / 4 : a.n_out);
-  if (staged) grid = dim3(std::min((a.n_out + 3) / 4, 2048));
+  if (staged && !gather) grid = dim3(std::min((a.n_out + 3) / 4, 2048));
 #define KPDI_PREP_H(T, H)                                                                                \
   if (H && vec4 && lines_lds <= 64 * 1024)                                                               \
     hipLaunchKernelGGL((prep_wave_lines_kernel<T>), grid, block, lines_lds, s, (const T *)a.raw, a.npix, a.row_map, a.k, \
@@ -641,16 +750,23 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
     hipLaunchKernelGGL((prep_wave_kernel<T, 1, H>), grid, block, 0, s, (const T *)a.raw, a.npix,        \
                        a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, H ? form : 0);       \
   else if (block_vec)                                                                                    \
-    hipLaunchKernelGGL((prep_block_kernel<T, false, H>), grid, block, 0, s, (const T *)a.raw, a.npix,   \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, form);                        \
+    hipLaunchKernelGGL((prep_block_kernel<T, false, H>), H ? dim3(round_up(a.n_out, 32)) : grid, block, 0, s,            \
+                       (const T *)a.raw, a.npix, a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, form, H ? a.n_out : 0); \
   else if (block_masked)                                                                                 \
-    hipLaunchKernelGGL((prep_block_kernel<T, true, H>), grid, block, 0, s, (const T *)a.raw, a.npix,    \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, form);                        \
+    hipLaunchKernelGGL((prep_block_kernel<T, true, H>), H ? dim3(round_up(a.n_out, 32)) : grid, block, 0, s,             \
+                       (const T *)a.raw, a.npix, a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.out, form, H ? a.n_out : 0); \
   else                                                                                                   \
     hipLaunchKernelGGL((prep_kernel<T>), grid, block, 0, s, (const T *)a.raw, a.npix, a.row_map,        \
                        a.pix_map, a.k, a.kpad, a.metric, a.out, H ? form : 0);
 #define KPDI_PREP(T)                  \
-  if (a.operand_form == 3 && (block_vec || block_masked)) {                                              \
+  if (gather) {                                                                                           \
+    if (a.operand_form >= 2)                                                                              \
+      hipLaunchKernelGGL((prep_wave_gather_kernel<true>), grid, block, lines_lds, s, (const float *)a.raw, a.npix,       \
+                         a.row_map, a.quad_desc, a.k, a.kpad, a.metric, a.n_out, a.out, form);            \
+    else                                                                                                  \
+      hipLaunchKernelGGL((prep_wave_gather_kernel<false>), grid, block, 0, s, (const float *)a.raw, a.npix,              \
+                         a.row_map, a.quad_desc, a.k, a.kpad, a.metric, a.n_out, a.out, form);            \
+  } else if (a.operand_form == 3 && (block_vec || block_masked)) {                                              \
     const size_t lds32 = (size_t)4 * (8 * ((a.kpad / 8 + 1) / 2) + 4) * 4;                               \
     auto k32 = block_masked ? prep32_block4_kernel<T, true> : prep32_block4_kernel<T, false>;            \
     if (lds32 > 64 * 1024) {                                                                             \
@@ -659,15 +775,18 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
     }                                                                                                    \
     hipLaunchKernelGGL(k32, dim3((a.n_out + 3) / 4), dim3(PREP16_THREADS), lds32, s, (const T *)a.raw, a.npix, \
                        a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form);               \
-  } else if (a.operand_form == 2 && (block_vec || block_masked)) {                                       \
-    const size_t lds16 = (size_t)4 * (2 * a.kpad + 8) * 2;                                               \
-    auto k16 = block_masked ? prep16_block4_kernel<T, true> : prep16_block4_kernel<T, false>;            \
+  } else if (a.operand_form == 2 && (block_vec || block_masked) && !prep16_affine) {                     \
+    const int np = prep16_np;                                                                            \
+    const size_t lds16 = (size_t)np * (2 * a.kpad + 8) * 2;                                              \
+    auto k16 = np == 2 ? (block_masked ? prep16_block4_kernel<T, true, 2> : prep16_block4_kernel<T, false, 2>)           \
+                       : (block_masked ? prep16_block4_kernel<T, true, 4> : prep16_block4_kernel<T, false, 4>);          \
     if (lds16 > 64 * 1024) {                                                                             \
       hipError_t e = hipFuncSetAttribute((const void *)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16); \
       if (e != hipSuccess) return e;                                                                     \
     }                                                                                                    \
-    hipLaunchKernelGGL(k16, dim3((a.n_out + 3) / 4), dim3(PREP16_THREADS), lds16, s, (const T *)a.raw, a.npix, \
-                       a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form);               \
+    /* NP = 2: the affine mapping walks row groups of 4 in blocks of 16 units */                         \
+    hipLaunchKernelGGL(k16, dim3(np == 2 ? round_up((a.n_out + 1) / 2, 16) : (a.n_out + 3) / 4), dim3(256 * np), lds16, s, \
+                       (const T *)a.raw, a.npix, a.row_map, a.pix_map, a.k, a.kpad, a.metric, a.n_out, a.out, form);     \
   } else if (a.operand_form >= 2) {   \
     KPDI_PREP_H(T, true)              \
   } else {                            \
@@ -693,7 +812,7 @@ hipError_t launch_prep(const PrepLaunch &a, hipStream_t s) {
   // paths that store whole float4 slots write the split-f16 form themselves; the others are
   // converted in place afterwards (rows beyond n_out are zero in either form).  The float16
   // form is written directly by every path.
-  if (a.operand_form == 1 && !(vec4 || staged || block_vec || block_masked))
+  if (a.operand_form == 1 && !(vec4 || staged || gather || block_vec || block_masked))
     return launch_split_f16(a.out, round_up(a.n_out, TILE_DICT), a.kpad, s);
   return hipSuccess;
 }

@@ -34,6 +34,47 @@ struct alignas(sizeof(T) * 4) Quad {
   T v[4];
 };
 
+// Four consecutive values of a raw pattern.  Raw patterns are read exactly once per preparation: the load is marked
+// non-temporal (KPDI_PREP_NT, default on) so that the stream does not push the prepared matrices the match kernel is
+// about to read out of the L2 / Infinity Cache.
+#ifndef KPDI_PREP_NT
+#define KPDI_PREP_NT 1
+#endif
+template <typename T>
+__device__ __forceinline__ Quad<T> load_quad(const T *p) {
+#if KPDI_PREP_NT
+  Quad<T> q;
+  if constexpr (sizeof(T) == 4) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    __builtin_memcpy(&q, &x, sizeof q);
+    return q;
+  } else if constexpr (sizeof(T) == 2) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 x = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p));
+    __builtin_memcpy(&q, &x, sizeof q);
+    return q;
+  } else if constexpr (sizeof(T) == 1) {
+    const unsigned x = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p));
+    __builtin_memcpy(&q, &x, sizeof q);
+    return q;
+  } else {
+    return *reinterpret_cast<const Quad<T> *>(p);
+  }
+#else
+  return *reinterpret_cast<const Quad<T> *>(p);
+#endif
+}
+// 8 / 16 bytes of a prepared row on their way out (KPDI_PREP_NT_STORE: non-temporal as well)
+template <typename V>
+__device__ __forceinline__ void store_out(V *dst, const V &v) {
+#if defined(KPDI_PREP_NT_STORE) && KPDI_PREP_NT_STORE
+  __builtin_nontemporal_store(v, dst);
+#else
+  *dst = v;
+#endif
+}
+
 // ---- float16 form (KPDI_COMPUTE_F16): a row holds 2 * kpad f16, value * 2^12, in the layout of
 // match16.hip: patterns in tiles of R rows (256, or 128 for the dictionary of the 4-wave variant),
 // pixels in steps of B (48 or 32); one (tile, step) block is contiguous and stored PLANE-major:
@@ -173,7 +214,9 @@ __device__ __forceinline__ void write_lines4(float *out, const float *stage, int
     const size_t block = (size_t)(r0 >> lr) * nsteps + step;
     char *line = (char *)out + ((block * bk) << (lr + 1)) + (((size_t)pl << lr) + row0) * 32;
     const float4 q = *reinterpret_cast<const float4 *>(stage + (size_t)row * row_floats + 8 * P + 4 * (half ^ swz));
-    *reinterpret_cast<float4 *>(line + 32 * row + 16 * half) = q;
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const f32x4v qv = {q.x, q.y, q.z, q.w};
+    store_out(reinterpret_cast<f32x4v *>(line + 32 * row + 16 * half), qv);
   }
 }
 
