@@ -79,9 +79,14 @@ typedef struct kpdi_ctx kpdi_ctx;
 /* FLOAT64 ARITHMETIC (the reference's `dtype=float64`, _similarity_metric.py:244-253): scores are those of a
  * float64 evaluation (to ~1e-15; summation order differs from a dgemm's), returned by kpdi_finalize_f64.  The
  * KPDI_COMPUTE_F32 path screens keep_n + 12 candidates per pattern and chunk, csrc/rescore.hip rescores them in
- * double from the RAW patterns, keeps the best keep_n in double and certifies that no unscreened candidate can
- * belong to them (more screening passes where it cannot; kpdi_counters.uncertified_patterns counts what is
- * left, 0 in practice).  Needs the raw chunk: not available for resident (held) dictionaries. */
+ * double from the RAW patterns, keeps the best keep_n in double and checks that no unscreened candidate can
+ * belong to them: an unscreened candidate's float32 score is at most the last screened one's, and its float64
+ * score at most eps above its float32 score.  eps = 8 x the largest |f32 - f64| difference seen among the rescored
+ * pairs of the sweep, at least 1e-6 - a STATISTICAL bound (about 1e5 samples per chunk, drawn from the best-scoring
+ * pairs); with KPDI_F64_EPS=worstcase in the environment its floor is the worst-case error of a K-term float32 dot
+ * product of unit vectors, (K + 2) 2^-24, i.e. a certificate for any data.  Where the check fails more screening
+ * passes run; kpdi_counters.uncertified_patterns counts what is left (0 in every test and stress case).  Needs the
+ * raw chunk: not available for resident (held) dictionaries. */
 #define KPDI_COMPUTE_F64 3
 
 /* background operations (`operation=` of remove_*_background) */

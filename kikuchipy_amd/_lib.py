@@ -520,7 +520,7 @@ class Context:
             scores = np.empty((m, keep_n), dtype=np.float32)
             check(load().kpdi_finalize(self._h, _ptr(scores), _ptr(indices)))
         self.result_token += 1
-        self._last_indices = indices  # what is now resident in HBM (holds_result)
+        self._last_indices = None
         if indices.size and indices[:, -1].max() >= 2**31 - 1:  # unfilled entries rank last
             # unfilled list entries (index INT_MAX, score -inf): fewer than keep_n candidates ranked, which
             # only happens when scores are NaN (NaN / inf in the patterns) - the reference propagates
@@ -529,6 +529,9 @@ class Context:
             raise KpdiError(f"{bad.size} experimental pattern(s) (first: {bad[0]}) ranked fewer than {keep_n} "
                             "dictionary patterns: NaN scores (NaN or inf in the patterns?) or a dictionary "
                             "smaller than keep_n")
+        # what is now resident in HBM (holds_result): a COPY - the caller may mask or remap the returned array in place,
+        # and must then not be told that the device still holds "these" lists
+        self._last_indices = indices.copy()
         return scores, indices
 
     # -- multi-GPU

@@ -987,7 +987,16 @@ int sweep_exact64(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_s
       g.s32_col = done + kp - 1;
       g.enumerated_all = done + kp >= n_chunk;
       g.max_diff = cert;
-      g.eps_floor = 1e-6f;
+      // what an unscreened candidate's float64 score may exceed its float32 score by: 8 x the largest difference seen
+      // among the rescored pairs of the sweep (a STATISTICAL bound: ~130 000 samples per chunk at configs[1], taken
+      // from the best-scoring pairs, whose partial sums - and rounding errors - are the largest), never less than
+      // 1e-6; KPDI_F64_EPS=worstcase raises the floor to the worst-case accumulation bound of a K-term float32 dot
+      // product of unit vectors, (K + 2) 2^-24 (2.1e-4 at K = 3600): a certificate that holds for any data, at the price
+      // of more screening passes where the k-th and the screened-last scores are closer than that
+      {
+        static const bool worstcase = getenv("KPDI_F64_EPS") && !strcmp(getenv("KPDI_F64_EPS"), "worstcase");
+        g.eps_floor = worstcase ? (float)((c->k_kept + 2) * 0x1p-24 * 1.01) + 1e-6f : 1e-6f;
+      }
       g.uncertified = (int *)(cert + 1);
       HIPCHK(kpdi::launch_merge64(g, c->stream));
       done += kp;
@@ -1414,7 +1423,7 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   const int wide_mode = getenv("KPDI_F32_WIDE") ? (atoi(getenv("KPDI_F32_WIDE")) != 0) : -1;
   bool wide32 = compute_dtype == KPDI_COMPUTE_F32 && (wide_mode == 1 || (wide_mode < 0 && c->have_problem && c->wide32));
   if (!c->have_problem || sy != c->sy || sx != c->sx || metric != c->metric || compute_dtype != c->compute ||
-      (signal_mask != nullptr) != c->have_sig_mask || keep != c->kept_pixels || waves != c->f16_waves || wide32 != c->wide32)
+      (signal_mask != nullptr) != c->have_sig_mask || keep != c->kept_pixels || wide32 != c->wide32)
     release_held(c);
   c->f16_waves = waves;
   c->wide32 = wide32;
@@ -2188,30 +2197,57 @@ int finalize64(kpdi_ctx *c, double *scores64, float *scores32, int64_t *indices_
       if (r == ncclSuccess) r = r2;
     }
     if (r != ncclSuccess) return fail(KPDI_ECOMM, "RCCL all-gather failed: %s", g_rccl.GetErrorString(r));
-    kpdi::Merge64Launch g{};
-    g.m = c->m;
-    g.k = k;
-    g.cand_s64 = c->gather64_s.as<double>();
-    g.cand_i = c->gather64_i.as<int>();
-    g.lists = c->nranks;
-    g.len = k;
-    g.row_stride = k;
-    g.list_stride = (int64_t)n;
-    g.out_s = c->final64_s.as<double>();
-    g.out_i = c->final64_i.as<int>();
+    // merge64_kernel ranks a pattern's candidates in LDS (12 bytes each): the per-rank lists join in groups that fit -
+    // all at once for ordinary keep_n, a few ranks at a time for very long lists (8 ranks x keep_n > 1600 exceeded the
+    // LDS of one launch and used to fail here, after the whole sweep, with a bare HIP error)
+    const size_t lds_entries = (150 * 1024) / (sizeof(double) + sizeof(int));
+    if ((size_t)2 * k > lds_entries)
+      return fail(KPDI_EINVAL, "keep_n = %d is too large for the float64 merge of several ranks (limit %zu)", k, lds_entries / 2);
     {
       ScopedTimer t(c, &c->ev_merge);
-      HIPCHK(kpdi::launch_merge64(g, c->stream));
+      for (int r0 = 0; r0 < c->nranks;) {
+        const size_t room = lds_entries - (r0 ? (size_t)k : 0);
+        const int group = (int)std::min<size_t>(c->nranks - r0, std::max<size_t>(room / k, 1));
+        kpdi::Merge64Launch g{};
+        g.m = c->m;
+        g.k = k;
+        g.run_s = r0 ? c->final64_s.as<double>() : nullptr;  // the result so far (in place: read into LDS first)
+        g.run_i = r0 ? c->final64_i.as<int>() : nullptr;
+        g.cand_s64 = c->gather64_s.as<double>() + (size_t)r0 * n;
+        g.cand_i = c->gather64_i.as<int>() + (size_t)r0 * n;
+        g.lists = group;
+        g.len = k;
+        g.row_stride = k;
+        g.list_stride = (int64_t)n;
+        g.out_s = c->final64_s.as<double>();
+        g.out_i = c->final64_i.as<int>();
+        HIPCHK(kpdi::launch_merge64(g, c->stream));
+        r0 += group;
+      }
     }
     d_s = c->final64_s.as<double>();
     d_i = c->final64_i.as<int>();
   }
   c->final_idx = d_i;
   c->final_valid = true;
-  std::vector<double> hs(n);
-  std::vector<int> hi(n);
-  HIPCHK(hipMemcpyAsync(hs.data(), d_s, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(hi.data(), d_i, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  // through the page-locked staging buffer of kpdi_finalize (a copy into pageable memory is pinned on the fly by the
+  // runtime: milliseconds, and slower kernels behind it)
+  std::vector<double> hs_pageable;
+  std::vector<int> hi_pageable;
+  double *hs;
+  int *hi;
+  if (c->pin_out.reserve(n * (sizeof(double) + sizeof(int))) == hipSuccess) {
+    hs = (double *)c->pin_out.p;
+    hi = (int *)(hs + n);
+  } else {
+    (void)hipGetLastError();
+    hs_pageable.resize(n);
+    hi_pageable.resize(n);
+    hs = hs_pageable.data();
+    hi = hi_pageable.data();
+  }
+  HIPCHK(hipMemcpyAsync(hs, d_s, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(hi, d_i, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   for (size_t i = 0; i < n; ++i) {
     if (scores64) scores64[i] = hs[i];

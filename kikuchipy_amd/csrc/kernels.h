@@ -15,8 +15,9 @@ constexpr int MATCH_THREADS = 256;
 constexpr int KMAX_LIMIT = 32;  // longest register-resident list of one pass
 
 // ---- the float16 form (KPDI_COMPUTE_F16) has its own kernel and layout (match16.hip, prep_device.h: half_slot)
-// Two variants (match16.hip): 8 waves = one workgroup per CU, 256 x 256 tiles, steps of 48 pixels; 4 waves = two
-// workgroups per CU, 128 (dictionary) x 256 tiles, steps of 32 pixels.
+// Two variants of ONE geometry (256 x 256 workgroup tiles, operand steps of 48 pixels): 8 waves = two per SIMD (default),
+// 4 waves = one per SIMD with a 128 x 128 wave tile (KPDI_F16_WAVES=4; also the skeleton of the f32 form).  Operands and
+// lists are the same for both: a change of the variant does not change the prepared layout.
 constexpr int F16_TILE = 256;     // experimental patterns per tile; dictionary patterns per tile of the 8-wave variant
 constexpr int F16_STEP = 48;      // pixels (float16) per LDS step of the 8-wave variant
 struct F16Geometry {

@@ -464,12 +464,16 @@ int match_blocks_per_cu() { return 1; }
 
 template <int KMAX, bool BOUNDED, int FORM, int ROWT = 4>
 static hipError_t launch_t(const MatchArgs &args, int grid, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  // (the attribute belongs to the function ON A DEVICE: remembered per device, not per process - a second context
+  // on another GPU would otherwise launch a 144 KB kernel without it)
+  static unsigned long long attr_set = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (!((attr_set >> (dev & 63)) & 1ull)) {
     hipError_t e = hipFuncSetAttribute((const void *)match_topk_kernel<KMAX, BOUNDED, FORM, ROWT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 32);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set |= 1ull << (dev & 63);
   }
   hipLaunchKernelGGL((match_topk_kernel<KMAX, BOUNDED, FORM, ROWT>), dim3(grid), dim3(MATCH_THREADS), LDS_BYTES + 32,
                      s, args);

@@ -607,12 +607,16 @@ size_t match16_scratch_bytes(int grid, int waves, int list_len) {
 
 template <int KMAX, bool BOUNDED, int WAVES, bool F32 = false>
 static hipError_t launch16_t(const MatchArgs &args, int grid, void *scratch, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  // (the attribute belongs to the function ON A DEVICE: remembered per device, not per process - a second context
+  // on another GPU would otherwise launch a 144 KB kernel without it)
+  static unsigned long long attr_set = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (!((attr_set >> (dev & 63)) & 1ull)) {
     hipError_t e = hipFuncSetAttribute((const void *)match16_kernel<KMAX, BOUNDED, WAVES, F32>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Geo<WAVES>::LDS + 32);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set |= 1ull << (dev & 63);
   }
   // scratch: scores of all lists, then their indices
   float *ls = (float *)scratch;

@@ -17,7 +17,9 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ float block_sum(float v, float *red) {
+// sum over a workgroup of NT threads; `red`: NT / 64 floats
+template <int NT>
+__device__ __forceinline__ float block_sum_n(float v, float *red) {
   v = wave_sum(v);
   const int w = threadIdx.x >> 6;
   __syncthreads();  // protect `red` from the previous use
@@ -25,9 +27,10 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
   __syncthreads();
   float t = 0.f;
 #pragma unroll
-  for (int i = 0; i < PREP_THREADS / 64; ++i) t += red[i];
+  for (int i = 0; i < NT / 64; ++i) t += red[i];
   return t;
 }
+__device__ __forceinline__ float block_sum(float v, float *red) { return block_sum_n<PREP_THREADS>(v, red); }
 
 template <typename T>
 struct alignas(sizeof(T) * 4) Quad {
@@ -116,7 +119,7 @@ __device__ __forceinline__ char *half_slot(float *out, int r, int c, int kpad, i
 template <int NT>
 __device__ __forceinline__ float group_sum(float v, float *red) {
   if (NT == 64) return wave_sum(v);
-  return block_sum(v, red);
+  return block_sum_n<NT>(v, red);
 }
 
 // H16: the kernel was instantiated FOR the float16 form (split & 0xff == 2) / for the other two forms: with one

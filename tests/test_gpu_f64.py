@@ -113,6 +113,37 @@ def test_equal_scores_need_more_screening_passes():
     assert cnt["uncertified_patterns"] == 0
 
 
+@pytest.mark.parametrize("n_near", [40, 300])
+def test_near_ties_below_the_f32_resolution(monkeypatch, n_near):
+    """Adversarial for the certification: dictionary patterns that differ from one base pattern by 1e-8 .. 1e-5
+    relative - their float32 scores cannot rank them, their float64 scores can.  Whatever the engine returns with
+    `uncertified_patterns == 0` must BE the float64 best-20 (scores, indices, order); where the near-copies
+    outnumber what the screening passes can rescore (300 of them against 32 + 3 x 32) it must SAY so.  With the
+    statistical bound (8 x the largest |f32 - f64| seen) and with the worst-case one (KPDI_F64_EPS=worstcase)."""
+    rng = np.random.default_rng(12)
+    m, n, s = 24, 900, 24
+    dic = rng.random((n, s, s), dtype=np.float32)
+    base = rng.random((s, s)).astype(np.float32)
+    near = rng.permutation(n)[:n_near]
+    for j, d in enumerate(near):  # near-copies: each differs in a few pixels by a few ulps
+        t = base.copy()
+        px = rng.integers(0, s * s, 3)
+        t.ravel()[px] *= np.float32(1 + (j + 1) * 3e-8)
+        dic[d] = t
+    exp = np.clip(base * 255 + rng.normal(0, 2, (m, s, s)), 0, 255).astype(np.uint8)
+    ref_s, ref_i = oracle64(exp, dic, "ncc", 20)
+    for mode in (None, "worstcase"):
+        if mode:
+            monkeypatch.setenv("KPDI_F64_EPS", mode)
+        scores, idx, cnt = engine64(exp, dic, "ncc", 20)
+        if n_near == 40:
+            assert cnt["uncertified_patterns"] == 0 and cnt["rescore_extra_passes"] >= 1, (mode, cnt)
+        else:
+            assert cnt["uncertified_patterns"] > 0, (mode, cnt)  # honest: more near-ties than it can rescore
+        if cnt["uncertified_patterns"] == 0:
+            assert_exact(scores, idx, ref_s, ref_i)
+
+
 def test_config2_shape_sample():
     """4096 x 20 000 x 60 x 60 (a fifth of configs[1]'s dictionary): 256 rows against the float64 C oracle."""
     from oracle import c_oracle
