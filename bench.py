@@ -88,14 +88,15 @@ def dictionary_block(w, b, exp=None):
     return blk
 
 
-def upload_generated_shard(ctx, w, lo, hi, exp):
-    """Device buffer with dictionary patterns [lo, hi) of a large workload (never whole on the host)."""
-    row = w["sy"] * w["sx"] * 4
+def upload_generated_shard(ctx, w, lo, hi, exp, dtype=np.float32):
+    """Device buffer with dictionary patterns [lo, hi) of a large workload (never whole on the host), stored as
+    `dtype` (float16: a dictionary kept at half the bytes, cast exactly to float32 by the preparation kernels)."""
+    row = w["sy"] * w["sx"] * np.dtype(dtype).itemsize
     d = ctx.dev_alloc((hi - lo) * row)
     for b in range(lo // BLOCK, (hi - 1) // BLOCK + 1):
         blk = dictionary_block(w, b, exp)
         a0, a1 = max(lo, b * BLOCK), min(hi, b * BLOCK + len(blk))
-        ctx.h2d(d + (a0 - lo) * row, blk[a0 - b * BLOCK:a1 - b * BLOCK])
+        ctx.h2d(d + (a0 - lo) * row, blk[a0 - b * BLOCK:a1 - b * BLOCK].astype(dtype, copy=False))
     return d
 
 

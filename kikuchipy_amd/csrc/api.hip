@@ -11,6 +11,7 @@
 // reference's loop (indexing/_dictionary_indexing.py:97-98).
 #include "../../include/kpdi.h"
 #include "kernels.h"
+#include "form_model.h"
 
 #include <dlfcn.h>
 #include <limits.h>
@@ -393,16 +394,22 @@ int use_device(kpdi_ctx *c) {
 // its dynamic tile counter, and a launch covers as many row blocks as fit the chip; larger
 // experimental sets take several launches.  The plan minimises the makespan counted in
 // tiles: launches * ceil(n_tiles / nsplit), plus a small per-launch cost.
-int choose_nsplit(const kpdi_ctx *c, int row_blocks, int n_tiles, int *rows_per_launch) {
+int choose_nsplit(const kpdi_ctx *c, int row_blocks, int n_tiles, int *rows_per_launch, int wide = -1) {
   // (the 4-wave float16 variant runs two workgroups per CU)
   const int cap = c->n_cu * kpdi::match_blocks_per_cu();
+  // splits that are not a multiple of 8 leave the launch without an XCD grid (plan_xcd_grid); the kernels of match16.hip
+  // (static hand-out) pay more for that than match.hip does (profiles/r03_form_choice.json)
+  if (wide < 0) wide = uses16(c) ? 1 : 0;
+  static const double odd_wide = getenv("KPDI_NS_ODD_WIDE") ? atof(getenv("KPDI_NS_ODD_WIDE")) : kpdi::FORM_ODD_SPLIT_WIDE;
+  static const double odd_classic = getenv("KPDI_NS_ODD_CLASSIC") ? atof(getenv("KPDI_NS_ODD_CLASSIC")) : kpdi::FORM_ODD_SPLIT_CLASSIC;
+  const double odd = wide ? odd_wide : odd_classic;
   int best_ns = 1, best_rpl = std::max(1, std::min(row_blocks, cap));
   double best_cost = 1e30;
   for (int ns = 1; ns <= std::min(cap, n_tiles); ++ns) {
     const int rpl = std::max(1, std::min(row_blocks, cap / ns));
     const int launches = (row_blocks + rpl - 1) / rpl;
     // multiples of 8 keep the workgroups of one XCD (block id % 8) on the same row block
-    const double cost = launches * ((n_tiles + ns - 1) / ns + 0.5) * (ns % 8 == 0 ? 1.0 : 1.02);
+    const double cost = launches * ((n_tiles + ns - 1) / ns + 0.5) * (ns % 8 == 0 ? 1.0 : odd);
     if (cost < best_cost - 1e-9) {
       best_cost = cost;
       best_ns = ns;
@@ -795,21 +802,26 @@ void decide_form(kpdi_ctx *c, int64_t n_chunk) {
   int rpl = 0;
   // match.hip: whole rounds of 128-pattern tiles + (when few rounds) a quarter-tile tail launch
   const int t128 = (int)((n_chunk + 127) / 128);
-  const int ns = choose_nsplit(c, row_blocks, t128, &rpl);
+  const int ns = choose_nsplit(c, row_blocks, t128, &rpl, 0);
   const int launches = (row_blocks + rpl - 1) / rpl;
   double classic = (t128 + ns - 1) / ns;
   if (launches == 1) {
     const int rounds = t128 / ns, rem = t128 % ns;
-    if (rounds >= 1 && rounds < 32 && rem > 0 && 4 * rem <= 3 * ns) classic = rounds + ((4 * rem + ns - 1) / ns) * 0.25 + 0.25;
+    if (rounds >= 1 && rounds < 32 && rem > 0 && 4 * rem <= 3 * ns)
+      classic = rounds + ((4 * rem + ns - 1) / ns) * 0.25 + kpdi::FORM_CLASSIC_TAIL;
   }
-  classic = launches * (classic + 0.25);  // + ~0.1 ms per launch
+  classic = launches * (classic + kpdi::FORM_CLASSIC_LAUNCH);  // + ~0.1 ms per launch
   // match16.hip, float32 form: whole rounds of 256-pattern tiles, two 128-tile units each at 1 / 1.03 of the time
   const int t256 = (int)((n_chunk + 255) / 256);
-  const int nsw = choose_nsplit(c, row_blocks, t256, &rpl);
+  const int nsw = choose_nsplit(c, row_blocks, t256, &rpl, 1);
   int shift = 0;
   // (its launch costs more: the first tile's 64 candidates per lane go to the buffers, the lists are built at the end -
   // 0.27 ms against 0.1 ms, measured on one rank's share of configs[1] at N = 8)
-  const double wide = ((row_blocks + rpl - 1) / rpl) * ((t256 / nsw + wide_tail_plan(t256, nsw, &shift)) * 2.0 / 1.03 + 0.65);
+  // (fitted between K = 2819 and 14 400: no extrapolation below)
+  const double gain = kpdi::FORM_WIDE_GAIN + kpdi::FORM_WIDE_GAIN_K * std::max(-0.3, 1.0 - 3600.0 / std::max(c->k_kept, 1));
+  const double wide = ((row_blocks + rpl - 1) / rpl) *
+                      ((t256 / nsw + wide_tail_plan(t256, nsw, &shift)) * 2.0 / gain + kpdi::FORM_WIDE_LAUNCH) *
+                      (nsw % 8 == 0 ? 1.0 : kpdi::FORM_WIDE_ODD);
   const bool w = wide < classic;
   if (w == c->wide32) return;
   c->wide32 = w;
@@ -828,7 +840,8 @@ double wide_tail_plan(int n_tiles, int nsplit, int *shift) {
   double best = 1.0;
   if (!getenv("KPDI_NO_TAIL"))
     for (int sh = 1; sh <= 2; ++sh) {
-      const double cost = (double)(((left << sh) + nsplit - 1) / nsplit) / (1 << sh) * (sh == 1 ? 1.1 : 1.25);
+      const double cost = (double)(((left << sh) + nsplit - 1) / nsplit) / (1 << sh) *
+                          (sh == 1 ? kpdi::FORM_WIDE_HALF : kpdi::FORM_WIDE_QUARTER);
       if (cost < best - 1e-9) best = cost, *shift = sh;
     }
   return best;

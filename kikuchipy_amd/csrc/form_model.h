@@ -1,0 +1,30 @@
+// form_model.h - constants of the cost model that picks the f32 match kernel of a sweep (api.hip: decide_form,
+// choose_nsplit).  Units: the time of one 128-pattern dictionary tile of match.hip against one 256-pattern row block.
+// Fitted on profiles/r03_form_choice.json (tools/form_probe.py: both kernels forced over N = 6 250 .. 300 000, M = 512 ..
+// 40 000, K = 2819 / 3600 / 14 400 on one MI355X); tests/test_gpu_engine.py re-measures a sub-grid and fails when the
+// automatic choice is more than 2 % behind the better kernel.
+#pragma once
+namespace kpdi {
+// PLANNING (choose_nsplit): cost factor of a plan whose dictionary splits are not a multiple of 8 - such a launch has no XCD
+// grid (plan_xcd_grid) and its workgroups of one row block are spread over all XCDs.  Round 2 priced that at 1.02; forcing
+// multiples of 8 measured 3 - 7 % FASTER steps wherever a plan changed (M = 10 000 / 40 000: 40 / 157 row blocks, e.g.
+// 10 000 x 37 500 x 60^2 on match.hip 21.4 -> 20.5 ms with 8 splits x 32 row blocks x 2 launches instead of 6 x 40 x 1;
+// 40 000 x 12 500 on the wide kernel 30.6 -> 28.4 ms).
+constexpr double FORM_ODD_SPLIT_CLASSIC = 1.25;
+constexpr double FORM_ODD_SPLIT_WIDE = 1.2;
+// CHOICE (decide_form): a wide plan that still ends on such a split count is this much slower than its tile count says
+constexpr double FORM_WIDE_ODD = 1.16;
+// match.hip: fixed cost of a launch, and of its quarter-tile tail launch
+constexpr double FORM_CLASSIC_LAUNCH = 0.25;
+constexpr double FORM_CLASSIC_TAIL = 0.25;
+// match16.hip's f32 form: a 256-pattern tile costs 2 / FORM_WIDE_GAIN units; fixed cost of a launch (the first tile's
+// candidates go through the buffers, the lists are built at the end)
+// FORM_WIDE_GAIN(K) = FORM_WIDE_GAIN + FORM_WIDE_GAIN_K (1 - 3600 / K): the per-tile work outside the MFMA loop (epilogue,
+// list handling) is amortised over more steps at large K - measured wide / classic 0.99 at K = 3600, 0.97 at K = 14 400
+constexpr double FORM_WIDE_GAIN = 1.03;
+constexpr double FORM_WIDE_GAIN_K = 0.03;
+constexpr double FORM_WIDE_LAUNCH = 1.3;
+// ... its partial units (halves / quarters of a tile) cost this much more per row than whole tiles
+constexpr double FORM_WIDE_HALF = 1.1;
+constexpr double FORM_WIDE_QUARTER = 1.25;
+}  // namespace kpdi

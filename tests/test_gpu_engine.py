@@ -339,15 +339,57 @@ def test_the_two_f32_kernels_agree_and_are_chosen_by_size(monkeypatch):
         assert np.array_equal(out["0", metric][0], out["1", metric][0])
         assert np.array_equal(out["0", metric][1], out["1", metric][1])
     monkeypatch.delenv("KPDI_F32_WIDE")
-    big = rng.random((100000, 8, 8), dtype=np.float32)
+    big = rng.random((100000, 60, 60), dtype=np.float32)   # (the model is fitted for K = 2819 .. 14 400 kept pixels)
     with _lib.Context(0) as c:
-        c.set_problem(8, 8, None, _lib.METRIC_NCC, 20)
-        c.set_experimental(rng.integers(0, 256, (4096, 8, 8), dtype=np.uint8))
+        c.set_problem(60, 60, None, _lib.METRIC_NCC, 20)
+        c.set_experimental(rng.integers(0, 256, (4096, 60, 60), dtype=np.uint8))
         d = c.dev_alloc(big.nbytes)
         c.h2d(d, big)
         c.push_dictionary_chunk_dev(d, np.float32, 100000, 0)   # 391 tiles of 256 over 16 splits: the one-wave kernel
         assert c.counters()["match_form"] == 3
-        c.set_experimental(rng.integers(0, 256, (4096, 8, 8), dtype=np.uint8))
+        c.set_experimental(rng.integers(0, 256, (4096, 60, 60), dtype=np.uint8))
         c.push_dictionary_chunk_dev(d, np.float32, 12500, 0)    # one rank's share at N = 8: match.hip + quarter-tile tail
         assert c.counters()["match_form"] == 0
         c.dev_free(d)
+
+
+def test_the_automatic_kernel_choice_is_within_2_percent_of_the_better_kernel(monkeypatch):
+    """decide_form's cost model (csrc/form_model.h, fitted on profiles/r03_form_choice.json) against live timings: at
+    every point of a sub-grid of tools/form_probe.py - a rank's share at N = 8, configs[1], map-sized experimental sets,
+    60 x 60 masked and unmasked - the step with the automatically chosen kernel takes at most 2 % (+ 30 us of timer
+    noise on the millisecond-sized steps) longer than with the better of the two kernels forced."""
+    import importlib.util
+    import os
+
+    from conftest import ROOT
+    from kikuchipy_amd import _lib
+
+    spec = importlib.util.spec_from_file_location("form_probe", os.path.join(ROOT, "tools", "form_probe.py"))
+    fp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fp)
+    rng = np.random.default_rng(5)
+    points = [(4096, 12500, 3600), (4096, 100000, 3600), (4096, 37500, 2819), (10000, 37500, 3600), (10000, 50000, 3600),
+              (40000, 12500, 3600), (512, 25000, 3600), (10000, 12500, 2819)]
+    pool = rng.random(100000 * 3600, dtype=np.float32)
+    exp_pool = rng.integers(0, 256, 40000 * 3600, dtype=np.uint8)
+    worst = []
+    with _lib.Context(0) as ctx:
+        ctx.set_problem(60, 60, None, _lib.METRIC_NCC, 20)
+        d_dic = ctx.dev_alloc(pool.nbytes)
+        ctx.h2d(d_dic, pool)
+        d_exp = ctx.dev_alloc(exp_pool.nbytes)
+        ctx.h2d(d_exp, exp_pool)
+        for m, n, k in points:
+            mask = fp.circular_mask(60) if k == 2819 else None
+            ms = {}
+            for name, env in (("classic", "0"), ("wide", "1"), ("auto", None)):
+                if env is None:
+                    monkeypatch.delenv("KPDI_F32_WIDE", raising=False)
+                else:
+                    monkeypatch.setenv("KPDI_F32_WIDE", env)
+                ms[name], _ = fp.time_step(ctx, d_exp, m, d_dic, n, 60, mask, _lib.METRIC_NCC, 5)
+            monkeypatch.delenv("KPDI_F32_WIDE", raising=False)
+            better = min(ms["classic"], ms["wide"])
+            worst.append((round(ms["auto"] / better, 4), m, n, k, ms))
+            assert ms["auto"] <= 1.02 * better + 0.03, (m, n, k, ms)
+    print("auto / better per point:", [w[0] for w in worst])

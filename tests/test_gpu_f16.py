@@ -119,3 +119,27 @@ def test_python_api_and_chunking_invariance():
     assert 0 < np.abs(a.scores - f.scores).max() < 2e-3
     with pytest.raises(ValueError, match="compute must be one of"):
         ka.dictionary_indexing(exp, dic, "ncc", 10, compute="bf16", verbose=False)
+
+
+@pytest.mark.parametrize("sy,sx,n", [(120, 120, 700), (60, 60, 1500), (60, 60, 1501)])
+def test_float16_dictionaries_skip_the_cast(sy, sx, n):
+    """A dictionary HANDED OVER as float16 (KPDI_F16: half the bytes in host memory, over PCIe and in HBM) is cast exactly
+    by the preparation kernels: bit-identical results to the same values handed over as float32, in the float16
+    arithmetic and in the default float32 one."""
+    from kikuchipy_amd import _lib
+
+    rng = np.random.default_rng(sy + n)
+    exp = rng.integers(0, 256, (70, sy, sx), dtype=np.uint8)
+    dic16 = rng.random((n, sy, sx), dtype=np.float32).astype(np.float16)
+    yy, xx = np.mgrid[:sy, :sx]
+    mask = (yy - sy / 2) ** 2 + (xx - sx / 2) ** 2 > (sy / 2) ** 2
+    for compute in (_lib.COMPUTE_F16, _lib.COMPUTE_F32):
+        for sm in (None, mask):
+            got = []
+            for dic in (dic16, dic16.astype(np.float32)):
+                with _lib.Context(0) as ctx:
+                    ctx.set_problem(sy, sx, sm, _lib.METRIC_NCC, 10, compute)
+                    ctx.set_experimental(exp)
+                    ctx.push_dictionary_chunk(dic, 0)
+                    got.append(ctx.finalize(10))
+            assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])

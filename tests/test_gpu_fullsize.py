@@ -3,7 +3,7 @@ properties (planted exact matches, invariance to chunking) AND against the C
 oracle (oracle/kpdi_oracle_c.c: float64-accumulated dot products, OpenMP over
 the host cores) on HUNDREDS of experimental rows over the whole dictionary:
 512 rows of configs[1], 320 of configs[2] (tests/test_gpu_config3.py), 256 of a
-rank's share of configs[3], 128 of a rank's share of configs[4]."""
+rank's share of configs[3], 128 of a rank's share of configs[4] (the float32 path and the float16 kernel configs[4] names)."""
 
 import numpy as np
 import pytest
@@ -134,17 +134,67 @@ def test_config5_large_detector():
     spot_check(exp, dic, np.array([0, 7, 150, 299]), "ncc", 20, s, i)
 
 
-def test_config5_rank_share():
-    """configs[4], one rank's share at full size: 4096 patterns of 120 x 120 against 62 500 (= 500k / 8)
-    dictionary patterns (3.6 GB raw), f32 MFMA path; 128 rows against the C oracle + planted copies."""
-    from kikuchipy_amd import _lib
-
+@pytest.fixture(scope="module")
+def config5_share():
+    """One rank's share of configs[4]: 4096 patterns of 120 x 120 against 62 500 (= 500k / 8) dictionary patterns
+    (3.6 GB raw), 8 experimental patterns planted into the dictionary as affine copies."""
     rng = np.random.default_rng(6)
     exp = rng.integers(0, 256, (4096, 120, 120), dtype=np.uint8)
     dic = rng.random((62500, 120, 120), dtype=np.float32)
     planted_rows = rng.choice(4096, 8, replace=False)
     planted_at = rng.choice(62500, 8, replace=False)
     dic[planted_at] = exp[planted_rows].astype(np.float32) * 2.0 + 1.0
+    return exp, dic, planted_rows, planted_at
+
+
+def test_config5_rank_share_f16(config5_share):
+    """The kernel configs[4] NAMES ("fp16 MFMA accumulate-fp32", compute="f16", reduced precision) at the full size of a
+    rank's share.  128 rows over the whole shard against (a) the exact products of the float16-rounded prepared
+    operands (3e-5: what the mode computes), (b) the float64-accumulated C oracle over the float32 operands (2e-3:
+    the mode's documented bound against the reference); planted copies first with score 1."""
+    from kikuchipy_amd import _lib
+
+    exp, dic, planted_rows, planted_at = config5_share
+    start = 5 * 62500
+    with _lib.Context(0) as ctx:
+        ctx.set_problem(120, 120, None, _lib.METRIC_NCC, 20, _lib.COMPUTE_F16)
+        ctx.set_experimental(exp)
+        ctx.push_dictionary_chunk(dic, start)
+        s, i = ctx.finalize(20)
+        cnt = ctx.counters()
+    assert cnt["match_form"] == 2
+    assert np.array_equal(i[planted_rows, 0], planted_at + start)
+    assert np.allclose(s[planted_rows, 0], 1, atol=2e-3)
+    rows = np.sort(np.random.default_rng(1).choice(4096, 128, replace=False))
+    # (a) rounded operands, float64 products, block by block over the shard
+    x = np.asarray(ko.prepare_experimental(exp[rows], metric="ncc", dtype=np.float64, n_experimental=len(rows)))
+    xh = (x * 4096).astype(np.float32).astype(np.float16).astype(np.float64)
+    best_s = np.full((len(rows), 0), -np.inf)
+    best_i = np.zeros((len(rows), 0), dtype=np.int64)
+    for lo in range(0, len(dic), 5000):
+        y = np.asarray(ko.prepare_dictionary(dic[lo:lo + 5000].reshape(-1, 14400), metric="ncc", dtype=np.float64))
+        yh = (y * 4096).astype(np.float32).astype(np.float16).astype(np.float64)
+        sc = (xh @ yh.T) * 2.0**-24
+        cat_s = np.concatenate([best_s, sc], axis=1)
+        cat_i = np.concatenate([best_i, np.broadcast_to(np.arange(lo, lo + sc.shape[1]), sc.shape)], axis=1)
+        order = np.lexsort((cat_i, -cat_s), axis=1)[:, :20]
+        best_s, best_i = np.take_along_axis(cat_s, order, 1), np.take_along_axis(cat_i, order, 1)
+    ko.assert_topk_parity(s[rows], i[rows] - start, best_s.astype(np.float32), best_i, atol=3e-5, tie=6e-5)
+    # (b) the float32-operand reference arithmetic (float64-accumulated): the ranked scores stay within 2e-3
+    rs, ri = c_oracle.rows_topk_f64(exp, dic, rows, "ncc", 20)
+    worst = float(np.abs(s[rows] - rs).max())
+    assert worst < 2e-3
+    agree = float(np.mean(i[rows][:, 0] - start == ri[:, 0]))
+    print(f"configs[4] share, float16: 128 rows, max |dscore| vs rounded operands {np.abs(s[rows] - best_s).max():.2e}, "
+          f"vs the f32 reference {worst:.2e}, best-match agreement {agree:.3f}")
+
+
+def test_config5_rank_share(config5_share):
+    """configs[4], one rank's share at full size: 4096 patterns of 120 x 120 against 62 500 (= 500k / 8)
+    dictionary patterns (3.6 GB raw), f32 MFMA path; 128 rows against the C oracle + planted copies."""
+    from kikuchipy_amd import _lib
+
+    exp, dic, planted_rows, planted_at = config5_share
     start = 5 * 62500
     with _lib.Context(0) as ctx:
         ctx.set_problem(120, 120, None, _lib.METRIC_NCC, 20)

@@ -31,6 +31,7 @@ ap.add_argument("--ranks", default="1,2,4,8")
 ap.add_argument("--reps", type=int, default=0)
 ap.add_argument("--no-whole-tiles", action="store_true", help="skip the second pass with KPDI_NO_TAIL=1")
 ap.add_argument("--pmc-shard", type=int, default=0)
+ap.add_argument("--dict-dtype", default="f32", choices=["f32", "f16"], help="dtype the raw dictionary is resident in")
 a = ap.parse_args()
 
 w = bench.WORKLOADS[a.workload]
@@ -40,7 +41,8 @@ ranks_list = [int(x) for x in a.ranks.split(",")] if not a.pmc_shard else [a.pmc
 rng = np.random.default_rng(2024)
 exp = rng.integers(0, 256, (m, sy, sx), dtype=np.uint8)
 n_need = max(shard_range(n, 0, r)[1] for r in ranks_list)  # rank 0's shards are prefixes of the dictionary
-out = {"workload": w["name"] + f"; rank 0's shard on one MI355X, compute {a.compute}", "ranks": {}}
+out = {"workload": w["name"] + f"; rank 0's shard on one MI355X, compute {a.compute}, raw dictionary resident as {a.dict_dtype}",
+       "ranks": {}}
 with _lib.Context(0) as ctx:
     metric = {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[w["metric"]]
     compute = {"f32": _lib.COMPUTE_F32, "f16": _lib.COMPUTE_F16}[a.compute]
@@ -49,9 +51,9 @@ with _lib.Context(0) as ctx:
     ctx.h2d(d_exp, exp)
     t_gen = time.perf_counter()
     if large:
-        d_dic = bench.upload_generated_shard(ctx, w, 0, n_need, None)
+        d_dic = bench.upload_generated_shard(ctx, w, 0, n_need, None, np.float16 if a.dict_dtype == "f16" else np.float32)
     else:
-        dic = rng.random((n, sy, sx), dtype=np.float32)
+        dic = rng.random((n, sy, sx), dtype=np.float32).astype(np.float16 if a.dict_dtype == "f16" else np.float32, copy=False)
         d_dic = ctx.dev_alloc(dic.nbytes)
         ctx.h2d(d_dic, dic)
     print(f"dictionary prefix of {n_need} patterns resident after {time.perf_counter() - t_gen:.1f} s", flush=True)
@@ -71,7 +73,7 @@ with _lib.Context(0) as ctx:
                     ctx.synchronize()
                     t0 = time.perf_counter()
                 ctx.set_experimental_dev(d_exp, exp.dtype, m)
-                ctx.push_dictionary_chunk_dev(d_dic, np.float32, hi - lo, lo)
+                ctx.push_dictionary_chunk_dev(d_dic, np.float16 if a.dict_dtype == "f16" else np.float32, hi - lo, lo)
                 ctx.finalize(keep)
             dt = (time.perf_counter() - t0) / reps * 1e3
             c = ctx.counters()
