@@ -175,6 +175,11 @@ int kpdi_reset_topk(kpdi_ctx *ctx);
  * all-gathers the per-shard lists over RCCL and merges them, so all ranks get
  * the same, global result. */
 int kpdi_finalize(kpdi_ctx *ctx, float *scores_out, int64_t *indices_out);
+/* The indices kpdi_finalize handed out last, as it left them in its page-locked staging buffer (int32, row-major
+ * (m, keep_n)): valid until the next kpdi_finalize / kpdi_destroy of this context; *indices = NULL when there is none.
+ * What a host layer compares a caller's array with before it tells kpdi_orientation_similarity_map to use the lists still
+ * resident in HBM (indexing/_orientation_similarity_map.py:30-152 reads `simulation_indices` the caller may have edited). */
+int kpdi_result_indices_i32(kpdi_ctx *ctx, const int32_t **indices, int64_t *n);
 /* KPDI_COMPUTE_F64: the float64 scores (kpdi_finalize then returns them rounded to float32) */
 int kpdi_finalize_f64(kpdi_ctx *ctx, double *scores_out, int64_t *indices_out);
 

@@ -131,6 +131,7 @@ SIGNATURES = {
     "kpdi_reset_topk": (_i, [_vp]),
     "kpdi_finalize": (_i, [_vp, _vp, _vp]),
     "kpdi_finalize_f64": (_i, [_vp, _vp, _vp]),
+    "kpdi_result_indices_i32": (_i, [_vp, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(_i64)]),
     "kpdi_comm_unique_id": (_i, [_vp]),
     "kpdi_comm_init": (_i, [_vp, _i, _i, _vp]),
     "kpdi_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
@@ -240,7 +241,7 @@ class Context:
         self._compute = COMPUTE_F32
         self._projection_key = None  # simulations.ProjectedDictionary.configure
         self.result_token = 0     # bumped by every finalize()
-        self._last_indices = None  # the indices the last finalize() returned
+        self._last_valid = False   # the last finalize() succeeded: its lists may still be resident in HBM
 
     # -- lifetime
     def close(self):
@@ -492,16 +493,22 @@ class Context:
 
     def reset_topk(self):
         check(load().kpdi_reset_topk(self._h))
-        self._last_indices = None
+        self._last_valid = False
 
     def holds_result(self, simulation_indices):
         """Whether `simulation_indices` (n, keep_n) are the lists the last finalize() returned
         (and that may therefore still be resident in HBM)."""
-        last = self._last_indices
-        if last is None:
+        if not self._last_valid:
             return False
+        # what kpdi_finalize left in its page-locked staging buffer (no copy was kept: the caller may have masked or
+        # remapped the array it got in place, and must then not be told that the device still holds "these" lists)
+        p, n = C.POINTER(C.c_int32)(), C.c_int64(0)
+        check(load().kpdi_result_indices_i32(self._h, C.byref(p), C.byref(n)))
         idx = np.asarray(simulation_indices)
-        return idx.shape == last.shape and np.array_equal(idx, last)
+        if not p or n.value != idx.size:
+            return False
+        last = np.ctypeslib.as_array(p, shape=(n.value,))
+        return bool(np.array_equal(idx.ravel(), last))
 
     def finalize(self, keep_n=None):
         """(scores (m, keep_n) float32 - float64 with COMPUTE_F64 -, indices (m, keep_n) int64).  `keep_n` must be the value
@@ -520,7 +527,7 @@ class Context:
             scores = np.empty((m, keep_n), dtype=np.float32)
             check(load().kpdi_finalize(self._h, _ptr(scores), _ptr(indices)))
         self.result_token += 1
-        self._last_indices = None
+        self._last_valid = False
         if indices.size and indices[:, -1].max() >= 2**31 - 1:  # unfilled entries rank last
             # unfilled list entries (index INT_MAX, score -inf): fewer than keep_n candidates ranked, which
             # only happens when scores are NaN (NaN / inf in the patterns) - the reference propagates
@@ -529,9 +536,7 @@ class Context:
             raise KpdiError(f"{bad.size} experimental pattern(s) (first: {bad[0]}) ranked fewer than {keep_n} "
                             "dictionary patterns: NaN scores (NaN or inf in the patterns?) or a dictionary "
                             "smaller than keep_n")
-        # what is now resident in HBM (holds_result): a COPY - the caller may mask or remap the returned array in place,
-        # and must then not be told that the device still holds "these" lists
-        self._last_indices = indices.copy()
+        self._last_valid = self._compute != COMPUTE_F64
         return scores, indices
 
     # -- multi-GPU

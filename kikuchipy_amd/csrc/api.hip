@@ -245,6 +245,8 @@ struct kpdi_ctx {
   DevBuf cert64;                          // [0]: bits of max |f32 - f64| over the sweep; [1]: uncertified patterns of a merge
   DevBuf gather64_s, gather64_i, final64_s, final64_i;
   PinBuf pin_out;                         // kpdi_finalize: scores + indices on their way to the caller
+  const int32_t *result_i32 = nullptr;    // the indices of the last kpdi_finalize in that buffer (kpdi_result_indices_i32)
+  int64_t result_n = 0;
 
   // pre-processing: kpdi_remove_*_background only RECORD the step; the kernels run (fused with the
   // preparation of the patterns when those are about to be matched) in flush_preprocess
@@ -676,7 +678,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
     // several launches (large experimental sets) alternate between two streams: the workgroups
     // of launch j+1 start on the CUs that launch j's tail leaves idle
     const bool two = row_blocks > rows_per_launch && !getenv("KPDI_ONE_STREAM");
-    const bool tail2 = tail_tiles > 0 && !getenv("KPDI_TAIL_SERIAL");  // the tail launch runs on the second stream
+    const bool tail2 = tail_tiles > 0 && getenv("KPDI_TAIL_STREAM2");  // the tail launch runs on the second stream
     if (two || tail2) {
       if (!c->stream2) {
         HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
@@ -729,10 +731,11 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
       tl.row_first = 0;
       tl.rows = row_blocks;
       // The tail launch does not depend on the main launch (lists of its own, counters of its own, the shared bound is a
-      // filter that is valid however stale): on the second stream its workgroups start on the CUs the main launch's
-      // workgroups free one by one, instead of after the main launch has drained and a new one has ramped up.
-      // KPDI_TAIL_SERIAL=1 keeps it behind the main launch on the same stream.
-      static const bool serial = getenv("KPDI_TAIL_SERIAL") != nullptr;
+      // filter that is valid however stale).  On the second stream (KPDI_TAIL_STREAM2=1) it is dispatched beside the main
+      // launch - measured (round 3, rocprofv3 trace of one rank's share at N = 8): no gain, the main launch's persistent
+      // workgroups hold every CU until they all finish within microseconds of each other, and the join event costs 10 us -
+      // so it stays behind the main launch on the same stream.
+      static const bool serial = getenv("KPDI_TAIL_STREAM2") == nullptr;
       if (serial) {
         HIPCHK(kpdi::launch_match(tl, c->stream));
       } else {
@@ -2259,6 +2262,7 @@ int finalize64(kpdi_ctx *c, double *scores64, float *scores32, int64_t *indices_
     hs = hs_pageable.data();
     hi = hi_pageable.data();
   }
+  c->result_i32 = nullptr;
   HIPCHK(hipMemcpyAsync(hs, d_s, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(hi, d_i, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -2355,11 +2359,21 @@ int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
     pageable.resize(n);
     h_i = pageable.data();
   }
+  c->result_i32 = nullptr;
   HIPCHK(hipMemcpyAsync(h_s, d_s, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(h_i, d_i, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (h_s != scores_out) memcpy(scores_out, h_s, n * sizeof(float));
   for (size_t i = 0; i < n; ++i) indices_out[i] = (int64_t)h_i[i];
+  c->result_i32 = h_s != scores_out ? (const int32_t *)h_i : nullptr;  // (only the page-locked buffer outlives this call)
+  c->result_n = (int64_t)n;
+  return KPDI_OK;
+}
+
+int kpdi_result_indices_i32(kpdi_ctx *c, const int32_t **indices, int64_t *n) {
+  if (!c || !indices || !n) return fail(KPDI_EINVAL, "NULL argument");
+  *indices = c->result_i32;
+  *n = c->result_i32 ? c->result_n : 0;
   return KPDI_OK;
 }
 

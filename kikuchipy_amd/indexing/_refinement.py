@@ -9,9 +9,10 @@ pattern to SciPy, which calls a Numba objective a few hundred times; here the
 whole map is ONE kernel launch (`kpdi_refine_solve`): a workgroup per (pattern,
 start) evaluates the objective and walks SciPy's simplex on the device.
 
-The other optimisers the reference can dispatch to (NLopt's LN_NELDERMEAD and
-SciPy's global methods) are not part of this path and raise
-`NotImplementedError`.
+Every other optimiser the reference can dispatch to (SciPy's local methods and their options, its global
+methods, NLopt's LN_NELDERMEAD) keeps ITS optimiser on the host, called with the reference's arguments, with
+the objective evaluated on the device (`_HostOptimizer`); `compute=False` returns a `DeferredRefinement`
+in place of the reference's lazy Dask array.
 """
 
 import time
@@ -265,7 +266,15 @@ def _host_solve(ctx, mode_code, host, x0, fixed, lower, upper):
             fx = None if fixed is None else fixed[i, s][None]
 
             def fun(x, _i=i, _fx=fx):
-                return float(ctx.refine_objective(mode_code, [_i], np.asarray(x, dtype=np.float64)[None], _fx)[0])
+                x = np.asarray(x, dtype=np.float64)
+                if x.ndim == 2:
+                    # a whole population at once, (variables, S) -> (S,): ONE launch per generation
+                    # (differential_evolution(vectorized=True, updating="deferred"); an extension - the reference's
+                    # objective takes one point)
+                    pop = np.ascontiguousarray(x.T)
+                    fxs = None if _fx is None else np.repeat(_fx, len(pop), axis=0)
+                    return ctx.refine_objective(mode_code, np.full(len(pop), _i), pop, fxs)
+                return float(ctx.refine_objective(mode_code, [_i], x[None], _fx)[0])
 
             bounds = None if lower is None else list(zip(lower[i, s], upper[i, s]))
             f, nfev, nit, x = host.run(fun, x0[i, s], bounds)
@@ -330,8 +339,13 @@ def _master_pattern_data(master_pattern, energy):
 
 def refine(mode, patterns, rotations, detector, master_pattern, energy=None, navigation_mask=None,
            signal_mask=None, pseudo_symmetry_ops=None, method="minimize", method_kwargs=None, trust_region=None,
-           initial_step=None, rtol=1e-4, maxeval=None, context=None, device=0, verbose=True, comm=None):
+           initial_step=None, rtol=1e-4, maxeval=None, context=None, device=0, verbose=True, comm=None, compute=True):
     """Shared driver of the three refinements.
+
+    compute
+        False: validate, set everything up, print the information message and return a `DeferredRefinement` -
+        what the reference returns as a lazy Dask array (indexing/_refinement/_refinement.py:355, :429-437);
+        `.compute()` (or `compute_refine_*_results`) runs it.
 
     patterns
         (..., rows, cols) experimental patterns with 0-2 navigation axes.
@@ -411,15 +425,31 @@ def refine(mode, patterns, rotations, detector, master_pattern, energy=None, nav
     lower, upper = _bounds(mode, x0, trust_region)
     if verbose:
         print(_info_message(mode, trust_region, shown, n_pseudo, plan))
-        what = {"ori": "orientation(s)", "pc": "projection center(s)", "ori_pc": "orientation(s) and projection center(s)"}
-        print(f"Refining {n} {what[mode]}:")
 
+    def run():
+        return _run_refinement(mode, n, starts, x0, fixed, lower, upper, pats, signal_mask, detector, master_pattern,
+                               energy, nm, host, context, device, comm, verbose, n_pseudo, points, nav_shape,
+                               navigation_mask)
+
+    if not compute:
+        return DeferredRefinement(mode, run, n_pseudo > 0)
+    result, new_detector, _ = run()
+    return result, new_detector
+
+
+def _run_refinement(mode, n, starts, x0, fixed, lower, upper, pats, signal_mask, detector, master_pattern, energy, nm, host,
+                    context, device, comm, verbose, n_pseudo, points, nav_shape, navigation_mask):
+    """The solve + the assembly of the result (what `compute_refine_*_results` do in the reference,
+    indexing/_refinement/_refinement.py:58-290).  Returns (RefinementResult, new detector | None, raw rows)."""
     lo_i, hi_i = 0, n
     if comm is not None and comm.world_size > 1:
         from kikuchipy_amd.parallel import shard_range
 
         lo_i, hi_i = shard_range(n, comm.rank, comm.world_size)
     part = slice(lo_i, hi_i)
+    if verbose:
+        what = {"ori": "orientation(s)", "pc": "projection center(s)", "ori_pc": "orientation(s) and projection center(s)"}
+        print(f"Refining {n} {what[mode]}:")
     ctx = context if context is not None else _lib.Context(device)
     try:
         t0 = time.time()
@@ -459,4 +489,64 @@ def refine(mode, patterns, rotations, detector, master_pattern, energy=None, nav
         if navigation_mask is None and nav_shape:
             new_pc = new_pc.reshape(nav_shape + (3,))
         new_detector.pc = new_pc
-    return result, new_detector
+    # the reference's result rows (_refinement.py:120-128, :184-190, :284-290): score, number of evaluations, the refined
+    # variables, [pseudo-symmetry index]
+    raw = np.column_stack([scores, num_evals, x] + ([ps_index] if ps_index is not None else []))
+    return result, new_detector, raw
+
+
+class DeferredRefinement:
+    """`refine_*(..., compute=False)`: everything is validated and set up, nothing has run.  The reference hands out a
+    lazy Dask array here and finishes with `kikuchipy.indexing.compute_refine_*_results(results, ...)`
+    (indexing/_refinement/_refinement.py:58-290); this object plays that array's part: `.compute()` returns the rows
+    the Dask array would hold - (score, number of evaluations, refined variables[, pseudo-symmetry index]) per refined
+    point - and the `compute_refine_*_results` functions of this module return what `compute=True` returns."""
+
+    def __init__(self, mode, run, pseudo_symmetry_checked):
+        self.mode = mode
+        self._run = run
+        self.pseudo_symmetry_checked = bool(pseudo_symmetry_checked)
+        self._done = None
+
+    def _finish(self):
+        if self._done is None:
+            self._done = self._run()
+            self._run = None  # drops the patterns
+        return self._done
+
+    def compute(self):
+        return self._finish()[2]
+
+    def __repr__(self):
+        state = "computed" if self._done is not None else "not computed"
+        return f"DeferredRefinement(mode={self.mode!r}, {state})"
+
+
+def _deferred(results, mode, pseudo_symmetry_checked=None):
+    if not isinstance(results, DeferredRefinement):
+        raise TypeError("`results` must be what refine_*(..., compute=False) returned")
+    if results.mode != mode:
+        raise ValueError(f"`results` come from a {results.mode!r} refinement, not {mode!r}")
+    if pseudo_symmetry_checked is not None and bool(pseudo_symmetry_checked) != results.pseudo_symmetry_checked:
+        raise ValueError("`pseudo_symmetry_checked` does not match the refinement that produced `results`")
+    return results._finish()
+
+
+def compute_refine_orientation_results(results, xmap=None, master_pattern=None, navigation_mask=None,
+                                       pseudo_symmetry_checked=None):
+    """indexing/_refinement/_refinement.py:58-131: the `RefinementResult` of `refine_orientation(compute=False)`
+    (the other arguments are those of the reference; the deferred object already carries them)."""
+    return _deferred(results, "ori", pseudo_symmetry_checked)[0]
+
+
+def compute_refine_projection_center_results(results, detector=None, xmap=None, navigation_mask=None):
+    """:133-197: `(scores, new detector, num_evals)`."""
+    res, det, _ = _deferred(results, "pc")
+    return res.scores, det, res.num_evals
+
+
+def compute_refine_orientation_projection_center_results(results, detector=None, xmap=None, master_pattern=None,
+                                                         navigation_mask=None, pseudo_symmetry_checked=None):
+    """:199-290: `(RefinementResult, new detector)`."""
+    res, det, _ = _deferred(results, "ori_pc", pseudo_symmetry_checked)
+    return res, det

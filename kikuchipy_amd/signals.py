@@ -119,12 +119,9 @@ class EBSD:
                 verbose, comm=None):
         from kikuchipy_amd.indexing._refinement import refine
 
-        if not compute:
-            raise NotImplementedError("compute=False (a lazy Dask result) is not available: the whole "
-                                      "refinement is one GPU launch")
         return refine(mode, np.asarray(self.data), _rotations_of(xmap), detector, master_pattern, energy,
                       navigation_mask, signal_mask, pseudo_symmetry_ops, method, method_kwargs, trust_region,
-                      initial_step, rtol, maxeval, context=self.context, verbose=verbose, comm=comm)
+                      initial_step, rtol, maxeval, context=self.context, verbose=verbose, comm=comm, compute=compute)
 
     def refine_orientation(self, xmap, detector, master_pattern, energy=None, navigation_mask=None,
                            signal_mask=None, pseudo_symmetry_ops=None, method="minimize", method_kwargs=None,
@@ -133,10 +130,12 @@ class EBSD:
         """signals/ebsd.py:1986-2185.  `xmap`: anything with `.rotations`
         (e.g. the result of `dictionary_indexing`) or a quaternion array.
         Returns a `RefinementResult` (`rotations`, `scores`, `num_evals`,
-        `pseudo_symmetry_index`)."""
-        return self._refine("ori", xmap, detector, master_pattern, energy, navigation_mask, signal_mask,
-                            pseudo_symmetry_ops, method, method_kwargs, trust_region, initial_step, rtol, maxeval,
-                            compute, verbose, comm)[0]
+        `pseudo_symmetry_index`); with `compute=False` a `DeferredRefinement`, finished by
+        `kikuchipy_amd.indexing.compute_refine_orientation_results` (the reference: a lazy Dask array)."""
+        out = self._refine("ori", xmap, detector, master_pattern, energy, navigation_mask, signal_mask,
+                           pseudo_symmetry_ops, method, method_kwargs, trust_region, initial_step, rtol, maxeval,
+                           compute, verbose, comm)
+        return out[0] if compute else out  # compute=False: a DeferredRefinement (compute_refine_orientation_results)
 
     def refine_projection_center(self, xmap, detector, master_pattern, energy=None, navigation_mask=None,
                                  signal_mask=None, method="minimize", method_kwargs=None, trust_region=None,
@@ -144,9 +143,11 @@ class EBSD:
                                  chunk_kwargs=None, *, verbose=True, comm=None):
         """signals/ebsd.py:2187-2390.  Returns `(scores, new_detector, num_evals)`
         like the reference."""
-        res, det = self._refine("pc", xmap, detector, master_pattern, energy, navigation_mask, signal_mask, None,
-                                method, method_kwargs, trust_region, initial_step, rtol, maxeval, compute, verbose,
-                                comm)
+        out = self._refine("pc", xmap, detector, master_pattern, energy, navigation_mask, signal_mask, None,
+                           method, method_kwargs, trust_region, initial_step, rtol, maxeval, compute, verbose, comm)
+        if not compute:
+            return out  # a DeferredRefinement (compute_refine_projection_center_results)
+        res, det = out
         return res.scores, det, res.num_evals
 
     def refine_orientation_projection_center(self, xmap, detector, master_pattern, energy=None,

@@ -78,6 +78,15 @@ def test_osm_from_resident_result(synth_inputs):
         # resident lists (another run's result, a merged or refined map of the same shape ...)
         other = idx[:, ::-1].copy()
         assert not ctx.holds_result(other)
+        # ... including the returned array itself once the caller has edited it IN PLACE (the context keeps no
+        # reference to it: it compares with what kpdi_finalize left in its own staging buffer)
+        keep = idx.copy()
+        idx[3, 0] = idx[3, 1]
+        assert not ctx.holds_result(idx)
+        got = ka.orientation_similarity_map(idx, shape=(6, 8), n_best=10, context=ctx)
+        assert np.array_equal(got, ko.orientation_similarity_map(idx, (6, 8), n_best=10))
+        idx[:] = keep
+        assert ctx.holds_result(idx)
         got = ka.orientation_similarity_map(other, shape=(6, 8), context=ctx)
         assert np.array_equal(got, ko.orientation_similarity_map(other, (6, 8)))
         got = ka.orientation_similarity_map(idx[:40], shape=(5, 8), context=ctx)

@@ -282,6 +282,27 @@ def test_refine_orientation_api(api_inputs, g, g115, capsys):
     assert np.all(res3.num_evals == 30)
 
 
+def test_compute_false_equals_compute_true(api_inputs, g115):
+    """`compute=False` (indexing/_refinement/_refinement.py:355-437): the deferred result, computed later, is what
+    `compute=True` returns; its rows are the reference's (score, number of evaluations, Euler angles)."""
+    import kikuchipy_amd.indexing as ki
+
+    s, det, mp, rot0 = api_inputs
+    now = s.refine_orientation(rot0, det, mp, energy=20, verbose=False)
+    later = s.refine_orientation(rot0, det, mp, energy=20, compute=False, verbose=False)
+    rows = later.compute()
+    assert rows.shape == (4, 5)
+    assert np.array_equal(rows[:, 0], now.scores) and np.array_equal(rows[:, 1], now.num_evals)
+    assert np.array_equal(rows[:, 2:5], now.euler)
+    assert np.allclose(rows[:, 2:5], g115["ori_nm"][:, 2:5], atol=5e-4)
+    res = ki.compute_refine_orientation_results(later, rot0, mp)
+    assert np.array_equal(res.rotations, now.rotations)
+    d_pc = s.refine_projection_center(rot0, det, mp, compute=False, verbose=False)
+    scores, new_det, num_evals = ki.compute_refine_projection_center_results(d_pc, det)
+    scores2, new_det2, num_evals2 = s.refine_projection_center(rot0, det, mp, verbose=False)
+    assert np.array_equal(scores, scores2) and np.array_equal(new_det.pc, new_det2.pc) and np.array_equal(num_evals, num_evals2)
+
+
 def test_refine_pseudo_symmetry_api(api_inputs, g):
     """A 'pseudo-symmetry' operator that is a real 20 degree rotation: the indexed
     orientation (index 0) must win everywhere and the bookkeeping must hold."""

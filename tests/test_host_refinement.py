@@ -134,8 +134,75 @@ def test_argument_validation():
         rf.refine("ori", pats, rot, det, ka.EBSDMasterPattern(np.zeros((11, 11)), projection="stereographic"))
     with pytest.raises(ValueError, match="mode must be"):
         rf.refine("both", pats, rot, det, mp)
-    with pytest.raises(NotImplementedError, match="compute=False"):
-        ka.EBSD(pats).refine_orientation(rot, det, mp, compute=False)
+
+
+class _SolveRecorder:
+    """Stands in for the engine context of `refine`: records the calls, returns a fixed solve result."""
+
+    def __init__(self):
+        self.calls = []
+
+    def set_master_pattern(self, up, lo):
+        self.calls.append("master")
+
+    def refine_set_patterns(self, pats, signal_mask, rescale, om):
+        self.calls.append(("patterns", len(pats)))
+
+    def refine_solve(self, mode, x0, fixed, lower, upper, xatol, fatol, maxiter, maxfev):
+        self.calls.append(("solve", mode))
+        out = np.zeros(x0.shape[:2] + (3 + x0.shape[2],))
+        out[:, :, 0] = 0.25 + 0.01 * np.arange(x0.shape[1])   # 1 - ncc: the first start wins
+        out[:, :, 1] = 77
+        out[:, :, 3:] = x0 + 0.001
+        return out
+
+
+def test_compute_false_defers_the_solve(capsys):
+    """compute=False (indexing/_refinement/_refinement.py:355, :429-437, :58-290): validation, set-up and the
+    information message happen at the call; nothing runs until `.compute()` / `compute_refine_*_results`, which
+    return the reference's result rows / what compute=True returns."""
+    import kikuchipy_amd.indexing as ki
+
+    det = ka.EBSDDetector(shape=(6, 6), pc=(0.4, 0.6, 0.5))
+    mp = ka.EBSDMasterPattern(np.random.default_rng(0).random((11, 11), dtype=np.float32))
+    pats = np.random.default_rng(1).integers(0, 255, (2, 3, 6, 6), dtype=np.uint8)
+    rot = np.tile([1.0, 0, 0, 0], (2, 3, 1))
+    nav = np.zeros((2, 3), bool)
+    nav[0, 1] = True
+    ctx = _SolveRecorder()
+    s = ka.EBSD(pats)
+    s._ctx = ctx  # (the engine context the signal would create lazily)
+    with pytest.raises(ValueError, match="Signal mask shape"):   # validation is NOT deferred
+        s.refine_orientation(rot, det, mp, signal_mask=np.zeros((5, 5), bool), compute=False)
+    d = s.refine_orientation(rot, det, mp, navigation_mask=nav, trust_region=[1, 1, 1], compute=False)
+    assert isinstance(d, ki.DeferredRefinement) and ctx.calls == [] and "not computed" in repr(d)
+    out = capsys.readouterr().out
+    assert "Refinement information:" in out and "Refining" not in out
+    rows = d.compute()
+    assert ctx.calls == ["master", ("patterns", 5), ("solve", 0)]
+    assert rows.shape == (5, 5) and np.allclose(rows[:, 0], 0.75) and np.all(rows[:, 1] == 77)
+    out = capsys.readouterr().out
+    assert "Refining 5 orientation(s):" in out and "Refinement speed:" in out
+    res = ki.compute_refine_orientation_results(d, rot, mp, nav)
+    assert ctx.calls == ["master", ("patterns", 5), ("solve", 0)]          # computed once
+    assert isinstance(res, ki.RefinementResult) and res.scores.shape == (5,) and np.array_equal(res.is_in_data, ~nav.ravel())
+    assert np.allclose(res.euler, rows[:, 2:5])
+    with pytest.raises(ValueError, match="'ori' refinement, not 'pc'"):
+        ki.compute_refine_projection_center_results(d, det)
+    with pytest.raises(TypeError, match="compute=False"):
+        ki.compute_refine_orientation_results(rows)
+    # the other two modes; pseudo-symmetry adds the index column
+    ops = np.array([[0.0, 1, 0, 0]])
+    d2 = s.refine_orientation_projection_center(rot, det, mp, pseudo_symmetry_ops=ops, compute=False, verbose=False)
+    rows2 = d2.compute()
+    assert rows2.shape == (6, 9) and np.all(rows2[:, -1] == 0)
+    res2, det2 = ki.compute_refine_orientation_projection_center_results(d2, det, pseudo_symmetry_checked=True)
+    assert det2.pc.shape == (2, 3, 3) and np.all(res2.pseudo_symmetry_index == 0)
+    with pytest.raises(ValueError, match="pseudo_symmetry_checked"):
+        ki.compute_refine_orientation_projection_center_results(d2, det, pseudo_symmetry_checked=False)
+    d3 = s.refine_projection_center(rot, det, mp, compute=False, verbose=False)
+    scores, det3, nev = ki.compute_refine_projection_center_results(d3, det)
+    assert scores.shape == (6,) and np.all(nev == 77) and np.allclose(det3.pc, 0.001 + np.asarray([0.4, 0.6, 0.5]))
 
 
 # ------------------------------------------------------------------ optimisers driven from the host
@@ -185,6 +252,33 @@ def test_host_driven_optimisers_call_scipy_like_the_reference(method, kwargs):
             want = solver(fun, bounds=bounds, **kwargs)
         assert res[i, 0, 0] == want.fun and res[i, 0, 1] == want.nfev and np.array_equal(res[i, 0, 3:], want.x)
         assert np.abs(res[i, 0, 3:] - centres[i]).max() < 2e-2
+
+
+def test_a_population_is_one_objective_call():
+    """differential_evolution(vectorized=True): SciPy hands the objective a whole generation, (variables, S); the
+    device evaluates it in ONE kpdi_refine_objective launch (S evaluations of the same pattern)."""
+    import scipy.optimize
+
+    centres = np.array([[0.3, -0.2, 0.5]])
+    w = np.array([1.0, 2.0, 0.5])
+
+    class Ctx(_QuadraticContext):
+        launches = 0
+
+        def refine_objective(self, mode, pattern_index, x, fixed=None):
+            Ctx.launches += 1
+            return super().refine_objective(mode, pattern_index, x, fixed)
+
+    ctx = Ctx(centres, w)
+    kwargs = dict(seed=3, maxiter=12, tol=1e-8, vectorized=True, updating="deferred", polish=False)
+    nm, host, plan = rf._optimization_plan("differential_evolution", kwargs, None, 1e-4, None, "ori")
+    x0 = np.zeros((1, 1, 3))
+    res = rf._host_solve(ctx, 0, host, x0, np.zeros((1, 1, 3)), x0 - 2.0, x0 + 2.0)
+    fun = lambda x: np.sum(w[:, None] * (np.asarray(x) - centres[0][:, None]) ** 2, axis=0) + 0.1  # noqa: E731
+    want = scipy.optimize.differential_evolution(fun, bounds=[(-2.0, 2.0)] * 3, **kwargs)
+    assert res[0, 0, 0] == want.fun and res[0, 0, 1] == want.nfev and np.array_equal(res[0, 0, 3:], want.x)
+    # one launch per generation (SciPy counts a vectorised call as one evaluation), 45 points each
+    assert Ctx.launches == want.nfev == 13 and ctx.calls == 13 * 45
 
 
 def test_global_methods_need_a_trust_region_and_messages():
