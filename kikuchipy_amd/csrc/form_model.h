@@ -1,6 +1,6 @@
 // form_model.h - constants of the cost model that picks the f32 match kernel of a sweep (api.hip: decide_form,
 // choose_nsplit).  Units: the time of one 128-pattern dictionary tile of match.hip against one 256-pattern row block.
-// Fitted on profiles/r03_form_choice.json (tools/form_probe.py: both kernels forced over N = 6 250 .. 300 000, M = 512 ..
+// Fitted on profiles/r03_form_choice.json and r03_form_choice_run3.json (tools/form_probe.py: both kernels forced over N = 6 250 .. 300 000, M = 512 ..
 // 40 000, K = 2819 / 3600 / 14 400 on one MI355X); tests/test_gpu_engine.py re-measures a sub-grid and fails when the
 // automatic choice is more than 2 % behind the better kernel.
 #pragma once
@@ -13,7 +13,7 @@ namespace kpdi {
 constexpr double FORM_ODD_SPLIT_CLASSIC = 1.25;
 constexpr double FORM_ODD_SPLIT_WIDE = 1.2;
 // CHOICE (decide_form): a wide plan that still ends on such a split count is this much slower than its tile count says
-constexpr double FORM_WIDE_ODD = 1.16;
+constexpr double FORM_WIDE_ODD = 1.12;
 // match.hip: fixed cost of a launch, and of its quarter-tile tail launch
 constexpr double FORM_CLASSIC_LAUNCH = 0.25;
 constexpr double FORM_CLASSIC_TAIL = 0.25;
@@ -21,9 +21,9 @@ constexpr double FORM_CLASSIC_TAIL = 0.25;
 // candidates go through the buffers, the lists are built at the end)
 // FORM_WIDE_GAIN(K) = FORM_WIDE_GAIN + FORM_WIDE_GAIN_K (1 - 3600 / K): the per-tile work outside the MFMA loop (epilogue,
 // list handling) is amortised over more steps at large K - measured wide / classic 0.99 at K = 3600, 0.97 at K = 14 400
-constexpr double FORM_WIDE_GAIN = 1.03;
-constexpr double FORM_WIDE_GAIN_K = 0.03;
-constexpr double FORM_WIDE_LAUNCH = 1.3;
+constexpr double FORM_WIDE_GAIN = 1.035;
+constexpr double FORM_WIDE_GAIN_K = 0.02;
+constexpr double FORM_WIDE_LAUNCH = 1.1;
 // ... its partial units (halves / quarters of a tile) cost this much more per row than whole tiles
 constexpr double FORM_WIDE_HALF = 1.1;
 constexpr double FORM_WIDE_QUARTER = 1.25;

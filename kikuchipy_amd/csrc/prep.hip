@@ -245,9 +245,36 @@ __global__ __launch_bounds__(256 * NP) void prep16_block4_kernel(const T *raw, i
   const bool live = r < n_out;
   const int row_halves = 2 * kpad + 8;  // + 16 bytes: the rows start in different banks
   _Float16 *stage = (_Float16 *)smem_raw + (size_t)g * row_halves;
+  // a thread's 64 values are VW consecutive pixels per load: 4 (one 4- / 8- / 16-byte load), or 8 for 2-byte raw types
+  // without a mask (a float16-resident dictionary: 16-byte loads as for float32 rows - with 8-byte loads the kernel
+  // read half the bytes in MORE time) - value idx of a thread is pixel VW * (t + 256 * (idx / VW)) + idx % VW
+  constexpr int VW = (!MASKED && sizeof(T) == 2) ? 8 : 4;
   float v[WAVE_VALUES];
   float s = 0.f;
-  if (live) {
+  if (live && VW == 8) {
+    const int64_t src = row_map ? row_map[r] : r;
+    const T *p = raw + src * (int64_t)npix;
+#pragma unroll
+    for (int j = 0; j < WAVE_VALUES / 8; ++j) {
+      const int c = 8 * (t + 256 * j);
+      Quad<T> q0, q1;
+      q0.v[0] = q0.v[1] = q0.v[2] = q0.v[3] = q1.v[0] = q1.v[1] = q1.v[2] = q1.v[3] = (T)0;
+      if (c + 8 <= k) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + c));
+        __builtin_memcpy(&q0, &x, 8);
+        __builtin_memcpy(&q1, (const char *)&x + 8, 8);
+      } else {  // (k % 8 == 4: the last quad of the row)
+        if (c < k) q0 = load_quad(p + c);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[8 * j + e] = (float)q0.v[e];
+        v[8 * j + 4 + e] = (float)q1.v[e];
+      }
+      s += ((v[8 * j] + v[8 * j + 1]) + (v[8 * j + 2] + v[8 * j + 3])) + ((v[8 * j + 4] + v[8 * j + 5]) + (v[8 * j + 6] + v[8 * j + 7]));
+    }
+  } else if (live) {
     const int64_t src = row_map ? row_map[r] : r;
     const T *p = raw + src * (int64_t)npix;
 #pragma unroll
@@ -279,7 +306,7 @@ __global__ __launch_bounds__(256 * NP) void prep16_block4_kernel(const T *raw, i
   float q2 = 0.f;
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES; ++i) {
-    const int c = 4 * (t + 256 * (i / 4)) + (i & 3);
+    const int c = VW * (t + 256 * (i / VW)) + (i % VW);
     if (c < k) {
       v[i] -= mean;
       q2 += v[i] * v[i];
@@ -293,7 +320,7 @@ __global__ __launch_bounds__(256 * NP) void prep16_block4_kernel(const T *raw, i
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES / 4; ++i) {
-    const int c = 4 * (t + 256 * i);
+    const int c = VW * (t + 256 * ((4 * i) / VW)) + (4 * i) % VW;
     if (c < 2 * kpad) {
       h4 h;
 #pragma unroll

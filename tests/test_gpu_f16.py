@@ -124,8 +124,8 @@ def test_python_api_and_chunking_invariance():
 @pytest.mark.parametrize("sy,sx,n", [(120, 120, 700), (60, 60, 1500), (60, 60, 1501)])
 def test_float16_dictionaries_skip_the_cast(sy, sx, n):
     """A dictionary HANDED OVER as float16 (KPDI_F16: half the bytes in host memory, over PCIe and in HBM) is cast exactly
-    by the preparation kernels: bit-identical results to the same values handed over as float32, in the float16
-    arithmetic and in the default float32 one."""
+    by the preparation kernels: the results of the same values handed over as float32 (bit for bit where the same
+    kernel serves both), in the float16 arithmetic and in the default float32 one."""
     from kikuchipy_amd import _lib
 
     rng = np.random.default_rng(sy + n)
@@ -142,4 +142,11 @@ def test_float16_dictionaries_skip_the_cast(sy, sx, n):
                     ctx.set_experimental(exp)
                     ctx.push_dictionary_chunk(dic, 0)
                     got.append(ctx.finalize(10))
-            assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+            if sy <= 64:  # one wave per pattern: the same kernel, the same order of every sum
+                assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+            else:
+                # 120 x 120 unmasked float16 rows are read 8 pixels per load (16 bytes, as float32 rows are): the mean
+                # and the norm are summed in another order than for the float32 copy - rounding-level differences
+                # (which can flip a float16 rounding of a prepared value: 3e-5 in the float16 arithmetic)
+                ko.assert_topk_parity(got[0][0], got[0][1], got[1][0], got[1][1], atol=3e-5 if compute == _lib.COMPUTE_F16 else 1e-6,
+                                      tie=6e-5 if compute == _lib.COMPUTE_F16 else 2e-6)
