@@ -207,8 +207,9 @@ def cpu_baseline(w, exp, dic, bg, mask, n_sample):
         "kind": "port",
         "best_variant": best,
         "variants": variants,
-        "sample": (f"{w['m']} exp x first {n_sample} dict patterns, n_per_iteration=2000, scaled linearly to "
-                   f"N={w['n']}; host: {visible} logical CPUs visible, {cores} usable (cgroup CPU quota / affinity), "
+        "sample": (f"{w['m']} exp x " + ("the WHOLE dictionary" if n_sample >= w["n"] else f"first {n_sample} dict patterns")
+                   + ", n_per_iteration=2000" + ("" if n_sample >= w["n"] else f", scaled linearly to N={w['n']}")
+                   + f"; host: {visible} logical CPUs visible, {cores} usable (cgroup CPU quota / affinity), "
                    f"BLAS pool {blas} threads"
                    + (f"; pre-processing (NumPy oracle) timed on 256 patterns, scaled to all cores "
                       f"({pp_time:.2f} s)" if w["preprocess"] else "")),
@@ -821,14 +822,15 @@ def main(argv=None, context_factory=None):
 
     if not a.no_cpu_baseline:  # rank 0 only, whatever N (the other ranks have left)
         try:
-            # bounded: ~10 s of CPU work on this host (20 000 dictionary patterns of configs[1] take ~4.5 s on 8
-            # cores with either variant), whatever the workload; never more than the dictionary
+            # bounded: 50 000 dictionary patterns of configs[1] per 8 usable cores (~10 s of wall time per variant on the
+            # build container's 8 vCPUs; on the GPU boxes' 16 usable cores that is the WHOLE 100 000-pattern dictionary
+            # in ~3 + ~4.5 s - no extrapolation), whatever the workload; never more than the dictionary
             from oracle import c_oracle
 
-            sample = a.cpu_sample or int(20000 * c_oracle.effective_cpus() / 8)
+            sample = a.cpu_sample or int(50000 * c_oracle.effective_cpus() / 8)
             n_sample = min(sample, w["n"])
             if large:
-                n_sample = max(500, min(BLOCK, int(sample * (4096 * 3600) / (w["m"] * w["sy"] * w["sx"]))))
+                n_sample = max(500, min(BLOCK, int(sample * (4096 * 3600) / (w["m"] * w["sy"] * w["sx"]) / 2.5)))
                 dic = dictionary_block(w, 0, exp)
             out["cpu_baseline"] = cpu_baseline(w, exp, dic, bg, mask, n_sample)
         except Exception as err:
