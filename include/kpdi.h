@@ -175,8 +175,19 @@ int kpdi_reset_topk(kpdi_ctx *ctx);
  * all-gathers the per-shard lists over RCCL and merges them, so all ranks get
  * the same, global result. */
 int kpdi_finalize(kpdi_ctx *ctx, float *scores_out, int64_t *indices_out);
+/* kpdi_finalize in two halves, for a caller that indexes map after map against one dictionary: kpdi_finalize_async queues
+ * the (all-gather + merge over the ranks and the) result's device-to-host copies and returns a ticket at once;
+ * kpdi_finalize_wait(ticket) blocks until they have landed and hands the result over.  Between the two the caller may
+ * already queue the NEXT map (kpdi_set_experimental*, kpdi_push_*): the hand-over of a result - synchronisation, copies,
+ * widening the indices, ~0.1 ms - then costs the GPU nothing.  At most two results may be pending; not available with
+ * KPDI_COMPUTE_F64.  Same results as kpdi_finalize (= async + wait); the reference has no counterpart (its loop is
+ * synchronous, indexing/_dictionary_indexing.py:94-128).  kpdi_pending_result_size: the number of (pattern, rank) entries
+ * kpdi_finalize_wait will write for a ticket (m * keep_n at the time of the async call). */
+int kpdi_finalize_async(kpdi_ctx *ctx, int *ticket);
+int kpdi_finalize_wait(kpdi_ctx *ctx, int ticket, float *scores_out, int64_t *indices_out);
+int kpdi_pending_result_size(kpdi_ctx *ctx, int ticket, int64_t *n);
 /* The indices kpdi_finalize handed out last, as it left them in its page-locked staging buffer (int32, row-major
- * (m, keep_n)): valid until the next kpdi_finalize / kpdi_destroy of this context; *indices = NULL when there is none.
+ * (m, keep_n)): valid until the next but one kpdi_finalize[_async] / kpdi_destroy of this context; *indices = NULL when there is none.
  * What a host layer compares a caller's array with before it tells kpdi_orientation_similarity_map to use the lists still
  * resident in HBM (indexing/_orientation_similarity_map.py:30-152 reads `simulation_indices` the caller may have edited). */
 int kpdi_result_indices_i32(kpdi_ctx *ctx, const int32_t **indices, int64_t *n);

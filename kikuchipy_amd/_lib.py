@@ -131,6 +131,9 @@ SIGNATURES = {
     "kpdi_reset_topk": (_i, [_vp]),
     "kpdi_finalize": (_i, [_vp, _vp, _vp]),
     "kpdi_finalize_f64": (_i, [_vp, _vp, _vp]),
+    "kpdi_finalize_async": (_i, [_vp, C.POINTER(_i)]),
+    "kpdi_finalize_wait": (_i, [_vp, _i, _vp, _vp]),
+    "kpdi_pending_result_size": (_i, [_vp, _i, C.POINTER(_i64)]),
     "kpdi_result_indices_i32": (_i, [_vp, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(_i64)]),
     "kpdi_comm_unique_id": (_i, [_vp]),
     "kpdi_comm_init": (_i, [_vp, _i, _i, _vp]),
@@ -528,6 +531,12 @@ class Context:
             check(load().kpdi_finalize(self._h, _ptr(scores), _ptr(indices)))
         self.result_token += 1
         self._last_valid = False
+        self._check_filled(indices, keep_n)
+        self._last_valid = self._compute != COMPUTE_F64
+        return scores, indices
+
+    @staticmethod
+    def _check_filled(indices, keep_n):
         if indices.size and indices[:, -1].max() >= 2**31 - 1:  # unfilled entries rank last
             # unfilled list entries (index INT_MAX, score -inf): fewer than keep_n candidates ranked, which
             # only happens when scores are NaN (NaN / inf in the patterns) - the reference propagates
@@ -536,7 +545,31 @@ class Context:
             raise KpdiError(f"{bad.size} experimental pattern(s) (first: {bad[0]}) ranked fewer than {keep_n} "
                             "dictionary patterns: NaN scores (NaN or inf in the patterns?) or a dictionary "
                             "smaller than keep_n")
-        self._last_valid = self._compute != COMPUTE_F64
+
+    def finalize_async(self, keep_n=None):
+        """Queue the hand-over of the result (all-gather + merge over the ranks, device-to-host copies) and return a
+        ticket at once; `finalize_wait(ticket)` collects it.  In between the NEXT map may already be queued
+        (`set_experimental*`, `push_*`): a series of maps then never leaves the GPU idle during a hand-over."""
+        if keep_n is None:
+            keep_n = self._keep_n
+        if self._keep_n is None or int(keep_n) != self._keep_n:
+            raise KpdiError(f"finalize_async(keep_n={keep_n}) but the context keeps {self._keep_n} entries per pattern")
+        t = C.c_int(-1)
+        check(load().kpdi_finalize_async(self._h, C.byref(t)))
+        self.result_token += 1
+        self._last_valid = False
+        return (t.value, int(keep_n))
+
+    def finalize_wait(self, ticket):
+        """(scores (m, keep_n) float32, indices (m, keep_n) int64) of a `finalize_async` ticket."""
+        slot, keep_n = ticket
+        n = C.c_int64(0)
+        check(load().kpdi_pending_result_size(self._h, int(slot), C.byref(n)))
+        m = n.value // keep_n
+        scores = np.empty((m, keep_n), dtype=np.float32)
+        indices = np.empty((m, keep_n), dtype=np.int64)
+        check(load().kpdi_finalize_wait(self._h, int(slot), _ptr(scores), _ptr(indices)))
+        self._check_filled(indices, keep_n)
         return scores, indices
 
     # -- multi-GPU

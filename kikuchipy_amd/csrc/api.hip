@@ -244,7 +244,20 @@ struct kpdi_ctx {
   DevBuf cand64;                          // float64 scores of the screened candidates [m][columns]
   DevBuf cert64;                          // [0]: bits of max |f32 - f64| over the sweep; [1]: uncertified patterns of a merge
   DevBuf gather64_s, gather64_i, final64_s, final64_i;
-  PinBuf pin_out;                         // kpdi_finalize: scores + indices on their way to the caller
+  PinBuf pin_out;                         // float64 results on their way to the caller
+  // kpdi_finalize[_async]: two page-locked slots (scores + indices on their way to the caller) with an event each
+  struct ResultSlot {
+    PinBuf pin;
+    hipEvent_t ready = nullptr;
+    size_t n = 0;
+    bool pending = false;
+  } slots[2];
+  int next_slot = 0;
+  // the copies of a result run on a stream of their own (the next map's kernels need not queue behind them); whoever
+  // next WRITES the lists they read (the merge into the running best-k) waits for `result_copy` first
+  hipStream_t result_stream = nullptr;
+  hipEvent_t result_done = nullptr;   // compute stream: the lists of the result are final
+  hipEvent_t result_copy = nullptr;   // = slots[].ready of the copy still to be waited for, or nullptr
   const int32_t *result_i32 = nullptr;    // the indices of the last kpdi_finalize in that buffer (kpdi_result_indices_i32)
   int64_t result_n = 0;
 
@@ -323,6 +336,15 @@ int drain_events(kpdi_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> &li
     c->ev_pool.push_back(pr.second);
   }
   list.clear();
+  return KPDI_OK;
+}
+
+// the copies of the last result (finalize_enqueue) read the running lists: whoever writes those next waits for them
+int wait_result_copy(kpdi_ctx *c) {
+  if (c->result_copy) {
+    HIPCHK(hipStreamWaitEvent(c->stream, c->result_copy, 0));
+    c->result_copy = nullptr;
+  }
   return KPDI_OK;
 }
 
@@ -1117,6 +1139,8 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
     mg.src_list_stride[ns] = k;
     mg.n_src = ns + 1;
   }
+  rc = wait_result_copy(c);
+  if (rc) return rc;
   {
     ScopedTimer t(c, &c->ev_merge);
     HIPCHK(kpdi::launch_merge(mg, c->stream));
@@ -1353,6 +1377,12 @@ int kpdi_destroy(kpdi_ctx *c) {
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   release_held(c);
   c->pin_out.release();
+  for (auto &rs : c->slots) {
+    rs.pin.release();
+    if (rs.ready) (void)hipEventDestroy(rs.ready);
+  }
+  if (c->result_done) (void)hipEventDestroy(c->result_done);
+  if (c->result_stream) (void)hipStreamDestroy(c->result_stream);
   for (DevBuf *b : {&c->pix_map, &c->quad_desc, &c->exp_raw, &c->row_map, &c->exp_x, &c->dict_raw, &c->dict_y, &c->part_s,
                     &c->part_i, &c->tail_s, &c->tail_i, &c->list16, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
                     &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps, &c->inv_map, &c->pre_scratch,
@@ -1390,6 +1420,7 @@ int kpdi_synchronize(kpdi_ctx *c) {
   int rc = use_device(c);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->result_stream) HIPCHK(hipStreamSynchronize(c->result_stream));
   return KPDI_OK;
 }
 
@@ -2289,19 +2320,20 @@ int kpdi_finalize_f64(kpdi_ctx *c, double *scores_out, int64_t *indices_out) {
   return finalize64(c, scores_out, nullptr, indices_out);
 }
 
-int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
-  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
-  if (!c->have_exp || !c->have_problem) return fail(KPDI_EINVAL, "nothing to finalise");
-  if (!scores_out || !indices_out) return fail(KPDI_EINVAL, "output pointer is NULL");
-  int rc = use_device(c);
+// kpdi_finalize in two halves.  finalize_enqueue: (all-gather + merge over the ranks,) the result's device-to-host copies
+// into page-locked slot `slot`, an event behind them - nothing waits.  finalize_collect: wait for that event, hand the slot's
+// contents to the caller.  kpdi_finalize = both; kpdi_finalize_async / kpdi_finalize_wait let a caller that indexes map
+// after map queue the NEXT map's kernels before it collects this one's result (the hand-over - synchronisation, copies,
+// widening the indices - is ~0.1 ms of host time per call during which the GPU otherwise idles: 3 % of one rank's 3 ms
+// share of configs[1] at N = 8).
+namespace {
+int finalize_enqueue(kpdi_ctx *c, int slot, bool own_stream) {
+  int rc = ensure_running(c);  // a rank that pushed nothing contributes empty lists
   if (rc) return rc;
-  if (c->m == 0) return KPDI_OK;
-  rc = ensure_running(c);  // a rank that pushed nothing contributes empty lists
-  if (rc) return rc;
-  if (c->exact64) return finalize64(c, nullptr, scores_out, indices_out);
   if (c->run_empty) {
     const size_t n0 = (size_t)c->m * c->keep_n;
-    rc = queue_fill_topk(c, c->run_s[c->run_cur].as<float>(), c->run_i[c->run_cur].as<int>(), n0);
+    rc = wait_result_copy(c);
+    if (!rc) rc = queue_fill_topk(c, c->run_s[c->run_cur].as<float>(), c->run_i[c->run_cur].as<int>(), n0);
     if (!rc) rc = flush_fills(c);
     if (rc) return rc;
     c->run_empty = false;
@@ -2311,6 +2343,8 @@ int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
   const float *d_s = c->run_s[c->run_cur].as<float>();
   const int *d_i = c->run_i[c->run_cur].as<int>();
   if (c->comm) {  // also with one rank: keeps the RCCL path testable on a single GPU
+    rc = wait_result_copy(c);  // (the merge below writes the other half of the ping-pong pair)
+    if (rc) return rc;
     HIPCHK(c->gather_s.reserve(n * c->nranks * sizeof(float)));
     HIPCHK(c->gather_i.reserve(n * c->nranks * sizeof(int)));
     ncclResult_t r;
@@ -2348,25 +2382,100 @@ int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
   }
   c->final_idx = d_i;
   c->final_valid = true;
-  std::vector<int> pageable;
-  float *h_s = scores_out;
-  int *h_i = nullptr;
-  if (c->pin_out.reserve(n * (sizeof(float) + sizeof(int))) == hipSuccess) {
-    h_s = (float *)c->pin_out.p;
-    h_i = (int *)(h_s + n);
-  } else {  // no page-locked memory to be had: copy directly
-    (void)hipGetLastError();
-    pageable.resize(n);
-    h_i = pageable.data();
-  }
+  kpdi_ctx::ResultSlot &rs = c->slots[slot];
+  HIPCHK(rs.pin.reserve(n * (sizeof(float) + sizeof(int))));
+  if (!rs.ready) HIPCHK(hipEventCreateWithFlags(&rs.ready, hipEventDisableTiming));
+  rs.n = n;
+  rs.pending = true;
   c->result_i32 = nullptr;
-  HIPCHK(hipMemcpyAsync(h_s, d_s, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(h_i, d_i, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  if (h_s != scores_out) memcpy(scores_out, h_s, n * sizeof(float));
+  float *h_s = (float *)rs.pin.p;
+  if (!own_stream) {  // kpdi_finalize waits right away: the hop to another stream would only add latency (+15 us measured)
+    HIPCHK(hipMemcpyAsync(h_s, d_s, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(h_s + n, d_i, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(rs.ready, c->stream));
+    return KPDI_OK;
+  }
+  if (!c->result_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->result_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->result_done, hipEventDisableTiming));
+  }
+  HIPCHK(hipEventRecord(c->result_done, c->stream));
+  HIPCHK(hipStreamWaitEvent(c->result_stream, c->result_done, 0));
+  HIPCHK(hipMemcpyAsync(h_s, d_s, n * sizeof(float), hipMemcpyDeviceToHost, c->result_stream));
+  HIPCHK(hipMemcpyAsync(h_s + n, d_i, n * sizeof(int), hipMemcpyDeviceToHost, c->result_stream));
+  HIPCHK(hipEventRecord(rs.ready, c->result_stream));
+  c->result_copy = rs.ready;
+  return KPDI_OK;
+}
+
+int finalize_collect(kpdi_ctx *c, int slot, float *scores_out, int64_t *indices_out) {
+  kpdi_ctx::ResultSlot &rs = c->slots[slot];
+  if (!rs.pending) return fail(KPDI_EINVAL, "no result is pending in slot %d", slot);
+  HIPCHK(hipEventSynchronize(rs.ready));
+  rs.pending = false;
+  const size_t n = rs.n;
+  const float *h_s = (const float *)rs.pin.p;
+  const int *h_i = (const int *)(h_s + n);
+  memcpy(scores_out, h_s, n * sizeof(float));
   for (size_t i = 0; i < n; ++i) indices_out[i] = (int64_t)h_i[i];
-  c->result_i32 = h_s != scores_out ? (const int32_t *)h_i : nullptr;  // (only the page-locked buffer outlives this call)
+  c->result_i32 = (const int32_t *)h_i;  // (valid until this slot is used again: two finalize calls on)
   c->result_n = (int64_t)n;
+  return KPDI_OK;
+}
+
+int finalize_args(kpdi_ctx *c) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!c->have_exp || !c->have_problem) return fail(KPDI_EINVAL, "nothing to finalise");
+  return use_device(c);
+}
+}  // namespace
+
+int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
+  int rc = finalize_args(c);
+  if (rc) return rc;
+  if (!scores_out || !indices_out) return fail(KPDI_EINVAL, "output pointer is NULL");
+  if (c->m == 0) return KPDI_OK;
+  if (c->exact64) {
+    rc = ensure_running(c);
+    if (rc) return rc;
+    return finalize64(c, nullptr, scores_out, indices_out);
+  }
+  const int slot = c->next_slot;
+  c->next_slot ^= 1;
+  rc = finalize_enqueue(c, slot, false);
+  if (rc) return rc;
+  return finalize_collect(c, slot, scores_out, indices_out);
+}
+
+int kpdi_finalize_async(kpdi_ctx *c, int *ticket) {
+  int rc = finalize_args(c);
+  if (rc) return rc;
+  if (!ticket) return fail(KPDI_EINVAL, "ticket is NULL");
+  if (c->exact64) return fail(KPDI_EINVAL, "kpdi_finalize_async: not available in float64 arithmetic (use kpdi_finalize_f64)");
+  if (c->m == 0) return fail(KPDI_EINVAL, "no experimental patterns to finalise");
+  const int slot = c->next_slot;
+  if (c->slots[slot].pending)
+    return fail(KPDI_EINVAL, "two results are already pending: collect one with kpdi_finalize_wait first");
+  c->next_slot ^= 1;
+  rc = finalize_enqueue(c, slot, true);
+  if (rc) return rc;
+  *ticket = slot;
+  return KPDI_OK;
+}
+
+int kpdi_finalize_wait(kpdi_ctx *c, int ticket, float *scores_out, int64_t *indices_out) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!scores_out || !indices_out) return fail(KPDI_EINVAL, "output pointer is NULL");
+  if (ticket < 0 || ticket > 1) return fail(KPDI_EINVAL, "bad ticket %d", ticket);
+  int rc = use_device(c);
+  if (rc) return rc;
+  return finalize_collect(c, ticket, scores_out, indices_out);
+}
+
+int kpdi_pending_result_size(kpdi_ctx *c, int ticket, int64_t *n) {
+  if (!c || !n) return fail(KPDI_EINVAL, "NULL argument");
+  if (ticket < 0 || ticket > 1 || !c->slots[ticket].pending) return fail(KPDI_EINVAL, "no result is pending for ticket %d", ticket);
+  *n = (int64_t)c->slots[ticket].n;
   return KPDI_OK;
 }
 

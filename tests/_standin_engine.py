@@ -108,6 +108,15 @@ class StandInContext:
             s, i = ko.merge_topk(s, i, np.asarray(s_r), np.asarray(i_r), self.keep_n)
         return s, i
 
+    def finalize_async(self, keep_n=None):
+        self._pending = getattr(self, "_pending", {})
+        ticket = len(self._pending)
+        self._pending[ticket] = self.finalize(keep_n)  # (the stand-in has nothing to overlap: it finishes here)
+        return ticket
+
+    def finalize_wait(self, ticket):
+        return self._pending.pop(ticket)
+
     # -- multi-rank
     @staticmethod
     def comm_unique_id():

@@ -31,6 +31,7 @@ ap.add_argument("--ranks", default="1,2,4,8")
 ap.add_argument("--reps", type=int, default=0)
 ap.add_argument("--no-whole-tiles", action="store_true", help="skip the second pass with KPDI_NO_TAIL=1")
 ap.add_argument("--pmc-shard", type=int, default=0)
+ap.add_argument("--pipeline", action="store_true", help="collect step i's result while step i + 1 runs (finalize_async / finalize_wait)")
 ap.add_argument("--dict-dtype", default="f32", choices=["f32", "f16"], help="dtype the raw dictionary is resident in")
 a = ap.parse_args()
 
@@ -41,7 +42,8 @@ ranks_list = [int(x) for x in a.ranks.split(",")] if not a.pmc_shard else [a.pmc
 rng = np.random.default_rng(2024)
 exp = rng.integers(0, 256, (m, sy, sx), dtype=np.uint8)
 n_need = max(shard_range(n, 0, r)[1] for r in ranks_list)  # rank 0's shards are prefixes of the dictionary
-out = {"workload": w["name"] + f"; rank 0's shard on one MI355X, compute {a.compute}, raw dictionary resident as {a.dict_dtype}",
+out = {"workload": w["name"] + f"; rank 0's shard on one MI355X, compute {a.compute}, raw dictionary resident as {a.dict_dtype}"
+                   + ("; results collected while the next step runs (finalize_async / finalize_wait)" if a.pipeline else ""),
        "ranks": {}}
 with _lib.Context(0) as ctx:
     metric = {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[w["metric"]]
@@ -67,14 +69,26 @@ with _lib.Context(0) as ctx:
             reps = a.reps or int(max(3, min(20, 1.5 / est)))
             warm = 1 if a.pmc_shard else 3
             ctx.set_profiling(True)
+            pending = None
             for r in range(reps + warm):
                 if r == warm:
+                    if pending is not None:
+                        ctx.finalize_wait(pending)
+                        pending = None
                     ctx.reset_counters()
                     ctx.synchronize()
                     t0 = time.perf_counter()
                 ctx.set_experimental_dev(d_exp, exp.dtype, m)
                 ctx.push_dictionary_chunk_dev(d_dic, np.float16 if a.dict_dtype == "f16" else np.float32, hi - lo, lo)
-                ctx.finalize(keep)
+                if a.pipeline:
+                    ticket = ctx.finalize_async(keep)
+                    if pending is not None:
+                        ctx.finalize_wait(pending)
+                    pending = ticket
+                else:
+                    ctx.finalize(keep)
+            if pending is not None:
+                ctx.finalize_wait(pending)
             dt = (time.perf_counter() - t0) / reps * 1e3
             c = ctx.counters()
             ctx.set_profiling(False)
