@@ -404,35 +404,38 @@ def test_finalize_async_pipelines_a_series_of_maps():
     rng = np.random.default_rng(23)
     dic = rng.random((3000, 24, 24), dtype=np.float32)
     maps = [rng.integers(0, 256, (m, 24, 24), dtype=np.uint8) for m in (300, 300, 77, 300, 512)]
-    with _lib.Context(0) as c:
-        c.set_problem(24, 24, None, _lib.METRIC_NCC, 10)
-        want = []
-        for e in maps:
-            c.set_experimental(e)
-            c.push_dictionary_chunk(dic[:1700], 0)
-            c.push_dictionary_chunk(dic[1700:], 1700)
-            want.append(c.finalize(10))
-        got, pending = [], None
-        for e in maps:
-            c.set_experimental(e)
-            c.push_dictionary_chunk(dic[:1700], 0)
-            c.push_dictionary_chunk(dic[1700:], 1700)
-            ticket = c.finalize_async(10)
-            if pending is not None:
-                got.append(c.finalize_wait(pending))
-            pending = ticket
-        got.append(c.finalize_wait(pending))
-        for (ws, wi), (gs, gi) in zip(want, got):
-            assert gs.shape == ws.shape and np.array_equal(gs, ws) and np.array_equal(gi, wi)
-        # two pending results are the limit; a collected ticket cannot be collected again
-        c.set_experimental(maps[0])
-        c.push_dictionary_chunk(dic, 0)
-        t1 = c.finalize_async(10)
-        t2 = c.finalize_async(10)
-        with pytest.raises(_lib.KpdiError, match="already pending"):
-            c.finalize_async(10)
-        a = c.finalize_wait(t1)
-        b = c.finalize_wait(t2)
-        assert np.array_equal(a[1], b[1]) and np.array_equal(a[1], c.finalize(10)[1])
-        with pytest.raises(_lib.KpdiError, match="no result is pending"):
-            c.finalize_wait(t1)
+    for with_comm in (False, True):  # (True: the RCCL all-gather + rank merge of a one-rank communicator inside the async half)
+        with _lib.Context(0) as c:
+            if with_comm:
+                c.comm_init(0, 1, _lib.Context.comm_unique_id())
+            c.set_problem(24, 24, None, _lib.METRIC_NCC, 10)
+            want = []
+            for e in maps:
+                c.set_experimental(e)
+                c.push_dictionary_chunk(dic[:1700], 0)
+                c.push_dictionary_chunk(dic[1700:], 1700)
+                want.append(c.finalize(10))
+            got, pending = [], None
+            for e in maps:
+                c.set_experimental(e)
+                c.push_dictionary_chunk(dic[:1700], 0)
+                c.push_dictionary_chunk(dic[1700:], 1700)
+                ticket = c.finalize_async(10)
+                if pending is not None:
+                    got.append(c.finalize_wait(pending))
+                pending = ticket
+            got.append(c.finalize_wait(pending))
+            for (ws, wi), (gs, gi) in zip(want, got):
+                assert gs.shape == ws.shape and np.array_equal(gs, ws) and np.array_equal(gi, wi)
+            # two pending results are the limit; a collected ticket cannot be collected again
+            c.set_experimental(maps[0])
+            c.push_dictionary_chunk(dic, 0)
+            t1 = c.finalize_async(10)
+            t2 = c.finalize_async(10)
+            with pytest.raises(_lib.KpdiError, match="already pending"):
+                c.finalize_async(10)
+            a = c.finalize_wait(t1)
+            b = c.finalize_wait(t2)
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[1], c.finalize(10)[1])
+            with pytest.raises(_lib.KpdiError, match="no result is pending"):
+                c.finalize_wait(t1)
