@@ -643,7 +643,14 @@ def main(argv=None, context_factory=None):
                 t0 = time.perf_counter()
                 ctx.push_dictionary_chunk(dic, 0)
                 ctx.finalize(w["keep_n"])
-                out["extra"]["pcie_inclusive_patterns_per_s"] = round(w["m"] / (time.perf_counter() - t0), 1)
+                dt_pcie = time.perf_counter() - t0
+                out["extra"]["pcie_inclusive_patterns_per_s"] = round(w["m"] / dt_pcie, 1)
+                # its roofline is the host link, not the matrix pipe: the whole dictionary crosses PCIe inside the step
+                # (pageable memory; 63 GB/s = the link's rate in MI355X_MICROARCH.md / SURVEY.md 8(f1))
+                out["extra"]["pcie_inclusive"] = {
+                    "ms_per_step": round(dt_pcie * 1e3, 3), "bound": "host link (PCIe, pageable source)",
+                    "bytes_over_link": int(dic.nbytes), "achieved_GBps": round(dic.nbytes / dt_pcie / 1e9, 1),
+                    "peak_GBps": 63.0, "frac": round(dic.nbytes / dt_pcie / 63e9, 3)}
         except Exception as err:  # an informational leg must not cost the bench line
             out["extra"]["pcie_inclusive_error"] = f"{type(err).__name__}: {err}"
 
