@@ -162,7 +162,8 @@ int kpdi_get_experimental(kpdi_ctx *ctx, void *patterns_out);
  * The host-pointer form returns as soon as the upload has consumed `patterns` (the sweep
  * of the chunk is still running; it is ordered before every later call on the context);
  * uploads go through two staging buffers on a copy stream and overlap the sweep of the
- * previous piece / chunk. */
+ * previous piece / chunk - also with KPDI_COMPUTE_F64, whose look at a chunk's certification (and the extra screening
+ * passes it may ask for) is left to the next call on the context. */
 int kpdi_push_dictionary_chunk(kpdi_ctx *ctx, const void *patterns, int dtype,
                                int64_t n_chunk, int64_t global_start);
 int kpdi_push_dictionary_chunk_dev(kpdi_ctx *ctx, const void *d_patterns, int dtype,

@@ -245,6 +245,16 @@ struct kpdi_ctx {
   DevBuf cert64;                          // [0]: bits of max |f32 - f64| over the sweep; [1]: uncertified patterns of a merge
   DevBuf gather64_s, gather64_i, final64_s, final64_i;
   PinBuf pin_out;                         // float64 results on their way to the caller
+  // the certification read-back of the last float64 chunk, not yet looked at (sweep_exact64 / resolve_exact64)
+  struct Pending64 {
+    bool active = false, defer = false;
+    const float *y = nullptr;
+    const void *raw = nullptr;
+    int raw_dtype = 0, n_tiles = 0, nsplit = 0, rows_per_launch = 0, cap = 0, done = 0, extra = 0;
+    int64_t n_chunk = 0, global_start = 0;
+    hipEvent_t ready = nullptr;
+    PinBuf flag;  // int: patterns the last merge could not certify
+  } pend64;
   // kpdi_finalize[_async]: two page-locked slots (scores + indices on their way to the caller) with an event each
   struct ResultSlot {
     PinBuf pin;
@@ -408,8 +418,12 @@ int lists_per_split(const kpdi_ctx *c) { return uses16(c) ? 4 : 2; }
 // entries ranked per pass when keep_n needs several (bounded) passes
 int pass_entries(const kpdi_ctx *c) { return c->wide32 ? 20 : kpdi::KMAX_LIMIT; }
 
-int use_device(kpdi_ctx *c) {
+int resolve_exact64(kpdi_ctx *c);
+// first thing every entry point does.  `keep_pending`: the one caller (kpdi_push_dictionary_chunk) that starts its upload
+// BEFORE it looks at the float64 certification of the previous chunk
+int use_device(kpdi_ctx *c, bool keep_pending = false) {
   HIPCHK(hipSetDevice(c->device));
+  if (c->pend64.active && !keep_pending) return resolve_exact64(c);
   return KPDI_OK;
 }
 
@@ -886,7 +900,9 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
 void release_held(kpdi_ctx *c);
 
 int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start) {
-  int rc = check_chunk_args(c, dtype, n_chunk, global_start);
+  int rc = resolve_exact64(c);  // (before this chunk's preparation overwrites what extra passes of the last one would read)
+  if (rc) return rc;
+  rc = check_chunk_args(c, dtype, n_chunk, global_start);
   if (rc) return rc;
   if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
   if (c->m == 0) return KPDI_OK;
@@ -962,6 +978,109 @@ int local_pass(kpdi_ctx *c, const float *y, int n_chunk, int n_tiles, int nsplit
 // the raw patterns, merge into the running float64 best-k, certify; uncertified patterns get up to EXTRA64 more
 // screening passes of 32 candidates
 constexpr int MARGIN64 = 12, EXTRA64 = 3;
+
+// screening passes of the pending chunk up to `target` candidates per pattern (each: f32 match + rescoring in double +
+// merge into the running float64 best-k with its certification), then the read-back of the last merge's verdict
+int exact64_passes(kpdi_ctx *c, int64_t target) {
+  kpdi_ctx::Pending64 &q = c->pend64;
+  const int k = c->keep_n;
+  const int pass = pass_entries(c);
+  unsigned *cert = c->cert64.as<unsigned>();
+  while (q.done < target) {
+    const int kp = (int)std::min<int64_t>(q.done == 0 ? kpdi::KMAX_LIMIT : pass, target - q.done);
+    int rc = local_pass(c, q.y, (int)q.n_chunk, q.n_tiles, q.nsplit, q.rows_per_launch, q.global_start, q.done, kp, q.cap);
+    if (rc) return rc;
+    ScopedTimer t(c, &c->ev_rescore);
+    kpdi::RescoreLaunch r{};
+    r.exp_raw = c->exp_raw.p;
+    r.exp_dtype = c->exp_dtype;
+    r.row_map = c->have_nav_mask ? c->row_map.as<int>() : nullptr;
+    r.dict_raw = q.raw;
+    r.dict_dtype = q.raw_dtype;
+    r.n_chunk = q.n_chunk;
+    r.global_start = q.global_start;
+    r.pix_map = c->have_sig_mask ? c->pix_map.as<int>() : nullptr;
+    r.k = c->k_kept;
+    r.npix = c->npix;
+    r.metric = c->metric;
+    r.m = c->m;
+    r.cand_s = c->loc_s.as<float>();
+    r.cand_i = c->loc_i.as<int>();
+    r.cand_stride = q.cap;
+    r.cand_offset = q.done;
+    r.n_cand = kp;
+    r.cand_s64 = c->cand64.as<double>();
+    r.max_diff = cert;
+    HIPCHK(kpdi::launch_rescore(r, c->stream));
+    HIPCHK(hipMemsetAsync(cert + 1, 0, sizeof(unsigned), c->stream));
+    kpdi::Merge64Launch g{};
+    g.m = c->m;
+    g.k = k;
+    g.run_s = c->run64_s.as<double>();
+    g.run_i = c->run64_i.as<int>();
+    g.cand_s64 = c->cand64.as<double>() + q.done;
+    g.cand_i = c->loc_i.as<int>() + q.done;
+    g.lists = 1;
+    g.len = kp;
+    g.row_stride = q.cap;
+    g.list_stride = 0;
+    g.out_s = c->run64_s.as<double>();
+    g.out_i = c->run64_i.as<int>();
+    g.cand_s32 = c->loc_s.as<float>();
+    g.s32_stride = q.cap;
+    g.s32_col = q.done + kp - 1;
+    g.enumerated_all = q.done + kp >= q.n_chunk;
+    g.max_diff = cert;
+    // what an unscreened candidate's float64 score may exceed its float32 score by: 8 x the largest difference seen
+    // among the rescored pairs of the sweep (a STATISTICAL bound: ~130 000 samples per chunk at configs[1], taken
+    // from the best-scoring pairs, whose partial sums - and rounding errors - are the largest), never less than
+    // 1e-6; KPDI_F64_EPS=worstcase raises the floor to the worst-case accumulation bound of a K-term float32 dot
+    // product of unit vectors, (K + 2) 2^-24 (2.1e-4 at K = 3600): a certificate that holds for any data, at the price
+    // of more screening passes where the k-th and the screened-last scores are closer than that
+    {
+      static const bool worstcase = getenv("KPDI_F64_EPS") && !strcmp(getenv("KPDI_F64_EPS"), "worstcase");
+      g.eps_floor = worstcase ? (float)((c->k_kept + 2) * 0x1p-24 * 1.01) + 1e-6f : 1e-6f;
+    }
+    g.uncertified = (int *)(cert + 1);
+    HIPCHK(kpdi::launch_merge64(g, c->stream));
+    q.done += kp;
+  }
+  HIPCHK(hipMemcpyAsync(q.flag.p, cert + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipEventRecord(q.ready, c->stream));
+  return KPDI_OK;
+}
+
+// Look at the pending chunk's verdict; patterns it left uncertified get up to EXTRA64 more screening passes of the SAME
+// chunk - whose prepared form, raw patterns and candidate buffers are still in place: every entry point comes through
+// here (use_device) before it touches them.
+int resolve_exact64(kpdi_ctx *c) {
+  kpdi_ctx::Pending64 &q = c->pend64;
+  if (!q.active) return KPDI_OK;
+  q.active = false;  // (an error below leaves no half-resolved chunk behind)
+  bool more = false;
+  int uncertified = 0;
+  for (;;) {
+    HIPCHK(hipEventSynchronize(q.ready));
+    uncertified = *(volatile int *)q.flag.p;
+    if (uncertified == 0 || q.done >= q.n_chunk || q.extra == EXTRA64) break;
+    ++q.extra;
+    c->cnt.rescore_extra_passes += 1;
+    more = true;
+    int rc = exact64_passes(c, std::min<int64_t>((int64_t)q.done + pass_entries(c), q.n_chunk));
+    if (rc) return rc;
+  }
+  c->cnt.uncertified_patterns += uncertified;
+  // the extra passes read the chunk's staging buffer after staged_upload released it: release both again, behind them
+  if (more && c->copy_stream)
+    for (int b = 0; b < 2; ++b) HIPCHK(hipEventRecord(c->stage_free[b], c->stream));
+  return KPDI_OK;
+}
+
+// float64 arithmetic (rescore.hip): screen keep_n + 12 candidates of the chunk in f32, rescore them in double from
+// the raw patterns, merge into the running float64 best-k, certify; uncertified patterns get up to EXTRA64 more
+// screening passes of 32 candidates.  The verdict of the first passes is read back asynchronously: a caller streaming
+// host chunks (kpdi_push_dictionary_chunk) looks at it only after the NEXT chunk's upload has been queued, so that
+// upload and sweep overlap as they do in the float32 modes; everyone else resolves it before returning.
 int sweep_exact64(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_start, const void *raw, int raw_dtype,
                   int n_tiles, int nsplit, int rows_per_launch) {
   const int k = c->keep_n;
@@ -976,78 +1095,25 @@ int sweep_exact64(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_s
   HIPCHK(c->bound_i.reserve((size_t)c->m_pad * sizeof(int)));
   HIPCHK(kpdi::launch_fill_topk(c->bound_s.as<float>(), c->bound_i.as<int>(), c->m_pad, c->stream));
   HIPCHK(kpdi::launch_fill_topk(c->loc_s.as<float>(), c->loc_i.as<int>(), (int64_t)n, c->stream));
-  unsigned *cert = c->cert64.as<unsigned>();
-  int done = 0, extra = 0, uncertified = 0;
-  int64_t target = std::min<int64_t>((int64_t)k + MARGIN64, n_chunk);
-  for (;;) {
-    while (done < target) {
-      const int kp = (int)std::min<int64_t>(done == 0 ? kpdi::KMAX_LIMIT : pass, target - done);
-      int rc = local_pass(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, global_start, done, kp, cap);
-      if (rc) return rc;
-      ScopedTimer t(c, &c->ev_rescore);
-      kpdi::RescoreLaunch r{};
-      r.exp_raw = c->exp_raw.p;
-      r.exp_dtype = c->exp_dtype;
-      r.row_map = c->have_nav_mask ? c->row_map.as<int>() : nullptr;
-      r.dict_raw = raw;
-      r.dict_dtype = raw_dtype;
-      r.n_chunk = n_chunk;
-      r.global_start = global_start;
-      r.pix_map = c->have_sig_mask ? c->pix_map.as<int>() : nullptr;
-      r.k = c->k_kept;
-      r.npix = c->npix;
-      r.metric = c->metric;
-      r.m = c->m;
-      r.cand_s = c->loc_s.as<float>();
-      r.cand_i = c->loc_i.as<int>();
-      r.cand_stride = cap;
-      r.cand_offset = done;
-      r.n_cand = kp;
-      r.cand_s64 = c->cand64.as<double>();
-      r.max_diff = cert;
-      HIPCHK(kpdi::launch_rescore(r, c->stream));
-      HIPCHK(hipMemsetAsync(cert + 1, 0, sizeof(unsigned), c->stream));
-      kpdi::Merge64Launch g{};
-      g.m = c->m;
-      g.k = k;
-      g.run_s = c->run64_s.as<double>();
-      g.run_i = c->run64_i.as<int>();
-      g.cand_s64 = c->cand64.as<double>() + done;
-      g.cand_i = c->loc_i.as<int>() + done;
-      g.lists = 1;
-      g.len = kp;
-      g.row_stride = cap;
-      g.list_stride = 0;
-      g.out_s = c->run64_s.as<double>();
-      g.out_i = c->run64_i.as<int>();
-      g.cand_s32 = c->loc_s.as<float>();
-      g.s32_stride = cap;
-      g.s32_col = done + kp - 1;
-      g.enumerated_all = done + kp >= n_chunk;
-      g.max_diff = cert;
-      // what an unscreened candidate's float64 score may exceed its float32 score by: 8 x the largest difference seen
-      // among the rescored pairs of the sweep (a STATISTICAL bound: ~130 000 samples per chunk at configs[1], taken
-      // from the best-scoring pairs, whose partial sums - and rounding errors - are the largest), never less than
-      // 1e-6; KPDI_F64_EPS=worstcase raises the floor to the worst-case accumulation bound of a K-term float32 dot
-      // product of unit vectors, (K + 2) 2^-24 (2.1e-4 at K = 3600): a certificate that holds for any data, at the price
-      // of more screening passes where the k-th and the screened-last scores are closer than that
-      {
-        static const bool worstcase = getenv("KPDI_F64_EPS") && !strcmp(getenv("KPDI_F64_EPS"), "worstcase");
-        g.eps_floor = worstcase ? (float)((c->k_kept + 2) * 0x1p-24 * 1.01) + 1e-6f : 1e-6f;
-      }
-      g.uncertified = (int *)(cert + 1);
-      HIPCHK(kpdi::launch_merge64(g, c->stream));
-      done += kp;
-    }
-    HIPCHK(hipMemcpyAsync(&uncertified, cert + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (uncertified == 0 || done >= n_chunk || extra == EXTRA64) break;
-    target = std::min<int64_t>((int64_t)done + pass, n_chunk);
-    ++extra;
-    c->cnt.rescore_extra_passes += 1;
-  }
-  c->cnt.uncertified_patterns += uncertified;
-  return KPDI_OK;
+  kpdi_ctx::Pending64 &q = c->pend64;
+  if (!q.ready) HIPCHK(hipEventCreateWithFlags(&q.ready, hipEventDisableTiming));
+  HIPCHK(q.flag.reserve(sizeof(int)));
+  q.y = y;
+  q.raw = raw;
+  q.raw_dtype = raw_dtype;
+  q.n_tiles = n_tiles;
+  q.nsplit = nsplit;
+  q.rows_per_launch = rows_per_launch;
+  q.cap = cap;
+  q.done = 0;
+  q.extra = 0;
+  q.n_chunk = n_chunk;
+  q.global_start = global_start;
+  int rc = exact64_passes(c, std::min<int64_t>((int64_t)k + MARGIN64, n_chunk));
+  if (rc) return rc;
+  q.active = true;
+  static const bool always_now = getenv("KPDI_F64_SYNC") != nullptr;  // (A/B switch: round 2's behaviour)
+  return q.defer && !always_now ? KPDI_OK : resolve_exact64(c);
 }
 
 // every experimental pattern against one prepared chunk, merged into the running best-k
@@ -1216,7 +1282,10 @@ int staged_upload(kpdi_ctx *c, const void *patterns, size_t row_bytes, const std
   }
   for (int b = 0; b < 2; ++b)
     if (c->stage[b].cap < (size_t)per * row_bytes) {
-      // growing a buffer frees it: everything queued on it must have finished
+      // growing a buffer frees it: everything queued on it must have finished (and a float64 chunk whose certification
+      // has not been looked at yet may still want to read it)
+      int rc = resolve_exact64(c);
+      if (rc) return rc;
       HIPCHK(hipStreamSynchronize(c->copy_stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       HIPCHK(c->stage[b].reserve((size_t)per * row_bytes));
@@ -1377,6 +1446,8 @@ int kpdi_destroy(kpdi_ctx *c) {
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   release_held(c);
   c->pin_out.release();
+  c->pend64.flag.release();
+  if (c->pend64.ready) (void)hipEventDestroy(c->pend64.ready);
   for (auto &rs : c->slots) {
     rs.pin.release();
     if (rs.ready) (void)hipEventDestroy(rs.ready);
@@ -1642,13 +1713,17 @@ int kpdi_push_dictionary_chunk(kpdi_ctx *c, const void *patterns, int dtype, int
   const size_t es = kpdi::dtype_size(dtype);
   if (es == 0) return fail(KPDI_EINVAL, "unknown dtype %d", dtype);
   if (n_chunk <= 0) return fail(KPDI_EINVAL, "dictionary chunk must hold at least one pattern");
-  int rc = use_device(c);
+  int rc = use_device(c, true);
   if (rc) return rc;
-  // the sweep of the last piece may still be running on return
-  return staged_upload(c, patterns, (size_t)c->npix * es, upload_pieces(c, n_chunk, (size_t)c->npix * es),
-                       [&](const void *d_piece, int64_t n, int64_t offset) {
-                         return push_chunk_dev(c, d_piece, dtype, n, global_start + offset);
-                       });
+  // the sweep of the last piece may still be running on return (KPDI_COMPUTE_F64: with the look at its certification
+  // left to the next call on the context, resolve_exact64)
+  c->pend64.defer = true;
+  rc = staged_upload(c, patterns, (size_t)c->npix * es, upload_pieces(c, n_chunk, (size_t)c->npix * es),
+                     [&](const void *d_piece, int64_t n, int64_t offset) {
+                       return push_chunk_dev(c, d_piece, dtype, n, global_start + offset);
+                     });
+  c->pend64.defer = false;
+  return rc;
 }
 
 int kpdi_push_dictionary_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk,
@@ -2215,6 +2290,8 @@ size_t kpdi_dtype_size(int dtype) { return kpdi::dtype_size(dtype); }
 
 int kpdi_reset_topk(kpdi_ctx *c) {
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  int rc = use_device(c);
+  if (rc) return rc;
   c->run_valid = false;
   c->final_valid = false;
   return KPDI_OK;

@@ -113,6 +113,26 @@ def test_equal_scores_need_more_screening_passes():
     assert cnt["uncertified_patterns"] == 0
 
 
+def test_extra_passes_of_an_earlier_host_chunk():
+    """Host chunks stream through two staging buffers and the look at a chunk's certification is left to the next call
+    (api.hip: resolve_exact64): the 60 equal-scoring twins sit in the FIRST of four chunks, so its extra screening
+    passes are queued while the second chunk's upload is already in flight - same result as one chunk."""
+    rng = np.random.default_rng(21)
+    m, n, s = 30, 800, 20
+    dic = rng.random((n, s, s), dtype=np.float32)
+    exp = rng.integers(0, 256, (m, s, s), dtype=np.uint8)
+    twins = rng.permutation(200)[:60]
+    base = rng.random((s, s), dtype=np.float32)
+    dic[twins] = base
+    exp[:] = np.clip(base * 255 + rng.normal(0, 3, (m, s, s)), 0, 255).astype(np.uint8)
+    ref_s, ref_i = oracle64(exp, dic, "ncc", 20)
+    for chunk in (200, 800):
+        scores, idx, cnt = engine64(exp, dic, "ncc", 20, chunk=chunk)
+        assert np.abs(scores - ref_s).max() <= TOL
+        assert np.array_equal(idx, np.broadcast_to(np.sort(twins)[:20], idx.shape))
+        assert cnt["rescore_extra_passes"] >= 1 and cnt["uncertified_patterns"] == 0
+
+
 @pytest.mark.parametrize("n_near", [40, 300])
 def test_near_ties_below_the_f32_resolution(monkeypatch, n_near):
     """Adversarial for the certification: dictionary patterns that differ from one base pattern by 1e-8 .. 1e-5
