@@ -301,6 +301,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
 
     int stage = 0;
     int tiles_done = 0, refresh_at = 0;
+#ifdef KPDI16_TIME_EPI  // developer build (tools/build_variant.sh + tools/probes/one_step.py): where the cycles between tiles go
+    unsigned long long epi_cycles = 0, epi_drain = 0;
+    const unsigned long long kern_t0 = __builtin_readcyclecounter();
+#endif
 #pragma clang loop unroll(disable)
     for (;;) {  // dictionary tiles (units)
       const int rt_n = F32 ? KPDI16_UNIT_RT(t0) : 4;                        // row groups of this wave in this unit
@@ -398,6 +402,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
         KPDI16_CURSOR_ADVANCE();
         stage = nstage;
       }  // steps
+#ifdef KPDI16_TIME_EPI
+      const unsigned long long epi_t0 = __builtin_readcyclecounter();
+#endif
       // the last MFMAs (8 passes) must have written the accumulators before they are read
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg)
@@ -408,6 +415,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
           else
             asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[cg][rt]));
         }
+#ifdef KPDI16_TIME_EPI
+      epi_drain += __builtin_readcyclecounter() - epi_t0;
+#endif
       {
         // ---- epilogue of the tile.  Steady state (per column group): the 64 accumulator registers are
         // compared with the pre-scaled threshold (a v_max3 tree per 16 registers first) and the few
@@ -449,6 +459,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
             float m = acc[cg][rt][0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[cg][rt][r]);
+#ifdef KPDI16_SCAN_NEVER  // timing-only ablation: the screen (maxima + ballot) runs, no candidate is ever taken
+            if (__builtin_amdgcn_ballot_w64(m >= thr_raw) != 0xdeadbeefull) continue;
+#endif
             if (__builtin_amdgcn_ballot_w64(m >= thr_raw) == 0) continue;  // wave-uniform
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -526,6 +539,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
             }
           }
         }
+#ifdef KPDI16_TIME_EPI
+        epi_cycles += __builtin_readcyclecounter() - epi_t0;
+#endif
         ++tiles_done;
         t0 = t1;
         t1 = t2;
@@ -534,6 +550,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
         if (t0 >= n_units) break;
       }
     }
+#ifdef KPDI16_TIME_EPI
+    if ((blockIdx.x == 0 || blockIdx.x == 100) && lane == 0)
+      printf("block %d wave %d: %d tiles, %llu cycles between tiles (%llu of them waiting for the last MFMAs) of %llu in the tile loop "
+             "(%.2f %%)\n", (int)blockIdx.x, wv, tiles_done, epi_cycles, epi_drain, __builtin_readcyclecounter() - kern_t0,
+             100.0 * epi_cycles / (double)(__builtin_readcyclecounter() - kern_t0));
+#endif
   }
 
   // ---- the buffered candidates that pass the FINAL shared bound join their lists (in arrival order = by

@@ -31,7 +31,10 @@ with _lib.Context(0) as ctx:
                 ctx.reset_counters()
             ctx.set_experimental_dev(d_exp, exp.dtype, 4096)
             ctx.push_dictionary_chunk_dev(d_dic, np.float32, n, 0)
-            ctx.finalize(20)
+            try:
+                ctx.finalize(20)
+            except _lib.KpdiError:  # (timing-only ablation builds of the kernel hand out empty lists)
+                pass
         c = ctx.counters()
         ms = c["match_ms"] / 10
         xs.append(j)
