@@ -540,7 +540,8 @@ def main(argv=None, context_factory=None):
     if a.workload == "config2" and world == 1 and a.compute == "f32":
         import glob
 
-        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+        # (r03_pmc.json: the passes of THIS command; not r03_config3_pmc.json / r03_rank_share_pmc.json)
+        pmc = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))
         if pmc:
             with open(pmc[-1]) as f:
                 prof = json.load(f)

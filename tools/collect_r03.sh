@@ -18,6 +18,7 @@ bash tools/collect_profiles.sh r03 --no-config3 --no-traffic > $O/collect.log 2>
 bash tools/collect_profiles.sh r03_config3 --workload config3 --no-traffic >> $O/collect.log 2>&1
 # ---- one rank's share of configs[1], [3], [4] (f32, float16, float16 from a float16-resident dictionary)
 timeout 300 python tools/rank_share_probe.py $O/rank_share_config2.json > $O/rank_share_config2.log 2>&1
+timeout 300 python tools/rank_share_probe.py $O/rank_share_config2_pipeline.json --pipeline --no-whole-tiles > $O/rank_share_config2_pipeline.log 2>&1
 timeout 600 python tools/rank_share_probe.py $O/rank_share_config4.json --workload config4 --no-whole-tiles > $O/rank_share_config4.log 2>&1
 timeout 900 python tools/rank_share_probe.py $O/rank_share_config5.json --workload config5 --no-whole-tiles > $O/rank_share_config5.log 2>&1
 timeout 900 python tools/rank_share_probe.py $O/rank_share_config5_f16.json --workload config5 --compute f16 > $O/rank_share_config5_f16.log 2>&1
@@ -81,4 +82,9 @@ for v in "ship -" ; do set -- $v; bash tools/pmc_busy.sh $1 $2 >> $O/match16_bus
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_peak.hip -o /tmp/mfma_peak > /dev/null 2>&1 && /tmp/mfma_peak > $O/mfma_peak.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/probes/div_check.hip -o /tmp/div_check > /dev/null 2>&1 && /tmp/div_check > $O/div_check.txt 2>&1
 timeout 1200 python tools/form_probe.py $O/form_choice.json > $O/form_probe.log 2>&1
+# ---- per-launch cost of the f32 match kernels; float64 host-chunk streaming; the float64 matrix pipe beside the vector ALU
+{ echo "== match.hip (128 x 256 tiles, 16 workgroups per row block): python tools/tile_ramp_probe.py"; timeout 200 python tools/tile_ramp_probe.py
+  echo; echo "== match16.hip f32 form (256 x 256 tiles): python tools/tile_ramp_probe.py wide"; timeout 200 python tools/tile_ramp_probe.py wide; } > $O/tile_ramp_probe.txt 2>&1
+{ timeout 200 python tools/f64_stream_probe.py; echo "== KPDI_F64_SYNC=1 (round 2: the certification read back after every chunk)"; KPDI_F64_SYNC=1 timeout 200 python tools/f64_stream_probe.py; } > $O/f64_stream_probe.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/probes/mfma_f64_overlap.hip -o /tmp/overlap > /dev/null 2>&1 && timeout 120 /tmp/overlap > $O/mfma_f64_overlap.txt 2>&1
 ls -la $O

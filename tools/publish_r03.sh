@@ -10,7 +10,7 @@ import json
 out = {"what": "one rank's share of a dictionary-sharded job on ONE MI355X (tools/rank_share_probe.py): rank 0's shard of an "
                "N-rank job, inputs resident, whole step incl. preparation, merge and hand-over of the result; "
                "step_over_even_share = step / (t_1 / N) = what strong scaling can reach before the RCCL all-gather"}
-for key in ("config2", "config4", "config5", "config5_f16", "config5_f16_dict16"):
+for key in ("config2", "config2_pipeline", "config4", "config5", "config5_f16", "config5_f16_dict16"):
     out[key] = json.load(open("$O/rank_share_%s.json" % key))
 json.dump(out, open("profiles/r03_rank_share.json", "w"), indent=1)
 PY
@@ -21,7 +21,10 @@ cp $O/prekernel_pmc.txt profiles/r03_prekernel_pmc.txt
 cp $O/match16_busy.txt profiles/r03_match16_busy.txt
 cp $O/mfma_peak.txt profiles/r03_mfma_power_probe.txt
 cp $O/div_check.txt profiles/r03_div_check.txt
-cp $O/form_choice.json profiles/r03_form_choice_run3.json
+cp $O/form_choice.json profiles/r03_form_choice_final.json
+cp $O/tile_ramp_probe.txt profiles/r03_tile_ramp_probe.txt
+cp $O/f64_stream_probe.txt profiles/r03_f64_stream_probe.txt
+cp $O/mfma_f64_overlap.txt profiles/r03_mfma_f64_overlap.txt
 grep -E "Duplicate GPU|invalid usage|exit code|bench.py: rank" $O/bench_2ranks_1gpu.err | sed 's#/longer_pathname[^ ]*/##' | sort -u > profiles/r03_rccl_two_ranks_one_gpu.txt
 for d in config4 config5_f16; do f=$(find $O/prof_$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f profiles/r03_${d}_kernel_stats.csv; done
 ls profiles | grep r03
