@@ -858,8 +858,9 @@ void decide_form(kpdi_ctx *c, int64_t n_chunk) {
   // 0.27 ms against 0.1 ms, measured on one rank's share of configs[1] at N = 8)
   // (fitted between K = 2819 and 14 400: no extrapolation below)
   const double gain = kpdi::FORM_WIDE_GAIN + kpdi::FORM_WIDE_GAIN_K * std::max(-0.3, 1.0 - 3600.0 / std::max(c->k_kept, 1));
+  static const double wide_launch = getenv("KPDI_FORM_WIDE_LAUNCH") ? atof(getenv("KPDI_FORM_WIDE_LAUNCH")) : kpdi::FORM_WIDE_LAUNCH;  // (fitting)
   const double wide = ((row_blocks + rpl - 1) / rpl) *
-                      ((t256 / nsw + wide_tail_plan(t256, nsw, &shift)) * 2.0 / gain + kpdi::FORM_WIDE_LAUNCH) *
+                      ((t256 / nsw + wide_tail_plan(t256, nsw, &shift)) * 2.0 / gain + wide_launch) *
                       (nsw % 8 == 0 ? 1.0 : kpdi::FORM_WIDE_ODD);
   const bool w = wide < classic;
   if (w == c->wide32) return;

@@ -23,6 +23,8 @@ constexpr double FORM_CLASSIC_TAIL = 0.25;
 // list handling) is amortised over more steps at large K - measured wide / classic 0.99 at K = 3600, 0.97 at K = 14 400
 constexpr double FORM_WIDE_GAIN = 1.035;
 constexpr double FORM_WIDE_GAIN_K = 0.02;
+// (KPDI_FORM_WIDE_LAUNCH overrides it for fitting runs of tools/form_probe.py; after the first tile's candidates left the
+// buffers - launch 0.20 -> 0.166 ms - 1.0 and 0.9 leave the grid's worst point and mean regret where they are, 0.8 adds a 7 % miss)
 constexpr double FORM_WIDE_LAUNCH = 1.1;
 // ... its partial units (halves / quarters of a tile) cost this much more per row than whole tiles
 constexpr double FORM_WIDE_HALF = 1.1;

@@ -451,10 +451,21 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
           int *bi = buf_i + cg * CAND_CAP * 64;
           unsigned *line = const_cast<unsigned *>(line0) + 32 * cg * BOUND_SLOTS;
           int c = cnt[cg];
-          bool overflow = false;
+          // The FIRST tile of a launch has no bound yet: every one of its 64 candidates per lane would be appended -
+          // 134 MB of stores from the whole chip at once, and as much to read back at the end: ~0.13 of the 0.20 ms a
+          // launch of the float32 form cost beyond its tiles (tools/tile_ramp_probe.py on the ablation builds).  It goes
+          // the way of a full buffer instead: the list is built from the accumulators directly (scan16: 20 entries stay,
+          // 40 stores), and its last entry screens the lane's next tiles beside the shared bound.
+#ifdef KPDI16_FIRST_TILE_APPENDS  // (developer build: round 2's behaviour)
+          const bool first_tile = false;
+#else
+          const bool first_tile = tiles_done == 0;
+#endif
+          bool overflow = first_tile;
           float mx = -INFINITY;
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt) {
+            if (first_tile) continue;
             if (F32 && rt >= rt_n) continue;
             float m = acc[cg][rt][0];
 #pragma unroll
