@@ -33,6 +33,11 @@ import socket
 import struct
 import time
 
+# RCCL shares buffers between the ranks of a node through dmabuf IPC; the legacy mode fails with `hipIpcGetMemHandle: invalid
+# argument` on hosts whose driver only supports dmabuf.  HSA reads this when the runtime initialises, i.e. at the first
+# call into libkpdi - which this import precedes.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 
