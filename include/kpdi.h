@@ -21,7 +21,8 @@
  *  - plain C: pointers + sizes, no C++ or torch types; every function returns
  *    0 on success or a negative KPDI_E* code, and kpdi_last_error() returns
  *    the message for the calling thread's last failure.
- *  - one context = one GPU = one HIP stream; one OS thread drives a context.
+ *  - one context (kpdi_ctx) = one GPU = one HIP stream; one OS thread drives a context.  Several GPUs from ONE
+ *    thread of ONE process: a kpdi_group (below) - the kpdi_create(device_ids*, n_dev, &ctx) of SURVEY.md 8(b).
  *  - the caller owns all host buffers; the library owns all device buffers.
  *  - host inputs are never modified (tests/test_indexing/test_dictionary_indexing.py:41-43).
  *  - masks follow the reference: nonzero = EXCLUDED (similarity_metrics/_similarity_metric.py:51-58).
@@ -354,6 +355,81 @@ int kpdi_set_experimental_h5ebsd(kpdi_ctx *ctx, const char *path, const char *sc
 int kpdi_comm_unique_id(uint8_t *id_out /* KPDI_UNIQUE_ID_BYTES */);
 int kpdi_comm_init(kpdi_ctx *ctx, int rank, int nranks, const uint8_t *id);
 
+/* ---- multi-GPU from ONE process: a group of contexts ----------------------------------------------------
+ * The reference's call is one call in one interpreter (signals/ebsd.py:1827-1984; its loop over dictionary
+ * chunks, indexing/_dictionary_indexing.py:100-128, never crosses a process boundary).  A kpdi_group keeps that
+ * shape on a node with several MI355X: it owns one context per entry of `device_ids` and one host thread per
+ * member, and its entry points are the per-context ones fanned out -
+ *   set_problem / set_keep_n / set_experimental / remove_*_background / set_master_pattern / set_detector: every member
+ *       (the experimental set is replicated from the caller's ONE host buffer);
+ *   push_* / hold_*: every dictionary chunk is block-assigned - member i takes rows
+ *       [start_i, end_i) = the contiguous i-th of n_dev parts of the chunk (sizes differ by at most one), pushed with
+ *       global_start + start_i, so a global index is still chunk start + row (`simulation_indices_i += start`, :118);
+ *   finalize: the members' best-k lists are gathered and merged by the same (score desc, index asc) kernel used
+ *       between chunks, and the caller gets ONE result - identical, bit for bit, to the single-context result.
+ * Gather = KPDI_GATHER_RCCL: an in-process RCCL communicator (ncclCommInitAll - no sockets, no environment) and the
+ * ncclAllGather of kpdi_finalize, or KPDI_GATHER_P2P: hipMemcpyPeerAsync of the members' M * keep_n * 8 bytes into
+ * member 0 (xGMI between devices) - which also works when several members share ONE device (RCCL refuses duplicate
+ * devices), so the whole multi-device code path runs on a 1-GPU box.  KPDI_GATHER_AUTO: $KPDI_GATHER = "rccl" | "p2p"
+ * if set, else P2P when a device appears twice, else RCCL (falling back to P2P, with the reason kept for
+ * kpdi_group_describe, if the communicator cannot be created).  A group of one device gathers nothing.
+ * Calls on a group are synchronous with respect to the members' host work (they return when every member's call has)
+ * and, like the per-context calls, asynchronous with respect to the GPUs.  One thread at a time drives a group.
+ * The members stay reachable (kpdi_group_member) for the per-context calls that have no group form - device buffers,
+ * counters, refinement; the caller must not use a member while a group call is running. */
+typedef struct kpdi_group kpdi_group;
+#define KPDI_GATHER_AUTO 0
+#define KPDI_GATHER_RCCL 1
+#define KPDI_GATHER_P2P 2
+#define KPDI_GATHER_NONE 3 /* reported by kpdi_group_gather for a group of one device */
+int kpdi_group_create(const int *device_ids, int n_dev, int gather, kpdi_group **out);
+int kpdi_group_destroy(kpdi_group *g);
+int kpdi_group_size(const kpdi_group *g);
+int kpdi_group_gather(const kpdi_group *g);        /* the KPDI_GATHER_* mode in use */
+const char *kpdi_group_describe(const kpdi_group *g); /* "8 devices [0,1,...], gather rccl" (+ why a fallback was taken) */
+kpdi_ctx *kpdi_group_member(kpdi_group *g, int i); /* borrowed; NULL when i is out of range */
+/* rows [*start, *end) of an n-row chunk that member i of n_dev takes (the block assignment of the push / hold calls) */
+int kpdi_group_chunk_share(int64_t n_chunk, int i, int n_dev, int64_t *start, int64_t *end);
+int kpdi_group_synchronize(kpdi_group *g);
+int kpdi_group_set_problem(kpdi_group *g, int sy, int sx, const uint8_t *signal_mask, int metric, int compute_dtype,
+                           int keep_n);
+int kpdi_group_set_keep_n(kpdi_group *g, int keep_n);
+int kpdi_group_set_experimental(kpdi_group *g, const void *patterns, int dtype, int64_t m_all, const uint8_t *nav_mask);
+/* d_patterns[i]: the set in the memory of member i's device (callers that keep their inputs resident) */
+int kpdi_group_set_experimental_dev(kpdi_group *g, const void *const *d_patterns, int dtype, int64_t m_all,
+                                    const uint8_t *nav_mask);
+int64_t kpdi_group_n_experimental(kpdi_group *g);
+int kpdi_group_remove_static_background(kpdi_group *g, const float *static_bg, int operation, int scale_bg);
+int kpdi_group_remove_dynamic_background(kpdi_group *g, int operation, int filter_domain, double std, double truncate);
+int kpdi_group_get_experimental(kpdi_group *g, void *patterns_out); /* member 0's (all members hold the same) */
+int kpdi_group_push_dictionary_chunk(kpdi_group *g, const void *patterns, int dtype, int64_t n_chunk,
+                                     int64_t global_start);
+/* explicit per-member chunks in device memory: member i sweeps n_chunk[i] patterns at d_patterns[i] (n_chunk[i] = 0:
+ * nothing) whose first pattern has dictionary index global_start[i] */
+int kpdi_group_push_dictionary_chunk_dev(kpdi_group *g, const void *const *d_patterns, int dtype, const int64_t *n_chunk,
+                                         const int64_t *global_start);
+int kpdi_group_set_master_pattern(kpdi_group *g, const void *upper, const void *lower, int dtype, int npx, int npy);
+int kpdi_group_set_detector(kpdi_group *g, const double *gnomonic_bounds, double pcz, int nrows, int ncols,
+                            const double *om_detector_to_sample);
+int kpdi_group_push_rotations_chunk(kpdi_group *g, const double *rotations, int64_t n, int64_t global_start, int rescale,
+                                    double out_min, double out_max);
+int kpdi_group_hold_dictionary_chunk(kpdi_group *g, const void *patterns, int dtype, int64_t n_chunk,
+                                     int64_t global_start);
+int kpdi_group_hold_rotations_chunk(kpdi_group *g, const double *rotations, int64_t n, int64_t global_start, int rescale,
+                                    double out_min, double out_max);
+int kpdi_group_sweep_held(kpdi_group *g);
+int kpdi_group_release_held(kpdi_group *g);
+int kpdi_group_held_size(kpdi_group *g, int64_t *n_patterns, int64_t *n_bytes); /* summed over the members */
+int kpdi_group_reset_topk(kpdi_group *g);
+/* as kpdi_finalize / _f64 / _async / _wait / kpdi_pending_result_size, the result being the merge over all members */
+int kpdi_group_finalize(kpdi_group *g, float *scores_out, int64_t *indices_out);
+int kpdi_group_finalize_f64(kpdi_group *g, double *scores_out, int64_t *indices_out);
+int kpdi_group_finalize_async(kpdi_group *g, int *ticket);
+int kpdi_group_finalize_wait(kpdi_group *g, int ticket, float *scores_out, int64_t *indices_out);
+int kpdi_group_pending_result_size(kpdi_group *g, int ticket, int64_t *n);
+int kpdi_group_set_profiling(kpdi_group *g, int on);
+int kpdi_group_reset_counters(kpdi_group *g);
+
 /* ---- device buffers for callers that keep data resident (bench.py) -------- */
 int kpdi_dev_alloc(kpdi_ctx *ctx, size_t bytes, void **d_out);
 int kpdi_dev_free(kpdi_ctx *ctx, void *d_ptr);
@@ -387,7 +463,13 @@ typedef struct kpdi_counters {
   double comm_ms;                /* RCCL all-gather of the per-rank best-k lists inside kpdi_finalize (incl. waiting for the
                                     slowest rank to arrive) */
   double fixed_ms;               /* per-sweep bookkeeping kernels around the match: list / bound / counter initialisation */
+  int32_t f64_certificate;       /* KPDI_COMPUTE_F64: 1 = statistical bound (default), 2 = worst-case bound (KPDI_F64_EPS=worstcase
+                                    at kpdi_set_problem); 0 = not float64 arithmetic.  `uncertified_patterns == 0` is a proof only for 2 */
+  int32_t gather_ranks;          /* lists merged by the last finalize: RCCL ranks or peer-copied group members, 0 = this context's own only */
 } kpdi_counters;
+/* sizeof(kpdi_counters) as the LIBRARY was built: a binding whose struct differs must refuse to call kpdi_get_counters
+ * (the struct has grown between versions; kpdi_version() changes with it) */
+size_t kpdi_counters_size(void);
 int kpdi_set_profiling(kpdi_ctx *ctx, int on);
 int kpdi_get_counters(kpdi_ctx *ctx, kpdi_counters *out);
 int kpdi_reset_counters(kpdi_ctx *ctx);

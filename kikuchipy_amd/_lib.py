@@ -16,6 +16,9 @@ LIB_PATH = os.environ.get("KPDI_LIB_PATH") or os.path.join(_HERE, "csrc", "libkp
 
 METRIC_NCC, METRIC_NDP = 0, 1
 COMPUTE_F32, COMPUTE_F16X2, COMPUTE_F16, COMPUTE_F64 = 0, 1, 2, 3
+GATHER_AUTO, GATHER_RCCL, GATHER_P2P, GATHER_NONE = 0, 1, 2, 3
+GATHER_NAMES = {GATHER_RCCL: "rccl", GATHER_P2P: "p2p", GATHER_NONE: "none"}
+F64_CERTIFICATES = {0: None, 1: "statistical", 2: "worstcase"}
 OP_SUBTRACT, OP_DIVIDE = 0, 1
 DOMAIN_FREQUENCY, DOMAIN_SPATIAL = 0, 1
 UNIQUE_ID_BYTES = 128
@@ -63,6 +66,8 @@ class Counters(C.Structure):
         ("comm_ranks", C.c_int32),
         ("comm_ms", C.c_double),
         ("fixed_ms", C.c_double),
+        ("f64_certificate", C.c_int32),
+        ("gather_ranks", C.c_int32),
     ]
 
     def as_dict(self):
@@ -144,6 +149,42 @@ SIGNATURES = {
     "kpdi_set_profiling": (_i, [_vp, _i]),
     "kpdi_get_counters": (_i, [_vp, C.POINTER(Counters)]),
     "kpdi_reset_counters": (_i, [_vp]),
+    "kpdi_counters_size": (_sz, []),
+    # a group of contexts: several GPUs from one thread of one process
+    "kpdi_group_create": (_i, [C.POINTER(_i), _i, _i, C.POINTER(_vp)]),
+    "kpdi_group_destroy": (_i, [_vp]),
+    "kpdi_group_size": (_i, [_vp]),
+    "kpdi_group_gather": (_i, [_vp]),
+    "kpdi_group_describe": (C.c_char_p, [_vp]),
+    "kpdi_group_member": (_vp, [_vp, _i]),
+    "kpdi_group_chunk_share": (_i, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "kpdi_group_synchronize": (_i, [_vp]),
+    "kpdi_group_set_problem": (_i, [_vp, _i, _i, _vp, _i, _i, _i]),
+    "kpdi_group_set_keep_n": (_i, [_vp, _i]),
+    "kpdi_group_set_experimental": (_i, [_vp, _vp, _i, _i64, _vp]),
+    "kpdi_group_set_experimental_dev": (_i, [_vp, C.POINTER(_vp), _i, _i64, _vp]),
+    "kpdi_group_n_experimental": (_i64, [_vp]),
+    "kpdi_group_remove_static_background": (_i, [_vp, _vp, _i, _i]),
+    "kpdi_group_remove_dynamic_background": (_i, [_vp, _i, _i, C.c_double, C.c_double]),
+    "kpdi_group_get_experimental": (_i, [_vp, _vp]),
+    "kpdi_group_push_dictionary_chunk": (_i, [_vp, _vp, _i, _i64, _i64]),
+    "kpdi_group_push_dictionary_chunk_dev": (_i, [_vp, C.POINTER(_vp), _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "kpdi_group_set_master_pattern": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "kpdi_group_set_detector": (_i, [_vp, _vp, C.c_double, _i, _i, _vp]),
+    "kpdi_group_push_rotations_chunk": (_i, [_vp, _vp, _i64, _i64, _i, C.c_double, C.c_double]),
+    "kpdi_group_hold_dictionary_chunk": (_i, [_vp, _vp, _i, _i64, _i64]),
+    "kpdi_group_hold_rotations_chunk": (_i, [_vp, _vp, _i64, _i64, _i, C.c_double, C.c_double]),
+    "kpdi_group_sweep_held": (_i, [_vp]),
+    "kpdi_group_release_held": (_i, [_vp]),
+    "kpdi_group_held_size": (_i, [_vp, _vp, _vp]),
+    "kpdi_group_reset_topk": (_i, [_vp]),
+    "kpdi_group_finalize": (_i, [_vp, _vp, _vp]),
+    "kpdi_group_finalize_f64": (_i, [_vp, _vp, _vp]),
+    "kpdi_group_finalize_async": (_i, [_vp, C.POINTER(_i)]),
+    "kpdi_group_finalize_wait": (_i, [_vp, _i, _vp, _vp]),
+    "kpdi_group_pending_result_size": (_i, [_vp, _i, C.POINTER(_i64)]),
+    "kpdi_group_set_profiling": (_i, [_vp, _i]),
+    "kpdi_group_reset_counters": (_i, [_vp]),
 }
 
 _lib = None
@@ -164,6 +205,11 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        # kpdi_counters has grown between versions: a stale struct here would be written past its end
+        if lib.kpdi_counters_size() != C.sizeof(Counters):
+            raise KpdiError(f"{LIB_PATH} ({lib.kpdi_version().decode()}) was built with a kpdi_counters of "
+                            f"{lib.kpdi_counters_size()} bytes, this binding expects {C.sizeof(Counters)}: rebuild "
+                            "the library (make -C kikuchipy_amd/csrc)")
         _lib = lib
     return _lib
 
@@ -232,12 +278,32 @@ def _mask_bytes(mask):
     return np.ascontiguousarray(np.asarray(mask).ravel().astype(np.uint8))
 
 
+class _Functions:
+    """`f.set_problem` -> `libkpdi.kpdi_set_problem` (prefix "kpdi_") or `kpdi_group_set_problem`
+    (prefix "kpdi_group_"): lets `Group` reuse `Context`'s methods for every call that has a group form."""
+
+    def __init__(self, prefix):
+        self._prefix = prefix
+
+    def __getattr__(self, name):
+        fn = getattr(load(), self._prefix + name)
+        setattr(self, name, fn)
+        return fn
+
+
 class Context:
     """One GPU, one stream: thin object wrapper over a `kpdi_ctx*`."""
 
-    def __init__(self, device=0):
-        self._h = C.c_void_p()
-        check(load().kpdi_create(int(device), C.byref(self._h)))
+    _prefix = "kpdi_"
+
+    def __init__(self, device=0, _borrowed=None):
+        self._f = _Functions(self._prefix)
+        self._owned = _borrowed is None
+        if _borrowed is not None:  # a member of a `Group`: the group owns the kpdi_ctx
+            self._h = C.c_void_p(_borrowed)
+        else:
+            self._h = C.c_void_p()
+            check(self._f.create(int(device), C.byref(self._h)))
         self.device = int(device)
         self._keep = {}  # host arrays the library may still be reading
         self._keep_n = None       # what kpdi_finalize will write per pattern
@@ -249,7 +315,8 @@ class Context:
     # -- lifetime
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            load().kpdi_destroy(self._h)
+            if self._owned:
+                self._f.destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -265,20 +332,20 @@ class Context:
         self.close()
 
     def synchronize(self):
-        check(load().kpdi_synchronize(self._h))
+        check(self._f.synchronize(self._h))
 
     # -- set-up
     def set_problem(self, sy, sx, signal_mask=None, metric=METRIC_NCC, keep_n=20, compute=COMPUTE_F32):
         sm = _mask_bytes(signal_mask)
         if sm is not None and sm.size != sy * sx:
             raise KpdiError(f"signal mask has {sm.size} elements, detector has {sy * sx}")
-        check(load().kpdi_set_problem(self._h, int(sy), int(sx), _ptr(sm), int(metric), int(compute),
+        check(self._f.set_problem(self._h, int(sy), int(sx), _ptr(sm), int(metric), int(compute),
                                       int(keep_n)))
         self._keep_n = int(keep_n)
         self._compute = int(compute)
 
     def set_keep_n(self, keep_n):
-        check(load().kpdi_set_keep_n(self._h, int(keep_n)))
+        check(self._f.set_keep_n(self._h, int(keep_n)))
         self._keep_n = int(keep_n)
 
     def set_experimental(self, patterns, navigation_mask=None):
@@ -288,8 +355,8 @@ class Context:
         m_all = p.shape[0]
         if nm is not None and nm.size != m_all:
             raise KpdiError(f"navigation mask has {nm.size} elements, there are {m_all} patterns")
-        check(load().kpdi_set_experimental(self._h, _ptr(p), dtype_code(p.dtype), m_all, _ptr(nm)))
-        check(load().kpdi_synchronize(self._h))  # upload done: `p` may be a temporary
+        check(self._f.set_experimental(self._h, _ptr(p), dtype_code(p.dtype), m_all, _ptr(nm)))
+        check(self._f.synchronize(self._h))  # upload done: `p` may be a temporary
         self._exp_shape, self._exp_dtype = p.shape, p.dtype
 
     def set_experimental_h5ebsd(self, path, scan=None, navigation_mask=None):
@@ -298,71 +365,71 @@ class Context:
         nm = _mask_bytes(navigation_mask)
         if nm is not None and nm.size != info.ny * info.nx:
             raise KpdiError(f"navigation mask has {nm.size} elements, the scan has {info.ny * info.nx} patterns")
-        check(load().kpdi_set_experimental_h5ebsd(self._h, _cstr(path), info.scan, _ptr(nm)))
+        check(self._f.set_experimental_h5ebsd(self._h, _cstr(path), info.scan, _ptr(nm)))
         self._exp_shape = (info.ny * info.nx, info.sy, info.sx)
         self._exp_dtype = DTYPE_FROM_CODE[info.dtype]
         return info
 
     def set_experimental_dev(self, d_ptr, dtype, m_all, navigation_mask=None):
         nm = _mask_bytes(navigation_mask)
-        check(load().kpdi_set_experimental_dev(self._h, C.c_void_p(d_ptr), dtype_code(dtype), int(m_all),
+        check(self._f.set_experimental_dev(self._h, C.c_void_p(d_ptr), dtype_code(dtype), int(m_all),
                                                _ptr(nm)))
 
     @property
     def n_experimental(self):
-        return int(load().kpdi_n_experimental(self._h))
+        return int(self._f.n_experimental(self._h))
 
     # -- pre-processing
     def remove_static_background(self, static_bg_f32, operation=OP_SUBTRACT, scale_bg=False):
         bg = np.ascontiguousarray(static_bg_f32, dtype=np.float32)
-        check(load().kpdi_remove_static_background(self._h, _ptr(bg), int(operation), int(bool(scale_bg))))
+        check(self._f.remove_static_background(self._h, _ptr(bg), int(operation), int(bool(scale_bg))))
 
     def remove_dynamic_background(self, operation=OP_SUBTRACT, filter_domain=DOMAIN_FREQUENCY, std=0.0,
                                   truncate=4.0):
-        check(load().kpdi_remove_dynamic_background(self._h, int(operation), int(filter_domain),
+        check(self._f.remove_dynamic_background(self._h, int(operation), int(filter_domain),
                                                     float(std), float(truncate)))
 
     def get_experimental(self):
         out = np.empty(self._exp_shape, dtype=self._exp_dtype)
-        check(load().kpdi_get_experimental(self._h, _ptr(out)))
+        check(self._f.get_experimental(self._h, _ptr(out)))
         return out
 
     # -- sweep
     def push_dictionary_chunk(self, patterns, global_start):
         p = np.ascontiguousarray(patterns)
         # returns when the upload has consumed `p`; the sweep of the chunk runs on
-        check(load().kpdi_push_dictionary_chunk(self._h, _ptr(p), dtype_code(p.dtype), p.shape[0],
+        check(self._f.push_dictionary_chunk(self._h, _ptr(p), dtype_code(p.dtype), p.shape[0],
                                                 int(global_start)))
 
     def push_dictionary_chunk_dev(self, d_ptr, dtype, n_chunk, global_start):
-        check(load().kpdi_push_dictionary_chunk_dev(self._h, C.c_void_p(d_ptr), dtype_code(dtype),
+        check(self._f.push_dictionary_chunk_dev(self._h, C.c_void_p(d_ptr), dtype_code(dtype),
                                                     int(n_chunk), int(global_start)))
 
     # -- resident dictionary: prepared once, swept against several experimental sets
     def hold_dictionary_chunk(self, patterns, global_start):
         p = np.ascontiguousarray(patterns)
-        check(load().kpdi_hold_dictionary_chunk(self._h, _ptr(p), dtype_code(p.dtype), p.shape[0],
+        check(self._f.hold_dictionary_chunk(self._h, _ptr(p), dtype_code(p.dtype), p.shape[0],
                                                 int(global_start)))
 
     def hold_dictionary_chunk_dev(self, d_ptr, dtype, n_chunk, global_start):
-        check(load().kpdi_hold_dictionary_chunk_dev(self._h, C.c_void_p(d_ptr), dtype_code(dtype),
+        check(self._f.hold_dictionary_chunk_dev(self._h, C.c_void_p(d_ptr), dtype_code(dtype),
                                                     int(n_chunk), int(global_start)))
 
     def hold_rotations_chunk(self, rotations, global_start, rescale=False, out_min=-1.0, out_max=1.0):
         rot = np.ascontiguousarray(rotations, dtype=np.float64).reshape(-1, 4)
-        check(load().kpdi_hold_rotations_chunk(self._h, _ptr(rot), rot.shape[0], int(global_start),
+        check(self._f.hold_rotations_chunk(self._h, _ptr(rot), rot.shape[0], int(global_start),
                                                int(bool(rescale)), float(out_min), float(out_max)))
 
     def sweep_held(self):
-        check(load().kpdi_sweep_held(self._h))
+        check(self._f.sweep_held(self._h))
 
     def release_held(self):
-        check(load().kpdi_release_held(self._h))
+        check(self._f.release_held(self._h))
 
     def held_size(self):
         """(patterns held, bytes of device memory they occupy)."""
         n, b = C.c_int64(0), C.c_int64(0)
-        check(load().kpdi_held_size(self._h, C.byref(n), C.byref(b)))
+        check(self._f.held_size(self._h, C.byref(n), C.byref(b)))
         return n.value, b.value
 
     # -- dictionary generation on the device
@@ -373,7 +440,7 @@ class Context:
         if up.ndim != 2 or (lo is not None and lo.shape != up.shape):
             raise KpdiError("master pattern hemispheres must be 2D arrays of equal shape")
         self._projection_key = None  # whoever cached "my master pattern is loaded" must load it again
-        check(load().kpdi_set_master_pattern(self._h, _ptr(up), _ptr(lo), dtype_code(up.dtype),
+        check(self._f.set_master_pattern(self._h, _ptr(up), _ptr(lo), dtype_code(up.dtype),
                                              up.shape[1], up.shape[0]))
 
     def set_detector(self, gnomonic_bounds, pcz, nrows, ncols, om_detector_to_sample):
@@ -382,24 +449,24 @@ class Context:
         if gb.size != 4 or om.size != 9:
             raise KpdiError("gnomonic_bounds must have 4 and om_detector_to_sample 9 elements")
         self._projection_key = None
-        check(load().kpdi_set_detector(self._h, _ptr(gb), float(pcz), int(nrows), int(ncols), _ptr(om)))
+        check(self._f.set_detector(self._h, _ptr(gb), float(pcz), int(nrows), int(ncols), _ptr(om)))
         self._dc_npix = int(nrows) * int(ncols)
 
     def set_direction_cosines(self, direction_cosines):
         dc = np.ascontiguousarray(direction_cosines, dtype=np.float64).reshape(-1, 3)
         self._projection_key = None
-        check(load().kpdi_set_direction_cosines(self._h, _ptr(dc), dc.shape[0]))
+        check(self._f.set_direction_cosines(self._h, _ptr(dc), dc.shape[0]))
         self._dc_npix = dc.shape[0]
 
     def get_direction_cosines(self):
         out = np.empty((self._dc_npix, 3), dtype=np.float64)
-        check(load().kpdi_get_direction_cosines(self._h, _ptr(out)))
+        check(self._f.get_direction_cosines(self._h, _ptr(out)))
         return out
 
     def project_patterns(self, rotations, rescale=False, out_min=-1.0, out_max=1.0, dtype_out=np.float32):
         rot = np.ascontiguousarray(rotations, dtype=np.float64).reshape(-1, 4)
         out = np.empty((rot.shape[0], self._dc_npix), dtype=dtype_out)
-        check(load().kpdi_project_patterns(self._h, _ptr(rot), rot.shape[0], int(bool(rescale)),
+        check(self._f.project_patterns(self._h, _ptr(rot), rot.shape[0], int(bool(rescale)),
                                            float(out_min), float(out_max), dtype_code(out.dtype), _ptr(out)))
         return out
 
@@ -411,14 +478,14 @@ class Context:
             raise KpdiError(f"{rot.shape[0]} rotations but {pc.shape[0]} projection centres")
         om = np.ascontiguousarray(om_detector_to_sample, dtype=np.float64).ravel()
         out = np.empty((rot.shape[0], shape[0] * shape[1]), dtype=dtype_out)
-        check(load().kpdi_project_patterns_varying_pc(self._h, _ptr(rot), _ptr(pc), rot.shape[0], int(shape[0]),
+        check(self._f.project_patterns_varying_pc(self._h, _ptr(rot), _ptr(pc), rot.shape[0], int(shape[0]),
                                                       int(shape[1]), _ptr(om), int(bool(rescale)), float(out_min),
                                                       float(out_max), dtype_code(out.dtype), _ptr(out)))
         return out
 
     def push_rotations_chunk(self, rotations, global_start, rescale=False, out_min=-1.0, out_max=1.0):
         rot = np.ascontiguousarray(rotations, dtype=np.float64).reshape(-1, 4)
-        check(load().kpdi_push_rotations_chunk(self._h, _ptr(rot), rot.shape[0], int(global_start),
+        check(self._f.push_rotations_chunk(self._h, _ptr(rot), rot.shape[0], int(global_start),
                                                int(bool(rescale)), float(out_min), float(out_max)))
 
     # -- refinement
@@ -431,7 +498,7 @@ class Context:
         om = np.ascontiguousarray(om_detector_to_sample, dtype=np.float64).ravel()
         if om.size != 9:
             raise KpdiError("om_detector_to_sample must have 9 elements")
-        check(load().kpdi_refine_set_patterns(self._h, _ptr(p), dtype_code(p.dtype), p.shape[0], p.shape[1],
+        check(self._f.refine_set_patterns(self._h, _ptr(p), dtype_code(p.dtype), p.shape[0], p.shape[1],
                                               p.shape[2], _ptr(sm), int(bool(rescale)), _ptr(om)))
         self._ref_n = p.shape[0]
         self._ref_k = p.shape[1] * p.shape[2] if sm is None else int(np.count_nonzero(sm == 0))
@@ -439,7 +506,7 @@ class Context:
     def refine_get_prepared(self):
         pat = np.empty((self._ref_n, self._ref_k), dtype=np.float32)
         sqn = np.empty(self._ref_n, dtype=np.float64)
-        check(load().kpdi_refine_get_prepared(self._h, _ptr(pat), _ptr(sqn)))
+        check(self._f.refine_get_prepared(self._h, _ptr(pat), _ptr(sqn)))
         return pat, sqn
 
     def refine_objective(self, mode, pattern_index, x, fixed=None):
@@ -448,7 +515,7 @@ class Context:
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(idx.size, nvar)
         f = None if nfixed == 0 else np.ascontiguousarray(fixed, dtype=np.float64).reshape(idx.size, nfixed)
         out = np.empty(idx.size, dtype=np.float64)
-        check(load().kpdi_refine_objective(self._h, int(mode), idx.size, _ptr(idx), _ptr(x), _ptr(f), _ptr(out)))
+        check(self._f.refine_objective(self._h, int(mode), idx.size, _ptr(idx), _ptr(x), _ptr(f), _ptr(out)))
         return out
 
     def refine_solve(self, mode, x0, fixed=None, lower=None, upper=None, xatol=1e-4, fatol=1e-4, maxiter=0,
@@ -464,7 +531,7 @@ class Context:
         lo = None if lower is None else np.ascontiguousarray(lower, dtype=np.float64).reshape(x0.shape)
         hi = None if upper is None else np.ascontiguousarray(upper, dtype=np.float64).reshape(x0.shape)
         res = np.empty((n, starts, REFINE_RESULT_STRIDE), dtype=np.float64)
-        check(load().kpdi_refine_solve(self._h, int(mode), n, starts, _ptr(x0), _ptr(f), _ptr(lo), _ptr(hi),
+        check(self._f.refine_solve(self._h, int(mode), n, starts, _ptr(x0), _ptr(f), _ptr(lo), _ptr(hi),
                                        float(xatol), float(fatol), int(maxiter or 0), int(maxfev or 0), _ptr(res)))
         return res[:, :, :3 + nvar]
 
@@ -473,7 +540,7 @@ class Context:
         lo = None if lower is None else np.ascontiguousarray(lower, dtype=np.float64).ravel()
         hi = None if upper is None else np.ascontiguousarray(upper, dtype=np.float64).ravel()
         res = np.empty(3 + x0.size, dtype=np.float64)
-        check(load().kpdi_nelder_mead_selftest(self._h, int(kind), x0.size, _ptr(x0), _ptr(lo), _ptr(hi),
+        check(self._f.nelder_mead_selftest(self._h, int(kind), x0.size, _ptr(x0), _ptr(lo), _ptr(hi),
                                                float(xatol), float(fatol), int(maxiter or 0), int(maxfev or 0),
                                                _ptr(res)))
         return res
@@ -489,13 +556,13 @@ class Context:
             idx = np.ascontiguousarray(simulation_indices, dtype=np.int64).reshape(ny * nx, keep_n)
         off = np.ascontiguousarray(offsets, dtype=np.int32).reshape(-1, 2)
         out = np.empty((ny, nx, n_best - from_n_best + 1), dtype=np.float32)
-        check(load().kpdi_orientation_similarity_map(self._h, _ptr(idx), int(ny), int(nx), int(keep_n), int(n_best),
+        check(self._f.orientation_similarity_map(self._h, _ptr(idx), int(ny), int(nx), int(keep_n), int(n_best),
                                                      int(from_n_best), _ptr(off), off.shape[0], int(center_index),
                                                      int(bool(normalize)), _ptr(out)))
         return out
 
     def reset_topk(self):
-        check(load().kpdi_reset_topk(self._h))
+        check(self._f.reset_topk(self._h))
         self._last_valid = False
 
     def holds_result(self, simulation_indices):
@@ -506,7 +573,7 @@ class Context:
         # what kpdi_finalize left in its page-locked staging buffer (no copy was kept: the caller may have masked or
         # remapped the array it got in place, and must then not be told that the device still holds "these" lists)
         p, n = C.POINTER(C.c_int32)(), C.c_int64(0)
-        check(load().kpdi_result_indices_i32(self._h, C.byref(p), C.byref(n)))
+        check(self._f.result_indices_i32(self._h, C.byref(p), C.byref(n)))
         idx = np.asarray(simulation_indices)
         if not p or n.value != idx.size:
             return False
@@ -525,10 +592,10 @@ class Context:
         indices = np.empty((m, keep_n), dtype=np.int64)
         if self._compute == COMPUTE_F64:  # float64 arithmetic: the rescored scores (csrc/rescore.hip)
             scores = np.empty((m, keep_n), dtype=np.float64)
-            check(load().kpdi_finalize_f64(self._h, _ptr(scores), _ptr(indices)))
+            check(self._f.finalize_f64(self._h, _ptr(scores), _ptr(indices)))
         else:
             scores = np.empty((m, keep_n), dtype=np.float32)
-            check(load().kpdi_finalize(self._h, _ptr(scores), _ptr(indices)))
+            check(self._f.finalize(self._h, _ptr(scores), _ptr(indices)))
         self.result_token += 1
         self._last_valid = False
         self._check_filled(indices, keep_n)
@@ -555,7 +622,7 @@ class Context:
         if self._keep_n is None or int(keep_n) != self._keep_n:
             raise KpdiError(f"finalize_async(keep_n={keep_n}) but the context keeps {self._keep_n} entries per pattern")
         t = C.c_int(-1)
-        check(load().kpdi_finalize_async(self._h, C.byref(t)))
+        check(self._f.finalize_async(self._h, C.byref(t)))
         self.result_token += 1
         self._last_valid = False
         return (t.value, int(keep_n))
@@ -564,11 +631,11 @@ class Context:
         """(scores (m, keep_n) float32, indices (m, keep_n) int64) of a `finalize_async` ticket."""
         slot, keep_n = ticket
         n = C.c_int64(0)
-        check(load().kpdi_pending_result_size(self._h, int(slot), C.byref(n)))
+        check(self._f.pending_result_size(self._h, int(slot), C.byref(n)))
         m = n.value // keep_n
         scores = np.empty((m, keep_n), dtype=np.float32)
         indices = np.empty((m, keep_n), dtype=np.int64)
-        check(load().kpdi_finalize_wait(self._h, int(slot), _ptr(scores), _ptr(indices)))
+        check(self._f.finalize_wait(self._h, int(slot), _ptr(scores), _ptr(indices)))
         self._check_filled(indices, keep_n)
         return scores, indices
 
@@ -583,32 +650,243 @@ class Context:
         buf = np.frombuffer(unique_id, dtype=np.uint8).copy()
         if buf.size != UNIQUE_ID_BYTES:
             raise KpdiError("unique id must be 128 bytes")
-        check(load().kpdi_comm_init(self._h, int(rank), int(nranks), _ptr(buf)))
+        check(self._f.comm_init(self._h, int(rank), int(nranks), _ptr(buf)))
 
     # -- device buffers
     def dev_alloc(self, nbytes):
         p = C.c_void_p()
-        check(load().kpdi_dev_alloc(self._h, int(nbytes), C.byref(p)))
+        check(self._f.dev_alloc(self._h, int(nbytes), C.byref(p)))
         return p.value
 
     def dev_free(self, d_ptr):
-        check(load().kpdi_dev_free(self._h, C.c_void_p(d_ptr)))
+        check(self._f.dev_free(self._h, C.c_void_p(d_ptr)))
 
     def h2d(self, d_ptr, array):
         a = np.ascontiguousarray(array)
-        check(load().kpdi_h2d(self._h, C.c_void_p(d_ptr), _ptr(a), a.nbytes))
+        check(self._f.h2d(self._h, C.c_void_p(d_ptr), _ptr(a), a.nbytes))
 
     def d2h(self, array, d_ptr):
-        check(load().kpdi_d2h(self._h, _ptr(array), C.c_void_p(d_ptr), array.nbytes))
+        check(self._f.d2h(self._h, _ptr(array), C.c_void_p(d_ptr), array.nbytes))
 
     # -- measurement
     def set_profiling(self, on=True):
-        check(load().kpdi_set_profiling(self._h, int(bool(on))))
+        check(self._f.set_profiling(self._h, int(bool(on))))
 
     def counters(self):
         c = Counters()
-        check(load().kpdi_get_counters(self._h, C.byref(c)))
+        check(self._f.get_counters(self._h, C.byref(c)))
         return c.as_dict()
 
     def reset_counters(self):
-        check(load().kpdi_reset_counters(self._h))
+        check(self._f.reset_counters(self._h))
+
+
+def resolve_devices(devices):
+    """`devices=` of the host layer -> list of device ids, or None (= not given).
+    "all": every visible GPU; an int: that many GPUs (0 .. n-1); a sequence of ids (an id may
+    repeat: several members then share that GPU - the rehearsal form for 1-GPU hosts)."""
+    if devices is None:
+        return None
+    if isinstance(devices, str):
+        if devices.strip().lower() == "all":
+            return list(range(max(device_count(), 1)))
+        try:
+            return [int(d) for d in devices.replace(",", " ").split()]
+        except ValueError:
+            raise KpdiError(f"devices={devices!r}: expected 'all' or a list of device ids") from None
+    if isinstance(devices, (int, np.integer)):
+        if devices < 1:
+            raise KpdiError("devices must name at least one GPU")
+        return list(range(int(devices)))
+    out = [int(d) for d in devices]
+    if not out:
+        raise KpdiError("devices must name at least one GPU")
+    return out
+
+
+def default_devices():
+    """What a call that says nothing about devices runs on: $KPDI_DEVICES ("all" or ids like "0,1,2") if
+    set, else every visible GPU - the counterpart of the reference using every core of the host
+    (its Dask scheduler's default)."""
+    env = os.environ.get("KPDI_DEVICES")
+    return resolve_devices(env if env else "all")
+
+
+def make_engine(device=0, devices=None, gather=None):
+    """A `Context` on one GPU, or - for more than one device id - a `Group` over them."""
+    ids = resolve_devices(devices)
+    if ids is None:
+        return Context(device)
+    if len(ids) == 1 and gather is None:
+        return Context(ids[0])
+    return Group(ids, gather=gather)
+
+
+class Group(Context):
+    """Several GPUs behind the interface of one `Context` (`kpdi_group`, include/kpdi.h): the
+    experimental set is replicated, every dictionary chunk is block-assigned to the members,
+    `finalize()` returns the one merged result.  One Python thread drives it; the members' host
+    work runs on the library's own threads.
+
+    gather: None (automatic: RCCL when the devices are distinct, peer copies otherwise,
+    $KPDI_GATHER overrides), "rccl" or "p2p"."""
+
+    _prefix = "kpdi_group_"
+    _GATHER = {None: GATHER_AUTO, "auto": GATHER_AUTO, "rccl": GATHER_RCCL, "p2p": GATHER_P2P}
+
+    def __init__(self, devices="all", gather=None):
+        ids = resolve_devices(devices)
+        if gather not in self._GATHER:
+            raise KpdiError(f"gather must be None, 'rccl' or 'p2p', not {gather!r}")
+        self._f = _Functions(self._prefix)
+        self._owned = True
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(ids))(*ids)
+        check(self._f.create(arr, len(ids), self._GATHER[gather], C.byref(self._h)))
+        self.devices = list(ids)
+        self.device = ids[0]
+        self.members = [Context(d, _borrowed=self._f.member(self._h, i)) for i, d in enumerate(ids)]
+        self.root = self.members[0]
+        self._keep = {}
+        self._keep_n = None
+        self._compute = COMPUTE_F32
+        self._projection_key = None
+        self.result_token = 0
+        self._last_valid = False
+
+    def __len__(self):
+        return len(self.devices)
+
+    @property
+    def gather(self):
+        """"rccl", "p2p" or "none" (one device): how the members' lists reach member 0."""
+        return GATHER_NAMES[int(self._f.gather(self._h))]
+
+    def describe(self):
+        return (self._f.describe(self._h) or b"").decode()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            for m in self.members:
+                m._h = C.c_void_p()
+            self._f.destroy(self._h)
+            self._h = C.c_void_p()
+
+    @staticmethod
+    def chunk_share(n_chunk, i, n_dev):
+        """Rows [start, end) of an `n_chunk`-row chunk that member `i` of `n_dev` takes."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(load().kpdi_group_chunk_share(int(n_chunk), int(i), int(n_dev), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # -- what differs from a single context
+    def set_problem(self, sy, sx, signal_mask=None, metric=METRIC_NCC, keep_n=20, compute=COMPUTE_F32):
+        super().set_problem(sy, sx, signal_mask, metric, keep_n, compute)
+        for m in self.members:
+            m._keep_n, m._compute = self._keep_n, self._compute
+
+    def set_keep_n(self, keep_n):
+        super().set_keep_n(keep_n)
+        for m in self.members:
+            m._keep_n = self._keep_n
+
+    def set_experimental(self, patterns, navigation_mask=None):
+        p = np.ascontiguousarray(patterns)
+        nm = _mask_bytes(navigation_mask)
+        if nm is not None and nm.size != p.shape[0]:
+            raise KpdiError(f"navigation mask has {nm.size} elements, there are {p.shape[0]} patterns")
+        # (returns when every member's upload has consumed `p`)
+        check(self._f.set_experimental(self._h, _ptr(p), dtype_code(p.dtype), p.shape[0], _ptr(nm)))
+        self._exp_shape, self._exp_dtype = p.shape, p.dtype
+
+    def set_experimental_h5ebsd(self, path, scan=None, navigation_mask=None):
+        info, pats, _, _ = h5ebsd_read(path, scan)
+        self.set_experimental(pats.reshape((-1,) + pats.shape[-2:]), navigation_mask)
+        return info
+
+    def set_experimental_dev(self, d_ptrs, dtype, m_all, navigation_mask=None):
+        """d_ptrs: one device pointer per member (the set in that member's HBM)."""
+        if len(d_ptrs) != len(self.members):
+            raise KpdiError(f"{len(d_ptrs)} device pointers for {len(self.members)} members")
+        nm = _mask_bytes(navigation_mask)
+        arr = (C.c_void_p * len(d_ptrs))(*[int(p) for p in d_ptrs])
+        check(self._f.set_experimental_dev(self._h, arr, dtype_code(dtype), int(m_all), _ptr(nm)))
+
+    def push_dictionary_chunk_dev(self, d_ptrs, dtype, n_chunk, global_start):
+        """One device chunk per member: d_ptrs[i], n_chunk[i] patterns (0 = none), first dictionary
+        index global_start[i]."""
+        n = len(self.members)
+        if not (len(d_ptrs) == len(n_chunk) == len(global_start) == n):
+            raise KpdiError(f"push_dictionary_chunk_dev needs one entry per member ({n})")
+        ptrs = (C.c_void_p * n)(*[int(p) if p else None for p in d_ptrs])
+        cnt = (C.c_int64 * n)(*[int(v) for v in n_chunk])
+        st = (C.c_int64 * n)(*[int(v) for v in global_start])
+        check(self._f.push_dictionary_chunk_dev(self._h, ptrs, dtype_code(dtype), cnt, st))
+
+    def hold_dictionary_chunk_dev(self, d_ptrs, dtype, n_chunk, global_start):
+        for m, p, n, s0 in zip(self.members, d_ptrs, n_chunk, global_start):
+            if n > 0:
+                m.hold_dictionary_chunk_dev(p, dtype, n, s0)
+
+    def set_direction_cosines(self, direction_cosines):
+        for m in self.members:
+            m.set_direction_cosines(direction_cosines)
+        self._projection_key = None
+        self._dc_npix = self.root._dc_npix
+
+    def set_detector(self, gnomonic_bounds, pcz, nrows, ncols, om_detector_to_sample):
+        super().set_detector(gnomonic_bounds, pcz, nrows, ncols, om_detector_to_sample)
+        self.root._dc_npix = self._dc_npix
+
+    # -- calls without a group form run on member 0 (every member holds the same patterns / master pattern; the merged
+    # lists of the last finalize live there)
+    def get_direction_cosines(self):
+        return self.root.get_direction_cosines()
+
+    def project_patterns(self, *args, **kwargs):
+        return self.root.project_patterns(*args, **kwargs)
+
+    def project_patterns_varying_pc(self, *args, **kwargs):
+        return self.root.project_patterns_varying_pc(*args, **kwargs)
+
+    def refine_set_patterns(self, *args, **kwargs):
+        return self.root.refine_set_patterns(*args, **kwargs)
+
+    def refine_get_prepared(self):
+        return self.root.refine_get_prepared()
+
+    def refine_objective(self, *args, **kwargs):
+        return self.root.refine_objective(*args, **kwargs)
+
+    def refine_solve(self, *args, **kwargs):
+        return self.root.refine_solve(*args, **kwargs)
+
+    def nelder_mead_selftest(self, *args, **kwargs):
+        return self.root.nelder_mead_selftest(*args, **kwargs)
+
+    def orientation_similarity_map(self, *args, **kwargs):
+        return self.root.orientation_similarity_map(*args, **kwargs)
+
+    def holds_result(self, simulation_indices):
+        self.root._last_valid = self._last_valid
+        return self.root.holds_result(simulation_indices)
+
+    def comm_init(self, rank, nranks, unique_id):
+        raise KpdiError("a Group gathers inside one process; ranks of a multi-process job attach a Context each")
+
+    def dev_alloc(self, nbytes):
+        raise KpdiError("device buffers belong to one GPU: use group.members[i].dev_alloc()")
+
+    dev_free = h2d = d2h = dev_alloc
+
+    # -- measurement
+    def set_profiling(self, on=True):
+        check(self._f.set_profiling(self._h, int(bool(on))))
+
+    def counters(self):
+        """Member 0's counters (its merge / gather figures are the group's) + `members`: every member's."""
+        per = [m.counters() for m in self.members]
+        out = dict(per[0])
+        out["members"] = per
+        out["gather"] = self.gather
+        return out

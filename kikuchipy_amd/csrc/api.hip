@@ -12,6 +12,7 @@
 #include "../../include/kpdi.h"
 #include "kernels.h"
 #include "form_model.h"
+#include "group_hooks.h"
 
 #include <dlfcn.h>
 #include <limits.h>
@@ -94,6 +95,7 @@ struct Rccl {
   void *lib = nullptr;
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -126,6 +128,7 @@ struct Rccl {
   }
     KPDI_SYM(GetUniqueId, "ncclGetUniqueId")
     KPDI_SYM(CommInitRank, "ncclCommInitRank")
+    KPDI_SYM(CommInitAll, "ncclCommInitAll")
     KPDI_SYM(CommDestroy, "ncclCommDestroy")
     KPDI_SYM(AllGather, "ncclAllGather")
     KPDI_SYM(GroupStart, "ncclGroupStart")
@@ -135,6 +138,7 @@ struct Rccl {
 #undef KPDI_SYM
     GetUniqueId = t.GetUniqueId;
     CommInitRank = t.CommInitRank;
+    CommInitAll = t.CommInitAll;
     CommDestroy = t.CommDestroy;
     AllGather = t.AllGather;
     GroupStart = t.GroupStart;
@@ -161,10 +165,39 @@ int fail_msg(int code, const char *fmt, ...) {
 }
 }  // namespace kpdi
 
+// Developer / A-B switches: ONE convention - read from the environment by kpdi_set_problem and
+// fixed for the context until the next kpdi_set_problem (a variable changed in between is seen then, never mid-sweep).
+struct Switches {
+  double odd_wide = kpdi::FORM_ODD_SPLIT_WIDE, odd_classic = kpdi::FORM_ODD_SPLIT_CLASSIC;
+  double wide_launch = kpdi::FORM_WIDE_LAUNCH, fixed_frac = 0.8;
+  bool xcd_grid = true, no_tail = false, one_stream = false, tail_stream2 = false;
+  bool f64_worstcase = false, f64_sync = false;
+  long upload_tiles = 0;
+  void read() {
+    *this = Switches{};
+    auto num = [](const char *name, double dflt) {
+      const char *e = getenv(name);
+      return e ? atof(e) : dflt;
+    };
+    odd_wide = num("KPDI_NS_ODD_WIDE", odd_wide);
+    odd_classic = num("KPDI_NS_ODD_CLASSIC", odd_classic);
+    wide_launch = num("KPDI_FORM_WIDE_LAUNCH", wide_launch);
+    fixed_frac = num("KPDI_FIXED_FRAC", fixed_frac);
+    if (const char *e = getenv("KPDI_XCD_GRID")) xcd_grid = atoi(e) != 0;
+    no_tail = getenv("KPDI_NO_TAIL") != nullptr;
+    one_stream = getenv("KPDI_ONE_STREAM") != nullptr;
+    tail_stream2 = getenv("KPDI_TAIL_STREAM2") != nullptr;
+    if (const char *e = getenv("KPDI_F64_EPS")) f64_worstcase = !strcmp(e, "worstcase");
+    f64_sync = getenv("KPDI_F64_SYNC") != nullptr;
+    if (const char *e = getenv("KPDI_UPLOAD_TILES")) upload_tiles = atol(e);
+  }
+};
+
 struct kpdi_ctx {
   int device = 0;
   int n_cu = 256;
   hipStream_t stream = nullptr;
+  Switches sw;
 
   // problem
   bool have_problem = false;
@@ -297,6 +330,11 @@ struct kpdi_ctx {
   // comm
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
+  // in-process groups (group.hip): the members' lists peer-copied into gather_s / gather_i (gather64_*) of the ROOT
+  // member instead of an RCCL all-gather; `p2p_ranks` > 0 = that many lists are waiting there for the next finalize
+  int p2p_ranks = 0;
+  hipEvent_t lists_final = nullptr;  // this member's running lists are final (recorded on `stream`)
+  hipEvent_t peer_read = nullptr;    // root: the peer copies of the members' lists have run
 
   // measurement
   bool profiling = false;
@@ -438,9 +476,7 @@ int choose_nsplit(const kpdi_ctx *c, int row_blocks, int n_tiles, int *rows_per_
   // splits that are not a multiple of 8 leave the launch without an XCD grid (plan_xcd_grid); the kernels of match16.hip
   // (static hand-out) pay more for that than match.hip does (profiles/r03_form_choice.json)
   if (wide < 0) wide = uses16(c) ? 1 : 0;
-  static const double odd_wide = getenv("KPDI_NS_ODD_WIDE") ? atof(getenv("KPDI_NS_ODD_WIDE")) : kpdi::FORM_ODD_SPLIT_WIDE;
-  static const double odd_classic = getenv("KPDI_NS_ODD_CLASSIC") ? atof(getenv("KPDI_NS_ODD_CLASSIC")) : kpdi::FORM_ODD_SPLIT_CLASSIC;
-  const double odd = wide ? odd_wide : odd_classic;
+  const double odd = wide ? c->sw.odd_wide : c->sw.odd_classic;
   int best_ns = 1, best_rpl = std::max(1, std::min(row_blocks, cap));
   double best_cost = 1e30;
   for (int ns = 1; ns <= std::min(cap, n_tiles); ++ns) {
@@ -584,9 +620,9 @@ int ensure_running(kpdi_ctx *c) {
 // (xr x xs = 8) that divide both extents, the one whose XCDs stream the fewest operand bytes per tile round -
 // (rows / xr) experimental blocks of 256 patterns + (nsplit / xs) dictionary tiles.  0 x 0 = plain mapping
 // (KPDI_XCD_GRID=0 forces it).
-void plan_xcd_grid(int rows, int nsplit, int tile_dict, int *xr, int *xs) {
+void plan_xcd_grid(const kpdi_ctx *c, int rows, int nsplit, int tile_dict, int *xr, int *xs) {
   *xr = *xs = 0;
-  if (getenv("KPDI_XCD_GRID") && atoi(getenv("KPDI_XCD_GRID")) == 0) return;
+  if (!c->sw.xcd_grid) return;
   if ((rows * nsplit) % 8 != 0) return;
   long best = -1;
   for (int r = 1; r <= 8; r *= 2) {
@@ -608,7 +644,7 @@ void plan_xcd_grid(int rows, int nsplit, int tile_dict, int *xr, int *xs) {
 // whole tiles would leave most workgroups idle during the last round (makespan 7 tile-times for 6.1 of
 // work).  The last n_tiles % nsplit tiles are then handed out as QUARTER tiles by a second launch of the
 // kernel's 32-row form, whose lists join the merge as a third source.
-double wide_tail_plan(int n_tiles, int nsplit, int *shift);
+double wide_tail_plan(const kpdi_ctx *c, int n_tiles, int nsplit, int *shift);
 // What a match launch needs initialised before it starts - the shared bound (when its plan changes), the tile counters of
 // the main and the tail launch - is QUEUED here (queue_fill), so that it shares one launch with whatever else the sweep
 // initialises; the plan itself is returned for run_match.
@@ -618,7 +654,7 @@ int match_setup(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int rows_per_
   const int row_blocks = c->m_pad / kpdi::TILE_EXP;
   *pl = MatchPlan{};
   if (allow_tail && c->compute == KPDI_COMPUTE_F32 && !c->wide32 && !bounded && row_blocks <= rows_per_launch &&
-      !getenv("KPDI_NO_TAIL")) {
+      !c->sw.no_tail) {
     const int rounds = n_tiles / nsplit, rem = n_tiles % nsplit;
     if (rounds >= 1 && rounds < 32 && rem > 0 && 4 * rem <= 3 * nsplit) pl->tail_tiles = rem;
   }
@@ -641,8 +677,7 @@ int match_setup(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int rows_per_
   // which evens out the speeds at the end (all tiles fixed left CUs idle for the last ~10 % of the launch).
   // KPDI_FIXED_FRAC overrides the fixed share.
   {
-    double frac = 0.8;
-    if (const char *e = getenv("KPDI_FIXED_FRAC")) frac = atof(e);
+    const double frac = c->sw.fixed_frac;
     const int per_wg = pl->n_main / nsplit;
     pl->fixed_draws = (pl->tail_tiles > 0 || pl->n_main % nsplit == 0) && frac > 0 ? per_wg + 1 : std::max(3, (int)(frac * per_wg));
   }
@@ -698,7 +733,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   ml.bound_idx = bound_i;
   ml.operand_form = operand_form(c);
   if (c->wide32) {  // (float32 form only: the same guards in the float16 schedule cost its 32-cycle MFMAs 10 %)
-    (void)wide_tail_plan(n_main, nsplit, &ml.tail_shift);
+    (void)wide_tail_plan(c, n_main, nsplit, &ml.tail_shift);
     ml.tail_first = n_main - n_main % nsplit;
   }
   ml.bound_rank = pl.bound_rank;
@@ -713,8 +748,8 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
     ScopedTimer t(c, &c->ev_match);  // one timed region = the whole sweep of this chunk
     // several launches (large experimental sets) alternate between two streams: the workgroups
     // of launch j+1 start on the CUs that launch j's tail leaves idle
-    const bool two = row_blocks > rows_per_launch && !getenv("KPDI_ONE_STREAM");
-    const bool tail2 = tail_tiles > 0 && getenv("KPDI_TAIL_STREAM2");  // the tail launch runs on the second stream
+    const bool two = row_blocks > rows_per_launch && !c->sw.one_stream;
+    const bool tail2 = tail_tiles > 0 && c->sw.tail_stream2;  // the tail launch runs on the second stream
     if (two || tail2) {
       if (!c->stream2) {
         HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
@@ -731,7 +766,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
     for (int r0 = 0; r0 < row_blocks; r0 += rows_per_launch, ++j) {
       ml.row_first = r0;
       ml.rows = std::min(rows_per_launch, row_blocks - r0);
-      plan_xcd_grid(ml.rows, nsplit, dict_tile(c), &ml.xcd_rows, &ml.xcd_splits);
+      plan_xcd_grid(c, ml.rows, nsplit, dict_tile(c), &ml.xcd_rows, &ml.xcd_splits);
       hipStream_t st = (two && (j & 1)) ? c->stream2 : c->stream;
       if (f16) {
         // launches on the two streams overlap: each stream has its own list scratch
@@ -771,8 +806,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
       // launch - measured (round 3, rocprofv3 trace of one rank's share at N = 8): no gain, the main launch's persistent
       // workgroups hold every CU until they all finish within microseconds of each other, and the join event costs 10 us -
       // so it stays behind the main launch on the same stream.
-      static const bool serial = getenv("KPDI_TAIL_STREAM2") == nullptr;
-      if (serial) {
+      if (!tail2) {
         HIPCHK(kpdi::launch_match(tl, c->stream));
       } else {
         HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));  // recorded in front of the main launch (below)
@@ -833,7 +867,7 @@ int prepare_chunk(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chun
 // statically, match.hip 128-pattern tiles with a dynamic tail of quarter tiles: the estimated makespans decide.  The two
 // kernels read different operand layouts (and row paddings), so the choice is made when the first chunk of a sweep
 // arrives - nothing prepared yet, no resident chunks - and stands until then again.  KPDI_F32_WIDE = 1 / 0 forces it.
-double wide_tail_plan(int n_tiles, int nsplit, int *shift);
+double wide_tail_plan(const kpdi_ctx *c, int n_tiles, int nsplit, int *shift);
 void decide_form(kpdi_ctx *c, int64_t n_chunk) {
   if (c->compute != KPDI_COMPUTE_F32 || c->wide_mode >= 0) return;
   if (c->exp_prepared || !c->held.empty()) return;
@@ -858,9 +892,9 @@ void decide_form(kpdi_ctx *c, int64_t n_chunk) {
   // 0.27 ms against 0.1 ms, measured on one rank's share of configs[1] at N = 8)
   // (fitted between K = 2819 and 14 400: no extrapolation below)
   const double gain = kpdi::FORM_WIDE_GAIN + kpdi::FORM_WIDE_GAIN_K * std::max(-0.3, 1.0 - 3600.0 / std::max(c->k_kept, 1));
-  static const double wide_launch = getenv("KPDI_FORM_WIDE_LAUNCH") ? atof(getenv("KPDI_FORM_WIDE_LAUNCH")) : kpdi::FORM_WIDE_LAUNCH;  // (fitting)
+  const double wide_launch = c->sw.wide_launch;  // (KPDI_FORM_WIDE_LAUNCH: fitting runs)
   const double wide = ((row_blocks + rpl - 1) / rpl) *
-                      ((t256 / nsw + wide_tail_plan(t256, nsw, &shift)) * 2.0 / gain + wide_launch) *
+                      ((t256 / nsw + wide_tail_plan(c, t256, nsw, &shift)) * 2.0 / gain + wide_launch) *
                       (nsw % 8 == 0 ? 1.0 : kpdi::FORM_WIDE_ODD);
   const bool w = wide < classic;
   if (w == c->wide32) return;
@@ -873,12 +907,12 @@ void decide_form(kpdi_ctx *c, int64_t n_chunk) {
 // round, shift 0) or as halves / quarters of a tile (a half / a quarter of a round each, at ~1.1 / 1.25 of the time per
 // row because the experimental fragments are reused by fewer row groups).  Returns the cost of that last round in
 // tile-times.
-double wide_tail_plan(int n_tiles, int nsplit, int *shift) {
+double wide_tail_plan(const kpdi_ctx *c, int n_tiles, int nsplit, int *shift) {
   *shift = 0;
   const int left = n_tiles % nsplit;
   if (left == 0) return 0.0;
   double best = 1.0;
-  if (!getenv("KPDI_NO_TAIL"))
+  if (!c->sw.no_tail)
     for (int sh = 1; sh <= 2; ++sh) {
       const double cost = (double)(((left << sh) + nsplit - 1) / nsplit) / (1 << sh) *
                           (sh == 1 ? kpdi::FORM_WIDE_HALF : kpdi::FORM_WIDE_QUARTER);
@@ -1038,10 +1072,7 @@ int exact64_passes(kpdi_ctx *c, int64_t target) {
     // 1e-6; KPDI_F64_EPS=worstcase raises the floor to the worst-case accumulation bound of a K-term float32 dot
     // product of unit vectors, (K + 2) 2^-24 (2.1e-4 at K = 3600): a certificate that holds for any data, at the price
     // of more screening passes where the k-th and the screened-last scores are closer than that
-    {
-      static const bool worstcase = getenv("KPDI_F64_EPS") && !strcmp(getenv("KPDI_F64_EPS"), "worstcase");
-      g.eps_floor = worstcase ? (float)((c->k_kept + 2) * 0x1p-24 * 1.01) + 1e-6f : 1e-6f;
-    }
+    g.eps_floor = c->sw.f64_worstcase ? (float)((c->k_kept + 2) * 0x1p-24 * 1.01) + 1e-6f : 1e-6f;
     g.uncertified = (int *)(cert + 1);
     HIPCHK(kpdi::launch_merge64(g, c->stream));
     q.done += kp;
@@ -1113,8 +1144,7 @@ int sweep_exact64(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_s
   int rc = exact64_passes(c, std::min<int64_t>((int64_t)k + MARGIN64, n_chunk));
   if (rc) return rc;
   q.active = true;
-  static const bool always_now = getenv("KPDI_F64_SYNC") != nullptr;  // (A/B switch: round 2's behaviour)
-  return q.defer && !always_now ? KPDI_OK : resolve_exact64(c);
+  return q.defer && !c->sw.f64_sync ? KPDI_OK : resolve_exact64(c);  // (KPDI_F64_SYNC: round 2's behaviour, A/B)
 }
 
 // every experimental pattern against one prepared chunk, merged into the running best-k
@@ -1326,8 +1356,8 @@ int staged_upload(kpdi_ctx *c, const void *patterns, size_t row_bytes, const std
 std::vector<int64_t> upload_pieces(const kpdi_ctx *c, int64_t n_chunk, size_t row_bytes) {
   const int64_t tiles = (n_chunk + kpdi::TILE_DICT - 1) / kpdi::TILE_DICT;
   int64_t piece = tiles;
-  if (const char *env = getenv("KPDI_UPLOAD_TILES"); env && atol(env) > 0) {
-    piece = atol(env);
+  if (c->sw.upload_tiles > 0) {
+    piece = c->sw.upload_tiles;
   } else if (c->have_exp && c->m_pad > 0) {
     const int row_blocks = c->m_pad / kpdi::TILE_EXP;
     const double t_tile = 2.0 * kpdi::TILE_EXP * kpdi::TILE_DICT * c->kpad / (157.3e12 / 256 * 0.88);
@@ -1406,7 +1436,9 @@ int results_to_host(kpdi_ctx *c, void *dst, const void *d_src, size_t bytes) {
 
 extern "C" {
 
-const char *kpdi_version(void) { return "kpdi 0.1.0 (gfx950)"; }
+const char *kpdi_version(void) { return "kpdi 0.2.0 (gfx950)"; }
+
+size_t kpdi_counters_size(void) { return sizeof(kpdi_counters); }
 
 const char *kpdi_last_error(void) { return g_err.c_str(); }
 
@@ -1455,6 +1487,8 @@ int kpdi_destroy(kpdi_ctx *c) {
   }
   if (c->result_done) (void)hipEventDestroy(c->result_done);
   if (c->result_stream) (void)hipStreamDestroy(c->result_stream);
+  if (c->lists_final) (void)hipEventDestroy(c->lists_final);
+  if (c->peer_read) (void)hipEventDestroy(c->peer_read);
   for (DevBuf *b : {&c->pix_map, &c->quad_desc, &c->exp_raw, &c->row_map, &c->exp_x, &c->dict_raw, &c->dict_y, &c->part_s,
                     &c->part_i, &c->tail_s, &c->tail_i, &c->list16, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
                     &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps, &c->inv_map, &c->pre_scratch,
@@ -1510,6 +1544,7 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   if (keep_n <= 0) return fail(KPDI_EINVAL, "keep_n must be >= 1");
   int rc = use_device(c);
   if (rc) return rc;
+  c->sw.read();
   const int npix = sy * sx;
   std::vector<int> keep;
   if (signal_mask) {
@@ -2307,21 +2342,29 @@ int finalize64(kpdi_ctx *c, double *scores64, float *scores32, int64_t *indices_
   const size_t n = (size_t)c->m * k;
   const double *d_s = c->run64_s.as<double>();
   const int *d_i = c->run64_i.as<int>();
-  if (c->comm) {
-    HIPCHK(c->gather64_s.reserve(n * c->nranks * sizeof(double)));
-    HIPCHK(c->gather64_i.reserve(n * c->nranks * sizeof(int)));
+  // the lists of all ranks: RCCL all-gather (one process per GPU, or an in-process communicator), or - members of an
+  // in-process group with peer-copy gather - already copied into the gather buffers by kpdi::root_gather_p2p
+  const int ranks = c->p2p_ranks ? c->p2p_ranks : (c->comm ? c->nranks : 0);
+  const bool peer_copied = c->p2p_ranks > 0;
+  c->p2p_ranks = 0;
+  c->cnt.gather_ranks = ranks;
+  if (ranks) {
     HIPCHK(c->final64_s.reserve(n * sizeof(double)));
     HIPCHK(c->final64_i.reserve(n * sizeof(int)));
-    ncclResult_t r;
-    {
-      ScopedTimer t(c, &c->ev_comm);
-      r = g_rccl.GroupStart();
-      if (r == ncclSuccess) r = g_rccl.AllGather(d_s, c->gather64_s.p, n, ncclFloat64, c->comm, c->stream);
-      if (r == ncclSuccess) r = g_rccl.AllGather(d_i, c->gather64_i.p, n, ncclInt32, c->comm, c->stream);
-      ncclResult_t r2 = g_rccl.GroupEnd();
-      if (r == ncclSuccess) r = r2;
+    if (!peer_copied) {
+      HIPCHK(c->gather64_s.reserve(n * ranks * sizeof(double)));
+      HIPCHK(c->gather64_i.reserve(n * ranks * sizeof(int)));
+      ncclResult_t r;
+      {
+        ScopedTimer t(c, &c->ev_comm);
+        r = g_rccl.GroupStart();
+        if (r == ncclSuccess) r = g_rccl.AllGather(d_s, c->gather64_s.p, n, ncclFloat64, c->comm, c->stream);
+        if (r == ncclSuccess) r = g_rccl.AllGather(d_i, c->gather64_i.p, n, ncclInt32, c->comm, c->stream);
+        ncclResult_t r2 = g_rccl.GroupEnd();
+        if (r == ncclSuccess) r = r2;
+      }
+      if (r != ncclSuccess) return fail(KPDI_ECOMM, "RCCL all-gather failed: %s", g_rccl.GetErrorString(r));
     }
-    if (r != ncclSuccess) return fail(KPDI_ECOMM, "RCCL all-gather failed: %s", g_rccl.GetErrorString(r));
     // merge64_kernel ranks a pattern's candidates in LDS (12 bytes each): the per-rank lists join in groups that fit -
     // all at once for ordinary keep_n, a few ranks at a time for very long lists (8 ranks x keep_n > 1600 exceeded the
     // LDS of one launch and used to fail here, after the whole sweep, with a bare HIP error)
@@ -2330,9 +2373,9 @@ int finalize64(kpdi_ctx *c, double *scores64, float *scores32, int64_t *indices_
       return fail(KPDI_EINVAL, "keep_n = %d is too large for the float64 merge of several ranks (limit %zu)", k, lds_entries / 2);
     {
       ScopedTimer t(c, &c->ev_merge);
-      for (int r0 = 0; r0 < c->nranks;) {
+      for (int r0 = 0; r0 < ranks;) {
         const size_t room = lds_entries - (r0 ? (size_t)k : 0);
-        const int group = (int)std::min<size_t>(c->nranks - r0, std::max<size_t>(room / k, 1));
+        const int group = (int)std::min<size_t>(ranks - r0, std::max<size_t>(room / k, 1));
         kpdi::Merge64Launch g{};
         g.m = c->m;
         g.k = k;
@@ -2355,6 +2398,7 @@ int finalize64(kpdi_ctx *c, double *scores64, float *scores32, int64_t *indices_
   }
   c->final_idx = d_i;
   c->final_valid = true;
+  if (!indices_out) return KPDI_OK;  // a group member that only takes part in the all-gather (kpdi::finalize_participate)
   // through the page-locked staging buffer of kpdi_finalize (a copy into pageable memory is pinned on the fly by the
   // runtime: milliseconds, and slower kernels behind it)
   std::vector<double> hs_pageable;
@@ -2405,10 +2449,11 @@ int kpdi_finalize_f64(kpdi_ctx *c, double *scores_out, int64_t *indices_out) {
 // widening the indices - is ~0.1 ms of host time per call during which the GPU otherwise idles: 3 % of one rank's 3 ms
 // share of configs[1] at N = 8).
 namespace {
-int finalize_enqueue(kpdi_ctx *c, int slot, bool own_stream) {
-  int rc = ensure_running(c);  // a rank that pushed nothing contributes empty lists
+// this rank's running lists, made presentable: a rank that pushed nothing contributes empty lists
+int own_lists(kpdi_ctx *c) {
+  int rc = ensure_running(c);
   if (rc) return rc;
-  if (c->run_empty) {
+  if (c->run_empty && !c->exact64) {
     const size_t n0 = (size_t)c->m * c->keep_n;
     rc = wait_result_copy(c);
     if (!rc) rc = queue_fill_topk(c, c->run_s[c->run_cur].as<float>(), c->run_i[c->run_cur].as<int>(), n0);
@@ -2416,25 +2461,39 @@ int finalize_enqueue(kpdi_ctx *c, int slot, bool own_stream) {
     if (rc) return rc;
     c->run_empty = false;
   }
+  return KPDI_OK;
+}
+
+// the FINAL lists of the sweep on this rank: its own, or - with a communicator / in an in-process group - the merge of
+// every rank's (RCCL all-gather, or lists that kpdi::root_gather_p2p has already peer-copied into the gather buffers)
+int final_lists(kpdi_ctx *c, const float **out_s, const int **out_i) {
+  int rc = own_lists(c);
+  if (rc) return rc;
   const int k = c->keep_n;
   const size_t n = (size_t)c->m * k;
   const float *d_s = c->run_s[c->run_cur].as<float>();
   const int *d_i = c->run_i[c->run_cur].as<int>();
-  if (c->comm) {  // also with one rank: keeps the RCCL path testable on a single GPU
+  const int ranks = c->p2p_ranks ? c->p2p_ranks : (c->comm ? c->nranks : 0);
+  const bool peer_copied = c->p2p_ranks > 0;
+  c->p2p_ranks = 0;
+  c->cnt.gather_ranks = ranks;
+  if (ranks) {  // also with one rank: keeps the RCCL path testable on a single GPU
     rc = wait_result_copy(c);  // (the merge below writes the other half of the ping-pong pair)
     if (rc) return rc;
-    HIPCHK(c->gather_s.reserve(n * c->nranks * sizeof(float)));
-    HIPCHK(c->gather_i.reserve(n * c->nranks * sizeof(int)));
-    ncclResult_t r;
-    {
-      ScopedTimer t(c, &c->ev_comm);
-      r = g_rccl.GroupStart();
-      if (r == ncclSuccess) r = g_rccl.AllGather(d_s, c->gather_s.p, n, ncclFloat32, c->comm, c->stream);
-      if (r == ncclSuccess) r = g_rccl.AllGather(d_i, c->gather_i.p, n, ncclInt32, c->comm, c->stream);
-      ncclResult_t r2 = g_rccl.GroupEnd();
-      if (r == ncclSuccess) r = r2;
+    if (!peer_copied) {
+      HIPCHK(c->gather_s.reserve(n * ranks * sizeof(float)));
+      HIPCHK(c->gather_i.reserve(n * ranks * sizeof(int)));
+      ncclResult_t r;
+      {
+        ScopedTimer t(c, &c->ev_comm);
+        r = g_rccl.GroupStart();
+        if (r == ncclSuccess) r = g_rccl.AllGather(d_s, c->gather_s.p, n, ncclFloat32, c->comm, c->stream);
+        if (r == ncclSuccess) r = g_rccl.AllGather(d_i, c->gather_i.p, n, ncclInt32, c->comm, c->stream);
+        ncclResult_t r2 = g_rccl.GroupEnd();
+        if (r == ncclSuccess) r = r2;
+      }
+      if (r != ncclSuccess) return fail(KPDI_ECOMM, "RCCL all-gather failed: %s", g_rccl.GetErrorString(r));
     }
-    if (r != ncclSuccess) return fail(KPDI_ECOMM, "RCCL all-gather failed: %s", g_rccl.GetErrorString(r));
     const int nxt = c->run_cur ^ 1;
     kpdi::MergeLaunch mg{};
     mg.m = c->m;
@@ -2442,7 +2501,7 @@ int finalize_enqueue(kpdi_ctx *c, int slot, bool own_stream) {
     mg.n_src = 1;
     mg.src_scores[0] = c->gather_s.as<float>();
     mg.src_idx[0] = c->gather_i.as<int>();
-    mg.src_lists[0] = c->nranks;
+    mg.src_lists[0] = ranks;
     mg.src_len[0] = k;
     mg.src_row_stride[0] = k;
     mg.src_list_stride[0] = (int)n;
@@ -2460,6 +2519,17 @@ int finalize_enqueue(kpdi_ctx *c, int slot, bool own_stream) {
   }
   c->final_idx = d_i;
   c->final_valid = true;
+  *out_s = d_s;
+  *out_i = d_i;
+  return KPDI_OK;
+}
+
+int finalize_enqueue(kpdi_ctx *c, int slot, bool own_stream) {
+  const float *d_s = nullptr;
+  const int *d_i = nullptr;
+  int rc = final_lists(c, &d_s, &d_i);
+  if (rc) return rc;
+  const size_t n = (size_t)c->m * c->keep_n;
   kpdi_ctx::ResultSlot &rs = c->slots[slot];
   HIPCHK(rs.pin.reserve(n * (sizeof(float) + sizeof(int))));
   if (!rs.ready) HIPCHK(hipEventCreateWithFlags(&rs.ready, hipEventDisableTiming));
@@ -2518,8 +2588,13 @@ int kpdi_finalize(kpdi_ctx *c, float *scores_out, int64_t *indices_out) {
     if (rc) return rc;
     return finalize64(c, nullptr, scores_out, indices_out);
   }
-  const int slot = c->next_slot;
-  c->next_slot ^= 1;
+  // the slot of an outstanding kpdi_finalize_async ticket is never touched (its copy may still be in flight and its
+  // ticket must stay collectable): take the other one, or fail like kpdi_finalize_async does
+  int slot = c->next_slot;
+  if (c->slots[slot].pending) slot ^= 1;
+  if (c->slots[slot].pending)
+    return fail(KPDI_EINVAL, "two results are already pending: collect one with kpdi_finalize_wait first");
+  c->next_slot = slot ^ 1;
   rc = finalize_enqueue(c, slot, false);
   if (rc) return rc;
   return finalize_collect(c, slot, scores_out, indices_out);
@@ -2531,10 +2606,11 @@ int kpdi_finalize_async(kpdi_ctx *c, int *ticket) {
   if (!ticket) return fail(KPDI_EINVAL, "ticket is NULL");
   if (c->exact64) return fail(KPDI_EINVAL, "kpdi_finalize_async: not available in float64 arithmetic (use kpdi_finalize_f64)");
   if (c->m == 0) return fail(KPDI_EINVAL, "no experimental patterns to finalise");
-  const int slot = c->next_slot;
+  int slot = c->next_slot;
+  if (c->slots[slot].pending) slot ^= 1;
   if (c->slots[slot].pending)
     return fail(KPDI_EINVAL, "two results are already pending: collect one with kpdi_finalize_wait first");
-  c->next_slot ^= 1;
+  c->next_slot = slot ^ 1;
   rc = finalize_enqueue(c, slot, true);
   if (rc) return rc;
   *ticket = slot;
@@ -2656,6 +2732,7 @@ int kpdi_get_counters(kpdi_ctx *c, kpdi_counters *out) {
   if (rc) return rc;
   rc = drain_events(c, c->ev_fixed, &c->cnt.fixed_ms);
   if (rc) return rc;
+  c->cnt.f64_certificate = c->exact64 ? (c->sw.f64_worstcase ? 2 : 1) : 0;
   c->cnt.comm_ranks = 0;
   if (c->comm) {
     int count = 0;
@@ -2670,11 +2747,126 @@ int kpdi_reset_counters(kpdi_ctx *c) {
   kpdi_counters tmp;
   int rc = kpdi_get_counters(c, &tmp);  // recycles pending events
   if (rc) return rc;
-  const int kpad = c->cnt.kpad, kk = c->cnt.k_kept;
+  const int kpad = c->cnt.kpad, kk = c->cnt.k_kept, gr = c->cnt.gather_ranks;
   c->cnt = kpdi_counters{};
   c->cnt.kpad = kpad;
   c->cnt.k_kept = kk;
+  c->cnt.gather_ranks = gr;
   return KPDI_OK;
 }
 
 }  // extern "C"
+
+// ---- hooks for in-process groups of contexts (group.hip; declared in group_hooks.h) -------------------------------
+namespace kpdi {
+
+const char *thread_error() { return g_err.c_str(); }
+
+// one RCCL communicator over the contexts of ONE process (ncclCommInitAll: no unique id, no sockets, no environment)
+int comm_init_all(kpdi_ctx *const *ctx, int n) {
+  if (!ctx || n < 1) return fail(KPDI_EINVAL, "comm_init_all: no contexts");
+  if (!g_rccl.load()) return fail(KPDI_ECOMM, "cannot load librccl: %s", g_rccl.why.c_str());
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) {
+    if (!ctx[i]) return fail(KPDI_EINVAL, "comm_init_all: context %d is NULL", i);
+    if (ctx[i]->comm) return fail(KPDI_EINVAL, "comm_init_all: context %d already has a communicator", i);
+    devs[i] = ctx[i]->device;
+  }
+  std::vector<ncclComm_t> comms(n, nullptr);
+  ncclResult_t r = g_rccl.CommInitAll(comms.data(), n, devs.data());
+  if (r != ncclSuccess) return fail(KPDI_ECOMM, "ncclCommInitAll over %d device(s): %s", n, g_rccl.GetErrorString(r));
+  for (int i = 0; i < n; ++i) {
+    ctx[i]->comm = comms[i];
+    ctx[i]->rank = i;
+    ctx[i]->nranks = n;
+  }
+  return KPDI_OK;
+}
+
+// RCCL gather, members other than the one that hands the result to the host: the all-gather + merge of
+// kpdi_finalize without the copies (every rank of a collective has to take part in it)
+int finalize_participate(kpdi_ctx *c) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!c->have_exp || !c->have_problem) return fail(KPDI_EINVAL, "nothing to finalise");
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (c->m == 0) return KPDI_OK;
+  if (c->exact64) {
+    rc = ensure_running(c);
+    return rc ? rc : finalize64(c, nullptr, nullptr, nullptr);
+  }
+  const float *d_s = nullptr;
+  const int *d_i = nullptr;
+  return final_lists(c, &d_s, &d_i);
+}
+
+// peer-copy gather, every member: its running lists are presentable and final - an event on its stream says when
+int member_lists_ready(kpdi_ctx *c, ListsView *v) {
+  if (!c || !v) return fail(KPDI_EINVAL, "NULL argument");
+  if (!c->have_exp || !c->have_problem) return fail(KPDI_EINVAL, "nothing to finalise");
+  int rc = use_device(c);
+  if (rc) return rc;
+  *v = ListsView{};
+  v->device = c->device;
+  v->f64 = c->exact64;
+  v->n = (size_t)c->m * c->keep_n;
+  if (c->m == 0) return KPDI_OK;
+  rc = own_lists(c);
+  if (rc) return rc;
+  if (c->exact64) {
+    v->scores = c->run64_s.p;
+    v->idx = c->run64_i.as<int>();
+  } else {
+    v->scores = c->run_s[c->run_cur].p;
+    v->idx = c->run_i[c->run_cur].as<int>();
+  }
+  if (!c->lists_final) HIPCHK(hipEventCreateWithFlags(&c->lists_final, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(c->lists_final, c->stream));
+  v->ready = c->lists_final;
+  return KPDI_OK;
+}
+
+// peer-copy gather, the root member: every member's lists -> the root's gather buffers (hipMemcpyPeerAsync on the
+// root's stream behind the members' events; xGMI between devices, a plain device copy when members share a device).
+// The root's next finalize merges them exactly like all-gathered ones.  *read_done: recorded behind the copies.
+int root_gather_p2p(kpdi_ctx *c, const ListsView *v, int n, hipEvent_t *read_done) {
+  if (!c || !v || n < 1 || !read_done) return fail(KPDI_EINVAL, "root_gather_p2p: bad arguments");
+  int rc = use_device(c);
+  if (rc) return rc;
+  *read_done = nullptr;
+  const size_t cnt = (size_t)c->m * c->keep_n;
+  if (cnt == 0) return KPDI_OK;
+  const size_t es = c->exact64 ? sizeof(double) : sizeof(float);
+  DevBuf &gs = c->exact64 ? c->gather64_s : c->gather_s;
+  DevBuf &gi = c->exact64 ? c->gather64_i : c->gather_i;
+  for (int j = 0; j < n; ++j)
+    if (v[j].n != cnt || v[j].f64 != c->exact64 || !v[j].scores || !v[j].idx)
+      return fail(KPDI_EINVAL, "group member %d holds %zu list entries (%s), the root %zu (%s): the members of a group must "
+                  "be set up alike", j, v[j].n, v[j].f64 ? "float64" : "float32", cnt, c->exact64 ? "float64" : "float32");
+  HIPCHK(gs.reserve(cnt * n * es));
+  HIPCHK(gi.reserve(cnt * n * sizeof(int)));
+  {
+    ScopedTimer t(c, &c->ev_comm);
+    for (int j = 0; j < n; ++j) {
+      HIPCHK(hipStreamWaitEvent(c->stream, v[j].ready, 0));
+      HIPCHK(hipMemcpyPeerAsync((char *)gs.p + (size_t)j * cnt * es, c->device, v[j].scores, v[j].device, cnt * es, c->stream));
+      HIPCHK(hipMemcpyPeerAsync((char *)gi.p + (size_t)j * cnt * sizeof(int), c->device, v[j].idx, v[j].device,
+                                cnt * sizeof(int), c->stream));
+    }
+  }
+  if (!c->peer_read) HIPCHK(hipEventCreateWithFlags(&c->peer_read, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(c->peer_read, c->stream));
+  *read_done = c->peer_read;
+  c->p2p_ranks = n;
+  return KPDI_OK;
+}
+
+// peer-copy gather, the other members: whoever next writes this member's lists waits for the root's copies of them
+void member_lists_borrowed(kpdi_ctx *c, hipEvent_t read_done) {
+  if (c && read_done) c->result_copy = read_done;
+}
+
+int context_device(const kpdi_ctx *c) { return c ? c->device : -1; }
+int context_gather_ranks(const kpdi_ctx *c) { return c ? (c->comm ? c->nranks : 0) : 0; }
+
+}  // namespace kpdi

@@ -82,11 +82,36 @@ def _is_lazy(a):
     return hasattr(a, "compute") and hasattr(a, "chunksize")
 
 
+# below this many comparisons (experimental x dictionary patterns) a call that did not ask for devices stays on one GPU:
+# a group's set-up (one context per device, the in-process communicator) would cost more than the sweep
+GROUP_MIN_COMPARISONS = 1 << 26
+
+
+def pick_devices(device, devices, comm, n_experimental, dictionary_size):
+    """Which GPU(s) a `dictionary_indexing` call runs on -> (device, devices) for `make_engine`.
+    `comm` (one process per GPU): the rank's own device.  `devices` given: those.  `device` given:
+    that one.  Neither: every visible GPU ($KPDI_DEVICES overrides) - the reference call uses every
+    core of the host without being asked (signals/ebsd.py:1827-1984 on Dask's default scheduler) -
+    unless the job is too small to be worth a group."""
+    from kikuchipy_amd import _lib
+
+    if comm is not None:
+        return (0 if device is None else device), None
+    if devices is not None:
+        return 0, _lib.resolve_devices(devices)
+    if device is not None:
+        return device, None
+    ids = _lib.default_devices()
+    if len(ids) > 1 and n_experimental * dictionary_size < GROUP_MIN_COMPARISONS:
+        ids = ids[:1]
+    return ids[0], (ids if len(ids) > 1 else None)
+
+
 def prepare_metric(metric, navigation_mask, signal_mask, dtype, rechunk, n_experimental,
-                   n_dictionary_patterns, device=0, compute=None):
+                   n_dictionary_patterns, device=0, compute=None, devices=None):
     """EBSD._prepare_metric (signals/ebsd.py:3049-3088)."""
     if isinstance(metric, str) and metric in METRICS:
-        metric = METRICS[metric](device=device, compute=compute)
+        metric = METRICS[metric](device=device, devices=devices, compute=compute)
         metric.rechunk = rechunk
     if not isinstance(metric, SimilarityMetric):
         raise ValueError(
@@ -129,7 +154,8 @@ def dictionary_indexing(
     dictionary_rotations=None,
     phase_name="",
     scan_unit=None,
-    device=0,
+    device=None,
+    devices=None,
     comm=None,
     verbose=True,
     compute=None,
@@ -161,6 +187,13 @@ def dictionary_indexing(
         arithmetic like the reference: float32 screening + float64 rescoring), else "f32"; or the
         opt-in "f16x2" / "f16", see `NormalizedCrossCorrelationMetric`; ignored when `metric` is an
         instance.
+    device, devices
+        Where a metric given by NAME runs.  Neither given (the default): every visible GPU - the
+        dictionary is sharded over them inside this one process (`kikuchipy_amd._lib.Group`: one
+        host copy of the inputs, every dictionary chunk block-assigned to the devices, the
+        per-device best-k lists merged by an in-process RCCL all-gather) - or one GPU when there is
+        one, or when the job is tiny; $KPDI_DEVICES ("all" or ids like "0,1") overrides.  `devices="all"`
+        / a list of ids / `device=i` say it explicitly.  Results do not depend on the choice.
     comm
         `kikuchipy_amd.parallel.Communicator` to shard the dictionary over
         ranks (one process per GPU).  Every rank must pass the same arrays; each
@@ -224,8 +257,10 @@ def dictionary_indexing(
             )
 
     n_experimental_all = int(np.prod(nav_shape_exp)) if nav_shape_exp else 1
+    if isinstance(metric, str) and metric in METRICS:
+        device, devices = pick_devices(device, devices, comm, n_experimental_all, dict_size)
     metric = prepare_metric(metric, navigation_mask, signal_mask, dtype, rechunk, n_experimental_all,
-                            dict_size, device=device, compute=compute)
+                            dict_size, device=device, compute=compute, devices=devices)
     if not isinstance(metric, _HipMetric):
         raise ValueError("the stand-alone driver runs the GPU metrics of kikuchipy_amd only")
 

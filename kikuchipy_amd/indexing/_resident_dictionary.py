@@ -36,12 +36,15 @@ class ResidentDictionary:
         the dictionary's chunk size or everything.
     dictionary_rotations, phase_name
         Passed on to the results of `dictionary_indexing`.
+    device, devices
+        The GPU, or - `devices="all"` / a list of ids - the GPUs of one process the dictionary is
+        sharded over (every chunk block-assigned; each device keeps its part prepared).
     comm
         `kikuchipy_amd.parallel.Communicator`: every rank holds its own shard.
     """
 
     def __init__(self, dictionary, metric="ncc", signal_mask=None, n_per_iteration=None, *,
-                 dictionary_rotations=None, phase_name="", device=0, compute="f32", comm=None):
+                 dictionary_rotations=None, phase_name="", device=0, devices=None, compute="f32", comm=None):
         from kikuchipy_amd.indexing._dictionary_indexing import _is_lazy, chunk_bounds
         from kikuchipy_amd.parallel import shard_range
 
@@ -50,7 +53,7 @@ class ResidentDictionary:
         if isinstance(metric, str):
             if metric not in METRICS:
                 raise ValueError(f"'{metric}' must be either of {METRICS.keys()}")
-            metric = METRICS[metric](device=device, compute=compute)
+            metric = METRICS[metric](device=device, devices=None if comm is not None else devices, compute=compute)
         if not isinstance(metric, _HipMetric):
             raise ValueError("a resident dictionary needs one of the GPU metrics of kikuchipy_amd")
         if metric.compute == "f64":

@@ -151,8 +151,13 @@ class _HipMetric(SimilarityMetric):
     COMPUTE_MODES = {"f32": _lib.COMPUTE_F32, "f16x2": _lib.COMPUTE_F16X2, "f16": _lib.COMPUTE_F16,
                      "f64": _lib.COMPUTE_F64}
 
-    def __init__(self, *args, device=0, context=None, compute=None, **kwargs):
-        """compute
+    def __init__(self, *args, device=0, devices=None, context=None, compute=None, **kwargs):
+        """device, devices
+            The GPU the engine context is created on, or - `devices="all"` / a list of ids - the GPUs
+            of a `kikuchipy_amd._lib.Group`: the dictionary is then sharded over them inside this one
+            process and the per-device best-k lists are merged by an in-process RCCL all-gather (or peer
+            copies); results are identical to one device's.  `context`: an existing engine instead.
+        compute
             Arithmetic of the match kernel (not part of the reference's interface).  None (default):
             follows `dtype` like the reference does - "f64" for `dtype=float64`, else "f32".
             "f64" = float64 arithmetic: the float32 path screens keep_n + 12 candidates per pattern and
@@ -168,7 +173,8 @@ class _HipMetric(SimilarityMetric):
         if compute is not None and compute not in self.COMPUTE_MODES:
             raise ValueError(f"compute must be one of {sorted(self.COMPUTE_MODES)} or None, not {compute!r}")
         self.compute = compute
-        self._device = device
+        self._device = 0 if device is None else device
+        self._devices = devices
         self._ctx = context
         self._engine_m = 0
         self._problem = None
@@ -178,7 +184,7 @@ class _HipMetric(SimilarityMetric):
     def context(self):
         """The libkpdi context (created on first use: needs a GPU)."""
         if self._ctx is None:
-            self._ctx = _lib.Context(self._device)
+            self._ctx = _lib.make_engine(self._device, self._devices)
         return self._ctx
 
     @property

@@ -53,7 +53,10 @@ class DictionaryXmap:
 
 class EBSD:
     def __init__(self, data, static_background=None, xmap=None, step_sizes=None, scan_unit="px",
-                 device=0):
+                 device=None, devices=None):
+        """device: the GPU this signal's engine context lives on (None: GPU 0, and `dictionary_indexing`
+        is free to shard the dictionary over every visible GPU); devices: "all" / a list of ids for
+        `dictionary_indexing` (see `kikuchipy_amd.dictionary_indexing`)."""
         self.data = data
         ndim = data.ndim if hasattr(data, "ndim") else np.ndim(data)  # lazy data is not touched
         if ndim < 2 or ndim > 4:
@@ -63,7 +66,9 @@ class EBSD:
         self.step_sizes = step_sizes
         self.scan_unit = scan_unit
         self._device = device
+        self._devices = devices
         self._ctx = None
+        self._groups = {}  # device ids -> _lib.Group, kept from call to call (its communicator is made once)
 
     # ------------------------------------------------------------------ shapes
     @property
@@ -81,14 +86,30 @@ class EBSD:
     def deepcopy(self):
         out = EBSD(np.array(self.data, copy=True),
                    None if self.static_background is None else np.array(self.static_background),
-                   self.xmap, self.step_sizes, self.scan_unit, self._device)
+                   self.xmap, self.step_sizes, self.scan_unit, self._device, self._devices)
         return out
 
     @property
     def context(self):
         if self._ctx is None:
-            self._ctx = _lib.Context(self._device)
+            self._ctx = _lib.Context(self._device or 0)
         return self._ctx
+
+    def _engine(self, devices, comm, dictionary_size):
+        """The engine a `dictionary_indexing` call of this signal runs on: its own context, or a `Group`
+        over several GPUs (kept on the signal from call to call)."""
+        from kikuchipy_amd.indexing._dictionary_indexing import pick_devices
+
+        device, ids = pick_devices(self._device, devices if devices is not None else self._devices, comm,
+                                   max(self.navigation_size, 1), dictionary_size)
+        if ids is not None and len(ids) == 1:
+            device, ids = ids[0], None
+        if ids is None:
+            return device, (self.context if device == (self._device or 0) else _lib.Context(device))
+        key = tuple(ids)
+        if key not in self._groups:
+            self._groups[key] = _lib.make_engine(devices=ids)
+        return ids[0], self._groups[key]
 
     # ------------------------------------------------------------------ pre-processing
     def remove_static_background(self, operation="subtract", static_bg=None, scale_bg=False,
@@ -163,9 +184,10 @@ class EBSD:
     # ------------------------------------------------------------------ indexing
     def dictionary_indexing(self, dictionary, metric="ncc", keep_n=20, n_per_iteration=None,
                             navigation_mask=None, signal_mask=None, rechunk=False, dtype=None, *,
-                            comm=None, verbose=True, compute=None):
+                            devices=None, comm=None, verbose=True, compute=None):
         """See `kikuchipy_amd.dictionary_indexing`; `dictionary` is an `EBSD`
-        with a 1-D navigation axis and an `xmap` of equal size."""
+        with a 1-D navigation axis and an `xmap` of equal size.  As there, a call that names no
+        device shards the dictionary over every visible GPU from this one process."""
         from kikuchipy_amd.indexing._resident_dictionary import ResidentDictionary
 
         if isinstance(dictionary, ResidentDictionary):
@@ -198,8 +220,10 @@ class EBSD:
         from kikuchipy_amd.indexing.similarity_metrics import METRICS
 
         if isinstance(metric, str) and metric in METRICS:
-            # on this signal's engine context: its device buffers are reused from call to call
-            metric = METRICS[metric](device=self._device, compute=compute, context=self.context)
+            # on this signal's engine (one context, or a group over several GPUs): its device buffers - and a group's
+            # communicator - are reused from call to call
+            device, engine = self._engine(devices, comm, dict_size)
+            metric = METRICS[metric](device=device, compute=compute, context=engine)
             metric.rechunk = rechunk
         return _dictionary_indexing(
             self.data, dict_data, metric, keep_n, n_per_iteration, navigation_mask, signal_mask,

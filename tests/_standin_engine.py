@@ -169,3 +169,69 @@ class StandInContext:
 
     def close(self):
         self.mem = {}
+
+
+class StandInGroup:
+    """Stand-in for `kikuchipy_amd._lib.Group`: N `StandInContext` members driven by one thread each, every chunk
+    block-assigned with the library's own `kpdi_group_chunk_share` (host code: loads without a GPU), the members' lists
+    merged like the group's peer-copy gather does.  Lets the host layer's `devices=` logic run on CPU."""
+
+    def __init__(self, devices, gather=None):
+        from concurrent.futures import ThreadPoolExecutor
+
+        self.devices = list(devices)
+        self.device = self.devices[0]
+        self.members = [StandInContext(d) for d in self.devices]
+        self.root = self.members[0]
+        self.gather = "p2p"
+        self._pool = ThreadPoolExecutor(len(self.members))
+        self.threads_seen = set()
+
+    def __len__(self):
+        return len(self.members)
+
+    def _all(self, fn):
+        import threading
+
+        def run(im):
+            self.threads_seen.add(threading.get_ident())
+            return fn(*im)
+        return list(self._pool.map(run, enumerate(self.members)))
+
+    def set_problem(self, *a, **k):
+        self._all(lambda i, m: m.set_problem(*a, **k))
+        self.keep_n = self.root.keep_n
+
+    def set_keep_n(self, keep_n):
+        self._all(lambda i, m: m.set_keep_n(keep_n))
+        self.keep_n = keep_n
+
+    def set_experimental(self, patterns, navigation_mask=None):
+        self._all(lambda i, m: m.set_experimental(patterns, navigation_mask))
+
+    @property
+    def n_experimental(self):
+        return self.root.n_experimental
+
+    def push_dictionary_chunk(self, patterns, global_start):
+        from kikuchipy_amd import _lib
+
+        def push(i, m):
+            a, b = _lib.Group.chunk_share(len(patterns), i, len(self.members))
+            if b > a:
+                m.push_dictionary_chunk(patterns[a:b], global_start + a)
+        self._all(push)
+
+    def finalize(self, keep_n=None):
+        lists = self._all(lambda i, m: m.finalize(keep_n))
+        s = np.full_like(lists[0][0], -np.inf)
+        i = np.full_like(lists[0][1], np.iinfo(np.int64).max)
+        for s_r, i_r in lists:
+            s, i = ko.merge_topk(s, i, s_r, i_r, self.keep_n)
+        return s, i
+
+    def synchronize(self):
+        pass
+
+    def close(self):
+        self._pool.shutdown()

@@ -1,0 +1,239 @@
+"""One interpreter, several GPUs: `kpdi_group` (include/kpdi.h) / `kikuchipy_amd._lib.Group` /
+`dictionary_indexing(..., devices=...)`.
+
+The reference's `EBSD.dictionary_indexing` is ONE call in ONE process (signals/ebsd.py:1827-1984; the
+chunk loop of indexing/_dictionary_indexing.py:100-128).  A group shards every dictionary chunk over
+its members and hands back one merged result; because the merge is a total order (score desc, index
+asc) that result must equal the single-context result BIT FOR BIT - which is what these tests assert.
+Members may share a device (peer-copy gather), so the whole multi-device code path - threads, block
+assignment, gather, merge, pipelined hand-over - runs on a 1-GPU box; the in-process RCCL
+communicator is exercised with one member here and with one member per GPU in test_gpu_multigpu.py.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import synth
+from oracle import kpdi_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def patterns(seed, n, shape=(12, 10), dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    base = rng.random((n,) + shape)
+    if np.issubdtype(dtype, np.integer):
+        return (base * 255).astype(dtype)
+    return base.astype(dtype)
+
+
+def single(exp, dic, metric, keep_n, compute, signal_mask=None, nav_mask=None, start=0):
+    from kikuchipy_amd import _lib
+
+    with _lib.Context(0) as c:
+        c.set_problem(exp.shape[-2], exp.shape[-1], signal_mask, metric, keep_n, compute)
+        c.set_experimental(exp, nav_mask)
+        c.push_dictionary_chunk(dic, start)
+        return c.finalize(keep_n)
+
+
+def test_eight_in_process_shards_equal_the_single_sweep_at_full_size():
+    """configs[1] at full size (4096 x 100 000 x 60 x 60, ncc, keep_n 20): eight members on device 0,
+    each sweeping its eighth of the dictionary, peer-copy gather + merge == one context's sweep."""
+    from kikuchipy_amd import _lib
+
+    exp, dic = synth(2024, 4096, 100000)
+    s1, i1 = single(exp, dic, _lib.METRIC_NCC, 20, _lib.COMPUTE_F32)
+    with _lib.Group([0] * 8) as g:
+        assert len(g) == 8 and g.gather == "p2p" and "p2p" in g.describe()
+        g.set_problem(60, 60, None, _lib.METRIC_NCC, 20, _lib.COMPUTE_F32)
+        g.set_experimental(exp, None)
+        g.set_profiling(True)
+        g.push_dictionary_chunk(dic, 0)
+        s8, i8 = g.finalize(20)
+        cnt = g.counters()
+    assert np.array_equal(s1, s8) and np.array_equal(i1, i8)
+    # every member swept exactly its block of the chunk, member 0 merged eight lists
+    assert cnt["gather_ranks"] == 8 and cnt["gather"] == "p2p"
+    flops = [m["match_flops"] for m in cnt["members"]]
+    assert flops == [2.0 * 4096 * 12500 * 3600] * 8, flops
+    # and the oracle agrees on a sample of rows (float64 C oracle over the whole dictionary)
+    from oracle import c_oracle
+
+    rows = np.arange(0, 4096, 128)
+    rs, ri = c_oracle.rows_topk_f64(exp, [(0, dic)], rows, "ncc", 20, None)
+    ko.assert_topk_parity(s8[rows], i8[rows], rs, ri, atol=1e-5)
+
+
+@pytest.mark.parametrize("members,metric,keep_n,compute,masked,chunk", [
+    (3, "ncc", 10, "f32", False, 1000),
+    (4, "ndp", 1, "f32", True, 700),
+    (2, "ncc", 50, "f32", True, 3000),     # keep_n > 32: bounded passes on every member
+    (5, "ncc", 20, "f16x2", False, 1300),
+    (3, "ndp", 20, "f16", False, 3000),
+    (4, "ncc", 12, "f64", True, 900),      # float64 lists gathered and merged in double
+    (8, "ncc", 5, "f32", False, 5),        # chunks smaller than the group: some members get nothing
+])
+def test_group_equals_single_context(members, metric, keep_n, compute, masked, chunk):
+    """Host-level API: `devices=[0, 0, ...]` against `device=0` - chunked, masked, every arithmetic."""
+    import kikuchipy_amd as ka
+
+    dic = patterns(1, 3000 if chunk > 5 else 23)
+    exp = patterns(2, 63, dtype=np.uint8).reshape(7, 9, 12, 10)
+    signal_mask = nav_mask = None
+    if masked:
+        signal_mask = np.zeros((12, 10), dtype=bool)
+        signal_mask[:2] = True
+        signal_mask[5, 3:7] = True
+        nav_mask = np.zeros((7, 9), dtype=bool)
+        nav_mask[1, 2] = nav_mask[6, 8] = True
+    kw = dict(metric=metric, keep_n=keep_n, n_per_iteration=chunk, navigation_mask=nav_mask, signal_mask=signal_mask,
+              verbose=False)
+    if compute == "f64":
+        kw["dtype"] = np.float64
+    else:
+        kw["compute"] = compute
+    one = ka.dictionary_indexing(exp, dic, device=0, **kw)
+    grp = ka.dictionary_indexing(exp, dic, devices=[0] * members, **kw)
+    assert grp.scores.dtype == one.scores.dtype
+    assert np.array_equal(one.scores, grp.scores)
+    assert np.array_equal(one.simulation_indices, grp.simulation_indices)
+
+
+def test_in_process_rccl_communicator_with_one_member():
+    """gather="rccl" with ONE device: ncclCommInitAll + the all-gather of kpdi_finalize inside the process."""
+    from kikuchipy_amd import _lib
+
+    dic = patterns(3, 2500)
+    exp = patterns(4, 200, dtype=np.uint8)
+    s1, i1 = single(exp, dic, _lib.METRIC_NCC, 20, _lib.COMPUTE_F32, start=40)
+    with _lib.Group([0], gather="rccl") as g:
+        assert g.gather == "rccl"
+        g.set_problem(12, 10, None, _lib.METRIC_NCC, 20, _lib.COMPUTE_F32)
+        g.set_experimental(exp, None)
+        g.push_dictionary_chunk(dic, 40)
+        s, i = g.finalize(20)
+        c = g.counters()
+        assert c["comm_ranks"] == 1 and c["gather_ranks"] == 1
+    assert np.array_equal(s, s1) and np.array_equal(i, i1)
+    with pytest.raises(_lib.KpdiError, match="share a device"):
+        _lib.Group([0, 0], gather="rccl")  # RCCL refuses duplicate devices: the message says what to use instead
+
+
+def test_pipelined_series_of_maps_on_a_group():
+    """finalize_async / finalize_wait on a group: map i's merged result is collected after map i + 1 has been
+    queued on every member (what bench.py --single-process does); device-resident inputs per member."""
+    from kikuchipy_amd import _lib
+
+    n_dev, n, m, k = 4, 6000, 300, 20
+    dic = patterns(5, n)
+    maps = [patterns(10 + j, m, dtype=np.uint8) for j in range(5)]
+    want = [single(e, dic, _lib.METRIC_NCC, k, _lib.COMPUTE_F32) for e in maps]
+    with _lib.Group([0] * n_dev) as g:
+        g.set_problem(12, 10, None, _lib.METRIC_NCC, k, _lib.COMPUTE_F32)
+        shares = [_lib.Group.chunk_share(n, i, n_dev) for i in range(n_dev)]
+        d_dic, d_exp = [], []
+        for mem, (a, b) in zip(g.members, shares):
+            d = mem.dev_alloc(dic[a:b].nbytes)
+            mem.h2d(d, dic[a:b])
+            d_dic.append(d)
+            d_exp.append(mem.dev_alloc(maps[0].nbytes))
+        got, pending = [], None
+        for e in maps:
+            for mem, d in zip(g.members, d_exp):
+                mem.synchronize()  # (the previous map's kernels have read this buffer)
+                mem.h2d(d, e)
+            g.set_experimental_dev(d_exp, e.dtype, m)
+            g.push_dictionary_chunk_dev(d_dic, np.float32, [b - a for a, b in shares], [a for a, _ in shares])
+            ticket = g.finalize_async(k)
+            if pending is not None:
+                got.append(g.finalize_wait(pending))
+            pending = ticket
+        got.append(g.finalize_wait(pending))
+        # a synchronous finalize between two async ones must not disturb a pending ticket
+        t = g.finalize_async(k)
+        s_sync, i_sync = g.finalize(k)
+        s_t, i_t = g.finalize_wait(t)
+        assert np.array_equal(s_sync, s_t) and np.array_equal(i_sync, i_t)
+    for (s, i), (ws, wi) in zip(got, want):
+        assert np.array_equal(s, ws) and np.array_equal(i, wi)
+
+
+def test_group_preprocessing_resident_and_generated_dictionaries():
+    """The recorded background steps, `ResidentDictionary(devices=...)` and a `ProjectedDictionary` simulated on
+    every member: each equals the single-device result."""
+    import kikuchipy_amd as ka
+    from kikuchipy_amd import _lib
+
+    rng = np.random.default_rng(8)
+    exp = rng.integers(0, 256, (40, 60, 60), dtype=np.uint8)
+    dic = rng.random((2000, 60, 60), dtype=np.float32)
+    bg = rng.integers(1, 256, (60, 60)).astype(np.float32)
+    # static + dynamic background recorded on every member, fused with the preparation there
+    res = []
+    for engine in (_lib.Context(0), _lib.Group([0, 0, 0])):
+        with engine as c:
+            c.set_problem(60, 60, None, _lib.METRIC_NCC, 8, _lib.COMPUTE_F32)
+            c.set_experimental(exp, None)
+            c.remove_static_background(bg, _lib.OP_SUBTRACT, False)
+            c.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
+            c.push_dictionary_chunk(dic, 0)
+            res.append(c.finalize(8) + (c.get_experimental(),))
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+    # a dictionary prepared once, its chunks block-assigned to the members
+    r1 = ka.ResidentDictionary(dic, "ncc", n_per_iteration=900, device=0)
+    r3 = ka.ResidentDictionary(dic, "ncc", n_per_iteration=900, devices=[0, 0, 0])
+    assert r3.held[0] == 2000
+    for seed in (1, 2):
+        e = np.random.default_rng(seed).integers(0, 256, (5, 6, 60, 60), dtype=np.uint8)
+        a = ka.dictionary_indexing(e, r1, "ncc", 10, verbose=False)
+        b = ka.dictionary_indexing(e, r3, "ncc", 10, verbose=False)
+        assert np.array_equal(a.scores, b.scores) and np.array_equal(a.simulation_indices, b.simulation_indices)
+    # a lazy dictionary: every member simulates its share of the rotations in its own memory
+    mp = ka.EBSDMasterPattern(rng.random((2, 101, 101)).astype(np.float32), hemisphere="both")
+    det = ka.EBSDDetector(shape=(60, 60), pc=(0.42, 0.78, 0.5))
+    q = rng.standard_normal((700, 4))
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    sim = mp.get_patterns(q, det, compute=False)
+    s = ka.EBSD(exp.reshape(5, 8, 60, 60))
+    a = s.dictionary_indexing(sim, keep_n=6, devices=[0], verbose=False)
+    b = s.dictionary_indexing(sim, keep_n=6, devices=[0, 0, 0, 0], verbose=False)
+    assert np.array_equal(a.scores, b.scores) and np.array_equal(a.simulation_indices, b.simulation_indices)
+    assert list(s._groups) == [(0, 0, 0, 0)]  # the signal keeps its group (and the group its communicator)
+    b2 = s.dictionary_indexing(sim, keep_n=6, devices=[0, 0, 0, 0], verbose=False)
+    assert np.array_equal(b.scores, b2.scores) and len(s._groups) == 1
+
+
+def test_default_is_every_visible_device(monkeypatch):
+    """A call that names no device runs on `default_devices()`: $KPDI_DEVICES, else every visible GPU."""
+    import kikuchipy_amd as ka
+    from kikuchipy_amd import _lib
+    from kikuchipy_amd.indexing import _dictionary_indexing as di
+
+    assert _lib.default_devices() == list(range(_lib.device_count()))
+    monkeypatch.setenv("KPDI_DEVICES", "0,0,0")
+    assert _lib.default_devices() == [0, 0, 0]
+    monkeypatch.setattr(di, "GROUP_MIN_COMPARISONS", 0)
+    made = []
+    real = _lib.make_engine
+    monkeypatch.setattr(_lib, "make_engine", lambda *a, **k: made.append(real(*a, **k)) or made[-1])
+    dic = patterns(1, 500)
+    exp = patterns(2, 20, dtype=np.uint8)
+    got = ka.dictionary_indexing(exp, dic, keep_n=5, verbose=False)
+    assert isinstance(made[-1], _lib.Group) and len(made[-1]) == 3
+    one = ka.dictionary_indexing(exp, dic, keep_n=5, device=0, verbose=False)
+    assert isinstance(made[-1], _lib.Context) and not isinstance(made[-1], _lib.Group)
+    assert np.array_equal(got.scores, one.scores) and np.array_equal(got.simulation_indices, one.simulation_indices)
+
+
+def test_a_members_error_names_the_member():
+    from kikuchipy_amd import _lib
+
+    with _lib.Group([0, 0]) as g:
+        with pytest.raises(_lib.KpdiError, match=r"group member \d of 2.*kpdi_set_problem"):
+            g.set_experimental(patterns(1, 4, dtype=np.uint8), None)
+        with pytest.raises(_lib.KpdiError, match="one entry per member"):
+            g.push_dictionary_chunk_dev([0], np.float32, [1], [0])
+    with pytest.raises(_lib.KpdiError, match="out of range"):
+        _lib.Group([0, 99])
