@@ -2,6 +2,7 @@
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python bench.py --gpus 8 --steps 20 --warmup 3            # spawns its own 8 ranks (one per GPU)
+    python bench.py --gpus 8 --single-process                 # ONE process, a kpdi_group over the 8 GPUs
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3   # or under a launcher
 
@@ -24,6 +25,11 @@ TCP on the loopback interface, reading RANK / WORLD_SIZE / MASTER_ADDR /
 MASTER_PORT as a launcher exports them); the data path is libkpdi + RCCL.  For
 N > 1 rank 0 checks the MERGED result against the C oracle exactly as for
 N = 1, and every rank's result must be bit-identical to rank 0's.
+
+`--single-process`: the same sharded job driven from ONE interpreter - the shape of the reference's own
+call (signals/ebsd.py:1827-1984) - through `kikuchipy_amd._lib.Group` (kpdi_group, include/kpdi.h): one
+context and one host thread per GPU inside libkpdi, an in-process RCCL communicator (or peer copies,
+`--gather p2p`), one merged result.  Same timed region, same check, same JSON line.
 """
 
 import argparse
@@ -313,9 +319,10 @@ def spawn_ranks(n_ranks, argv, script=None):
     return rc
 
 
-def main(argv=None, context_factory=None):
-    """`context_factory(device) -> engine context` replaces `kikuchipy_amd._lib.Context` in the CPU
-    rehearsal of the multi-rank control flow (tests/_bench_worker.py); never set otherwise."""
+def main(argv=None, context_factory=None, group_factory=None):
+    """`context_factory(device) -> engine context` / `group_factory(devices, gather) -> engine group` replace
+    `kikuchipy_amd._lib.Context` / `_lib.Group` in the CPU rehearsal of the multi-rank / multi-device control flow
+    (tests/_bench_worker.py, tests/test_bench_multirank.py); never set otherwise."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -338,12 +345,19 @@ def main(argv=None, context_factory=None):
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two short rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE) of a sub-run of this command "
                          "that fill roofline.traffic")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1: ONE process drives all N GPUs through a kpdi_group (one host thread per GPU inside libkpdi, "
+                         "in-process RCCL communicator) instead of one process per GPU")
+    ap.add_argument("--gather", default=None, choices=["rccl", "p2p"],
+                    help="--single-process: how the per-GPU best-k lists reach GPU 0 (default: RCCL all-gather when the "
+                         "devices are distinct, peer copies otherwise)")
     ap.add_argument("--compute", default="f32", choices=["f32", "f16x2", "f16"],
                     help="arithmetic of the match kernel; f16x2 / f16 are the opt-in float16 modes (never the default; "
                          "f16 is reduced precision)")
     a = ap.parse_args(argv)
 
-    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+    single = a.single_process and a.gpus > 1 and "WORLD_SIZE" not in os.environ
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1 and not single:
         return spawn_ranks(a.gpus, sys.argv[1:] if argv is None else argv,
                            script=os.environ.get("KPDI_BENCH_SCRIPT"))
 
@@ -357,8 +371,10 @@ def main(argv=None, context_factory=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    a.gpus = world  # under a launcher the launcher's world size is what runs
-    if world > 1:
+    n_dev = a.gpus if single else 1  # devices THIS process drives
+    if not single:
+        a.gpus = world  # under a launcher the launcher's world size is what runs
+    if world > 1 or single:
         # one node: RCCL's bootstrap can always use the loopback interface (the container's
         # hostname may not resolve), and the host driver only supports dmabuf IPC
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
@@ -389,20 +405,39 @@ def main(argv=None, context_factory=None):
 
     if os.environ.get("KPDI_BENCH_FAIL_RANK") == str(rank):  # tests: a rank that dies must fail the whole run
         sys.exit(3)
-    ctx = make_context(device)
-    comm.attach(ctx)
     metric = {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[w["metric"]]
     compute = {"f32": _lib.COMPUTE_F32, "f16x2": _lib.COMPUTE_F16X2, "f16": _lib.COMPUTE_F16}[a.compute]
-    ctx.set_problem(w["sy"], w["sx"], mask, metric, w["keep_n"], compute)
-    # raw inputs resident in HBM before the timed region
-    d_exp = ctx.dev_alloc(exp.nbytes)
-    ctx.h2d(d_exp, exp)
-    if large:
-        d_dic = upload_generated_shard(ctx, w, lo, hi, exp)
+
+    def resident(c, a0, a1):
+        """raw inputs of one device resident in its HBM before the timed region: (experimental set, dictionary [a0, a1))"""
+        de = c.dev_alloc(exp.nbytes)
+        c.h2d(de, exp)
+        if large:
+            return de, upload_generated_shard(c, w, a0, a1, exp)
+        part = np.ascontiguousarray(dic[a0:a1])
+        dd = c.dev_alloc(part.nbytes)
+        c.h2d(dd, part)
+        return de, dd
+
+    if single:
+        # ONE process, a group of contexts: member i sweeps dictionary block i (the same contiguous blocks as the ranks of
+        # the multi-process form) and the group hands back one merged result
+        ids = list(range(n_dev))
+        if os.environ.get("KPDI_BENCH_SHARE_GPU") and group_factory is None:
+            ids = [i % max(_lib.device_count(), 1) for i in ids]
+        ctx = (group_factory or _lib.Group)(ids, a.gather)
+        device = ids
+        shards = [shard_range(w["n"], i, n_dev) for i in range(n_dev)]
+        ctx.set_problem(w["sy"], w["sx"], mask, metric, w["keep_n"], compute)
+        res = [resident(mem, a0, a1) for mem, (a0, a1) in zip(ctx.members, shards)]
+        # (per-member lists in place of one pointer / size / start: the group forms of the same calls)
+        d_exp, d_dic = [r[0] for r in res], [r[1] for r in res]
+        n_local, lo = [a1 - a0 for a0, a1 in shards], [a0 for a0, _ in shards]
     else:
-        shard = np.ascontiguousarray(dic[lo:hi])
-        d_dic = ctx.dev_alloc(shard.nbytes)
-        ctx.h2d(d_dic, shard)
+        ctx = make_context(device)
+        comm.attach(ctx)
+        ctx.set_problem(w["sy"], w["sx"], mask, metric, w["keep_n"], compute)
+        d_exp, d_dic = resident(ctx, lo, hi)
     bg_f32 = bg.astype(np.float32)
 
     def queue_step():
@@ -445,6 +480,14 @@ def main(argv=None, context_factory=None):
     cnt = ctx.counters()
     ctx.set_profiling(False)
     per_rank = None
+    if single:
+        digest = hashlib.sha256(np.ascontiguousarray(scores).tobytes() + np.ascontiguousarray(indices).tobytes()).hexdigest()
+        per_rank = [{
+            "rank": i, "device": ids[i], "shard": [int(a0), int(a1)], "result_sha256": digest,
+            "match_ms": c["match_ms"], "match_launches": int(c["match_launches"]), "match_flops": c["match_flops"],
+            "prep_ms": c["prep_ms"], "merge_ms": c["merge_ms"], "comm_ms": c.get("comm_ms", 0.0),
+            "fixed_ms": c.get("fixed_ms", 0.0), "comm_ranks": int(c.get("comm_ranks", 0)),
+            "match_form": int(c.get("match_form", 0))} for i, (c, (a0, a1)) in enumerate(zip(cnt["members"], shards))]
     if world > 1:
         elapsed = comm.all_reduce_max(elapsed)
         digest = hashlib.sha256(np.ascontiguousarray(scores).tobytes() + np.ascontiguousarray(indices).tobytes()).hexdigest()
@@ -460,6 +503,8 @@ def main(argv=None, context_factory=None):
         ctx.close()
         return 0
 
+    solo = world == 1 and not single  # one process, one GPU: the informational legs below belong to this form
+    n_gpus = n_dev if single else world
     ms_per_step = elapsed / a.steps * 1e3
     value = w["m"] * a.steps / elapsed
     k_kept = cnt["k_kept"]
@@ -476,7 +521,7 @@ def main(argv=None, context_factory=None):
                    f"experimental patterns indexed/sec (whole node), {w['sy']}x{w['sx']} px x {w['n'] // 1000}k dict"),
         "value": round(value, 1),
         "unit": "patterns/s",
-        "n_gpus": world,
+        "n_gpus": n_gpus,
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 3),
@@ -494,7 +539,9 @@ def main(argv=None, context_factory=None):
             "kept_pixels": k_kept,
             "metric": w["metric"],
             "keep_n": w["keep_n"],
-            "parallelism": f"dictionary sharded over {world} GPU(s)" + (", RCCL all-gather merge" if world > 1 else ""),
+            "parallelism": f"dictionary sharded over {n_gpus} GPU(s)" + (
+                f", ONE process (kpdi_group), {cnt.get('gather', '?')} gather + merge" if single else
+                ", one process per GPU, RCCL all-gather merge" if world > 1 else ""),
             "hand_over": ("every step's result is collected before the next step is queued" if a.no_pipeline else
                           "the result of step i reaches host memory while step i + 1 runs (finalize_async / finalize_wait); "
                           "all K results are collected inside the timed region"),
@@ -531,13 +578,13 @@ def main(argv=None, context_factory=None):
     # sub-run of THIS command, per launch of the match kernel, with the guide's corrections (KiB; FETCH_SIZE doubled on
     # gfx950).  A traffic regression then shows in the driver's own line.  Skipped (null + the reason) when rocprofv3 is
     # missing, when this process is itself being profiled, for N > 1, or with --no-traffic.
-    if world == 1 and not a.no_traffic and context_factory is None:
+    if solo and not a.no_traffic and context_factory is None:
         out["roofline"].update(measure_traffic(a, "match"))
     else:
-        out["roofline"]["traffic_note"] = "not measured: " + ("N > 1" if world > 1 else "--no-traffic")
+        out["roofline"]["traffic_note"] = "not measured: " + ("N > 1" if not solo else "--no-traffic")
     # The number of the committed rocprofv3 PMC passes of this same command (tools/summarize_pmc.py) is quoted beside it,
     # labelled as what it is: a static, earlier measurement.
-    if a.workload == "config2" and world == 1 and a.compute == "f32":
+    if a.workload == "config2" and solo and a.compute == "f32":
         import glob
 
         # (r03_pmc.json: the passes of THIS command; not r03_config3_pmc.json / r03_rank_share_pmc.json)
@@ -561,7 +608,11 @@ def main(argv=None, context_factory=None):
         same = all(p["result_sha256"] == per_rank[0]["result_sha256"] for p in per_rank)
         assert same, f"ranks disagree on the merged result: {[p['result_sha256'][:12] for p in per_rank]}"
         ranks_in_comm = sorted({p["comm_ranks"] for p in per_rank})
-        assert ranks_in_comm == [world], f"RCCL communicator sizes {ranks_in_comm}, expected {world} on every rank"
+        rccl = not single or cnt.get("gather") == "rccl"
+        if rccl:
+            assert ranks_in_comm == [n_gpus], f"RCCL communicator sizes {ranks_in_comm}, expected {n_gpus} on every rank"
+        if single:  # member 0 merged one list per member, however they reached it
+            assert cnt.get("gather_ranks") == n_gpus, f"{cnt.get('gather_ranks')} lists merged, expected {n_gpus}"
         avg = [p["match_ms"] / max(p["match_launches"], 1) for p in per_rank]
         tf = [p["match_flops"] / max(p["match_launches"], 1) / (m * 1e-3) / 1e12 if m > 0 else 0.0 for p, m in zip(per_rank, avg)]
         slow = int(np.argmax(avg))
@@ -569,8 +620,11 @@ def main(argv=None, context_factory=None):
             "rank": slow, "avg_launch_ms": round(avg[slow], 4), "achieved": round(tf[slow] * mfma_per_term, 2),
             "frac": round(tf[slow] * mfma_per_term / peak_tflops, 4)}
         out["multi_gpu"] = {
-            "rccl_ranks": world,  # ncclCommCount of every rank's communicator (asserted above)
-            "identical_result_on_every_rank": same,
+            "rccl_ranks": n_gpus if rccl else 0,  # ncclCommCount of every rank's communicator (asserted above)
+            "processes": 1 if single else world,
+            "gather": "rccl" if rccl else "p2p (hipMemcpyPeerAsync into GPU 0)",
+            "lists_merged": int(cnt.get("gather_ranks", 0)) if single else world,
+            "identical_result_on_every_rank": same if not single else None,  # (one process: one result)
             "allgather_ms_per_step": round(max(p["comm_ms"] for p in per_rank) / a.steps, 4),
             "allgather_ms_per_step_min_over_ranks": round(min(p["comm_ms"] for p in per_rank) / a.steps, 4),
             "per_rank": [{"rank": p["rank"], "device": p["device"], "shard": p["shard"],
@@ -580,12 +634,15 @@ def main(argv=None, context_factory=None):
                           "fixed_ms_per_step": round(p["fixed_ms"] / a.steps, 4),
                           "allgather_ms_per_step": round(p["comm_ms"] / a.steps, 4),
                           "match_form": p["match_form"]} for p in per_rank],
-            "control_plane": "kikuchipy_amd.parallel.SocketGroup (TCP, loopback); data path: ncclAllGather inside kpdi_finalize",
+            "control_plane": ("none: one process, one host thread per GPU inside libkpdi (kpdi_group); data path: "
+                              + ("ncclAllGather on an ncclCommInitAll communicator" if rccl else "peer copies") + " inside kpdi_group_finalize"
+                              if single else
+                              "kikuchipy_amd.parallel.SocketGroup (TCP, loopback); data path: ncclAllGather inside kpdi_finalize"),
         }
 
     # ---- configs[2] inside the default run: circular signal mask (K = 2819) + static and dynamic
     # background removal fused with the preparation of the patterns (ONE pre-kernel), then the match
-    if a.workload == "config2" and world == 1 and a.compute == "f32" and not a.no_config3:
+    if a.workload == "config2" and solo and a.compute == "f32" and not a.no_config3:
         try:
             w3 = WORKLOADS["config3"]
             mask3 = circular_mask(w3["sy"], w3["sx"])
@@ -634,7 +691,7 @@ def main(argv=None, context_factory=None):
         except Exception as err:  # an informational leg must not cost the bench line
             out["extra"]["config3_error"] = f"{type(err).__name__}: {err}"
 
-    if world == 1 and not a.no_pcie:
+    if solo and not a.no_pcie:
         try:
             # informational: the same sweep with the dictionary handed over as a HOST
             # buffer (pageable memory -> PCIe inside the step).  Never `value`.
@@ -655,7 +712,7 @@ def main(argv=None, context_factory=None):
         except Exception as err:  # an informational leg must not cost the bench line
             out["extra"]["pcie_inclusive_error"] = f"{type(err).__name__}: {err}"
 
-    if world == 1 and not a.no_pcie:
+    if solo and not a.no_pcie:
         try:
             # informational: a SERIES of maps against one dictionary that was handed over as a host
             # buffer once and stays prepared in HBM (kpdi_hold_dictionary_chunk / kpdi_sweep_held):
@@ -690,7 +747,7 @@ def main(argv=None, context_factory=None):
             ("f16_mode", "COMPUTE_F16", 1,
              "opt-in KPDI_COMPUTE_F16, REDUCED PRECISION: same sweep, operands rounded to one float16, 1 f16 MFMA "
              "per 16 product terms")):
-        if not (world == 1 and not a.no_generation and a.compute == "f32"):
+        if not (solo and not a.no_generation and a.compute == "f32"):
             break
         try:
             # informational: the same sweep with the OPT-IN float16 arithmetics of the match kernel.
@@ -728,7 +785,7 @@ def main(argv=None, context_factory=None):
         except Exception as err:  # an informational leg must not cost the bench line
             out["extra"][key + "_error"] = f"{type(err).__name__}: {err}"
 
-    if world == 1 and not a.no_generation and a.compute == "f32":
+    if solo and not a.no_generation and a.compute == "f32":
         try:
             # informational: float64 arithmetic (the reference's dtype=float64) - the f32 sweep as the screen,
             # float64 rescoring of keep_n + 12 candidates per pattern from the raw patterns (csrc/rescore.hip).
@@ -763,7 +820,7 @@ def main(argv=None, context_factory=None):
         except Exception as err:  # an informational leg must not cost the bench line
             out["extra"]["float64_mode_error"] = f"{type(err).__name__}: {err}"
 
-    if world == 1 and not a.no_generation:
+    if solo and not a.no_generation:
         try:
             # informational: the dictionary is SIMULATED on the device inside the step
             # from n rotations (32 B each over PCIe) and a 401 x 401 x 2 synthetic master pattern, then
@@ -800,7 +857,7 @@ def main(argv=None, context_factory=None):
         except Exception as err:  # an informational leg must not cost the bench line
             out["extra"]["dictionary_generation_error"] = f"{type(err).__name__}: {err}"
 
-    if world == 1 and not a.no_generation:
+    if solo and not a.no_generation:
         try:
             # informational: orientation refinement of m patterns simulated from the same
             # master pattern (1 degree off, noise added), SciPy-compatible Nelder-Mead on the device; beside

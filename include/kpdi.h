@@ -27,6 +27,25 @@
  *  - host inputs are never modified (tests/test_indexing/test_dictionary_indexing.py:41-43).
  *  - masks follow the reference: nonzero = EXCLUDED (similarity_metrics/_similarity_metric.py:51-58).
  *  - there is no CPU fallback: without a usable GPU kpdi_create() fails.
+ *
+ * Degenerate patterns
+ *  A pattern whose normalisation is undefined is DEGENERATE:
+ *    ncc - zero variance over the kept pixels: a constant pattern (a dead or saturated detector frame); "constant" =
+ *          centred sum of squares <= K (2^-20 mean)^2, i.e. constant to within the rounding of a float32 mean;
+ *    ndp - all kept pixels zero;
+ *    either metric - NaN or +-inf among the kept pixels.
+ *  The reference divides 0 by 0 there (similarity_metrics/_normalized_cross_correlation.py:228-233,
+ *  _normalized_dot_product.py:181-194): the prepared row is NaN, every score of it is NaN, and Dask's topk ranks NaN
+ *  FIRST (dask/array/chunk.py:167-258) - a degenerate dictionary pattern becomes every experimental pattern's best
+ *  match, a degenerate experimental pattern gets arbitrary indices with NaN scores.  SURVEY.md 8(a) puts that out
+ *  of contract; THIS library's rule, on the experimental and on the dictionary side, in every arithmetic
+ *  (KPDI_COMPUTE_*) and independent of chunking, tiling and sharding:
+ *    a degenerate pattern is prepared as the ALL-ZERO row, so its score against every pattern is exactly +0.0
+ *    ("no correlation") and ranks among the real scores like any other 0 - ties: lower dictionary index first.
+ *  Hence a degenerate EXPERIMENTAL pattern comes back with scores 0 and the indices global_start .. of the lowest
+ *  dictionary patterns pushed; a degenerate DICTIONARY pattern is selected only where fewer than keep_n real scores
+ *  are positive; no other pattern's result changes (tests/test_gpu_degenerate.py, against oracle/kpdi_oracle.py which
+ *  states the same rule).  Results never contain NaN.
  */
 #ifndef KPDI_H
 #define KPDI_H

@@ -31,9 +31,9 @@
 // round with a systematic bias) to the 1e-7 of `ncc`.  Not in the float16 form, whose 11 bits
 // cannot carry the constant.
 //
-// A pattern with zero norm (constant pattern; 0/0 = NaN in the reference, out of
-// contract per SURVEY.md 8(a)) becomes an all-zero row: it scores exactly 0
-// against everything.
+// A DEGENERATE pattern - zero variance (`ncc`) / all zeros (`ndp`) / NaN or inf among its kept pixels; 0/0 = NaN in
+// the reference - becomes an all-zero row: it scores exactly 0 against everything (prep_device.h: degenerate_norm2,
+// include/kpdi.h "Degenerate patterns").
 #include "prep_device.h"
 
 #include <algorithm>
@@ -74,24 +74,24 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const T *raw, int np
   }
   q = block_sum(q, red);
   const bool centred = metric == NORM_NDP_CENTRED;
-  const float norm = sqrtf(centred ? q + (float)k * mean * mean : q);
-  const float inv = norm > 0.f ? 1.f / norm : 0.f;
-  const float cval = sqrtf((float)k) * mean * inv;
+  const float norm2 = centred ? q + (float)k * mean * mean : q;
+  const bool degenerate = degenerate_norm2(norm2, centred ? 0.f : mean, k);  // -> an all-zero row (prep_device.h)
+  const float inv = degenerate ? 0.f : 1.f / sqrtf(norm2);
+  const float cval = degenerate ? 0.f : sqrtf((float)k) * mean * inv;
+  if (degenerate) mean = 0.f;
+  auto value = [&](int c) { return degenerate ? 0.f : ((float)p[pix_map ? pix_map[c] : c] - mean) * inv; };
   if ((form & 0xff) == 2) {
     for (int c = tid; c < 2 * kpad; c += PREP_THREADS)
-      *(_Float16 *)half_slot(out, r, c, kpad, form) =
-          (_Float16)((c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv * 4096.f : 0.f);
+      *(_Float16 *)half_slot(out, r, c, kpad, form) = (_Float16)((c < k) ? value(c) * 4096.f : 0.f);
     return;
   }
   if ((form & 0xff) == 3) {
     for (int c = tid; c < kpad; c += PREP_THREADS)
-      *(float *)half_slot(out, r, 2 * c, kpad, form) =
-          (c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv : ((centred && c == k) ? cval : 0.f);
+      *(float *)half_slot(out, r, 2 * c, kpad, form) = (c < k) ? value(c) : ((centred && c == k) ? cval : 0.f);
     return;
   }
   for (int c = tid; c < kpad; c += PREP_THREADS)
-    out[prepared_offset(r, c, nslab)] =
-        (c < k) ? ((float)p[pix_map ? pix_map[c] : c] - mean) * inv : ((centred && c == k) ? cval : 0.f);
+    out[prepared_offset(r, c, nslab)] = (c < k) ? value(c) : ((centred && c == k) ? cval : 0.f);
 }
 
 // ---- shared tail of the wave-per-pattern kernels: v[i] holds kept pixel lane + 64*i -----
@@ -113,9 +113,14 @@ __device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], flo
   }
   q2 = wave_sum(q2);
   const bool centred = metric == NORM_NDP_CENTRED;
-  const float norm = sqrtf(centred ? q2 + (float)k * mean * mean : q2);
-  const float inv = norm > 0.f ? 1.f / norm : 0.f;
-  const float cval = sqrtf((float)k) * mean * inv;
+  const float norm2 = centred ? q2 + (float)k * mean * mean : q2;
+  const bool degenerate = degenerate_norm2(norm2, centred ? 0.f : mean, k);  // -> an all-zero row (prep_device.h)
+  const float inv = degenerate ? 0.f : 1.f / sqrtf(norm2);
+  const float cval = degenerate ? 0.f : sqrtf((float)k) * mean * inv;
+  if (degenerate) {
+#pragma unroll
+    for (int i = 0; i < WAVE_VALUES; ++i) v[i] = 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES; ++i) {
     const int c = lane + 64 * i;
@@ -315,8 +320,12 @@ __global__ __launch_bounds__(256 * NP) void prep16_block4_kernel(const T *raw, i
     }
   }
   q2 = group_total(q2);
-  const float norm = sqrtf(q2);
-  const float inv = norm > 0.f ? 4096.f / norm : 0.f;  // float16 operands are stored scaled by 2^12
+  const bool degenerate = degenerate_norm2(q2, mean, k);  // -> an all-zero row (prep_device.h)
+  const float inv = degenerate ? 0.f : 4096.f / sqrtf(q2);  // float16 operands are stored scaled by 2^12
+  if (degenerate) {
+#pragma unroll
+    for (int i = 0; i < WAVE_VALUES; ++i) v[i] = 0.f;
+  }
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES / 4; ++i) {
@@ -404,9 +413,14 @@ __global__ __launch_bounds__(PREP16_THREADS) void prep32_block4_kernel(const T *
   }
   q2 = group_total(q2);
   const bool centred = metric == NORM_NDP_CENTRED;
-  const float norm = sqrtf(centred ? q2 + (float)k * mean * mean : q2);
-  const float inv = norm > 0.f ? 1.f / norm : 0.f;
-  const float cval = sqrtf((float)k) * mean * inv;
+  const float norm2 = centred ? q2 + (float)k * mean * mean : q2;
+  const bool degenerate = degenerate_norm2(norm2, centred ? 0.f : mean, k);  // -> an all-zero row (prep_device.h)
+  const float inv = degenerate ? 0.f : 1.f / sqrtf(norm2);
+  const float cval = degenerate ? 0.f : sqrtf((float)k) * mean * inv;
+  if (degenerate) {
+#pragma unroll
+    for (int i = 0; i < WAVE_VALUES; ++i) v[i] = 0.f;
+  }
   // two passes over the row: planes [0, half_planes) and the rest
   const int planes = kpad / 8, half_planes = (planes + 1) / 2;
   const int row_floats = 8 * half_planes + 4;  // + 16 bytes: the four rows start in different banks

@@ -8,6 +8,21 @@
 namespace kpdi {
 
 constexpr int NORM_NDP_CENTRED = 2;  // internal value of the `metric` argument: `ndp` in its centred form (prep.hip)
+
+// ---- degenerate patterns (include/kpdi.h, "Degenerate patterns") ---------------------------------------------------
+// A pattern whose normalisation is undefined is DEGENERATE: `ncc` - a constant pattern (dead or saturated detector
+// frame: zero variance; "constant" = centred sum of squares <= K (2^-20 mean)^2, i.e. constant to within the rounding
+// of a float32 mean), `ndp` - an all-zero pattern, either metric - NaN or inf among the kept pixels.  The reference
+// divides 0 by 0 there (similarity_metrics/_normalized_cross_correlation.py:228-233, _normalized_dot_product.py:181-194)
+// and ranks the resulting NaN FIRST (dask/array/chunk.py:167-258).  Here such a pattern is prepared as the all-zero
+// row: its score against every pattern is exactly +0 ("no correlation"), on the experimental and on the dictionary
+// side, in every arithmetic.  `norm2` = sum of squares the row is divided by the root of; `mean` = the mean that was
+// removed (0 for `ndp`).
+template <typename F>
+__host__ __device__ inline bool degenerate_norm2(F norm2, F mean, int k) {
+  const F tol = mean * (F)9.5367431640625e-07;  // 2^-20
+  return !(norm2 > (F)k * tol * tol && norm2 < (F)__builtin_inff());  // (NaN fails both comparisons)
+}
 constexpr int PREP_THREADS = 256;
 constexpr int WAVE_VALUES = 64;  // values per lane of the wave-per-pattern kernels (K <= 4096)
 
@@ -147,9 +162,14 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[NV], float 
   }
   q2 = group_sum<NT>(q2, red);
   const bool centred = metric == NORM_NDP_CENTRED;
-  const float norm = sqrtf(centred ? q2 + (float)k * mean * mean : q2);
-  const float inv = norm > 0.f ? 1.f / norm : 0.f;
-  const float cval = sqrtf((float)k) * mean * inv;
+  const float norm2 = centred ? q2 + (float)k * mean * mean : q2;
+  const bool degenerate = degenerate_norm2(norm2, centred ? 0.f : mean, k);  // (uniform over the NT threads of the row)
+  const float inv = degenerate ? 0.f : 1.f / sqrtf(norm2);
+  const float cval = degenerate ? 0.f : sqrtf((float)k) * mean * inv;
+  if (degenerate) {  // 0 x NaN is NaN: the row is written as zeros
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < NV / 4; ++i) {
     const int c = 4 * (lane + NT * i);

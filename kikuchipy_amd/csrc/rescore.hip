@@ -109,10 +109,12 @@ __global__ __launch_bounds__(RESCORE_THREADS) void rescore_kernel(RescoreLaunch 
       s2 = wave_sum_f64(s2);
       const double syy = centre ? s2 - s1 * s1 / (double)a.k : s2;
       if (centre) sxy -= (s1 / (double)a.k) * sx_res;
-      // a pattern without variance: the engine's f32 path prepares it as zeros (score 0); the reference
-      // divides by zero (NaN) - out of contract
-      score = (sxx > 0.0 && syy > 0.0) ? sxy / (sqrt(sxx) * sqrt(syy)) : 0.0;
-      if (!(score == score)) score = -INFINITY;  // NaN in the data
+      // degenerate patterns (zero variance / all zeros / NaN or inf in the data: include/kpdi.h) score exactly 0, as
+      // in the f32 path, which prepares them as all-zero rows; the reference divides 0 by 0 there
+      const double my = centre ? y0 + s1 / (double)a.k : 0.0;
+      const bool degenerate = degenerate_norm2(sxx, mx, a.k) || degenerate_norm2(syy, my, a.k);
+      score = degenerate ? 0.0 : sxy / (sqrt(sxx) * sqrt(syy));
+      if (!(score == score)) score = 0.0;
       if (score > -INFINITY) worst = fmaxf(worst, fabsf((float)(score - (double)s32)));
     }
     if (lane == 0) a.cand_s64[ci] = score;

@@ -26,7 +26,7 @@ class DictionaryIndexingResult:
 
     def __init__(self, scores, simulation_indices, nav_shape, step_sizes, is_in_data, keep_n,
                  rotations=None, phase_name=None, scan_unit=None, patterns_per_second=None,
-                 comparisons_per_second=None):
+                 comparisons_per_second=None, float64_certificate=None):
         self.scores = scores
         self.simulation_indices = simulation_indices
         self.shape = tuple(nav_shape)
@@ -38,6 +38,10 @@ class DictionaryIndexingResult:
         self.scan_unit = scan_unit
         self.patterns_per_second = patterns_per_second
         self.comparisons_per_second = comparisons_per_second
+        # float64 arithmetic (`dtype=float64`): how the float32 screen was certified - {"mode": "statistical" |
+        # "worstcase" (KPDI_F64_EPS=worstcase), "uncertified_patterns": n}; a result is the exact float64 best-k for
+        # ANY data only with mode "worstcase" and 0 uncertified patterns (include/kpdi.h, KPDI_COMPUTE_F64); else None
+        self.float64_certificate = float64_certificate
 
     @property
     def size(self):
@@ -128,6 +132,12 @@ def prepare_metric(metric, navigation_mask, signal_mask, dtype, rechunk, n_exper
         metric.dtype = dtype
     metric.raise_error_if_invalid()
     return metric
+
+
+def _uncertified(ctx):
+    """(pattern, chunk) pairs the float64 mode could not certify so far, over every device of the engine."""
+    c = ctx.counters()
+    return int(sum(m.get("uncertified_patterns", 0) for m in c.get("members", [c])))
 
 
 def chunk_bounds(dictionary_size, n_per_iteration):
@@ -295,8 +305,16 @@ def dictionary_indexing(
         if _is_lazy(chunk):
             chunk = chunk.compute()
         ctx.push_dictionary_chunk(np.asarray(chunk), start)
+    f64 = metric.effective_compute == "f64"
+    uncertified_before = _uncertified(ctx) if f64 else 0
     scores, simulation_indices = ctx.finalize(keep_n)
     total_time = time.time() - time_start
+    certificate = None
+    if f64:
+        from kikuchipy_amd import _lib
+
+        certificate = {"mode": _lib.F64_CERTIFICATES.get(ctx.counters().get("f64_certificate", 0)),
+                       "uncertified_patterns": _uncertified(ctx) - uncertified_before}
     scores = scores.astype(metric.dtype, copy=False)
     pps = n_experimental / total_time
     cps = n_experimental * dict_size / total_time
@@ -330,4 +348,5 @@ def dictionary_indexing(
     return DictionaryIndexingResult(
         scores, simulation_indices, nav_shape_exp, step_sizes, in_data, keep_n, rotations=rotations,
         phase_name=phase_name, scan_unit=scan_unit, patterns_per_second=pps, comparisons_per_second=cps,
+        float64_certificate=certificate,
     )

@@ -205,11 +205,24 @@ class _HipMetric(SimilarityMetric):
         self._problem = tuple(sig_shape)
 
     def _match_chunk(self, patterns, k):
+        """The best `k` of one chunk.  The reference's loop asks for `min(keep_n, end - start)` entries where `end` is
+        the chunk's NOMINAL end (indexing/_dictionary_indexing.py:104, :112): for a last chunk shorter than `keep_n`
+        that is more than the chunk holds.  Dask's `topk` then yields only as many columns as there are patterns (and
+        announces `k`, so the loop's `.reshape((-1, k))` is a no-op on it); a NumPy result cannot change shape behind
+        the loop's back, so the missing columns are returned as entries that can never be selected - score -inf -
+        which the host merge of :120-128 drops (`keep_n <= dictionary size`, :67, guarantees enough real ones)."""
         ctx = self.context
-        ctx.set_keep_n(k)
+        n = patterns.shape[0]
+        k_run = min(k, n)
+        ctx.set_keep_n(k_run)
         ctx.push_dictionary_chunk(patterns, 0)
-        scores, indices = ctx.finalize(k)
-        return scores.astype(self.dtype, copy=False), indices
+        scores, indices = ctx.finalize(k_run)
+        scores = scores.astype(self.dtype, copy=False)
+        if k_run < k:
+            pad = ((0, 0), (0, k - k_run))
+            scores = np.pad(scores, pad, constant_values=-np.inf)
+            indices = np.pad(indices, pad, constant_values=0)
+        return scores, indices
 
     # ------------------------------------------------------------------ plugin API
     def __call__(self, experimental, dictionary):

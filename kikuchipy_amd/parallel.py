@@ -26,6 +26,7 @@ accepts any other transport as three callables (tests/_gloo_worker.py passes
 """
 
 import hashlib
+import hmac
 import io
 import json
 import os
@@ -33,12 +34,15 @@ import socket
 import struct
 import time
 
-# RCCL shares buffers between the ranks of a node through dmabuf IPC; the legacy mode fails with `hipIpcGetMemHandle: invalid
-# argument` on hosts whose driver only supports dmabuf.  HSA reads this when the runtime initialises, i.e. at the first
-# call into libkpdi - which this import precedes.
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
 import numpy as np
+
+
+def _prefer_dmabuf_ipc():
+    """RCCL shares buffers between the PROCESSES of a node through dmabuf IPC; the legacy mode fails with
+    `hipIpcGetMemHandle: invalid argument` on hosts whose driver only supports dmabuf.  HSA reads the variable when the
+    runtime initialises (the first call into libkpdi), so it is set when a multi-rank `Communicator` is made - the only
+    place that needs it - and not as a side effect of importing this package (`setdefault`: the user's choice stands)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def shard_range(n_total, rank, world_size):
@@ -107,8 +111,13 @@ def _recv_exact(sock, n):
     return bytes(buf)
 
 
+_MAX_MESSAGE = 1 << 30  # the control plane carries ids, timings and a few result rows per pattern
+
+
 def _recv_msg(sock):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if n > _MAX_MESSAGE:
+        raise ConnectionError(f"control-plane message of {n} bytes announced (limit {_MAX_MESSAGE}): not a peer of this job?")
     return _recv_exact(sock, n)
 
 
@@ -116,12 +125,22 @@ _MAGIC = b"KPDI-RDV1"
 _PORT_CANDIDATES = 32
 
 
-def _job_token(world_size):
+def _job_token(world_size, addr="", port=0):
     """What tells this job's rendezvous from a stale / foreign one on a neighbouring port: the
     launcher's run id when it exports one (torchrun: TORCHELASTIC_RUN_ID; bench.py's own spawner:
-    KPDI_JOB_ID) and the world size."""
-    run = os.environ.get("KPDI_JOB_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or "none"
+    KPDI_JOB_ID) - else the rendezvous address itself, so that two jobs of equal size whose port
+    ranges overlap still cannot join each other - and the world size."""
+    run = os.environ.get("KPDI_JOB_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or f"rendezvous-{addr}:{int(port)}"
     return hashlib.sha256(f"{run}/{int(world_size)}".encode()).digest()[:16]
+
+
+def _rank_proof(token, rank, world_size):
+    """What a joining rank sends with its rank: shows that it knows the job token (the server's greeting alone would
+    let any local process that read it claim a rank)."""
+    return hmac.new(token, struct.pack("<ii", int(rank), int(world_size)), hashlib.sha256).digest()[:16]
+
+
+_ACCEPT, _REJECT = b"\x01", b"\x00"
 
 
 class SocketGroup:
@@ -136,18 +155,18 @@ class SocketGroup:
     result rows: latency of tens of microseconds on loopback, irrelevant next to a sweep)."""
 
     def __init__(self, rank, world_size, master_addr=None, master_port=None, timeout=120.0):
+        self._peers = {}  # rank 0: rank -> socket
+        self._up = None   # other ranks: socket to rank 0
+        self._server = None  # (set before anything can raise: __del__ closes what is there)
         self.rank, self.world_size = int(rank), int(world_size)
         if not 0 <= self.rank < self.world_size:
             raise ValueError(f"bad rank {rank} / world size {world_size}")
         self.timeout = float(timeout)
-        self._peers = {}  # rank 0: rank -> socket
-        self._up = None   # other ranks: socket to rank 0
-        self._server = None
         if self.world_size == 1:
             return
         addr = master_addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         port = int(master_port or os.environ.get("MASTER_PORT", "29500"))
-        token = _job_token(self.world_size)
+        token = _job_token(self.world_size, addr, port)
         if self.rank == 0:
             self._listen(addr, port, token)
         else:
@@ -188,11 +207,15 @@ class SocketGroup:
             conn.settimeout(5.0)
             try:
                 conn.sendall(_MAGIC + token)
-                peer, world = struct.unpack("<ii", _recv_exact(conn, 8))
+                hello = _recv_exact(conn, 8 + 16)
+                peer, world = struct.unpack("<ii", hello[:8])
+                ok = (world == self.world_size and 0 < peer < world and peer not in self._peers
+                      and hmac.compare_digest(hello[8:], _rank_proof(token, peer, world)))
+                conn.sendall(_ACCEPT if ok else _REJECT)  # the peer learns NOW, not at its first collective
             except (OSError, ConnectionError):
-                conn.close()  # a port scanner, a rank of another job that read the token and left
+                conn.close()  # a port scanner, a rank of another job that read the greeting and left
                 continue
-            if world != self.world_size or not 0 < peer < world or peer in self._peers:
+            if not ok:
                 conn.close()
                 continue
             conn.settimeout(self.timeout)
@@ -212,9 +235,15 @@ class SocketGroup:
                     if _recv_exact(s, len(want)) == want:
                         s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                         s.settimeout(self.timeout)
-                        s.sendall(struct.pack("<ii", self.rank, self.world_size))
+                        s.sendall(struct.pack("<ii", self.rank, self.world_size) + _rank_proof(token, self.rank, self.world_size))
+                        if _recv_exact(s, 1) != _ACCEPT:
+                            s.close()
+                            raise PermissionError(f"rank {self.rank}: the rendezvous server on {addr}:{cand} rejected this rank "
+                                                  "(rank already taken, or another world size)")
                         self._up, self.port = s, cand
                         return
+                except PermissionError:
+                    raise
                 except (OSError, ConnectionError):
                     pass
                 s.close()
@@ -252,7 +281,7 @@ class SocketGroup:
         return max(float(v) for v in self.all_gather(float(value)))
 
     def close(self):
-        for s in list(self._peers.values()) + [self._up, self._server]:
+        for s in list(getattr(self, "_peers", {}).values()) + [getattr(self, "_up", None), getattr(self, "_server", None)]:
             if s is not None:
                 try:
                     s.close()
@@ -274,6 +303,8 @@ class Communicator:
         self.rank = int(rank)
         self.world_size = int(world_size)
         self.group = group
+        if self.world_size > 1:
+            _prefer_dmabuf_ipc()
         if self.world_size > 1 and group is None and not (broadcast_bytes and barrier and all_gather):
             self.group = group = SocketGroup(self.rank, self.world_size)
         self._broadcast = broadcast_bytes or (group.broadcast_bytes if group else None)

@@ -49,21 +49,59 @@ ALLOWED_DTYPES = (np.dtype(np.float32), np.dtype(np.float64))
 # --------------------------------------------------------------------------
 # a4/a5/a6: pattern preparation
 # --------------------------------------------------------------------------
-def zero_mean_normalize(patterns):
+# Degenerate patterns.  Where a pattern's normalisation is undefined - zero variance for `ncc` (a constant pattern: a
+# dead or saturated detector frame), all zeros for `ndp`, NaN / inf among the kept pixels for either - the reference
+# divides 0 by 0 (`_normalized_cross_correlation.py:228-233`, `_normalized_dot_product.py:181-194`): the row is NaN,
+# every score of it is NaN, and Dask's `topk` ranks NaN FIRST (`dask/array/chunk.py:167-258`: NaN sorts as the largest
+# value) - a degenerate DICTIONARY pattern becomes everybody's best match, a degenerate experimental pattern gets
+# arbitrary indices with NaN scores.  SURVEY.md 8(a) puts that out of contract and asks the engine to document what it
+# does instead; the ENGINE'S RULE (include/kpdi.h "Degenerate patterns", csrc/prep_device.h: degenerate_norm2), which
+# the oracle applies with `degenerate="zero"` (the default: it is the engine's checker): the row becomes ALL ZEROS, so
+# its score against every pattern is exactly 0 - "no correlation" - on either side, and ranks among the real scores
+# like any other 0 (ties: lower dictionary index first).  `degenerate="reference"` leaves the reference's NaN.
+DEGENERATE_REL = 2.0**-20  # `ncc`: "constant" = centred sum of squares <= K (2^-20 mean)^2 (the rounding of a float32 mean)
+
+
+def degenerate_rows(norm2, mean, k):
+    """Rows whose normalisation is undefined (see above): `norm2` (n,) the sum of squares a row is divided by the root
+    of, `mean` (n,) the mean that was removed (0 for `ndp`)."""
+    with np.errstate(invalid="ignore", over="ignore"):
+        tol = np.asarray(mean, dtype=np.float64) * DEGENERATE_REL
+        norm2 = np.asarray(norm2, dtype=np.float64)
+        return ~((norm2 > k * tol * tol) & (norm2 < np.inf))
+
+
+def zero_mean_normalize(patterns, degenerate="zero"):
     """indexing/similarity_metrics/_normalized_cross_correlation.py:228-233
     (`_zero_mean_normalize_patterns_numpy`); in place on a private copy."""
-    patterns_mean = np.mean(patterns, axis=1, keepdims=True)
-    patterns -= patterns_mean
-    patterns_norm = np.sqrt(np.sum(np.square(patterns), axis=1, keepdims=True))
-    patterns /= patterns_norm
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        patterns_mean = np.mean(patterns, axis=1, keepdims=True)
+        patterns -= patterns_mean
+        norm2 = np.sum(np.square(patterns), axis=1, keepdims=True)
+        patterns_norm = np.sqrt(norm2)
+        patterns /= patterns_norm
+    if degenerate == "zero":
+        patterns[degenerate_rows(norm2[:, 0], patterns_mean[:, 0], patterns.shape[1])] = 0
     return patterns
 
 
-def normalize(patterns):
+def normalize(patterns, degenerate="zero"):
     """indexing/similarity_metrics/_normalized_dot_product.py:181-194
     (`_normalize_patterns`): L2 only, no mean subtraction."""
-    patterns_norm = np.sqrt(np.sum(np.square(patterns), axis=1))[..., np.newaxis]
-    return patterns / patterns_norm
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        norm2 = np.sum(np.square(patterns), axis=1)
+        out = patterns / np.sqrt(norm2)[..., np.newaxis]
+    if degenerate == "zero":
+        out[degenerate_rows(norm2, 0.0, patterns.shape[1])] = 0
+    return out
+
+
+def reference_topk_with_nan(similarities, k):
+    """What the reference's `argtopk` / `topk` return when scores are NaN (dask/array/chunk.py:167-258 + NumPy's sort
+    order: NaN is the largest value): the NaN entries FIRST.  Documentation of the difference to the engine's rule,
+    used by tests/test_gpu_degenerate.py; (indices, scores) of the k 'largest' per row."""
+    order = np.argsort(similarities, axis=1, kind="stable")[:, ::-1][:, :k]  # ascending with NaN last, reversed
+    return order, np.take_along_axis(similarities, order, axis=1)
 
 
 def check_dtype(dtype):
@@ -196,6 +234,108 @@ def dictionary_indexing(
         idx_i = idx_i + start  # :118
         scores, indices = merge_topk(scores, indices, scores_i, idx_i, keep_n)
     return scores, indices
+
+
+def plugin_prepare_metric(metric, navigation_size, navigation_mask, signal_mask, dtype, n_dictionary_patterns):
+    """What `EBSD._prepare_metric` does to a metric OBJECT it was handed (signals/ebsd.py:3072-3086; the
+    `isinstance` gate of :3065-3070 needs the reference's own ABC and is exercised by oracle/seam_check.py)."""
+    metric.n_experimental_patterns = max(navigation_size, 1)
+    metric.n_dictionary_patterns = max(n_dictionary_patterns, 1)
+    if navigation_mask is not None:
+        metric.navigation_mask = navigation_mask
+    if signal_mask is not None:
+        metric.signal_mask = signal_mask
+    if dtype is not None:
+        metric.dtype = dtype
+    metric.raise_error_if_invalid()
+    return metric
+
+
+def plugin_loop(metric, experimental, experimental_nav_shape, dictionary, keep_n, n_per_iteration, phase_name="ni"):
+    """The reference's loop around a metric PLUGIN - `_dictionary_indexing` (indexing/_dictionary_indexing.py:36-169)
+    and `_match_chunk` (:172-203) restated call for call: which methods of the metric object are called, in which
+    order, with what; the lazy-dictionary `.compute()` branch (:106-108), the host merge (:118-128), the scatter under
+    a navigation mask (:142-158, masked-out rows zero here, `np.empty` there).  Pinned against the reference's own
+    functions by oracle/seam_check.py (identical outputs for the same metric objects).  `dictionary`: NumPy, or
+    anything with `.reshape`, slicing and `.compute()` (the reference tests `isinstance(dictionary, da.Array)`).
+    Returns (scores, simulation_indices, information text of :77-85)."""
+    dictionary_size = metric.n_dictionary_patterns  # :66
+    keep_n = min(keep_n, dictionary_size)  # :67
+    n_iterations = int(np.ceil(dictionary_size / n_per_iteration))  # :68
+    experimental = metric.prepare_experimental(experimental)  # :70
+    dictionary = dictionary.reshape((dictionary_size, -1))  # :71
+    n_experimental_all = int(np.prod(experimental_nav_shape))  # :73
+    n_experimental = experimental.shape[0]  # :74
+    info = f"Dictionary indexing information:\n  Phase name: {phase_name}\n"  # :206-237
+    if n_experimental != n_experimental_all:
+        info += f"  Matching {n_experimental}/{n_experimental_all} experimental pattern(s)"
+    else:
+        info += f"  Matching {n_experimental_all} experimental pattern(s)"
+    info += f" to {dictionary_size} dictionary pattern(s)\n  {metric}\n"
+
+    def match_chunk(chunk, k):  # :172-203
+        simulated = metric.prepare_dictionary(chunk)
+        similarities = metric.match(experimental, simulated)
+        idx = similarities.argtopk(k, axis=-1)
+        sc = similarities.topk(k, axis=-1)
+        return idx.reshape((-1, k)), sc.reshape((-1, k))
+
+    if dictionary_size == n_per_iteration:  # :88-93 (da.compute passes NumPy arrays through)
+        simulation_indices, scores = match_chunk(dictionary, keep_n)
+    else:
+        negative_sign = -metric.sign
+        simulation_indices = np.zeros((n_experimental, keep_n), dtype=np.int32)  # :97
+        scores = np.full((n_experimental, keep_n), negative_sign, dtype=metric.dtype)  # :98
+        lazy = hasattr(dictionary, "compute")  # :100
+        starts = np.cumsum([0] + [n_per_iteration] * (n_iterations - 1))
+        ends = np.cumsum([n_per_iteration] * n_iterations)
+        ends[-1] = max(ends[-1], dictionary_size)
+        for start, end in zip(starts, ends):
+            chunk = dictionary[start:end]
+            if lazy:
+                chunk = chunk.compute()  # :106-108
+            idx_i, scores_i = match_chunk(chunk, min(keep_n, end - start))
+            idx_i = idx_i + start  # :118
+            all_scores = np.hstack((scores, scores_i))
+            all_idx = np.hstack((simulation_indices, idx_i))
+            best = np.argsort(negative_sign * all_scores, axis=1)[:, :keep_n]  # :123
+            scores = np.take_along_axis(all_scores, best, axis=1)
+            simulation_indices = np.take_along_axis(all_idx, best, axis=1)
+    if metric.navigation_mask is not None:  # :142-158
+        scores, simulation_indices, _ = scatter_navigation_mask(scores, simulation_indices, metric.navigation_mask, keep_n)
+    return scores, simulation_indices, info
+
+
+class LazyArray:
+    """The little of `dask.array.Array` that `_dictionary_indexing` touches on a lazy dictionary (`reshape`, slicing
+    along the first axis, `compute`, `chunksize`): Dask itself is not installed beside the system Python of the GPU box."""
+
+    def __init__(self, array, chunk):
+        self._a, self._chunk = array, int(chunk)
+        self.computed = []  # (start, stop) of every chunk that was materialised
+
+    shape = property(lambda self: self._a.shape)
+    ndim = property(lambda self: self._a.ndim)
+    dtype = property(lambda self: self._a.dtype)
+    chunksize = property(lambda self: (min(self._chunk, self._a.shape[0]),) + self._a.shape[1:])
+
+    def reshape(self, shape):
+        out = LazyArray(self._a.reshape(shape), self._chunk)
+        out.computed = self.computed
+        return out
+
+    def __getitem__(self, key):
+        if not isinstance(key, slice):
+            raise IndexError("LazyArray: slices along the first axis only")
+        start, stop, _ = key.indices(self._a.shape[0])
+        out = LazyArray(self._a[key], self._chunk)
+        out.computed = self.computed
+        out._span = (start, stop)
+        return out
+
+    def compute(self):
+        self.computed.append(getattr(self, "_span", (0, self._a.shape[0])))
+        return np.array(self._a)
 
 
 def scatter_navigation_mask(scores, indices, navigation_mask, keep_n):

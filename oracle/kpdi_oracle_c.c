@@ -26,19 +26,33 @@ void kpdi_c_set_threads(int n) {
   if (n > 0) omp_set_num_threads(n);
 }
 
+/* Degenerate patterns - zero variance (ncc) / all zeros (ndp) / NaN or inf among the pixels: the reference divides 0 by
+ * 0 (NaN, ranked first by Dask's topk); the ENGINE's documented rule (include/kpdi.h, "Degenerate patterns";
+ * csrc/prep_device.h: degenerate_norm2), which this checker follows: the row becomes all zeros, every score of it is
+ * exactly 0.  norm2 = the sum of squares the row is divided by the root of, mean = the mean removed (0 for ndp). */
+static int degenerate_norm2(double norm2, double mean, int64_t k) {
+  const double tol = mean * 9.5367431640625e-07; /* 2^-20 */
+  return !(norm2 > (double)k * tol * tol && norm2 < INFINITY);
+}
+
 /* rows: n x k, in place.  metric 0 = ncc (subtract mean first), 1 = ndp. */
 void kpdi_c_normalize(float *rows, int64_t n, int64_t k, int metric) {
 #pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < n; ++r) {
     float *p = rows + r * k;
+    float mean = 0.f;
     if (metric == 0) {
       double s = 0.0;
       for (int64_t i = 0; i < k; ++i) s += p[i];
-      const float mean = (float)(s / (double)k);
+      mean = (float)(s / (double)k);
       for (int64_t i = 0; i < k; ++i) p[i] -= mean;
     }
     double q = 0.0;
     for (int64_t i = 0; i < k; ++i) q += (double)p[i] * (double)p[i];
+    if (degenerate_norm2(q, mean, k)) {
+      for (int64_t i = 0; i < k; ++i) p[i] = 0.f;
+      continue;
+    }
     const float norm = (float)sqrt(q);
     for (int64_t i = 0; i < k; ++i) p[i] /= norm;
   }
@@ -170,6 +184,10 @@ void kpdi_c_prepare_f32(const float *raw, int64_t n, int64_t k_in, const int64_t
       o[i] -= mean;
       q += (double)o[i] * o[i];
     }
+    if (degenerate_norm2(q, mean, k)) {
+      for (int64_t i = 0; i < k; ++i) o[i] = 0.f;
+      continue;
+    }
     const float inv = 1.f / (float)sqrt(q);
     for (int64_t i = 0; i < k; ++i) o[i] *= inv;
   }
@@ -218,6 +236,10 @@ void kpdi_c_prepare_f64(const float *raw, int64_t n, int64_t k_in, const int64_t
     for (int64_t i = 0; i < k; ++i) {
       const double d = (double)p[pix_map ? pix_map[i] : i] - mean;
       q += d * d;
+    }
+    if (degenerate_norm2(q, mean, k)) {
+      for (int64_t i = 0; i < k; ++i) o[i] = 0.f;
+      continue;
     }
     const double norm = sqrt(q);
     for (int64_t i = 0; i < k; ++i) o[i] = (float)(((double)p[pix_map ? pix_map[i] : i] - mean) / norm);

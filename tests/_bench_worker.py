@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import bench  # noqa: E402
-from _standin_engine import StandInContext  # noqa: E402
+from _standin_engine import StandInContext, StandInGroup  # noqa: E402
 
 for name, small in (("config2", dict(m=40, n=701)), ("config3", dict(m=40, n=701)),
                     ("config4", dict(m=48, n=1001)), ("config5", dict(m=24, n=601))):
@@ -21,4 +21,4 @@ bench.BLOCK = 256
 os.environ["KPDI_BENCH_SCRIPT"] = os.path.abspath(__file__)  # the spawner starts THIS script per rank
 
 if __name__ == "__main__":
-    sys.exit(bench.main(sys.argv[1:], context_factory=StandInContext))
+    sys.exit(bench.main(sys.argv[1:], context_factory=StandInContext, group_factory=StandInGroup))

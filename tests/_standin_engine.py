@@ -230,6 +230,38 @@ class StandInGroup:
             s, i = ko.merge_topk(s, i, s_r, i_r, self.keep_n)
         return s, i
 
+    # -- what bench.py --single-process calls
+    def set_experimental_dev(self, d_ptrs, dtype, m_all, navigation_mask=None):
+        self._all(lambda i, m: m.set_experimental_dev(d_ptrs[i], dtype, m_all, navigation_mask))
+
+    def push_dictionary_chunk_dev(self, d_ptrs, dtype, n_chunk, global_start):
+        self._all(lambda i, m: n_chunk[i] > 0 and m.push_dictionary_chunk_dev(d_ptrs[i], dtype, n_chunk[i], global_start[i]))
+
+    def remove_static_background(self, *a, **k):
+        self._all(lambda i, m: m.remove_static_background(*a, **k))
+
+    def remove_dynamic_background(self, *a, **k):
+        self._all(lambda i, m: m.remove_dynamic_background(*a, **k))
+
+    def finalize_async(self, keep_n=None):
+        self._pending = getattr(self, "_pending", {})
+        ticket = len(self._pending)
+        self._pending[ticket] = self.finalize(keep_n)
+        return ticket
+
+    def finalize_wait(self, ticket):
+        return self._pending.pop(ticket)
+
+    def set_profiling(self, on=True):
+        pass
+
+    def reset_counters(self):
+        self._all(lambda i, m: m.reset_counters())
+
+    def counters(self):
+        per = [m.counters() for m in self.members]
+        return dict(per[0], members=per, gather=self.gather, gather_ranks=len(self.members))
+
     def synchronize(self):
         pass
 

@@ -58,6 +58,23 @@ def test_bench_spawns_its_own_ranks(workload, key, extra):
         assert out["check"]["planted_found"] == 16
 
 
+@pytest.mark.parametrize("workload,key,extra", [
+    ("config2", "configs[1]", []), ("config3", "configs[2]", []), ("config4", "configs[3]", ["--no-pipeline"]),
+])
+def test_bench_single_process_over_a_group(workload, key, extra):
+    """`python bench.py --gpus 3 --single-process`: ONE process, a group of engine contexts (stand-ins here), member i on
+    dictionary block i, one merged and oracle-checked result, the same JSON line."""
+    out = run([sys.executable, WORKER, "--gpus", "3", "--single-process", "--steps", "2", "--warmup", "1", "--workload",
+               workload, "--check-rows", "8", "--no-cpu-baseline"] + extra)
+    assert out["n_gpus"] == 3 and out["value"] > 0 and key in out["config"]["workload"]
+    assert "ONE process" in out["config"]["parallelism"] and out["check"]["rows"] == 8
+    mg = out["multi_gpu"]
+    assert mg["processes"] == 1 and mg["lists_merged"] == 3 and mg["gather"].startswith("p2p") and mg["rccl_ranks"] == 0
+    shards = [p["shard"] for p in mg["per_rank"]]
+    assert len(shards) == 3 and shards[0][0] == 0 and shards[-1][1] == out["config"]["dictionary_patterns"]
+    assert all(a[1] == b[0] for a, b in zip(shards, shards[1:]))
+
+
 def test_bench_under_the_launcher():
     """The driver's form.  Under torch.distributed.run MASTER_PORT belongs to the launcher's own
     store: the control plane must find its own port next to it."""

@@ -107,3 +107,69 @@ def test_socket_group_wire_format_and_port_walk():
     for r in range(2):
         assert [list(a) for a in res[r][1]] == [[0, 0, 0], [1, 1, 1]] and res[r][2] == b"uid" and res[r][3] == 11.0
     assert all(b == b"" for b in received), received  # nothing was ever sent to the foreign server
+
+
+def test_socket_group_rejects_what_is_not_a_rank_of_this_job(monkeypatch):
+    """A connector must PROVE it knows the job token (the greeting alone is readable by any local process), a rank
+    that is already taken is told at once, an absurd message length is refused, and a constructor that raises leaves an
+    object whose __del__ is harmless."""
+    import socket
+    import struct
+    import threading
+
+    import pytest
+
+    from kikuchipy_amd import parallel
+
+    monkeypatch.setenv("KPDI_JOB_ID", "handshake-test")
+    with pytest.raises(ValueError):
+        parallel.SocketGroup(5, 2)  # (and its __del__ must not raise: attributes are set first)
+    port = free_port()
+    box = {}
+
+    def server():
+        box["g"] = parallel.SocketGroup(0, 3, "127.0.0.1", port, timeout=30)
+
+    t = threading.Thread(target=server)
+    t.start()
+    token = parallel._job_token(3, "127.0.0.1", port)
+    # an impostor that read the greeting and claims rank 1 without the proof
+    for _ in range(100):
+        try:
+            s = socket.create_connection(("127.0.0.1", port), timeout=5)
+            break
+        except OSError:
+            import time
+            time.sleep(0.05)
+    assert parallel._recv_exact(s, len(parallel._MAGIC) + 16) == parallel._MAGIC + token
+    s.sendall(struct.pack("<ii", 1, 3) + b"\x00" * 16)
+    assert parallel._recv_exact(s, 1) == parallel._REJECT
+    s.close()
+    g1 = parallel.SocketGroup(1, 3, "127.0.0.1", port, timeout=30)   # the real rank 1 still gets in
+    with pytest.raises(PermissionError, match="rejected"):
+        parallel.SocketGroup(1, 3, "127.0.0.1", port, timeout=5)      # a second rank 1 learns at once
+    g2 = parallel.SocketGroup(2, 3, "127.0.0.1", port, timeout=30)
+    t.join(30)
+    g0 = box["g"]
+    # a peer announcing a 2^40-byte message is not believed
+    g1._up.sendall(struct.pack("<Q", 1 << 40))
+    with pytest.raises(ConnectionError, match="limit"):
+        parallel._recv_msg(g0._peers[1])
+    for g in (g0, g1, g2):
+        g.close()
+    # no job id: the rendezvous address is part of the token (two jobs on neighbouring ports do not mix)
+    monkeypatch.delenv("KPDI_JOB_ID")
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    assert parallel._job_token(2, "127.0.0.1", 29500) != parallel._job_token(2, "127.0.0.1", 29501)
+
+
+def test_import_has_no_side_effect_on_the_environment():
+    import subprocess
+    import sys
+
+    code = ("import os; os.environ.pop('HSA_ENABLE_IPC_MODE_LEGACY', None); import kikuchipy_amd, kikuchipy_amd.parallel as p; "
+            "assert 'HSA_ENABLE_IPC_MODE_LEGACY' not in os.environ; p.Communicator(0, 1); "
+            "assert 'HSA_ENABLE_IPC_MODE_LEGACY' not in os.environ; "
+            "p.Communicator(0, 2, broadcast_bytes=lambda *a: b'', barrier=lambda: None, all_gather=lambda o: [o, o]); "
+            "assert os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'")
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)

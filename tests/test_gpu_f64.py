@@ -156,6 +156,9 @@ def test_near_ties_below_the_f32_resolution(monkeypatch, n_near):
         if mode:
             monkeypatch.setenv("KPDI_F64_EPS", mode)
         scores, idx, cnt = engine64(exp, dic, "ncc", 20)
+        # the bound in force is read from the environment by every kpdi_set_problem and reported (a process-wide
+        # static used to make the second leg re-run the statistical bound silently)
+        assert cnt["f64_certificate"] == (2 if mode else 1), (mode, cnt["f64_certificate"])
         if n_near == 40:
             assert cnt["uncertified_patterns"] == 0 and cnt["rescore_extra_passes"] >= 1, (mode, cnt)
         else:
