@@ -406,14 +406,23 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
       const unsigned long long epi_t0 = __builtin_readcyclecounter();
 #endif
       // the last MFMAs (8 passes) must have written the accumulators before they are read
+      // (the pipe retires MFMAs in order: ONE wait covers all of them; the empty statements only tie every accumulator to
+      // this point - 16 x 24 wait states per tile were spent here before)
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg)
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-          if (G::ACC_A)
-            asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[cg][rt]));
-          else
-            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[cg][rt]));
+          if (cg == 0 && rt == 0) {
+            if (G::ACC_A)
+              asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[cg][rt]));
+            else
+              asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[cg][rt]));
+          } else {
+            if (G::ACC_A)
+              asm volatile("" : "+a"(acc[cg][rt]));
+            else
+              asm volatile("" : "+v"(acc[cg][rt]));
+          }
         }
 #ifdef KPDI16_TIME_EPI
       epi_drain += __builtin_readcyclecounter() - epi_t0;
@@ -474,6 +483,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
             if (__builtin_amdgcn_ballot_w64(m >= thr_raw) != 0xdeadbeefull) continue;
 #endif
             if (__builtin_amdgcn_ballot_w64(m >= thr_raw) == 0) continue;  // wave-uniform
+            // (the bounded 32-entry instantiation of the 8-wave form has no register to spare for the mask form below - it
+            // would reload a fragment from scratch inside the MFMA loop, tools/check_mfma_loops.py - and keeps round 3's
+            // form: one exec-masked block per accumulator register; KPDI16_APPEND_PER_REGISTER forces it everywhere, A/B)
+#ifdef KPDI16_APPEND_PER_REGISTER
+            constexpr bool PER_REGISTER = true;
+#else
+            constexpr bool PER_REGISTER = BOUNDED && KMAX == 32 && WAVES == 8;
+#endif
+            if (PER_REGISTER) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
@@ -483,16 +501,52 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
               if (BOUNDED) ok = ok && (v < ub_cg || (v == ub_cg && idx > ubi_cg));
               if (ok) {
                 if (c < cap) {
-#ifndef KPDI16_NO_APPEND_STORES
                   bs[c * 64 + ulane] = v;
                   bi[c * 64 + ulane] = idx;
-#endif
                   ++c;
                   mx = fmaxf(mx, v);
                 } else {
                   overflow = true;
                 }
               }
+            }
+            } else {
+            // ---- some lane of this block of 16 registers holds a candidate (typically ONE lane, one register).  Which of
+            // a lane's registers pass is folded into a per-lane bit mask with vector instructions only (compare -> select ->
+            // or: a per-register `if` costs a vector-compare -> scalar-and -> save-exec -> branch chain per register, ~150
+            // cycles of scalar dependency stalls each, 16 x 16 times per tile: 2 % of the kernel, profiles/r03_epilogue_cycles.txt);
+            // then ONE loop, as long as any lane has a bit left: lowest bit -> register (a 16-way select) -> append.  Bits
+            // are taken in ascending register order = ascending dictionary index, like the per-register form.
+            unsigned pm = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pm |= acc[cg][rt][r] >= thr_raw ? (1u << r) : 0u;
+#pragma unroll 1
+            while (__builtin_amdgcn_ballot_w64(pm != 0) != 0) {
+              if (pm != 0) {
+                const int r = __builtin_ctz(pm);
+                pm &= pm - 1;
+                float raw = acc[cg][rt][0];
+#pragma unroll
+                for (int q = 1; q < 16; ++q) raw = r == q ? acc[cg][rt][q] : raw;
+                const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
+                const float v = raw * unscale + 0.f;  // -0 -> +0 so that ties compare as the merge does
+                const int idx = idx_base + lrow;
+                bool ok = lrow < n_valid;
+                if (BOUNDED) ok = ok && (v < ub_cg || (v == ub_cg && idx > ubi_cg));
+                if (ok) {
+                  if (c < cap) {
+#ifndef KPDI16_NO_APPEND_STORES
+                    bs[c * 64 + ulane] = v;
+                    bi[c * 64 + ulane] = idx;
+#endif
+                    ++c;
+                    mx = fmaxf(mx, v);
+                  } else {
+                    overflow = true;
+                  }
+                }
+              }
+            }
             }
           }
           if (__builtin_amdgcn_ballot_w64(overflow) == 0) {

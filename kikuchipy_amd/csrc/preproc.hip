@@ -36,8 +36,11 @@
 // Larger detectors (raw 480 x 480 patterns ...) take the streaming kernels below: the same
 // arithmetic with the pattern re-read from L2 and the intermediate in a global scratch.
 //
-// HBM-bound by design: algorithmic bytes per pattern = 2 * npix * sizeof(dtype) (+ kpad * 4 for
-// the prepared row when fused).
+// Algorithmic bytes per pattern = 2 * npix * sizeof(dtype) (+ kpad * 4 for the prepared row when fused), and the
+// kernel moves just that (traffic ratio 1.0) - but it is NOT HBM-bound: the counters (profiles/r03_prekernel_pmc.txt)
+// put it at 0.07-0.11 of the HBM peak with SQ_INSTS_VALU x 4 cycles / SIMD = the kernel's duration: VALU-ISSUE-bound
+// (960 float64 FMAs of ~2900 vector instructions per pattern at 60 x 60), with 34-39 % of its LDS cycles in bank
+// conflicts.
 #include "prep_device.h"
 #include <math.h>
 #include <stdint.h>

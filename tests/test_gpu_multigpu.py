@@ -39,3 +39,53 @@ def test_bench_runs_sharded_over_rccl():
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["n_gpus"] == n and out["multi_gpu"]["rccl_ranks"] == n and out["check"]["rows"] == 64
+
+
+@pytest.mark.parametrize("gather", ["rccl", "p2p", None])
+def test_group_over_every_visible_gpu(gather):
+    """ONE process, one group member per GPU: the in-process RCCL communicator (ncclCommInitAll) and the peer-copy gather
+    over xGMI, each against the single-GPU result, bit for bit (the 1-GPU boxes run this with members sharing a device:
+    tests/test_gpu_group.py)."""
+    import numpy as np
+
+    import kikuchipy_amd as ka
+    from kikuchipy_amd import _lib
+
+    n = min(_lib.device_count(), 8)
+    if n < 2:
+        pytest.skip(f"{n} GPU visible: a group over distinct devices needs at least 2")
+    rng = np.random.default_rng(5)
+    exp = rng.integers(0, 256, (600, 60, 60), dtype=np.uint8)
+    dic = rng.random((20000, 60, 60), dtype=np.float32)
+    one = ka.dictionary_indexing(exp, dic, keep_n=20, device=0, verbose=False)
+    with _lib.Group(list(range(n)), gather=gather) as g:
+        assert g.gather == (gather or "rccl"), g.describe()
+        for chunk in (len(dic), 3000):  # one chunk, then streamed chunks: every GPU takes its part of each
+            g.set_problem(60, 60, None, _lib.METRIC_NCC, 20, _lib.COMPUTE_F32)
+            g.set_experimental(exp, None)
+            for a in range(0, len(dic), chunk):
+                g.push_dictionary_chunk(dic[a:a + chunk], a)
+            s, i = g.finalize(20)
+            assert np.array_equal(s, one.scores) and np.array_equal(i, one.simulation_indices)
+        c = g.counters()
+        assert c["gather_ranks"] == n and (c["comm_ranks"] == n) == (g.gather == "rccl")
+    # the call that names no device uses all of them
+    res = ka.dictionary_indexing(exp, dic, keep_n=20, verbose=False)
+    assert np.array_equal(res.scores, one.scores) and np.array_equal(res.simulation_indices, one.simulation_indices)
+
+
+def test_bench_single_process_over_every_visible_gpu():
+    """`python bench.py --gpus N --single-process`: the sharded benchmark driven from one interpreter."""
+    import json
+
+    from kikuchipy_amd import _lib
+
+    n = min(_lib.device_count(), 8)
+    if n < 2:
+        pytest.skip(f"{n} GPU visible: needs at least 2")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--single-process", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == n and out["multi_gpu"]["processes"] == 1 and out["multi_gpu"]["lists_merged"] == n
+    assert out["multi_gpu"]["rccl_ranks"] == n and out["check"]["rows"] == 64
