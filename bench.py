@@ -112,7 +112,7 @@ def circular_mask(sy, sx):
     return np.sqrt((yy - sy // 2) ** 2 + (xx - sx // 2) ** 2) > max(sy // 2, sx // 2)
 
 
-def check_result(w, exp, dic, bg, mask, scores, indices, n_rows, large, compute="f32"):
+def check_result(w, exp, dic, bg, mask, scores, indices, n_rows, large, compute="f32", dict_dtype=np.float32):
     """The result of the timed run against the C oracle (oracle/kpdi_oracle_c.c, float64-accumulated
     dot products, OpenMP over the host cores) on a sample of experimental rows over the WHOLE
     dictionary, plus the planted copies of the large workloads.  The oracle is the checker here,
@@ -125,10 +125,11 @@ def check_result(w, exp, dic, bg, mask, scores, indices, n_rows, large, compute=
     e = exp[rows]
     if w["preprocess"]:
         e = ko.remove_dynamic_background(ko.remove_static_background(e, bg))
+    seen = lambda d: d.astype(dict_dtype).astype(np.float32) if dict_dtype != np.float32 else d  # noqa: E731  (what the engine was given)
     if large:
-        chunks = ((b * BLOCK, dictionary_block(w, b, exp)) for b in range((w["n"] + BLOCK - 1) // BLOCK))
+        chunks = ((b * BLOCK, seen(dictionary_block(w, b, exp))) for b in range((w["n"] + BLOCK - 1) // BLOCK))
     else:
-        chunks = [(0, dic)]
+        chunks = [(0, seen(dic))]
     rs, ri = c_oracle.rows_topk_f64(e, chunks, np.arange(n_rows), w["metric"], w["keep_n"], mask)
     out = {"rows": int(n_rows), "oracle": "oracle/kpdi_oracle_c.c rows_topk_f64 (float64 accumulation)"}
     if w["preprocess"]:
@@ -345,6 +346,10 @@ def main(argv=None, context_factory=None, group_factory=None):
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two short rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE) of a sub-run of this command "
                          "that fill roofline.traffic")
+    ap.add_argument("--dict-dtype", default=None, choices=["f32", "f16"],
+                    help="dtype the raw dictionary is resident in (default: f32; f16 for --workload config5 --compute f16 - "
+                         "BASELINE.json configs[4] is the float16 path: the dictionary at half the bytes on the host, over "
+                         "PCIe and in HBM, cast exactly to float32 by the preparation kernels)")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1: ONE process drives all N GPUs through a kpdi_group (one host thread per GPU inside libkpdi, "
                          "in-process RCCL communicator) instead of one process per GPU")
@@ -392,6 +397,9 @@ def main(argv=None, context_factory=None, group_factory=None):
 
     w = WORKLOADS[a.workload]
     large = a.workload in ("config4", "config5")
+    if a.dict_dtype is None:
+        a.dict_dtype = "f16" if (a.workload == "config5" and a.compute == "f16") else "f32"
+    dict_np = np.float16 if a.dict_dtype == "f16" else np.float32
     if large:
         rng = np.random.default_rng(2024)
         exp = rng.integers(0, 256, (w["m"], w["sy"], w["sx"]), dtype=np.uint8)
@@ -413,8 +421,8 @@ def main(argv=None, context_factory=None, group_factory=None):
         de = c.dev_alloc(exp.nbytes)
         c.h2d(de, exp)
         if large:
-            return de, upload_generated_shard(c, w, a0, a1, exp)
-        part = np.ascontiguousarray(dic[a0:a1])
+            return de, upload_generated_shard(c, w, a0, a1, exp, dict_np)
+        part = np.ascontiguousarray(dic[a0:a1]).astype(dict_np, copy=False)
         dd = c.dev_alloc(part.nbytes)
         c.h2d(dd, part)
         return de, dd
@@ -445,7 +453,7 @@ def main(argv=None, context_factory=None, group_factory=None):
         if w["preprocess"]:
             ctx.remove_static_background(bg_f32, _lib.OP_SUBTRACT, False)
             ctx.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
-        ctx.push_dictionary_chunk_dev(d_dic, np.float32, n_local, lo)
+        ctx.push_dictionary_chunk_dev(d_dic, dict_np, n_local, lo)
 
     def step():
         queue_step()
@@ -530,7 +538,8 @@ def main(argv=None, context_factory=None, group_factory=None):
         "vs_baseline": None,
         "dtype": {"f32": "f32", "f16x2": "f16x2 (opt-in: values as two float16, f32 accumulate)",
                   "f16": "f16 (opt-in, REDUCED PRECISION: values as one float16, f32 accumulate)"}[a.compute],
-        "data": "synthetic (default_rng(2024): uint8 patterns, uniform float32 dictionary), raw inputs resident in HBM",
+        "data": "synthetic (default_rng(2024): uint8 patterns, uniform float32 dictionary"
+                + (" stored as float16" if a.dict_dtype == "f16" else "") + "), raw inputs resident in HBM",
         "config": {
             "workload": w["name"],
             "experimental_patterns": w["m"],
@@ -602,7 +611,7 @@ def main(argv=None, context_factory=None, group_factory=None):
     # ---- the result of the timed run is checked before anything is printed
     n_check = a.check_rows if a.check_rows is not None else (32 if large else 64)
     if n_check > 0:  # N > 1: the MERGED result (all shards, after the RCCL all-gather) is what rank 0 holds
-        out["check"] = check_result(w, exp, dic, bg, mask, scores, indices, n_check, large, a.compute)
+        out["check"] = check_result(w, exp, dic, bg, mask, scores, indices, n_check, large, a.compute, dict_np)
     if per_rank is not None:
         # every rank must end with the bit-identical global result (total order of the merge)
         same = all(p["result_sha256"] == per_rank[0]["result_sha256"] for p in per_rank)
@@ -658,7 +667,7 @@ def main(argv=None, context_factory=None, group_factory=None):
                 c3.set_experimental_dev(d_exp, exp.dtype, w3["m"])
                 c3.remove_static_background(bg_f32, _lib.OP_SUBTRACT, False)
                 c3.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
-                c3.push_dictionary_chunk_dev(d_dic, np.float32, n_local, lo)
+                c3.push_dictionary_chunk_dev(d_dic, dict_np, n_local, lo)
                 s3, i3 = c3.finalize(w3["keep_n"])
             c3.synchronize()
             dt3 = (time.perf_counter() - t0) / reps
@@ -764,7 +773,7 @@ def main(argv=None, context_factory=None, group_factory=None):
                 if w["preprocess"]:
                     c16.remove_static_background(bg_f32, _lib.OP_SUBTRACT, False)
                     c16.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
-                c16.push_dictionary_chunk_dev(d_dic, np.float32, n_local, lo)
+                c16.push_dictionary_chunk_dev(d_dic, dict_np, n_local, lo)
                 s16, i16 = c16.finalize(w["keep_n"])
             dt16 = (time.perf_counter() - t0) / 3
             cnt16 = c16.counters()
@@ -801,7 +810,7 @@ def main(argv=None, context_factory=None, group_factory=None):
                 if w["preprocess"]:
                     c64.remove_static_background(bg_f32, _lib.OP_SUBTRACT, False)
                     c64.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
-                c64.push_dictionary_chunk_dev(d_dic, np.float32, n_local, lo)
+                c64.push_dictionary_chunk_dev(d_dic, dict_np, n_local, lo)
                 s64, i64 = c64.finalize(w["keep_n"])
             dt64 = (time.perf_counter() - t0) / 3
             cnt64 = c64.counters()

@@ -338,7 +338,11 @@ __global__ __launch_bounds__(THREADS) void preproc_fused_kernel(PreArgs a, const
       correlate_slow_axis<NT, decltype(reflect)::value, THREADS>(
           sx, sy, ldt, tp, a.ntaps, a.centre, [&](int i) { return tt[i]; },
           [&](int c, int r, float b) {
+#ifdef KPDI_PRE_TIMING_NO_CONFLICT  // timing-only ablation (WRONG results): the pass's read-modify-write of x with unit stride
+            const int i = c * sx + r;  // across the lanes instead of stride sx (60: 8-way, 120: 16-way bank conflicts)
+#else
             const int i = r * sx + c;
+#endif
             const float y = dy_op == KPDI_OP_SUBTRACT ? x[i] - b : x[i] / b;
             x[i] = y;  // only this thread touches x[i] during the pass
             mn = fminf(mn, y);

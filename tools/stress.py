@@ -1,5 +1,7 @@
 """Randomised engine-vs-oracle sweep (developer tool): shapes, metrics, masks, keep_n,
-chunking, compute modes.  Exits non-zero on the first parity failure."""
+chunking, compute modes, degenerate patterns (constant / zero / NaN / inf rows on either side), one context or an
+in-process group of 2-5 members sharing device 0 (kpdi_group, peer-copy gather).  Exits non-zero on the first parity
+failure.    python tools/stress.py [cases] [seed]"""
 import os
 import sys
 
@@ -11,8 +13,14 @@ from oracle import kpdi_oracle as ko  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-ctx = _lib.Context(0)
+single = _lib.Context(0)
+groups = {}
 for case in range(n_cases):
+    members = int(rng.choice([1, 1, 2, 3, 5]))
+    if members == 1:
+        ctx = single
+    else:
+        ctx = groups.setdefault(members, _lib.Group([0] * members))
     sy, sx = int(rng.integers(2, 70)), int(rng.integers(2, 70))
     if rng.random() < 0.08:  # larger detectors: the other preparation kernels
         sy, sx = int(rng.integers(64, 133)), int(rng.integers(64, 133))
@@ -29,6 +37,21 @@ for case in range(n_cases):
     dt_d = rng.choice([np.float32, np.uint8, np.float64])
     exp = (rng.random((m, sy, sx)) * 250 + 1).astype(dt_e)
     dic = (rng.random((n, sy, sx)) * 250 + 1).astype(dt_d)
+    degenerate = ""
+    if rng.random() < 0.3 and sy * sx >= 4:
+        # patterns whose normalisation is undefined (include/kpdi.h "Degenerate patterns"): all-zero rows, score 0
+        for arr, side in ((exp, "e"), (dic, "d")):
+            for r in rng.choice(len(arr), min(len(arr), int(rng.integers(0, 4))), replace=False):
+                kind = int(rng.integers(0, 4 if arr.dtype.kind == "f" else 2))
+                if kind == 0:
+                    arr[r] = 0
+                elif kind == 1:
+                    arr[r] = arr[r].flat[0]
+                elif kind == 2:
+                    arr[r].flat[int(rng.integers(0, sy * sx))] = np.nan
+                else:
+                    arr[r].flat[int(rng.integers(0, sy * sx))] = np.inf * (1 if rng.random() < 0.5 else -1)
+                degenerate += side
     sig = None
     if rng.random() < 0.5 and sy * sx > 8:
         sig = rng.random((sy, sx)) < 0.3
@@ -68,7 +91,9 @@ for case in range(n_cases):
     try:
         if mode == _lib.COMPUTE_F64:
             # float64 arithmetic: scores to 1e-12, indices exact wherever the scores are not within that of each other
-            assert s.dtype == np.float64 and np.abs(s - rs).max() <= 1e-12 and ctx.counters()["uncertified_patterns"] == 0
+            cnt = ctx.counters()
+            assert s.dtype == np.float64 and np.abs(s - rs).max() <= 1e-12
+            assert sum(c["uncertified_patterns"] for c in cnt.get("members", [cnt])) == 0
             ko.assert_topk_parity(s, i, rs, ri, atol=1e-12, tie=4e-12)
         elif mode == _lib.COMPUTE_F16:
             # reduced precision: the scores only (11-bit operands: a few 1e-4 at small K), order not compared
@@ -83,8 +108,11 @@ for case in range(n_cases):
         if metric == "ncc":
             ee -= ee.mean(1, keepdims=True)
             dd -= dd.mean(1, keepdims=True)
-        ee /= np.linalg.norm(ee, axis=1, keepdims=True)
-        dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+        with np.errstate(all="ignore"):
+            ee /= np.linalg.norm(ee, axis=1, keepdims=True)
+            dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+        ee[~np.isfinite(ee).all(1)] = 0  # degenerate rows: score 0
+        dd[~np.isfinite(dd).all(1)] = 0
         exact = ee @ dd.T
         eng = np.abs(s - np.take_along_axis(exact, i, 1)).max()
         orc = np.abs(rs - np.take_along_axis(exact, ri, 1)).max()
@@ -107,6 +135,7 @@ for case in range(n_cases):
         print(f"FAIL case {case}: {sy}x{sx} m={m} n={n} k={k} {metric} mode={mode} {dt_e.__name__}/{dt_d.__name__} "
               f"sig={sig is not None} nav={nav is not None} chunk={chunk}: {err}")
         sys.exit(1)
-    print(f"ok {case}: {sy}x{sx} m={m} n={n} k={k} {metric} mode={mode} chunk={chunk} pre={pre or '-'} "
-          f"max|d|={np.abs(s - rs).max():.1e}", flush=True)
+    assert np.isfinite(s).all()
+    print(f"ok {case}: {sy}x{sx} m={m} n={n} k={k} {metric} mode={mode} chunk={chunk} pre={pre or '-'} members={members} "
+          f"degenerate={degenerate or '-'} max|d|={np.abs(s - rs).max():.1e}", flush=True)
 print("STRESS_OK")
