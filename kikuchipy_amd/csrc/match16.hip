@@ -436,6 +436,49 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
         // step), so every cycle spent here is lost on the matrix pipe: a list update per tile cost 23 %.
         const int row0 = F32 ? KPDI16_UNIT_TILE(t0) * G::DT + KPDI16_UNIT_ROW(t0) + wr * 32 * rt_n + 4 * (lane >> 5)
                              : t0 * G::DT + wr * 128 + 4 * (lane >> 5);
+        // ---- the FIRST tile of a launch has no bound to screen with.  Building every lane's list from all 64 candidates
+        // of each column group (scan16 below) is what a launch of this kernel costs beyond its tiles: ~360 000 cycles =
+        // 0.15 ms (profiles/r04_epilogue_ab.txt).  A bound needs no list, though - only every list's BEST entry (grouped
+        // form): each lane publishes the maximum of its 64 candidates right away, the workgroups of a row block do so
+        // within microseconds of each other (one launch, equal work), and a short poll later the bound stands near the
+        // 3 % quantile: ~2 of the 64 candidates pass and take the steady-state append path.  If the bound is not
+        // complete after the poll (a workgroup of the row block lags, or is not resident) the list is built directly, as before.
+        bool first_fast = false;
+#ifndef KPDI16_FIRST_TILE_DIRECT  // (developer build: rounds 3's first tile)
+        if (tiles_done == 0 && !BOUNDED && bound_rank == 1 && bound_grouped &&
+            (F32 ? KPDI16_UNIT_TILE(t0) : t0) * G::DT + G::DT <= n_valid) {
+#pragma unroll
+          for (int cg = 0; cg < NCG; ++cg) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+              if (F32 && rt >= rt_n) continue;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[cg][rt][r]);
+            }
+            m = m * (F32 ? 1.f : 0x1p-24f) + 0.f;
+            if (m > pub[cg]) {
+              pub[cg] = m;
+              __hip_atomic_fetch_max(const_cast<unsigned *>(line0) + 32 * cg * BOUND_SLOTS + my_slot, score_key(m),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+#pragma unroll 1
+          for (int it = 0; it < 48 && !first_fast; ++it) {
+            BoundHalf raw[NCG];
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg) bound_load_half(raw[cg], line0 + 32 * cg * BOUND_SLOTS, lane >> 5);
+            bool ready = true;
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg) {
+              g[cg] = bound_reduce_half<KMAX>(raw[cg], bound_grouped, lane >> 5);
+              ready = ready && g[cg] > -INFINITY;
+            }
+            first_fast = __builtin_amdgcn_ballot_w64(!ready) == 0;
+            if (!first_fast) __builtin_amdgcn_s_sleep(24);
+          }
+        }
+#endif
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) {
 #ifdef KPDI16_NO_EPILOGUE  // (the MFMAs are asm volatile: they stay)
@@ -468,7 +511,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
 #ifdef KPDI16_FIRST_TILE_APPENDS  // (developer build: round 2's behaviour)
           const bool first_tile = false;
 #else
-          const bool first_tile = tiles_done == 0;
+          const bool first_tile = tiles_done == 0 && !first_fast;
 #endif
           bool overflow = first_tile;
           float mx = -INFINITY;

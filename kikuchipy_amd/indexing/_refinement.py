@@ -339,8 +339,15 @@ def _master_pattern_data(master_pattern, energy):
 
 def refine(mode, patterns, rotations, detector, master_pattern, energy=None, navigation_mask=None,
            signal_mask=None, pseudo_symmetry_ops=None, method="minimize", method_kwargs=None, trust_region=None,
-           initial_step=None, rtol=1e-4, maxeval=None, context=None, device=0, verbose=True, comm=None, compute=True):
+           initial_step=None, rtol=1e-4, maxeval=None, context=None, device=0, verbose=True, comm=None, compute=True,
+           contexts=None):
     """Shared driver of the three refinements.
+
+    contexts
+        Several engine contexts (one per GPU - the members of a `kikuchipy_amd._lib.Group`): the points are independent,
+        so each context refines a contiguous block of them from a host thread of its own (the library calls release the
+        GIL) and the rows are concatenated - the results do not depend on the split.  The single-process counterpart of
+        `comm`.
 
     compute
         False: validate, set everything up, print the information message and return a `DeferredRefinement` -
@@ -429,7 +436,7 @@ def refine(mode, patterns, rotations, detector, master_pattern, energy=None, nav
     def run():
         return _run_refinement(mode, n, starts, x0, fixed, lower, upper, pats, signal_mask, detector, master_pattern,
                                energy, nm, host, context, device, comm, verbose, n_pseudo, points, nav_shape,
-                               navigation_mask)
+                               navigation_mask, contexts)
 
     if not compute:
         return DeferredRefinement(mode, run, n_pseudo > 0)
@@ -438,7 +445,7 @@ def refine(mode, patterns, rotations, detector, master_pattern, energy=None, nav
 
 
 def _run_refinement(mode, n, starts, x0, fixed, lower, upper, pats, signal_mask, detector, master_pattern, energy, nm, host,
-                    context, device, comm, verbose, n_pseudo, points, nav_shape, navigation_mask):
+                    context, device, comm, verbose, n_pseudo, points, nav_shape, navigation_mask, contexts=None):
     """The solve + the assembly of the result (what `compute_refine_*_results` do in the reference,
     indexing/_refinement/_refinement.py:58-290).  Returns (RefinementResult, new detector | None, raw rows)."""
     lo_i, hi_i = 0, n
@@ -450,27 +457,41 @@ def _run_refinement(mode, n, starts, x0, fixed, lower, upper, pats, signal_mask,
     if verbose:
         what = {"ori": "orientation(s)", "pc": "projection center(s)", "ori_pc": "orientation(s) and projection center(s)"}
         print(f"Refining {n} {what[mode]}:")
-    ctx = context if context is not None else _lib.Context(device)
+    ctx = context if context is not None else (_lib.Context(device) if not contexts else None)
+
+    def solve_block(c, part):
+        c.set_master_pattern(*_master_pattern_data(master_pattern, energy))
+        # rescale exactly when the patterns are float32 (_refinement.py:956)
+        c.refine_set_patterns(pats[part], signal_mask, pats.dtype == np.float32, detector.detector_to_sample)
+        if host is None:  # the whole simplex search on the device
+            return c.refine_solve(MODES[mode], x0[part], None if fixed is None else fixed[part],
+                                  None if lower is None else lower[part], None if upper is None else upper[part],
+                                  nm["xatol"], nm["fatol"], nm["maxiter"] or 0, nm["maxfev"] or 0)
+        # the reference's optimiser on the host, the objective on the device
+        return _host_solve(c, MODES[mode], host, x0[part], None if fixed is None else fixed[part],
+                           None if lower is None else lower[part], None if upper is None else upper[part])
+
     try:
         t0 = time.time()
-        if hi_i > lo_i:
-            ctx.set_master_pattern(*_master_pattern_data(master_pattern, energy))
-            # rescale exactly when the patterns are float32 (_refinement.py:956)
-            ctx.refine_set_patterns(pats[part], signal_mask, pats.dtype == np.float32, detector.detector_to_sample)
-            if host is None:  # the whole simplex search on the device
-                res = ctx.refine_solve(MODES[mode], x0[part], None if fixed is None else fixed[part],
-                                       None if lower is None else lower[part], None if upper is None else upper[part],
-                                       nm["xatol"], nm["fatol"], nm["maxiter"] or 0, nm["maxfev"] or 0)
-            else:  # the reference's optimiser on the host, the objective on the device
-                res = _host_solve(ctx, MODES[mode], host, x0[part], None if fixed is None else fixed[part],
-                                  None if lower is None else lower[part], None if upper is None else upper[part])
+        if hi_i > lo_i and contexts and len(contexts) > 1:
+            # one block of the points per GPU, each driven from its own host thread
+            from concurrent.futures import ThreadPoolExecutor
+
+            from kikuchipy_amd.parallel import shard_range
+
+            blocks = [shard_range(hi_i - lo_i, i, len(contexts)) for i in range(len(contexts))]
+            jobs = [(c, slice(lo_i + a, lo_i + b)) for c, (a, b) in zip(contexts, blocks) if b > a]
+            with ThreadPoolExecutor(len(jobs)) as pool:
+                res = np.concatenate(list(pool.map(lambda job: solve_block(*job), jobs)), axis=0)
+        elif hi_i > lo_i:
+            res = solve_block(ctx if ctx is not None else contexts[0], part)
         else:
             res = np.empty((0, starts, 3 + x0.shape[2]))
         if comm is not None and comm.world_size > 1:
             res = comm.all_gather_rows(res)
         total = time.time() - t0
     finally:
-        if context is None:
+        if context is None and ctx is not None:
             ctx.close()
     if verbose:
         print(f"Refinement speed: {n / total:.5f} patterns/s")

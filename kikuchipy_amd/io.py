@@ -13,7 +13,7 @@ from kikuchipy_amd.detectors import EBSDDetector
 from kikuchipy_amd.signals import EBSD, DictionaryXmap
 
 
-def load(filename, scan_group_names=None, device=0):
+def load(filename, scan_group_names=None, device=None, devices=None):
     """Load one scan of a kikuchipy h5ebsd file.
 
     scan_group_names
@@ -22,7 +22,7 @@ def load(filename, scan_group_names=None, device=0):
         list, like `kikuchipy.load`.
     """
     if isinstance(scan_group_names, (list, tuple)):
-        return [load(filename, name, device) for name in scan_group_names]
+        return [load(filename, name, device, devices) for name in scan_group_names]
     info, pats, bg, pc = _lib.h5ebsd_read(str(filename), scan_group_names)
     ny, nx, sy, sx = info.ny, info.nx, info.sy, info.sx
     # the reference squeezes singleton navigation axes (io/plugins/_h5ebsd.py:366)
@@ -52,7 +52,7 @@ def load(filename, scan_group_names=None, device=0):
                             pc=pc)
     step_sizes = tuple(s for s, n in ((info.step_y, ny), (info.step_x, nx)) if n > 1)
     s = EBSD(data, static_background=bg, xmap=DictionaryXmap.empty(nav_shape or (1,)), step_sizes=step_sizes,
-             device=device)
+             device=device, devices=devices)
     s.detector = detector
     s.original_metadata = {"scan": info.scan.decode(), "n_rows": ny, "n_columns": nx, "pattern_height": sy,
                            "pattern_width": sx, "binning": info.binning, "step_x": info.step_x, "step_y": info.step_y,

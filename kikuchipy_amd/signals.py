@@ -28,6 +28,11 @@ from kikuchipy_amd.pattern import _pattern
 from kikuchipy_amd.simulations import DTYPE_RANGE, ProjectedDictionary
 
 
+# a call that names no device spreads a refinement over every visible GPU from this many points on (one block of the
+# points per GPU; below, the set-up of a group costs more than it saves)
+REFINE_GROUP_MIN_POINTS = 2048
+
+
 class DictionaryXmap:
     """Stand-in for the `xmap` of a dictionary signal: one rotation
     (unit quaternion) per dictionary pattern."""
@@ -123,7 +128,7 @@ class EBSD:
         if inplace:
             self.data = out
             return None
-        return EBSD(out, self.static_background, self.xmap, self.step_sizes, self.scan_unit, self._device)
+        return EBSD(out, self.static_background, self.xmap, self.step_sizes, self.scan_unit, self._device, self._devices)
 
     def remove_dynamic_background(self, operation="subtract", filter_domain="frequency", std=None,
                                   truncate=4.0, inplace=True):
@@ -132,22 +137,34 @@ class EBSD:
         if inplace:
             self.data = out
             return None
-        return EBSD(out, self.static_background, self.xmap, self.step_sizes, self.scan_unit, self._device)
+        return EBSD(out, self.static_background, self.xmap, self.step_sizes, self.scan_unit, self._device, self._devices)
 
     # ------------------------------------------------------------------ refinement
     def _refine(self, mode, xmap, detector, master_pattern, energy, navigation_mask, signal_mask,
                 pseudo_symmetry_ops, method, method_kwargs, trust_region, initial_step, rtol, maxeval, compute,
-                verbose, comm=None):
+                verbose, comm=None, devices=None):
         from kikuchipy_amd.indexing._refinement import refine
 
+        # the points are independent: with several GPUs (named, or all of them for a map worth it) each refines a block
+        contexts = None
+        if comm is None:
+            ids = _lib.resolve_devices(devices if devices is not None else self._devices)
+            if ids is None and self._device is None and self.navigation_size >= REFINE_GROUP_MIN_POINTS:
+                ids = _lib.default_devices()
+            if ids is not None and len(ids) > 1:
+                key = tuple(ids)
+                if key not in self._groups:
+                    self._groups[key] = _lib.make_engine(devices=ids)
+                contexts = self._groups[key].members
         return refine(mode, np.asarray(self.data), _rotations_of(xmap), detector, master_pattern, energy,
                       navigation_mask, signal_mask, pseudo_symmetry_ops, method, method_kwargs, trust_region,
-                      initial_step, rtol, maxeval, context=self.context, verbose=verbose, comm=comm, compute=compute)
+                      initial_step, rtol, maxeval, context=None if contexts else self.context, verbose=verbose, comm=comm,
+                      compute=compute, contexts=contexts)
 
     def refine_orientation(self, xmap, detector, master_pattern, energy=None, navigation_mask=None,
                            signal_mask=None, pseudo_symmetry_ops=None, method="minimize", method_kwargs=None,
                            trust_region=None, initial_step=None, rtol=1e-4, maxeval=None, compute=True,
-                           rechunk=True, chunk_kwargs=None, *, verbose=True, comm=None):
+                           rechunk=True, chunk_kwargs=None, *, verbose=True, comm=None, devices=None):
         """signals/ebsd.py:1986-2185.  `xmap`: anything with `.rotations`
         (e.g. the result of `dictionary_indexing`) or a quaternion array.
         Returns a `RefinementResult` (`rotations`, `scores`, `num_evals`,
@@ -155,17 +172,17 @@ class EBSD:
         `kikuchipy_amd.indexing.compute_refine_orientation_results` (the reference: a lazy Dask array)."""
         out = self._refine("ori", xmap, detector, master_pattern, energy, navigation_mask, signal_mask,
                            pseudo_symmetry_ops, method, method_kwargs, trust_region, initial_step, rtol, maxeval,
-                           compute, verbose, comm)
+                           compute, verbose, comm, devices)
         return out[0] if compute else out  # compute=False: a DeferredRefinement (compute_refine_orientation_results)
 
     def refine_projection_center(self, xmap, detector, master_pattern, energy=None, navigation_mask=None,
                                  signal_mask=None, method="minimize", method_kwargs=None, trust_region=None,
                                  initial_step=None, rtol=1e-4, maxeval=None, compute=True, rechunk=True,
-                                 chunk_kwargs=None, *, verbose=True, comm=None):
+                                 chunk_kwargs=None, *, verbose=True, comm=None, devices=None):
         """signals/ebsd.py:2187-2390.  Returns `(scores, new_detector, num_evals)`
         like the reference."""
         out = self._refine("pc", xmap, detector, master_pattern, energy, navigation_mask, signal_mask, None,
-                           method, method_kwargs, trust_region, initial_step, rtol, maxeval, compute, verbose, comm)
+                           method, method_kwargs, trust_region, initial_step, rtol, maxeval, compute, verbose, comm, devices)
         if not compute:
             return out  # a DeferredRefinement (compute_refine_projection_center_results)
         res, det = out
@@ -175,11 +192,11 @@ class EBSD:
                                              navigation_mask=None, signal_mask=None, pseudo_symmetry_ops=None,
                                              method="minimize", method_kwargs=None, trust_region=None,
                                              initial_step=None, rtol=1e-4, maxeval=None, compute=True,
-                                             rechunk=True, chunk_kwargs=None, *, verbose=True, comm=None):
+                                             rechunk=True, chunk_kwargs=None, *, verbose=True, comm=None, devices=None):
         """signals/ebsd.py:2392-2700.  Returns `(RefinementResult, new_detector)`."""
         return self._refine("ori_pc", xmap, detector, master_pattern, energy, navigation_mask, signal_mask,
                             pseudo_symmetry_ops, method, method_kwargs, trust_region, initial_step, rtol, maxeval,
-                            compute, verbose, comm)
+                            compute, verbose, comm, devices)
 
     # ------------------------------------------------------------------ indexing
     def dictionary_indexing(self, dictionary, metric="ncc", keep_n=20, n_per_iteration=None,

@@ -431,3 +431,27 @@ def test_many_patterns_against_the_scipy_loop(ctx):
     # agree, and does for every pattern, is the optimum within the optimiser's own tolerances.
     assert same_path >= 0.25 * n, same_path
     assert np.median(np.abs(res[:, 3:6] - eu)) < np.median(np.abs(eu0 - eu)) / 3
+
+
+def test_refinement_over_a_group_of_devices(api_inputs):
+    """`devices=[...]`: the points are independent, every GPU of a group refines a contiguous block of them from a host
+    thread of its own (members sharing device 0 here) - the rows are those of the single-device run, bit for bit, for the
+    device search, a host optimiser (objective on the device), PC refinement with a navigation mask, and `compute=False`."""
+    s, det, mp, rot0 = api_inputs
+    one = s.refine_orientation(rot0, det, mp, energy=20, verbose=False)
+    grp = s.refine_orientation(rot0, det, mp, energy=20, devices=[0, 0, 0], verbose=False)
+    assert np.array_equal(one.scores, grp.scores) and np.array_equal(one.euler, grp.euler)
+    assert np.array_equal(one.num_evals, grp.num_evals)
+    assert (0, 0, 0) in s._groups and len(s._groups[(0, 0, 0)]) == 3
+    powell = dict(method="Powell", options=dict(maxfev=120))
+    a = s.refine_orientation(rot0, det, mp, method_kwargs=powell, verbose=False)
+    b = s.refine_orientation(rot0, det, mp, method_kwargs=powell, devices=[0, 0], verbose=False)
+    assert np.array_equal(a.scores, b.scores) and np.array_equal(a.num_evals, b.num_evals)
+    nav = np.array([[False, True], [False, False]])
+    sa, da, na = s.refine_projection_center(rot0, det, mp, navigation_mask=nav, verbose=False)
+    sb, db, nb = s.refine_projection_center(rot0, det, mp, navigation_mask=nav, devices=[0] * 5, verbose=False)  # more members than points
+    assert np.array_equal(sa, sb) and np.array_equal(da.pc, db.pc) and np.array_equal(na, nb)
+    later = s.refine_orientation_projection_center(rot0, det, mp, devices=[0, 0], compute=False, verbose=False)
+    rows = later.compute()
+    res, new_det = s.refine_orientation_projection_center(rot0, det, mp, verbose=False)
+    assert np.array_equal(rows[:, 0], res.scores) and np.array_equal(rows[:, -3:], new_det.pc.reshape(-1, 3))
