@@ -461,7 +461,10 @@ def main(argv=None, context_factory=None, group_factory=None):
 
     for _ in range(a.warmup):
         step()
-    ctx.set_profiling(True)
+    # HIP events around the MATCH launches only (roofline.achieved; + the all-gather for N > 1): an event record between two
+    # kernels idles the GPU for ~6 us - bracketing every phase costs 0.05 ms per step (profiles/r04_share_timeline.txt).  The
+    # per-phase breakdown of `extra` comes from a few untimed steps with full profiling behind the timed region.
+    ctx.set_profiling("match")
     ctx.reset_counters()
     comm.barrier()
     ctx.synchronize()
@@ -486,7 +489,28 @@ def main(argv=None, context_factory=None, group_factory=None):
     comm.barrier()
     elapsed = time.perf_counter() - t0
     cnt = ctx.counters()
+    # ---- untimed: the same step with every phase bracketed, for the breakdown (preparation, merge, bookkeeping) per step
+    n_break = max(2, min(a.steps, 5))
+    ctx.set_profiling(True)
+    ctx.reset_counters()
+    for _ in range(n_break):
+        step()
+    ctx.synchronize()
+    brk = ctx.counters()
     ctx.set_profiling(False)
+
+    def with_breakdown(c, b):
+        """the timed loop's counters + the per-phase times of the breakdown steps, scaled to the timed loop's step count"""
+        c = dict(c)
+        for key in ("prep_ms", "merge_ms", "fixed_ms", "preproc_ms"):
+            c[key] = b.get(key, 0.0) * a.steps / n_break
+        c["preproc_launches"] = b.get("preproc_launches", 0)
+        return c
+
+    members_brk = brk.get("members")
+    if "members" in cnt and members_brk:
+        cnt["members"] = [with_breakdown(c, b) for c, b in zip(cnt["members"], members_brk)]
+    cnt = dict(with_breakdown(cnt, brk), **({"members": cnt["members"]} if "members" in cnt else {}))
     per_rank = None
     if single:
         digest = hashlib.sha256(np.ascontiguousarray(scores).tobytes() + np.ascontiguousarray(indices).tobytes()).hexdigest()
@@ -657,21 +681,32 @@ def main(argv=None, context_factory=None, group_factory=None):
             mask3 = circular_mask(w3["sy"], w3["sx"])
             c3 = _lib.Context(device)
             c3.set_problem(w3["sy"], w3["sx"], mask3, metric, w3["keep_n"], compute)
-            c3.set_profiling(True)
+            c3.set_profiling("match")
             reps = max(3, min(a.steps, 10))
+
+            def step3():
+                c3.set_experimental_dev(d_exp, exp.dtype, w3["m"])
+                c3.remove_static_background(bg_f32, _lib.OP_SUBTRACT, False)
+                c3.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
+                c3.push_dictionary_chunk_dev(d_dic, dict_np, n_local, lo)
+                return c3.finalize(w3["keep_n"])
+
             for r in range(reps + 2):
                 if r == 2:
                     c3.reset_counters()
                     c3.synchronize()
                     t0 = time.perf_counter()
-                c3.set_experimental_dev(d_exp, exp.dtype, w3["m"])
-                c3.remove_static_background(bg_f32, _lib.OP_SUBTRACT, False)
-                c3.remove_dynamic_background(_lib.OP_SUBTRACT, _lib.DOMAIN_FREQUENCY, 0.0, 4.0)
-                c3.push_dictionary_chunk_dev(d_dic, dict_np, n_local, lo)
-                s3, i3 = c3.finalize(w3["keep_n"])
+                s3, i3 = step3()
             c3.synchronize()
             dt3 = (time.perf_counter() - t0) / reps
             cnt3 = c3.counters()
+            c3.set_profiling(True)  # (untimed: the pre-kernel and the preparation, every phase bracketed)
+            c3.reset_counters()
+            for r in range(reps):
+                step3()
+            full3 = c3.counters()
+            for key in ("preproc_ms", "preproc_launches", "prep_ms"):
+                cnt3[key] = full3[key]
             c3.close()
             pre_ms = cnt3["preproc_ms"] / max(cnt3["preproc_launches"], 1)
             # algorithmic bytes of the pre-kernel: the pattern read and written back + its prepared row

@@ -336,8 +336,10 @@ struct kpdi_ctx {
   hipEvent_t lists_final = nullptr;  // this member's running lists are final (recorded on `stream`)
   hipEvent_t peer_read = nullptr;    // root: the peer copies of the members' lists have run
 
-  // measurement
-  bool profiling = false;
+  // measurement: 0 off; 1 every phase bracketed by HIP events; 2 the match launches (and the all-gather) only - an event
+  // record between two kernels costs ~6 us of idle GPU (profiles/r04_share_timeline.txt: 71 us per 3 ms step with level 1)
+  int profiling = 0;
+  bool timed(const void *list) const { return profiling == 1 || (profiling == 2 && (list == &ev_match || list == &ev_comm)); }
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_match, ev_prep, ev_merge, ev_proj, ev_pre, ev_rescore, ev_comm, ev_fixed;
   std::vector<hipEvent_t> ev_pool;
   kpdi_counters cnt{};
@@ -361,14 +363,14 @@ struct ScopedTimer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> *list;
   hipEvent_t a = nullptr, b = nullptr;
   ScopedTimer(kpdi_ctx *ctx, std::vector<std::pair<hipEvent_t, hipEvent_t>> *l) : c(ctx), list(l) {
-    if (c->profiling) {
+    if (c->timed(list)) {
       a = c->get_event();
       b = c->get_event();
       (void)hipEventRecord(a, c->stream);
     }
   }
   ~ScopedTimer() {
-    if (c->profiling) {
+    if (a) {
       (void)hipEventRecord(b, c->stream);
       list->push_back({a, b});
     }
@@ -2707,7 +2709,8 @@ int kpdi_d2h(kpdi_ctx *c, void *dst, const void *d_src, size_t bytes) {
 
 int kpdi_set_profiling(kpdi_ctx *c, int on) {
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
-  c->profiling = on != 0;
+  if (on < 0 || on > 2) return fail(KPDI_EINVAL, "profiling level %d (0 off, 1 every phase, 2 match launches only)", on);
+  c->profiling = on;
   return KPDI_OK;
 }
 
