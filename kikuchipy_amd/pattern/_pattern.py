@@ -33,6 +33,38 @@ def _upload(ctx, patterns):
     return patterns.shape
 
 
+def _process(patterns, record, context, device, contexts):
+    """Upload -> `record(ctx)` (the recorded step) -> download, on one context or - `contexts`: one per GPU, the members of a
+    `_lib.Group` - block-wise: the patterns are independent, every GPU takes a contiguous block of them over its own host
+    link from a host thread of its own (the library calls release the GIL); the blocks are concatenated."""
+    patterns = np.asarray(patterns)
+    if contexts and len(contexts) > 1 and patterns.ndim > 2 and int(np.prod(patterns.shape[:-2])) >= len(contexts):
+        from concurrent.futures import ThreadPoolExecutor
+
+        from kikuchipy_amd.parallel import shard_range
+
+        flat = np.ascontiguousarray(patterns).reshape((-1,) + patterns.shape[-2:])
+        blocks = [shard_range(len(flat), i, len(contexts)) for i in range(len(contexts))]
+
+        def one(job):
+            c, (a, b) = job
+            _upload(c, flat[a:b])
+            record(c)
+            return c.get_experimental()
+
+        with ThreadPoolExecutor(len(contexts)) as pool:
+            parts = list(pool.map(one, zip(contexts, blocks)))
+        return np.concatenate(parts, axis=0).reshape(patterns.shape)
+    ctx = contexts[0] if contexts else _context(context, device)
+    try:
+        shape = _upload(ctx, patterns)
+        record(ctx)
+        return ctx.get_experimental().reshape(shape)
+    finally:
+        if context is None and not contexts:
+            ctx.close()
+
+
 def check_static_background(patterns_dtype, sig_shape, static_bg):
     """Validation of signals/ebsd.py:525-546."""
     if not isinstance(static_bg, np.ndarray):
@@ -55,7 +87,7 @@ def check_static_background(patterns_dtype, sig_shape, static_bg):
 
 
 def remove_static_background(patterns, static_bg, operation="subtract", scale_bg=False, *,
-                             context=None, device=0):
+                             context=None, device=0, contexts=None):
     """Remove the static background from every pattern; returns a new array of
     the input dtype.  `static_bg` must have the patterns' dtype and detector
     shape, as in the reference."""
@@ -63,18 +95,11 @@ def remove_static_background(patterns, static_bg, operation="subtract", scale_bg
         raise ValueError(f"operation '{operation}' must be either 'subtract' or 'divide'")
     patterns = np.asarray(patterns)
     bg = check_static_background(patterns.dtype, patterns.shape[-2:], static_bg)
-    ctx = _context(context, device)
-    try:
-        shape = _upload(ctx, patterns)
-        ctx.remove_static_background(bg, _OPS[operation], scale_bg)
-        return ctx.get_experimental().reshape(shape)
-    finally:
-        if context is None:
-            ctx.close()
+    return _process(patterns, lambda c: c.remove_static_background(bg, _OPS[operation], scale_bg), context, device, contexts)
 
 
 def remove_dynamic_background(patterns, operation="subtract", filter_domain="frequency", std=None,
-                              truncate=4.0, *, context=None, device=0):
+                              truncate=4.0, *, context=None, device=0, contexts=None):
     """Remove the dynamic background (Gaussian blur of each pattern, by
     subtraction or division) from every pattern; returns a new array of the
     input dtype.  `std` defaults to an eighth of the pattern width."""
@@ -85,11 +110,5 @@ def remove_dynamic_background(patterns, operation="subtract", filter_domain="fre
     patterns = np.asarray(patterns)
     if std is None:
         std = patterns.shape[-1] / 8
-    ctx = _context(context, device)
-    try:
-        shape = _upload(ctx, patterns)
-        ctx.remove_dynamic_background(_OPS[operation], _DOMAINS[filter_domain], std, truncate)
-        return ctx.get_experimental().reshape(shape)
-    finally:
-        if context is None:
-            ctx.close()
+    return _process(patterns, lambda c: c.remove_dynamic_background(_OPS[operation], _DOMAINS[filter_domain], std, truncate),
+                    context, device, contexts)

@@ -31,6 +31,9 @@ from kikuchipy_amd.simulations import DTYPE_RANGE, ProjectedDictionary
 # a call that names no device spreads a refinement over every visible GPU from this many points on (one block of the
 # points per GPU; below, the set-up of a group costs more than it saves)
 REFINE_GROUP_MIN_POINTS = 2048
+# ... and a background removal from this many patterns on (a block of the patterns per GPU, each over its own host link:
+# the call is transfer-bound - patterns up, patterns down)
+PREPROCESS_GROUP_MIN_POINTS = 16384
 
 
 class DictionaryXmap:
@@ -100,6 +103,20 @@ class EBSD:
             self._ctx = _lib.Context(self._device or 0)
         return self._ctx
 
+    def _member_contexts(self, devices, min_points):
+        """One engine context per GPU for work that splits over the map's points (pre-processing, refinement): the
+        members of this signal's group over `devices` (or over every visible GPU when nothing was named and the map has
+        `min_points` points or more), None = this signal's own context."""
+        ids = _lib.resolve_devices(devices if devices is not None else self._devices)
+        if ids is None and self._device is None and self.navigation_size >= min_points:
+            ids = _lib.default_devices()
+        if ids is None or len(ids) < 2:
+            return None
+        key = tuple(ids)
+        if key not in self._groups:
+            self._groups[key] = _lib.make_engine(devices=ids)
+        return self._groups[key].members
+
     def _engine(self, devices, comm, dictionary_size):
         """The engine a `dictionary_indexing` call of this signal runs on: its own context, or a `Group`
         over several GPUs (kept on the signal from call to call)."""
@@ -118,22 +135,24 @@ class EBSD:
 
     # ------------------------------------------------------------------ pre-processing
     def remove_static_background(self, operation="subtract", static_bg=None, scale_bg=False,
-                                 inplace=True):
+                                 inplace=True, *, devices=None):
         if static_bg is None:
             static_bg = self.static_background
             if not isinstance(static_bg, np.ndarray) and not hasattr(static_bg, "compute"):
                 raise ValueError("`EBSD.static_background` is not a valid array")
+        contexts = self._member_contexts(devices, PREPROCESS_GROUP_MIN_POINTS)
         out = _pattern.remove_static_background(np.asarray(self.data), static_bg, operation, scale_bg,
-                                                context=self.context)
+                                                context=None if contexts else self.context, contexts=contexts)
         if inplace:
             self.data = out
             return None
         return EBSD(out, self.static_background, self.xmap, self.step_sizes, self.scan_unit, self._device, self._devices)
 
     def remove_dynamic_background(self, operation="subtract", filter_domain="frequency", std=None,
-                                  truncate=4.0, inplace=True):
+                                  truncate=4.0, inplace=True, *, devices=None):
+        contexts = self._member_contexts(devices, PREPROCESS_GROUP_MIN_POINTS)
         out = _pattern.remove_dynamic_background(np.asarray(self.data), operation, filter_domain, std,
-                                                 truncate, context=self.context)
+                                                 truncate, context=None if contexts else self.context, contexts=contexts)
         if inplace:
             self.data = out
             return None
@@ -146,16 +165,7 @@ class EBSD:
         from kikuchipy_amd.indexing._refinement import refine
 
         # the points are independent: with several GPUs (named, or all of them for a map worth it) each refines a block
-        contexts = None
-        if comm is None:
-            ids = _lib.resolve_devices(devices if devices is not None else self._devices)
-            if ids is None and self._device is None and self.navigation_size >= REFINE_GROUP_MIN_POINTS:
-                ids = _lib.default_devices()
-            if ids is not None and len(ids) > 1:
-                key = tuple(ids)
-                if key not in self._groups:
-                    self._groups[key] = _lib.make_engine(devices=ids)
-                contexts = self._groups[key].members
+        contexts = self._member_contexts(devices, REFINE_GROUP_MIN_POINTS) if comm is None else None
         return refine(mode, np.asarray(self.data), _rotations_of(xmap), detector, master_pattern, energy,
                       navigation_mask, signal_mask, pseudo_symmetry_ops, method, method_kwargs, trust_region,
                       initial_step, rtol, maxeval, context=None if contexts else self.context, verbose=verbose, comm=comm,

@@ -237,3 +237,30 @@ def test_a_members_error_names_the_member():
             g.push_dictionary_chunk_dev([0], np.float32, [1], [0])
     with pytest.raises(_lib.KpdiError, match="out of range"):
         _lib.Group([0, 99])
+
+
+def test_background_removal_over_a_group():
+    """`remove_static_background` / `remove_dynamic_background` with `devices=`: every GPU takes a contiguous block of the
+    patterns (they are independent) - the output is the single-device output, byte for byte, for every dtype, with fewer
+    patterns than members, and through the array-level functions."""
+    import kikuchipy_amd as ka
+    from kikuchipy_amd import _lib
+    from kikuchipy_amd.pattern import _pattern
+
+    rng = np.random.default_rng(21)
+    for dtype, nav in ((np.uint8, (7, 9)), (np.uint16, (50,)), (np.float32, (3, 4))):
+        hi = 255 if dtype == np.uint8 else (60000 if dtype == np.uint16 else 1)
+        data = (rng.random(nav + (60, 60)) * hi).astype(dtype)
+        bg = (rng.random((60, 60)) * hi * 0.5 + hi * 0.25).astype(dtype)
+        one = ka.EBSD(data.copy(), static_background=bg, device=0)
+        grp = ka.EBSD(data.copy(), static_background=bg, devices=[0, 0, 0])
+        for s in (one, grp):
+            s.remove_static_background(scale_bg=(dtype == np.uint16))
+            s.remove_dynamic_background(operation="divide" if dtype == np.float32 else "subtract")
+        assert grp.data.dtype == one.data.dtype and grp.data.shape == data.shape
+        assert np.array_equal(one.data, grp.data)
+        assert list(grp._groups) == [(0, 0, 0)] and not one._groups
+    few = (rng.random((2, 60, 60)) * 255).astype(np.uint8)  # fewer patterns than members: one context does it
+    with _lib.Group([0] * 4) as g:
+        a = _pattern.remove_dynamic_background(few, contexts=g.members)
+    assert np.array_equal(a, _pattern.remove_dynamic_background(few, device=0))
