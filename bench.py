@@ -265,13 +265,13 @@ def measure_traffic(a, kernel_substring):
             per_counter[ctr] = vals
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    n_sweeps = 3  # warm-up + 2 steps of the sub-run
+    n_sweeps = 1 + 2 + max(2, min(2, 5))  # the sub-run's warm-up + 2 timed steps + its untimed breakdown steps (n_break in main)
     fetch = sum(per_counter["FETCH_SIZE"]) / n_sweeps * 1024 * 2   # KiB; gfx950 counts half of a wide coalesced read
     write = sum(per_counter["WRITE_SIZE"]) / n_sweeps * 1024
     return {"traffic": fetch + write,
             "traffic_detail": {"fetch_bytes": fetch, "write_bytes": write, "kernel_launches_per_sweep":
                                len(per_counter["FETCH_SIZE"]) / n_sweeps,
-                               "how": "rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE, around a 3-step sub-run of this "
+                               "how": "rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE, around a 5-sweep sub-run of this "
                                       "command inside this run; per sweep of the match kernel(s); FETCH_SIZE x 1024 x 2, "
                                       "WRITE_SIZE x 1024 (MI355X_MICROARCH.md, HBM)",
                                "seconds": round(time.perf_counter() - t0, 1)}}
