@@ -439,3 +439,82 @@ def test_finalize_async_pipelines_a_series_of_maps():
             assert np.array_equal(a[1], b[1]) and np.array_equal(a[1], c.finalize(10)[1])
             with pytest.raises(_lib.KpdiError, match="no result is pending"):
                 c.finalize_wait(t1)
+
+
+@pytest.mark.parametrize("metric,keep_n,sig", [("ncc", 20, (60, 60)), ("ndp", 40, (24, 20)), ("ncc", 5, (60, 60))])
+def test_pipelined_front_half_of_a_series_of_maps(monkeypatch, metric, keep_n, sig):
+    """A series of maps with device-resident inputs, queued ahead of the GPU (finalize_async), in which every step differs
+    from its neighbours - other patterns, another dictionary block of another size (partial last tiles), one or two chunks
+    per sweep, a host-pointer push, a recorded background step, a navigation mask, another keep_n: every result must
+    equal what a second context returns for the same calls, bit for bit, and the oracle's.  (Written as the hazard test of
+    a software-pipelined front half - the next map's preparation on a stream of its own into a second set of operand
+    buffers, `KPDI_OVERLAP` - which was built, measured at ~1 % and reverted, profiles/r04_front_half_overlap.txt; it pins
+    the pipelined single-stream loop just as well.)"""
+    from kikuchipy_amd import _lib
+
+    rng = np.random.default_rng(31)
+    sy, sx = sig
+    code = _lib.METRIC_NCC if metric == "ncc" else _lib.METRIC_NDP
+    dic = rng.random((9000, sy, sx), dtype=np.float32)
+    bg = rng.integers(1, 256, (sy, sx)).astype(np.float32)
+    # (experimental patterns, [dictionary slices of the sweep], variation)
+    steps = []
+    for j in range(14):
+        m = int(rng.choice([300, 512, 77, 1024]))
+        a = int(rng.integers(0, 3000))
+        n = int(rng.choice([2500, 2560, 3001, 1700, 4096]))
+        chunks = [(a, a + n)] if j % 3 else [(a, a + n // 2), (a + n // 2, a + n)]
+        steps.append((rng.integers(0, 256, (m, sy, sx), dtype=np.uint8), chunks,
+                      {5: "host", 8: "background", 10: "navmask", 12: "keep"}.get(j, "")))
+
+    def run(overlap):
+        monkeypatch.setenv("KPDI_OVERLAP", "1" if overlap else "0")
+        out = []
+        with _lib.Context(0) as c:
+            c.set_problem(sy, sx, None, code, keep_n)  # (reads KPDI_OVERLAP)
+            d_dic = c.dev_alloc(dic.nbytes)
+            c.h2d(d_dic, dic)
+            d_exp = [c.dev_alloc(1024 * sy * sx) for _ in range(2)]
+            row = sy * sx * 4
+            pending = None
+            for j, (e, chunks, what) in enumerate(steps):
+                d = d_exp[j & 1]  # (two source buffers: the copy of map i + 1 may still run while the host fills the other)
+                c.h2d(d, e)
+                k = keep_n
+                if what == "keep":
+                    k = 3
+                    c.set_keep_n(k)
+                nav = None
+                if what == "navmask":
+                    nav = np.zeros(len(e), dtype=bool)
+                    nav[::7] = True
+                c.set_experimental_dev(d, e.dtype, len(e), nav)
+                if what == "background":
+                    c.remove_static_background(bg, _lib.OP_SUBTRACT, False)
+                for a, b in chunks:
+                    if what == "host":
+                        c.push_dictionary_chunk(dic[a:b], a)
+                    else:
+                        c.push_dictionary_chunk_dev(d_dic + a * row, np.float32, b - a, a)
+                ticket = c.finalize_async(k)
+                if pending is not None:
+                    out.append(c.finalize_wait(pending))
+                pending = ticket
+                if what == "keep":
+                    out.append(c.finalize_wait(pending))
+                    pending = None
+                    c.set_keep_n(keep_n)
+            if pending is not None:
+                out.append(c.finalize_wait(pending))
+        return out
+
+    plain = run(False)
+    piped = run(True)
+    assert len(plain) == len(piped) == len(steps)
+    for j, ((ws, wi), (gs, gi)) in enumerate(zip(plain, piped)):
+        assert gs.shape == ws.shape and np.array_equal(gs, ws) and np.array_equal(gi, wi), f"step {j}: {steps[j][2] or 'plain'}"
+    # and the oracle on a plain step
+    e, chunks, _ = steps[1]
+    (a, b), = chunks
+    rs, ri = ko.dictionary_indexing(e, dic[a:b], metric=metric, keep_n=keep_n)
+    ko.assert_topk_parity(piped[1][0], piped[1][1], rs, ri + a, atol=1e-5)
