@@ -7,7 +7,7 @@ pattern (`EBSDMasterPattern.get_patterns`).  Python host code -> ctypes -> libkp
 gfx950).  No PyTorch, no CPU fallback.
 """
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
 from kikuchipy_amd.indexing import (  # noqa: E402,F401
     DictionaryIndexingResult,

@@ -41,6 +41,7 @@ def test_bench_runs_sharded_over_rccl():
     assert out["n_gpus"] == n and out["multi_gpu"]["rccl_ranks"] == n and out["check"]["rows"] == 64
 
 
+@pytest.mark.timeout(900)  # (a collective that does not complete must fail the test, not hang the suite)
 @pytest.mark.parametrize("gather", ["rccl", "p2p", None])
 def test_group_over_every_visible_gpu(gather):
     """ONE process, one group member per GPU: the in-process RCCL communicator (ncclCommInitAll) and the peer-copy gather
@@ -74,6 +75,7 @@ def test_group_over_every_visible_gpu(gather):
     assert np.array_equal(res.scores, one.scores) and np.array_equal(res.simulation_indices, one.simulation_indices)
 
 
+@pytest.mark.timeout(1200)
 def test_bench_single_process_over_every_visible_gpu():
     """`python bench.py --gpus N --single-process`: the sharded benchmark driven from one interpreter."""
     import json
