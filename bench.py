@@ -155,6 +155,87 @@ def check_result(w, exp, dic, bg, mask, scores, indices, n_rows, large, compute=
     return out
 
 
+def rank_share_leg(_lib, make_context, device, key, n_ranks, d_dic, dic_host, reps, n_check, shard_range, per=12500):
+    """One rank's share of an 8-GPU configuration, on this GPU, inside the default run (configs[3] /
+    configs[4] are quoted on 8 GPUs; what ONE of them does is measurable here): rank 0's dictionary shard
+    (`shard_range(n, 0, n_ranks)`), the whole experimental set, inputs resident, the step pipelined as the timed
+    region above, a sample of rows checked against the C oracle over the whole shard.  Informational, never `value`.
+
+    configs[3]: the shard is the first 37 500 patterns of the dictionary already resident (`d_dic`, the same uniform
+    float32 generator).  configs[4]: 62 500 patterns of 120 x 120 - one generated block of 12 500 and four copies of it
+    with the pixels rotated by a different offset each (distinct, mutually uncorrelated patterns; 3.6 GB on the device,
+    0.7 GB generated)."""
+    w = WORKLOADS[key]
+    m, sy, sx, keep = w["m"], w["sy"], w["sx"], w["keep_n"]
+    npix = sy * sx
+    lo, hi = shard_range(w["n"], 0, n_ranks)
+    n_shard = hi - lo
+    rng = np.random.default_rng(2024)
+    exp = rng.integers(0, 256, (m, sy, sx), dtype=np.uint8)
+    c = make_context(device)
+    try:
+        c.set_problem(sy, sx, None, {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[w["metric"]], keep, _lib.COMPUTE_F32)
+        d_exp = c.dev_alloc(exp.nbytes)
+        c.h2d(d_exp, exp)
+        if d_dic is not None:  # a prefix of the resident dictionary
+            blocks = lambda: [(0, dic_host[:n_shard])]  # noqa: E731
+            d_shard = d_dic
+        else:
+            base = rng.random((per, npix), dtype=np.float32)
+            shift = lambda b: base if b == 0 else np.roll(base, 2477 * b, axis=1)  # noqa: E731
+            blocks = lambda: ((b * per, shift(b)[:min(per, n_shard - b * per)]) for b in range(-(-n_shard // per)))  # noqa: E731
+            d_shard = c.dev_alloc(n_shard * npix * 4)
+            for at, blk in blocks():
+                c.h2d(d_shard + at * npix * 4, np.ascontiguousarray(blk))
+        c.set_profiling("match")
+        pending = None
+        scores = indices = None
+        for r in range(reps + 1):
+            if r == 1:
+                c.finalize_wait(pending)
+                pending = None
+                c.reset_counters()
+                c.synchronize()
+                t0 = time.perf_counter()
+            c.set_experimental_dev(d_exp, exp.dtype, m)
+            c.push_dictionary_chunk_dev(d_shard, np.float32, n_shard, lo)
+            ticket = c.finalize_async(keep)
+            if pending is not None:
+                scores, indices = c.finalize_wait(pending)
+            pending = ticket
+        scores, indices = c.finalize_wait(pending)
+        c.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        cnt = c.counters()
+    finally:
+        c.close()
+    match_ms = cnt["match_ms"] / reps
+    tflops = cnt["match_flops"] / reps / (match_ms * 1e-3) / 1e12
+    rec = {
+        "what": f"{w['name']}: rank 0's share of {n_ranks} ranks on ONE MI355X (the whole experimental set x dictionary "
+                f"patterns [{lo}, {hi})), inputs resident, results collected while the next step runs",
+        "shard_patterns": int(n_shard), "ms_per_step": round(dt * 1e3, 3),
+        "patterns_per_s_before_the_allgather": round(m / dt, 1),  # every rank sweeps the whole experimental set
+        "match_ms": round(match_ms, 3),
+        "match_tflops": round(tflops, 1), "match_frac": round(tflops / F32_MFMA_PEAK_TFLOPS, 4),
+        "match_form": int(cnt.get("match_form", 0)),
+    }
+    if n_check:
+        from oracle import c_oracle
+        from oracle import kpdi_oracle as ko
+
+        t0 = time.perf_counter()
+        rows = np.sort(np.random.default_rng(5).choice(m, n_check, replace=False))
+        rs, ri = c_oracle.rows_topk_f64(exp[rows], ((at, blk.reshape(-1, sy, sx)) for at, blk in blocks()),
+                                        np.arange(n_check), w["metric"], keep, None)
+        ko.assert_topk_parity(scores[rows], indices[rows], rs, ri, atol=1e-5)
+        rec["check"] = {"rows": int(n_check), "oracle": "oracle/kpdi_oracle_c.c rows_topk_f64 over the whole shard",
+                        "max_abs_score_diff": float(np.abs(scores[rows] - rs).max()),
+                        "index_agreement": float(np.mean(indices[rows] == ri)),
+                        "seconds": round(time.perf_counter() - t0, 2)}
+    return rec
+
+
 def cpu_baseline(w, exp, dic, bg, mask, n_sample):
     """The path on this host's CPU cores, on a bounded sample (all M experimental patterns against
     the first `n_sample` dictionary patterns, n_per_iteration=2000; the cost is linear in the
@@ -338,6 +419,8 @@ def main(argv=None, context_factory=None, group_factory=None):
                          "dictionary before the line is printed (default: 64; 32 for the large workloads; 0 = no check)")
     ap.add_argument("--no-config3", action="store_true", help="skip the configs[2] leg of the default run")
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-pointer sweep")
+    ap.add_argument("--no-rank-shares", action="store_true",
+                    help="skip the informational legs that run ONE rank's share of the 8-GPU configurations (configs[3], configs[4])")
     ap.add_argument("--no-generation", action="store_true",
                     help="skip the informational sweep with the dictionary simulated on the device")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -828,6 +911,15 @@ def main(argv=None, context_factory=None, group_factory=None):
             }
         except Exception as err:  # an informational leg must not cost the bench line
             out["extra"][key + "_error"] = f"{type(err).__name__}: {err}"
+
+    # ---- the 8-GPU configurations, as far as one GPU can show them: rank 0's share of configs[3] and of configs[4]
+    if a.workload == "config2" and solo and a.compute == "f32" and not a.no_rank_shares and context_factory is None:
+        for key, name, dd in (("config4", "config4_share_of_8", d_dic), ("config5", "config5_share_of_8", None)):
+            try:
+                out["extra"][name] = rank_share_leg(_lib, _lib.Context, device, key, 8, dd if dict_np == np.float32 else None, dic,
+                                                    3, 0 if a.check_rows == 0 else 16, shard_range)
+            except Exception as err:  # an informational leg must not cost the bench line
+                out["extra"][name + "_error"] = f"{type(err).__name__}: {err}"
 
     if solo and not a.no_generation and a.compute == "f32":
         try:

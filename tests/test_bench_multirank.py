@@ -94,3 +94,38 @@ def test_a_failing_rank_fails_the_run():
 def test_bench_imports_no_torch():
     text = open(os.path.join(ROOT, "bench.py")).read()
     assert "import torch" not in text and "from torch" not in text
+
+
+@pytest.mark.parametrize("resident_prefix", [True, False])
+def test_rank_share_leg_of_the_default_run(monkeypatch, resident_prefix):
+    """bench.py's informational legs for the 8-GPU configurations (one rank's share on one GPU), on a toy
+    workload with the stand-in engine: the shard is rank 0's block, the result is checked against the C oracle
+    over that shard (a prefix of a resident dictionary, or generated block + pixel-rotated copies)."""
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    from _standin_engine import StandInContext
+    from kikuchipy_amd import _lib
+    from kikuchipy_amd.parallel import shard_range
+
+    monkeypatch.setitem(bench.WORKLOADS, "toy", dict(m=96, n=1000, sy=6, sx=5, metric="ndp", keep_n=7, mask=False,
+                                                     preprocess=False, name="toy"))
+    dic = np.random.default_rng(3).random((400, 6, 5), dtype=np.float32)
+    made = []
+
+    def make(device):
+        made.append(StandInContext(device))
+        return made[-1]
+
+    d_dic = None
+    if resident_prefix:
+        holder = StandInContext(0)
+        d_dic = holder.dev_alloc(dic.nbytes)
+        holder.h2d(d_dic, dic)
+        # (the stand-in's device pointers are process-wide handles: the leg's own context reads the holder's buffer)
+        make = lambda device: holder  # noqa: E731
+    rec = bench.rank_share_leg(_lib, make, 0, "toy", 8, d_dic, dic, 2, 12, shard_range, per=50)
+    assert rec["shard_patterns"] == 125 and rec["check"]["rows"] == 12 and rec["check"]["index_agreement"] == 1.0
+    assert rec["check"]["max_abs_score_diff"] < 1e-5 and rec["ms_per_step"] > 0
