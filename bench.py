@@ -914,10 +914,15 @@ def main(argv=None, context_factory=None, group_factory=None):
 
     # ---- the 8-GPU configurations, as far as one GPU can show them: rank 0's share of configs[3] and of configs[4]
     if a.workload == "config2" and solo and a.compute == "f32" and not a.no_rank_shares and context_factory is None:
-        for key, name, dd in (("config4", "config4_share_of_8", d_dic), ("config5", "config5_share_of_8", None)):
+        for key, n_ranks, reps, dd in (("config2", 4, 40, d_dic), ("config2", 8, 40, d_dic), ("config4", 8, 3, d_dic),
+                                       ("config5", 8, 3, None)):
+            name = f"{key}_share_of_{n_ranks}"
             try:
-                out["extra"][name] = rank_share_leg(_lib, _lib.Context, device, key, 8, dd if dict_np == np.float32 else None, dic,
-                                                    3, 0 if a.check_rows == 0 else 16, shard_range)
+                rec = rank_share_leg(_lib, _lib.Context, device, key, n_ranks, dd if dict_np == np.float32 else None, dic,
+                                     reps, 0 if a.check_rows == 0 else 16, shard_range)
+                if key == "config2":  # strong scaling of the headline job before the all-gather: this step / (t_1 / N)
+                    rec["step_over_even_share"] = round(rec["ms_per_step"] / (ms_per_step / n_ranks), 4)
+                out["extra"][name] = rec
             except Exception as err:  # an informational leg must not cost the bench line
                 out["extra"][name + "_error"] = f"{type(err).__name__}: {err}"
 
