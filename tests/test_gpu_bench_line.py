@@ -1,0 +1,47 @@
+"""The driver's command on the GPU: `python bench.py` prints ONE JSON line that carries the contract's keys, `roofline`
+and `cpu_baseline`, and none of its informational legs failed (each of them swallows its own exception into
+`extra.<leg>_error` so that it cannot cost the line - this test is where such a failure shows)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_default_bench_line_and_its_legs():
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-sample", "4000"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["unit"] == "patterns/s" and out["dtype"] == "f32"
+    assert "configs[1]" in out["config"]["workload"] and out["vs_baseline"] is None
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and rf["peak"] == 157.3 and 0.5 < rf["frac"] < 1.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["avg_launch_ms"] <= out["ms_per_step"]
+    cb = out["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1
+    assert out["check"]["index_agreement"] == 1.0
+    failed = {k: v for k, v in out["extra"].items() if k.endswith("_error")}
+    assert not failed, failed
+    for leg in ("config3", "config2_share_of_4", "config2_share_of_8", "config4_share_of_8", "config5_share_of_8",
+                "float64_mode", "f16_mode", "split_f16_mode", "resident_dictionary", "dictionary_generation", "refinement"):
+        assert leg in out["extra"], leg
+    for leg in ("config2_share_of_8", "config4_share_of_8", "config5_share_of_8"):
+        assert out["extra"][leg]["check"]["index_agreement"] == 1.0
+    # one rank's share of an 8-rank job takes between an eighth and a quarter of the whole step
+    share = out["extra"]["config2_share_of_8"]
+    assert 1.0 <= share["step_over_even_share"] < 2.0, share
