@@ -170,7 +170,7 @@ int fail_msg(int code, const char *fmt, ...) {
 struct Switches {
   double odd_wide = kpdi::FORM_ODD_SPLIT_WIDE, odd_classic = kpdi::FORM_ODD_SPLIT_CLASSIC;
   double wide_launch = kpdi::FORM_WIDE_LAUNCH, fixed_frac = 0.8;
-  bool xcd_grid = true, no_tail = false, one_stream = false, tail_stream2 = false;
+  bool xcd_grid = true, xcd_pad = true, no_tail = false, one_stream = false, tail_stream2 = false;
   bool f64_worstcase = false, f64_sync = false;
   long upload_tiles = 0;
   void read() {
@@ -184,6 +184,7 @@ struct Switches {
     wide_launch = num("KPDI_FORM_WIDE_LAUNCH", wide_launch);
     fixed_frac = num("KPDI_FIXED_FRAC", fixed_frac);
     if (const char *e = getenv("KPDI_XCD_GRID")) xcd_grid = atoi(e) != 0;
+    if (const char *e = getenv("KPDI_XCD_PAD")) xcd_pad = atoi(e) != 0;
     no_tail = getenv("KPDI_NO_TAIL") != nullptr;
     one_stream = getenv("KPDI_ONE_STREAM") != nullptr;
     tail_stream2 = getenv("KPDI_TAIL_STREAM2") != nullptr;
@@ -619,22 +620,32 @@ int ensure_running(kpdi_ctx *c) {
 }
 
 // How the 8 XCDs tile a launch's rows x nsplit workgroups (match_device.h: block_rb_sp): among the grids
-// (xr x xs = 8) that divide both extents, the one whose XCDs stream the fewest operand bytes per tile round -
-// (rows / xr) experimental blocks of 256 patterns + (nsplit / xs) dictionary tiles.  0 x 0 = plain mapping
-// (KPDI_XCD_GRID=0 forces it).
-void plan_xcd_grid(const kpdi_ctx *c, int rows, int nsplit, int tile_dict, int *xr, int *xs) {
+// (xr x xs = 8) the one whose XCDs stream the fewest operand bytes per tile round - (rows / xr) experimental blocks
+// of 256 patterns + (nsplit / xs) dictionary tiles.  xs must divide nsplit; xr need not divide rows: the grid is then
+// laid over rows rounded up to a multiple of xr (`rows_grid`), and the workgroups of the missing row blocks leave at
+// once - the last launch of a large experimental set (configs[3]: 157 row blocks = 4 x 32 + 29) keeps the rectangles
+// of the others instead of 29 row blocks x 1 split per XCD, 2.5 x their operand traffic (KPDI_XCD_PAD=0: only
+// grids that divide rows, as before round 4).  At most an eighth more workgroups are launched for it.  Only for the
+// kernels of match16.hip (`may_pad`): measured on one rank's share of configs[3] the fabric traffic of a sweep falls
+// from 45.8 to 35.2 GB and the wide kernel's 40 000 x 12 500 step from 28.02 to 27.85 ms, while match.hip's step
+// (dynamic draws) gets SLOWER, 28.02 -> 28.4 ms (profiles/r04_xcd_pad.txt).
+// 0 x 0 = plain mapping (KPDI_XCD_GRID=0 forces it).
+void plan_xcd_grid(const kpdi_ctx *c, int rows, int nsplit, int tile_dict, bool may_pad, int *xr, int *xs, int *rows_grid) {
   *xr = *xs = 0;
+  *rows_grid = rows;
   if (!c->sw.xcd_grid) return;
-  if ((rows * nsplit) % 8 != 0) return;
   long best = -1;
   for (int r = 1; r <= 8; r *= 2) {
     const int sgrid = 8 / r;
-    if (rows % r != 0 || nsplit % sgrid != 0) continue;
-    const long cost = (long)(rows / r) * kpdi::TILE_EXP + (long)(nsplit / sgrid) * tile_dict;
+    const int rows_pad = (rows + r - 1) / r * r;
+    if (nsplit % sgrid != 0) continue;
+    if (rows_pad != rows && (!may_pad || !c->sw.xcd_pad || 8 * (rows_pad - rows) > rows)) continue;
+    const long cost = (long)(rows_pad / r) * kpdi::TILE_EXP + (long)(nsplit / sgrid) * tile_dict;
     if (best < 0 || cost < best) {
       best = cost;
       *xr = r;
       *xs = sgrid;
+      *rows_grid = rows_pad;
     }
   }
 }
@@ -746,6 +757,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   const size_t ctr_bytes = (size_t)(c->m_pad / kpdi::TILE_EXP) * sizeof(unsigned);
   ml.tile_ctr = c->tile_ctr.as<unsigned>();
   const int row_blocks = c->m_pad / kpdi::TILE_EXP;
+  int launched_rows = 0;
   {
     ScopedTimer t(c, &c->ev_match);  // one timed region = the whole sweep of this chunk
     // several launches (large experimental sets) alternate between two streams: the workgroups
@@ -762,13 +774,21 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
       HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
     int j = 0;
-    const size_t scratch16 =
-        f16 ? kpdi::match16_scratch_bytes(std::min(rows_per_launch, row_blocks) * nsplit, c->f16_waves, list_len) : 0;
+    // (a launch's grid may be padded, plan_xcd_grid: the largest of the sweep's launches - the full ones and the last one)
+    int grid_rows = 0;
+    const int full_rows = std::min(rows_per_launch, row_blocks);
+    for (int rows : {full_rows, row_blocks % rows_per_launch ? row_blocks % rows_per_launch : full_rows}) {
+      int xr, xs, rg;
+      plan_xcd_grid(c, rows, nsplit, dict_tile(c), f16, &xr, &xs, &rg);
+      grid_rows = std::max(grid_rows, rg);
+    }
+    const size_t scratch16 = f16 ? kpdi::match16_scratch_bytes(grid_rows * nsplit, c->f16_waves, list_len) : 0;
+    launched_rows = grid_rows;
     if (f16) HIPCHK(c->list16.reserve((two ? 2 : 1) * scratch16));
     for (int r0 = 0; r0 < row_blocks; r0 += rows_per_launch, ++j) {
       ml.row_first = r0;
       ml.rows = std::min(rows_per_launch, row_blocks - r0);
-      plan_xcd_grid(c, ml.rows, nsplit, dict_tile(c), &ml.xcd_rows, &ml.xcd_splits);
+      plan_xcd_grid(c, ml.rows, nsplit, dict_tile(c), f16, &ml.xcd_rows, &ml.xcd_splits, &ml.rows_grid);
       hipStream_t st = (two && (j & 1)) ? c->stream2 : c->stream;
       if (f16) {
         // launches on the two streams overlap: each stream has its own list scratch
@@ -797,7 +817,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
       tl.nsplit = ns_t;
       tl.tile_groups = 1;
       tl.fixed_draws = 3;
-      tl.xcd_rows = tl.xcd_splits = 0;
+      tl.xcd_rows = tl.xcd_splits = tl.rows_grid = 0;
       tl.part_scores = c->tail_s.as<float>();
       tl.part_idx = c->tail_i.as<int>();
       tl.tile_ctr = c->tile_ctr.as<unsigned>() + ctr_bytes / sizeof(unsigned);  // (initialised with the main launch's)
@@ -822,7 +842,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   c->cnt.match_launches += 1;
   c->cnt.match_form = operand_form(c);
   c->cnt.match_flops += 2.0 * (double)c->m * (double)n_chunk * (double)c->k_kept;
-  c->cnt.match_grid = std::min(rows_per_launch, row_blocks) * nsplit;
+  c->cnt.match_grid = launched_rows * nsplit;  // workgroups of the sweep's largest launch (its padding included)
   c->cnt.match_nsplit = nsplit;
   return KPDI_OK;
 }

@@ -2,7 +2,10 @@
 // choose_nsplit).  Units: the time of one 128-pattern dictionary tile of match.hip against one 256-pattern row block.
 // Fitted on profiles/r03_form_choice.json and r03_form_choice_run3.json (tools/form_probe.py: both kernels forced over N = 6 250 .. 300 000, M = 512 ..
 // 40 000, K = 2819 / 3600 / 14 400 on one MI355X); tests/test_gpu_engine.py re-measures a sub-grid and fails when the
-// automatic choice is more than 2 % behind the better kernel.
+// automatic choice is more than 3 % behind the better kernel.  Round 4 (profiles/r04_form_choice.json, 80 shapes, after the
+// wide kernel's first tile became 0.04 ms cheaper and launches of 29 row blocks kept their XCD grid): worst point 2.9 %
+// (10 000 x 50 000 x 120^2 -> wide), mean 0.08 %; FORM_WIDE_LAUNCH = 1.0 / 1.05 re-measured on the whole grid: worst 3.1 /
+// 3.0 %, mean 0.16 % - the constants stay.
 #pragma once
 namespace kpdi {
 // PLANNING (choose_nsplit): cost factor of a plan whose dictionary splits are not a multiple of 8 - such a launch has no XCD

@@ -73,6 +73,8 @@ struct MatchLaunch {
   int tile_groups;     // (unused)
   int fixed_draws = 3; // tiles per workgroup that are fixed (sp + j * nsplit) before it draws from the counter
   int xcd_rows = 0, xcd_splits = 0;  // XCD grid over a launch's (row block, split) workgroups, 0 = plain mapping
+  int rows_grid = 0;                 // rows rounded up to a multiple of xcd_rows (0 = rows): the launch has rows_grid * nsplit
+                                     // workgroups, those of the row blocks [rows, rows_grid) leave at once
   int operand_form;    // 0 = f32, 1 = split-f16 (KPDI_COMPUTE_F16X2), 2 = f16 (KPDI_COMPUTE_F16), see match.hip
   int row_tiles = 4;   // 4: units of work = 128-pattern tiles; 1: the tail form - 32-pattern units (f32 only)
   int row_base = 0;    // tail form: dictionary row (of this chunk) of unit 0, a multiple of 32; `n_tiles` counts units

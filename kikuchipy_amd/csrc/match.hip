@@ -161,6 +161,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 1) void match_topk_kernel(MatchArgs 
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   int sp, rb;
   block_rb_sp(a, blockIdx.x, &rb, &sp);
+  if (rb >= a.rows) return;  // (a workgroup of the padding of the XCD grid: whole workgroup, before any barrier)
   rb += a.row_first;
   // kernel arguments into locals (nothing below takes the address of `a`)
   const float *a_dict = a.dict;
@@ -505,8 +506,9 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   g.xcd_rows = a.xcd_rows;
   g.xcd_splits = a.xcd_splits;
   g.rows = a.rows;
+  g.rows_grid = a.xcd_rows > 0 && a.rows_grid > a.rows ? a.rows_grid : a.rows;
   g.row_base = a.row_base;
-  const int grid = a.rows * a.nsplit;
+  const int grid = g.rows_grid * a.nsplit;
   const bool bounded = a.bound_score != nullptr;
   if (a.operand_form == 2) return hipErrorInvalidValue;  // the float16 form has its own kernel: launch_match16
   if (a.row_tiles == 1) {  // tail form: f32, single pass

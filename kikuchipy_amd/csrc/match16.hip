@@ -171,6 +171,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
   const int wr = wv / G::WC, wc = wv % G::WC;
   int sp, rb;
   block_rb_sp(a, blockIdx.x, &rb, &sp);
+  if (rb >= a.rows) return;  // (a workgroup of the padding of the XCD grid: whole workgroup, before any barrier)
   rb += a.row_first;
   const int n_tiles = a.n_tiles, n_valid = a.n_valid, idx_base = a.idx_base;
   const int nsteps = (2 * a.kpad) / G::BK;
@@ -758,7 +759,7 @@ static hipError_t launch16_t(const MatchArgs &args, int grid, void *scratch, hip
 
 template <int WAVES>
 static hipError_t launch16_w(const MatchLaunch &a, const MatchArgs &g, void *scratch, hipStream_t s) {
-  const int grid = a.rows * a.nsplit;
+  const int grid = g.rows_grid * a.nsplit;
   const bool bounded = a.bound_score != nullptr;
   switch (a.list_len) {
     case 1: return bounded ? launch16_t<1, true, WAVES>(g, grid, scratch, s) : launch16_t<1, false, WAVES>(g, grid, scratch, s);
@@ -775,7 +776,7 @@ static hipError_t launch16_w(const MatchLaunch &a, const MatchArgs &g, void *scr
 
 // the float32 form (operand_form 3): exact f32 products on the one-wave-per-SIMD kernel
 static hipError_t launch16_f32(const MatchLaunch &a, const MatchArgs &g, void *scratch, hipStream_t s) {
-  const int grid = a.rows * a.nsplit;
+  const int grid = g.rows_grid * a.nsplit;
   const bool bounded = a.bound_score != nullptr;
   switch (a.list_len) {
     case 1:
@@ -819,6 +820,7 @@ hipError_t launch_match16(const MatchLaunch &a, int waves, void *list_scratch, h
   g.xcd_rows = a.xcd_rows;
   g.xcd_splits = a.xcd_splits;
   g.rows = a.rows;
+  g.rows_grid = a.xcd_rows > 0 && a.rows_grid > a.rows ? a.rows_grid : a.rows;
   if (a.operand_form == 3) return launch16_f32(a, g, list_scratch, s);
   return waves == 4 ? launch16_w<4>(a, g, list_scratch, s) : launch16_w<8>(a, g, list_scratch, s);
 }

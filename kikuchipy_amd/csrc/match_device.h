@@ -27,7 +27,7 @@ struct MatchArgs {
   // A workgroup's first `fixed_draws` tiles are fixed (split sp: sp, sp + nsplit, ...), the rest is drawn
   // from the row block's counter.  xcd_rows x xcd_splits = 8 arranges the 8 XCDs as a grid over the launch's
   // (row block, split) workgroups (block_rb_sp below); xcd_rows = 0: block b -> (b / nsplit, b % nsplit).
-  int fixed_draws, xcd_rows, xcd_splits, rows;
+  int fixed_draws, xcd_rows, xcd_splits, rows, rows_grid;  // rows_grid >= rows: see block_rb_sp
   // match16.hip, float32 form: the tiles [tail_first, n_tiles) are handed out as units of 256 >> tail_shift rows
   // (tail_shift = 1, 2; 0 = whole tiles only): the last round of a launch then costs a half / a quarter of a tile-time
   int tail_first, tail_shift;
@@ -41,6 +41,8 @@ struct MatchArgs {
 // that an XCD hosts (rows / xcd_rows) row blocks x (nsplit / xcd_splits) splits: its L2 then serves a
 // dictionary tile to all its row blocks and an experimental slab to all its splits - with fixed draws and
 // workgroups advancing at the same pace the operands cross the fabric once per XCD, not once per workgroup.
+// The grid is laid over rows_grid >= rows row blocks (rows rounded up to a multiple of xcd_rows, so that a launch of,
+// say, 29 row blocks keeps its rectangles): a workgroup whose row block is >= rows has nothing to do and returns.
 __device__ __forceinline__ void block_rb_sp(const MatchArgs &a, int b, int *rb, int *sp) {
   if (a.xcd_rows == 0) {
     *sp = b % a.nsplit;
@@ -48,8 +50,11 @@ __device__ __forceinline__ void block_rb_sp(const MatchArgs &a, int b, int *rb, 
     return;
   }
   const int x = b & 7, j = b >> 3;
-  const int rx = a.rows / a.xcd_rows, sx = a.nsplit / a.xcd_splits;
-  *rb = (x / a.xcd_splits) * rx + j % rx;
+  const int rx = a.rows_grid / a.xcd_rows, sx = a.nsplit / a.xcd_splits;
+  // (a padded grid numbers its row blocks across the XCD row groups, so that the missing ones - the highest numbers -
+  // fall into different groups: 29 of 32 row blocks leave three groups of XCDs with 7 of 8 row blocks each instead of
+  // one group with 5 of 8)
+  *rb = a.rows_grid != a.rows ? (j % rx) * a.xcd_rows + x / a.xcd_splits : (x / a.xcd_splits) * rx + j % rx;
   *sp = (x % a.xcd_splits) * sx + j / rx;
 }
 
