@@ -7,7 +7,7 @@ tag=${1:-r02}
 shift || true
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 # the default step counts of bench.py (what the driver runs), without the informational legs
-cmd="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pcie --no-generation --check-rows 0 $*"
+cmd="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pcie --no-generation --no-rank-shares --check-rows 0 $*"
 D=$R/gpurun_out/prof_$tag
 rm -rf "$D"; mkdir -p "$D"
 echo "$cmd" > "$D/command.txt"
