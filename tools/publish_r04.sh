@@ -20,6 +20,6 @@ for key in ("config2", "config2_pipeline", "config4", "config5", "config5_f16_di
 json.dump(out, open("profiles/r04_rank_share.json", "w"), indent=1)
 PY
 cp $O/tile_ramp_probe.txt profiles/r04_tile_ramp_probe.txt
-tail -3 $O/pytest_gpu.log > profiles/r04_pytest_gpu.txt
+grep -a "passed\|failed" $O/pytest_gpu.log | tail -2 > profiles/r04_pytest_gpu.txt  # (the RCCL banner of the group tests prints after the summary line)
 for d in config4 config5_f16; do f=$(find $O/prof_$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f profiles/r04_${d}_kernel_stats.csv; done
 ls profiles | grep r04
