@@ -315,12 +315,12 @@ def test_large_experimental_set_takes_several_launches(k, metric):
     ko.assert_topk_parity(s[pos], i[pos], rs, ri, atol=ATOL)
 
 
-@pytest.mark.parametrize("compute", ["f32", "f16"])
-def test_a_launch_of_29_row_blocks_keeps_its_xcd_grid(monkeypatch, compute):
+@pytest.mark.parametrize("compute,keep_n", [("f32", 20), ("f16", 20), ("f32", 45), ("f16", 40)])
+def test_a_launch_of_29_row_blocks_keeps_its_xcd_grid(monkeypatch, compute, keep_n):
     """api.hip: plan_xcd_grid lays the XCD rectangles of a match16.hip launch over its row blocks ROUNDED UP to the
     grid (29 -> 32: the workgroups of the three missing row blocks leave at once; configs[3]'s last launch).  Same
     lists, bit for bit, as with the padding switched off (KPDI_XCD_PAD=0: 29 row blocks x 1 split per XCD), a larger
-    launch, and the oracle agrees."""
+    launch, and the oracle agrees (keep_n > 32: the bounded passes are padded launches too)."""
     from kikuchipy_amd import _lib
 
     rng = np.random.default_rng(29)
@@ -332,15 +332,15 @@ def test_a_launch_of_29_row_blocks_keeps_its_xcd_grid(monkeypatch, compute):
     for pad in ("0", "1"):
         monkeypatch.setenv("KPDI_XCD_PAD", pad)
         with _lib.Context(0) as c:
-            c.set_problem(16, 16, None, _lib.METRIC_NCC, 20, {"f32": _lib.COMPUTE_F32, "f16": _lib.COMPUTE_F16}[compute])
+            c.set_problem(16, 16, None, _lib.METRIC_NCC, keep_n, {"f32": _lib.COMPUTE_F32, "f16": _lib.COMPUTE_F16}[compute])
             c.set_experimental(exp)
             c.push_dictionary_chunk(dic[:3100], 0)
             c.push_dictionary_chunk(dic[3100:], 3100)
-            out[pad] = c.finalize(20) + (c.counters()["match_grid"],)
+            out[pad] = c.finalize(keep_n) + (c.counters()["match_grid"],)
     assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
     assert out["1"][2] == out["0"][2] // 29 * 32, (out["0"][2], out["1"][2])  # 29 x nsplit -> 32 x nsplit workgroups
     rows = np.arange(0, m, 211)
-    rs, ri = ko.dictionary_indexing(exp[rows], dic, metric="ncc", keep_n=20)
+    rs, ri = ko.dictionary_indexing(exp[rows], dic, metric="ncc", keep_n=keep_n)
     if compute == "f32":
         ko.assert_topk_parity(out["1"][0][rows], out["1"][1][rows], rs, ri, atol=ATOL)
     else:
