@@ -381,9 +381,19 @@ int kpdi_comm_init(kpdi_ctx *ctx, int rank, int nranks, const uint8_t *id);
  * member, and its entry points are the per-context ones fanned out -
  *   set_problem / set_keep_n / set_experimental / remove_*_background / set_master_pattern / set_detector: every member
  *       (the experimental set is replicated from the caller's ONE host buffer);
- *   push_* / hold_*: every dictionary chunk is block-assigned - member i takes rows
- *       [start_i, end_i) = the contiguous i-th of n_dev parts of the chunk (sizes differ by at most one), pushed with
- *       global_start + start_i, so a global index is still chunk start + row (`simulation_indices_i += start`, :118);
+ *   push_* / hold_*: a dictionary chunk is handed to the member(s) the assignment rule names (csrc/group_assign.h,
+ *       kpdi_group_assign_chunk).  With the dictionary size announced (kpdi_group_set_dictionary_size) member i has
+ *       a quota = the i-th of n_dev near-equal parts of the dictionary; a chunk goes to the member that has taken the
+ *       fewest patterns so far, never beyond its quota - the rest spills to the next.  A single-pass call (one chunk =
+ *       the dictionary) is thereby cut into the contiguous n_dev parts, while the chunks of a CHUNKED call - the
+ *       reference's own shape: n_per_iteration patterns per iteration, _dictionary_indexing.py:100-128 - stay whole
+ *       and go round the members (a tenth of the dictionary cut 8 ways would leave a member a fraction of one tile
+ *       round per launch).  Size unknown: a chunk is cut into min(n_dev, n_chunk / (2 tile rounds)) >= 1 near-equal
+ *       pieces for the least-loaded members.  A piece is pushed with global_start + its first row, so a global
+ *       index is still chunk start + row (`simulation_indices_i += start`, :118).  Pushes only QUEUE the pieces on the
+ *       members' host threads and return (at most 2 chunks wait per member): the next chunk can be fetched while
+ *       the previous ones are uploaded / generated / swept.  A failure of queued work is reported by the next
+ *       joining call (synchronize, finalize, any set_* call);
  *   finalize: the members' best-k lists are gathered and merged by the same (score desc, index asc) kernel used
  *       between chunks, and the caller gets ONE result - identical, bit for bit, to the single-context result.
  * Gather = KPDI_GATHER_RCCL: an in-process RCCL communicator (ncclCommInitAll - no sockets, no environment) and the
@@ -392,8 +402,9 @@ int kpdi_comm_init(kpdi_ctx *ctx, int rank, int nranks, const uint8_t *id);
  * devices), so the whole multi-device code path runs on a 1-GPU box.  KPDI_GATHER_AUTO: $KPDI_GATHER = "rccl" | "p2p"
  * if set, else P2P when a device appears twice, else RCCL (falling back to P2P, with the reason kept for
  * kpdi_group_describe, if the communicator cannot be created).  A group of one device gathers nothing.
- * Calls on a group are synchronous with respect to the members' host work (they return when every member's call has)
- * and, like the per-context calls, asynchronous with respect to the GPUs.  One thread at a time drives a group.
+ * Calls other than the chunk pushes are synchronous with respect to the members' host work (they return when every
+ * member's call has) and, like the per-context calls, asynchronous with respect to the GPUs.  One thread at a time
+ * drives a group.
  * The members stay reachable (kpdi_group_member) for the per-context calls that have no group form - device buffers,
  * counters, refinement; the caller must not use a member while a group call is running. */
 typedef struct kpdi_group kpdi_group;
@@ -407,8 +418,17 @@ int kpdi_group_size(const kpdi_group *g);
 int kpdi_group_gather(const kpdi_group *g);        /* the KPDI_GATHER_* mode in use */
 const char *kpdi_group_describe(const kpdi_group *g); /* "8 devices [0,1,...], gather rccl" (+ why a fallback was taken) */
 kpdi_ctx *kpdi_group_member(kpdi_group *g, int i); /* borrowed; NULL when i is out of range */
-/* rows [*start, *end) of an n-row chunk that member i of n_dev takes (the block assignment of the push / hold calls) */
+/* rows [*start, *end) of the i-th of n_dev near-equal contiguous parts of n rows (a member's quota of the dictionary) */
 int kpdi_group_chunk_share(int64_t n_chunk, int i, int n_dev, int64_t *start, int64_t *end);
+/* The assignment rule as a pure function (planning, tests; needs no GPU): the pieces of a chunk of n_chunk patterns
+ * for a group of n_dev members that have taken load[i] patterns so far (updated), dictionary size n_total (0 =
+ * unknown, then min_piece decides between the n_dev-way cut and a whole chunk).  Up to max_pieces pieces are written
+ * (member, first row, rows - in row order), *n_pieces = how many there are. */
+int kpdi_group_assign_chunk(int n_dev, int64_t n_total, int64_t min_piece, int64_t *load, int64_t n_chunk, int max_pieces,
+                            int *member_out, int64_t *row0_out, int64_t *rows_out, int *n_pieces);
+/* Dictionary patterns the coming sweep(s) will push in total (0 = unknown); starts a new assignment.  The members'
+ * takes are also reset by set_problem / set_keep_n / set_experimental* / reset_topk (a new sweep). */
+int kpdi_group_set_dictionary_size(kpdi_group *g, int64_t n_total);
 int kpdi_group_synchronize(kpdi_group *g);
 int kpdi_group_set_problem(kpdi_group *g, int sy, int sx, const uint8_t *signal_mask, int metric, int compute_dtype,
                            int keep_n);
@@ -421,8 +441,14 @@ int64_t kpdi_group_n_experimental(kpdi_group *g);
 int kpdi_group_remove_static_background(kpdi_group *g, const float *static_bg, int operation, int scale_bg);
 int kpdi_group_remove_dynamic_background(kpdi_group *g, int operation, int filter_domain, double std, double truncate);
 int kpdi_group_get_experimental(kpdi_group *g, void *patterns_out); /* member 0's (all members hold the same) */
+/* returns when the members' uploads have consumed `patterns` (reference loop: the chunk is a temporary, :106-108) */
 int kpdi_group_push_dictionary_chunk(kpdi_group *g, const void *patterns, int dtype, int64_t n_chunk,
                                      int64_t global_start);
+/* the same, returning at once: `patterns` is BORROWED until kpdi_group_chunks_consumed reports a ticket >= *ticket
+ * (tickets count up from 1), or until kpdi_group_synchronize / a finalize has returned */
+int kpdi_group_push_dictionary_chunk_borrowed(kpdi_group *g, const void *patterns, int dtype, int64_t n_chunk,
+                                              int64_t global_start, int64_t *ticket);
+int kpdi_group_chunks_consumed(kpdi_group *g, int64_t *ticket); /* every borrowed chunk up to *ticket has been consumed */
 /* explicit per-member chunks in device memory: member i sweeps n_chunk[i] patterns at d_patterns[i] (n_chunk[i] = 0:
  * nothing) whose first pattern has dictionary index global_start[i] */
 int kpdi_group_push_dictionary_chunk_dev(kpdi_group *g, const void *const *d_patterns, int dtype, const int64_t *n_chunk,

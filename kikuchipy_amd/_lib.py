@@ -158,6 +158,11 @@ SIGNATURES = {
     "kpdi_group_describe": (C.c_char_p, [_vp]),
     "kpdi_group_member": (_vp, [_vp, _i]),
     "kpdi_group_chunk_share": (_i, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "kpdi_group_assign_chunk": (_i, [_i, _i64, _i64, C.POINTER(_i64), _i64, _i, C.POINTER(_i), C.POINTER(_i64),
+                                     C.POINTER(_i64), C.POINTER(_i)]),
+    "kpdi_group_set_dictionary_size": (_i, [_vp, _i64]),
+    "kpdi_group_push_dictionary_chunk_borrowed": (_i, [_vp, _vp, _i, _i64, _i64, C.POINTER(_i64)]),
+    "kpdi_group_chunks_consumed": (_i, [_vp, C.POINTER(_i64)]),
     "kpdi_group_synchronize": (_i, [_vp]),
     "kpdi_group_set_problem": (_i, [_vp, _i, _i, _vp, _i, _i, _i]),
     "kpdi_group_set_keep_n": (_i, [_vp, _i]),
@@ -395,6 +400,10 @@ class Context:
         return out
 
     # -- sweep
+    def set_dictionary_size(self, n_total):
+        """How many dictionary patterns the coming sweep pushes in total.  One context sweeps them all whatever the
+        number; a `Group` plans its chunk assignment with it."""
+
     def push_dictionary_chunk(self, patterns, global_start):
         p = np.ascontiguousarray(patterns)
         # returns when the upload has consumed `p`; the sweep of the chunk runs on
@@ -750,6 +759,7 @@ class Group(Context):
         self.members = [Context(d, _borrowed=self._f.member(self._h, i)) for i, d in enumerate(ids)]
         self.root = self.members[0]
         self._keep = {}
+        self._borrowed = []  # (ticket, array): host chunks the members' uploads may still be reading
         self._keep_n = None
         self._compute = COMPUTE_F32
         self._projection_key = None
@@ -771,15 +781,65 @@ class Group(Context):
         if getattr(self, "_h", None) is not None and self._h.value:
             for m in self.members:
                 m._h = C.c_void_p()
-            self._f.destroy(self._h)
+            self._f.destroy(self._h)  # (joins the members' threads: nothing reads a borrowed chunk afterwards)
             self._h = C.c_void_p()
+            self._borrowed = []
 
     @staticmethod
     def chunk_share(n_chunk, i, n_dev):
-        """Rows [start, end) of an `n_chunk`-row chunk that member `i` of `n_dev` takes."""
+        """Rows [start, end) of the `i`-th of `n_dev` near-equal contiguous parts of `n_chunk` rows (a member's quota)."""
         a, b = C.c_int64(0), C.c_int64(0)
         check(load().kpdi_group_chunk_share(int(n_chunk), int(i), int(n_dev), C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    @staticmethod
+    def assign_chunk(n_dev, n_total, loads, n_chunk, min_piece=1):
+        """The library's chunk assignment (csrc/group_assign.h) as a pure function: [(member, first row, rows), ...]
+        for a chunk of `n_chunk` patterns; `loads` (list, one entry per member) is updated in place."""
+        ld = (C.c_int64 * n_dev)(*[int(v) for v in loads])
+        cap = n_dev + 1
+        mem, row0, rows, n = (C.c_int * cap)(), (C.c_int64 * cap)(), (C.c_int64 * cap)(), C.c_int(0)
+        check(load().kpdi_group_assign_chunk(int(n_dev), int(n_total), int(min_piece), ld, int(n_chunk), cap, mem, row0,
+                                             rows, C.byref(n)))
+        loads[:] = list(ld)
+        return [(mem[i], row0[i], rows[i]) for i in range(n.value)]
+
+    def set_dictionary_size(self, n_total):
+        check(self._f.set_dictionary_size(self._h, int(n_total)))
+
+    def push_dictionary_chunk(self, patterns, global_start):
+        """Queue the chunk on the member(s) that take it and return: the array is borrowed by the library (and kept
+        alive here) until the members' uploads have read it."""
+        p = np.ascontiguousarray(patterns)
+        t = C.c_int64(0)
+        check(self._f.push_dictionary_chunk_borrowed(self._h, _ptr(p), dtype_code(p.dtype), p.shape[0], int(global_start),
+                                                     C.byref(t)))
+        self._borrowed.append((t.value, p))
+        self._drop_consumed()
+
+    def _drop_consumed(self, everything=False):
+        if everything:
+            self._borrowed.clear()
+        elif self._borrowed:
+            t = C.c_int64(0)
+            check(self._f.chunks_consumed(self._h, C.byref(t)))
+            self._borrowed = [(k, a) for k, a in self._borrowed if k > t.value]
+
+    def synchronize(self):
+        super().synchronize()
+        self._drop_consumed(True)
+
+    def finalize(self, keep_n=None):
+        try:
+            return super().finalize(keep_n)
+        finally:
+            self._drop_consumed(True)  # (the group joins its members' host work before anything is gathered)
+
+    def finalize_async(self, keep_n=None):
+        try:
+            return super().finalize_async(keep_n)
+        finally:
+            self._drop_consumed(True)
 
     # -- what differs from a single context
     def set_problem(self, sy, sx, signal_mask=None, metric=METRIC_NCC, keep_n=20, compute=COMPUTE_F32):

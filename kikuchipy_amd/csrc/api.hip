@@ -2806,6 +2806,29 @@ int comm_init_all(kpdi_ctx *const *ctx, int n) {
   return KPDI_OK;
 }
 
+int finalize_precheck(kpdi_ctx *c, int kind) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!c->have_exp || !c->have_problem) return fail(KPDI_EINVAL, "nothing to finalise");
+  if (kind == FINALIZE_F64 && !c->exact64) return fail(KPDI_EINVAL, "kpdi_finalize_f64 needs a problem set up with KPDI_COMPUTE_F64");
+  if (kind == FINALIZE_ASYNC && c->exact64)
+    return fail(KPDI_EINVAL, "kpdi_finalize_async: not available in float64 arithmetic (use kpdi_finalize_f64)");
+  if (kind == FINALIZE_ASYNC && c->m == 0) return fail(KPDI_EINVAL, "no experimental patterns to finalise");
+  if (!c->exact64 && c->m > 0 && c->slots[0].pending && c->slots[1].pending)
+    return fail(KPDI_EINVAL, "two results are already pending: collect one with kpdi_finalize_wait first");
+  return KPDI_OK;
+}
+
+void gather_abandon(kpdi_ctx *c) {
+  if (c) c->p2p_ranks = 0;
+}
+
+int64_t sweep_round_rows(const kpdi_ctx *c) {
+  if (!c || !c->have_exp || c->m_pad <= 0) return 4096;
+  const int row_blocks = c->m_pad / kpdi::TILE_EXP;
+  const int per_row_block = std::max(1, c->n_cu * kpdi::match_blocks_per_cu() / row_blocks);
+  return (int64_t)per_row_block * kpdi::F16_TILE;
+}
+
 // RCCL gather, members other than the one that hands the result to the host: the all-gather + merge of
 // kpdi_finalize without the copies (every rank of a collective has to take part in it)
 int finalize_participate(kpdi_ctx *c) {

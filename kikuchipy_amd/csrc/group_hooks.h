@@ -23,6 +23,15 @@ struct ListsView {
 };
 
 int comm_init_all(kpdi_ctx *const *ctx, int n);
+// what would make the ROOT's finalize call refuse before it touches a device (no experimental set, wrong arithmetic for
+// the entry point, both result slots taken): checked before any member queues its half of a collective
+enum FinalizeKind { FINALIZE_F32 = 0, FINALIZE_F64 = 1, FINALIZE_ASYNC = 2 };
+int finalize_precheck(kpdi_ctx *root, int kind);
+// the root's finalize did not run (or failed): lists peer-copied for it must not wait for a later one
+void gather_abandon(kpdi_ctx *root);
+// dictionary patterns one full round of the context's sweep covers (every CU one tile): the unit below which a piece of
+// a chunk wastes most of a launch
+int64_t sweep_round_rows(const kpdi_ctx *c);
 int finalize_participate(kpdi_ctx *c);
 int member_lists_ready(kpdi_ctx *c, ListsView *v);
 int root_gather_p2p(kpdi_ctx *root, const ListsView *v, int n, hipEvent_t *read_done);

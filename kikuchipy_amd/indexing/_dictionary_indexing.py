@@ -283,6 +283,8 @@ def dictionary_indexing(
 
     ctx = metric.context
     ctx.set_keep_n(keep_n)
+    if resident is None:
+        ctx.set_dictionary_size(dict_size)  # (a group plans which member takes which chunk: kpdi_group_set_dictionary_size)
     rank, world = (comm.rank, comm.world_size) if comm is not None else (0, 1)
     if comm is not None:
         comm.attach(ctx)

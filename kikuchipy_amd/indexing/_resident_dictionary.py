@@ -78,6 +78,7 @@ class ResidentDictionary:
         metric._set_problem(self.shape[1:], 1)
         ctx = metric.context
         ctx.release_held()
+        ctx.set_dictionary_size(self.shape[0])  # (a group plans which member holds which chunk)
         if n_per_iteration is None:
             n_per_iteration = dictionary.chunksize[0] if _is_lazy(dictionary) else self.shape[0]
         rank, world = (comm.rank, comm.world_size) if comm is not None else (0, 1)

@@ -215,6 +215,9 @@ class _HipMetric(SimilarityMetric):
         n = patterns.shape[0]
         k_run = min(k, n)
         ctx.set_keep_n(k_run)
+        # (inside the reference's loop every chunk is a sweep of its own, collected at once: a group cuts it over its
+        # members only when the pieces are worth a launch each - the rule for an unannounced dictionary size)
+        ctx.set_dictionary_size(0)
         ctx.push_dictionary_chunk(patterns, 0)
         scores, indices = ctx.finalize(k_run)
         scores = scores.astype(self.dtype, copy=False)

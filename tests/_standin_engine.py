@@ -46,6 +46,9 @@ class StandInContext:
         self.keep_n = keep_n
         self.scores = None
 
+    def set_dictionary_size(self, n_total):
+        pass
+
     def set_experimental(self, patterns, navigation_mask=None):
         nav = None if navigation_mask is None else np.asarray(navigation_mask, dtype=bool).ravel()
         self.exp = patterns if nav is None else patterns[~nav]
@@ -173,7 +176,7 @@ class StandInContext:
 
 class StandInGroup:
     """Stand-in for `kikuchipy_amd._lib.Group`: N `StandInContext` members driven by one thread each, every chunk
-    block-assigned with the library's own `kpdi_group_chunk_share` (host code: loads without a GPU), the members' lists
+    handed out by the library's own `kpdi_group_assign_chunk` (host code: loads without a GPU), the members' lists
     merged like the group's peer-copy gather does.  Lets the host layer's `devices=` logic run on CPU."""
 
     def __init__(self, devices, gather=None):
@@ -186,6 +189,9 @@ class StandInGroup:
         self.gather = "p2p"
         self._pool = ThreadPoolExecutor(len(self.members))
         self.threads_seen = set()
+        self.n_total = 0
+        self.loads = [0] * len(self.members)
+        self.pieces = []  # (member, global start, rows) of every piece handed out
 
     def __len__(self):
         return len(self.members)
@@ -205,9 +211,15 @@ class StandInGroup:
     def set_keep_n(self, keep_n):
         self._all(lambda i, m: m.set_keep_n(keep_n))
         self.keep_n = keep_n
+        self.loads = [0] * len(self.members)
+
+    def set_dictionary_size(self, n_total):
+        self.n_total = int(n_total)
+        self.loads = [0] * len(self.members)
 
     def set_experimental(self, patterns, navigation_mask=None):
         self._all(lambda i, m: m.set_experimental(patterns, navigation_mask))
+        self.loads = [0] * len(self.members)
 
     @property
     def n_experimental(self):
@@ -216,10 +228,15 @@ class StandInGroup:
     def push_dictionary_chunk(self, patterns, global_start):
         from kikuchipy_amd import _lib
 
+        mine = {}
+        for member, row0, rows in _lib.Group.assign_chunk(len(self.members), self.n_total, self.loads, len(patterns), 4096):
+            mine[member] = (row0, rows)
+            self.pieces.append((member, global_start + row0, rows))
+
         def push(i, m):
-            a, b = _lib.Group.chunk_share(len(patterns), i, len(self.members))
-            if b > a:
-                m.push_dictionary_chunk(patterns[a:b], global_start + a)
+            if i in mine:
+                a, n = mine[i]
+                m.push_dictionary_chunk(patterns[a:a + n], global_start + a)
         self._all(push)
 
     def finalize(self, keep_n=None):

@@ -5,8 +5,8 @@ The reference's `EBSD.dictionary_indexing` is ONE call in ONE process (signals/e
 chunk loop of indexing/_dictionary_indexing.py:100-128).  A group shards every dictionary chunk over
 its members and hands back one merged result; because the merge is a total order (score desc, index
 asc) that result must equal the single-context result BIT FOR BIT - which is what these tests assert.
-Members may share a device (peer-copy gather), so the whole multi-device code path - threads, block
-assignment, gather, merge, pipelined hand-over - runs on a 1-GPU box; the in-process RCCL
+Members may share a device (peer-copy gather), so the whole multi-device code path - threads, chunk
+assignment and queues, gather, merge, pipelined hand-over - runs on a 1-GPU box; the in-process RCCL
 communicator is exercised with one member here and with one member per GPU in test_gpu_multigpu.py.
 """
 
@@ -53,6 +53,7 @@ def test_eight_in_process_shards_equal_the_single_sweep_at_full_size():
         s8, i8 = g.finalize(20)
         cnt = g.counters()
     assert np.array_equal(s1, s8) and np.array_equal(i1, i8)
+    # (a single pass nobody announced is still cut eight ways: pieces of three tile rounds each)
     # every member swept exactly its block of the chunk, member 0 merged eight lists
     assert cnt["gather_ranks"] == 8 and cnt["gather"] == "p2p"
     flops = [m["match_flops"] for m in cnt["members"]]
@@ -63,6 +64,152 @@ def test_eight_in_process_shards_equal_the_single_sweep_at_full_size():
     rows = np.arange(0, 4096, 128)
     rs, ri = c_oracle.rows_topk_f64(exp, [(0, dic)], rows, "ncc", 20, None)
     ko.assert_topk_parity(s8[rows], i8[rows], rs, ri, atol=1e-5)
+
+
+class Lazy:
+    """A Dask-like dictionary: sliced along axis 0, chunks materialised by `.compute()` inside the loop."""
+
+    def __init__(self, a, chunk, log=None):
+        self._a, self.shape, self.ndim, self.chunksize = a, a.shape, a.ndim, (chunk,) + a.shape[1:]
+        self.dtype, self.log = a.dtype, log if log is not None else []
+
+    def __getitem__(self, sl):
+        return Lazy(self._a[sl], self.chunksize[0], self.log)
+
+    def compute(self):
+        self.log.append(len(self._a))
+        return np.array(self._a)  # a fresh temporary per chunk, like Dask's
+
+
+def test_the_tutorial_call_on_eight_members_equals_the_single_sweep_at_full_size():
+    """configs[1] through the reference tutorial's call shape - `n_per_iteration` = 3044 patterns per iteration
+    (doc/tutorials/pattern_matching.ipynb:582; the loop of indexing/_dictionary_indexing.py:100-128) - on eight
+    members: whole chunks go round the members (csrc/group_assign.h), and the merged result is the single sweep's,
+    BIT FOR BIT, for an in-memory dictionary and for a lazy one whose chunks are temporaries."""
+    import kikuchipy_amd as ka
+    from kikuchipy_amd import _lib
+
+    exp, dic = synth(2024, 4096, 100000)
+    s1, i1 = single(exp, dic, _lib.METRIC_NCC, 20, _lib.COMPUTE_F32)
+    made = []
+    real = _lib.make_engine
+    _lib.make_engine = lambda *a, **k: made.append(real(*a, **k)) or made[-1]
+    try:
+        got = ka.dictionary_indexing(exp, dic, keep_n=20, n_per_iteration=3044, devices=[0] * 8, verbose=False)
+        grp = made[-1]
+        cnt = grp.counters()
+        lazy = Lazy(dic, 3044)
+        got_lazy = ka.dictionary_indexing(exp, lazy, keep_n=20, devices=[0] * 8, verbose=False)
+    finally:
+        _lib.make_engine = real
+    assert isinstance(grp, _lib.Group) and len(grp) == 8
+    assert np.array_equal(got.scores, s1) and np.array_equal(got.simulation_indices, i1)
+    assert np.array_equal(got_lazy.scores, s1) and np.array_equal(got_lazy.simulation_indices, i1)
+    assert lazy.log == [3044] * 32 + [100000 - 32 * 3044]
+    # every member swept its quota, in 4 whole chunks + its 324 patterns of the last one (not 33 pieces of 380)
+    per = [(m["match_flops"], m["match_launches"]) for m in cnt["members"]]
+    assert per == [(2.0 * 4096 * 12500 * 3600, 5)] * 8, per
+
+
+def test_generated_chunks_on_a_group_equal_the_single_device():
+    """`get_patterns(..., chunk_shape=3044)`: a lazy dictionary whose chunks are SIMULATED on the member that
+    sweeps them (only the rotations are queued)."""
+    import kikuchipy_amd as ka
+
+    rng = np.random.default_rng(11)
+    mp = ka.EBSDMasterPattern(rng.random((2, 201, 201)).astype(np.float32), hemisphere="both")
+    det = ka.EBSDDetector(shape=(60, 60), pc=(0.42, 0.78, 0.5))
+    q = rng.standard_normal((25000, 4))
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    sim = mp.get_patterns(q, det, compute=False, chunk_shape=3044)
+    assert sim.data.chunksize[0] == 3044
+    exp = rng.integers(0, 256, (32, 32, 60, 60), dtype=np.uint8)
+    s = ka.EBSD(exp)
+    a = s.dictionary_indexing(sim, keep_n=20, devices=[0], verbose=False)
+    b = s.dictionary_indexing(sim, keep_n=20, devices=[0] * 8, verbose=False)
+    assert np.array_equal(a.scores, b.scores) and np.array_equal(a.simulation_indices, b.simulation_indices)
+
+
+def test_queued_chunks_borrowed_buffers_and_late_errors():
+    """The mechanics under the chunked call: a push returns at once and BORROWS the array (tickets), a synchronous
+    push returns when its buffer has been consumed, and a queued chunk that fails is reported - with its member
+    named - by the next joining call."""
+    import ctypes as C
+
+    from kikuchipy_amd import _lib
+
+    dic = patterns(7, 4000)
+    exp = patterns(8, 100, dtype=np.uint8)
+    s1, i1 = single(exp, dic, _lib.METRIC_NCC, 10, _lib.COMPUTE_F32)
+    lib = _lib.load()
+    with _lib.Group([0] * 3) as g:
+        g.set_problem(12, 10, None, _lib.METRIC_NCC, 10, _lib.COMPUTE_F32)
+        g.set_experimental(exp, None)
+        g.set_dictionary_size(4000)
+        tickets = []
+        for a in range(0, 4000, 500):
+            chunk = np.array(dic[a:a + 500])  # a temporary: the Group keeps it alive while it is borrowed
+            g.push_dictionary_chunk(chunk, a)
+            tickets.append(g._borrowed[-1][0])
+            del chunk
+        assert tickets == list(range(1, 9))
+        s, i = g.finalize(10)
+        assert not g._borrowed
+        t = C.c_int64(-1)
+        _lib.check(lib.kpdi_group_chunks_consumed(g._h, C.byref(t)))
+        assert t.value == 8
+        assert np.array_equal(s, s1) and np.array_equal(i, i1)
+        # the C ABI's synchronous form: the buffer may be overwritten as soon as the call returns
+        g.reset_topk()
+        buf = np.empty((500, 12, 10), dtype=np.float32)
+        for a in range(0, 4000, 500):
+            buf[:] = dic[a:a + 500]
+            _lib.check(lib.kpdi_group_push_dictionary_chunk(g._h, buf.ctypes.data_as(C.c_void_p), 2, 500, a))
+        s, i = g.finalize(10)
+        assert np.array_equal(s, s1) and np.array_equal(i, i1)
+        # a queued chunk that cannot be pushed (dictionary index beyond int32): the push itself returns, the failure
+        # surfaces at the next joining call and names the member
+        g.reset_topk()
+        g.set_dictionary_size(0)
+        g.push_dictionary_chunk(dic[:100], 2**31 - 50)
+        with pytest.raises(_lib.KpdiError, match=r"group member \d of 3.*int32"):
+            g.synchronize()
+        g.reset_topk()  # the group stays usable
+        g.set_dictionary_size(4000)
+        g.push_dictionary_chunk(dic, 0)
+        s, i = g.finalize(10)
+        assert np.array_equal(s, s1) and np.array_equal(i, i1)
+
+
+def test_a_refused_finalize_leaves_the_collective_in_step():
+    """Argument and slot errors of a group finalize are found BEFORE any member queues its half of the gather
+    (kpdi::finalize_precheck): the group is still usable and the next result is right."""
+    import ctypes as C
+
+    from kikuchipy_amd import _lib
+
+    dic = patterns(3, 2500)
+    exp = patterns(4, 200, dtype=np.uint8)
+    s1, i1 = single(exp, dic, _lib.METRIC_NCC, 20, _lib.COMPUTE_F32)
+    lib = _lib.load()
+    for gather, ids in (("rccl", [0]), ("p2p", [0, 0, 0])):
+        with _lib.Group(ids, gather=gather) as g:
+            g.set_problem(12, 10, None, _lib.METRIC_NCC, 20, _lib.COMPUTE_F32)
+            g.set_experimental(exp, None)
+            g.push_dictionary_chunk(dic, 0)
+            assert lib.kpdi_group_finalize(g._h, None, None) != 0 and "NULL" in _lib.last_error()
+            t1, t2 = g.finalize_async(20), g.finalize_async(20)
+            with pytest.raises(_lib.KpdiError, match="two results are already pending"):
+                g.finalize_async(20)
+            with pytest.raises(_lib.KpdiError, match="two results are already pending"):
+                g.finalize(20)
+            out = C.c_double()
+            assert lib.kpdi_group_finalize_f64(g._h, C.byref(out), C.byref(out)) != 0 and "KPDI_COMPUTE_F64" in _lib.last_error()
+            for t in (t1, t2):
+                s, i = g.finalize_wait(t)
+                assert np.array_equal(s, s1) and np.array_equal(i, i1)
+            s, i = g.finalize(20)
+            assert np.array_equal(s, s1) and np.array_equal(i, i1)
 
 
 @pytest.mark.parametrize("members,metric,keep_n,compute,masked,chunk", [
@@ -181,7 +328,7 @@ def test_group_preprocessing_resident_and_generated_dictionaries():
             res.append(c.finalize(8) + (c.get_experimental(),))
     for a, b in zip(*res):
         assert np.array_equal(a, b)
-    # a dictionary prepared once, its chunks block-assigned to the members
+    # a dictionary prepared once, its chunks handed to the members whole (quota 667 / 667 / 666)
     r1 = ka.ResidentDictionary(dic, "ncc", n_per_iteration=900, device=0)
     r3 = ka.ResidentDictionary(dic, "ncc", n_per_iteration=900, devices=[0, 0, 0])
     assert r3.held[0] == 2000
