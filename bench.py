@@ -949,8 +949,9 @@ def main(argv=None, context_factory=None, group_factory=None):
             c64.close()
             out["extra"]["float64_mode"] = {
                 "what": "KPDI_COMPUTE_F64 (dtype=float64): f32 MFMA screen + float64 rescoring of keep_n + 12 candidates "
-                        "per pattern and chunk, with a STATISTICAL certificate (eps = 8 x the largest |f32 - f64| seen; "
-                        "KPDI_F64_EPS=worstcase makes it a proof)",
+                        "per pattern and chunk, certified with the WORST-CASE bound of a K-term f32 dot product ((K + 2) 2^-24: a "
+                        "proof for any data, the default; KPDI_F64_EPS=statistical = round 4's bound).  Cost of the proof over the "
+                        "statistical bound: none at configs[1] nor on an adversarial near-tie set (profiles/r05_f64_bounds.txt)",
                 "certificate": {1: "statistical", 2: "worstcase"}.get(int(cnt64.get("f64_certificate", 0))),
                 "patterns_per_s": round(w["m"] / dt64, 1),
                 "match_ms": round(cnt64["match_ms"] / 3, 3),

@@ -101,11 +101,14 @@ typedef struct kpdi_ctx kpdi_ctx;
  * KPDI_COMPUTE_F32 path screens keep_n + 12 candidates per pattern and chunk, csrc/rescore.hip rescores them in
  * double from the RAW patterns, keeps the best keep_n in double and checks that no unscreened candidate can
  * belong to them: an unscreened candidate's float32 score is at most the last screened one's, and its float64
- * score at most eps above its float32 score.  eps = 8 x the largest |f32 - f64| difference seen among the rescored
- * pairs of the sweep, at least 1e-6 - a STATISTICAL bound (about 1e5 samples per chunk, drawn from the best-scoring
- * pairs); with KPDI_F64_EPS=worstcase in the environment its floor is the worst-case error of a K-term float32 dot
- * product of unit vectors, (K + 2) 2^-24, i.e. a certificate for any data.  Where the check fails more screening
- * passes run; kpdi_counters.uncertified_patterns counts what is left (0 in every test and stress case).  Needs the
+ * score at most eps above its float32 score.  eps = the worst-case error of a K-term float32 dot product of unit
+ * vectors, (K + 2) 2^-24 (2.1e-4 at K = 3600): a certificate that holds for ANY data - the default since round 5 (the
+ * gap between the keep_n-th and the last screened score is an order of magnitude wider on ordinary data, so the proof
+ * costs no extra pass: profiles/r05_f64_bounds.txt, also on an adversarial near-tie set).  KPDI_F64_EPS=statistical in
+ * the environment selects round 4's bound instead: 8 x the largest |f32 - f64| difference seen among the rescored pairs
+ * of the sweep, at least 1e-6 (about 1e5 samples per chunk, drawn from the best-scoring pairs) - fewer passes where
+ * scores are closer than the worst case, no proof.  Where the check fails more screening passes run;
+ * kpdi_counters.uncertified_patterns counts what is left (0 in every test and stress case).  Needs the
  * raw chunk: not available for resident (held) dictionaries. */
 #define KPDI_COMPUTE_F64 3
 
@@ -475,6 +478,28 @@ int kpdi_group_pending_result_size(kpdi_group *g, int ticket, int64_t *n);
 int kpdi_group_set_profiling(kpdi_group *g, int on);
 int kpdi_group_reset_counters(kpdi_group *g);
 
+/* ---- the launch planner, as data (csrc/plan.h; needs no GPU) -----------------
+ * How a sweep of n_chunk dictionary patterns against m experimental patterns (k_kept pixels, keep_n) is laid on a
+ * device of n_cu compute units: which f32 kernel (`form` -1 = the automatic choice, 0 = match.hip's 128-pattern
+ * tiles, 3 = match16.hip's 256-pattern tiles), how many workgroups share a row block's dictionary tiles (nsplit), how
+ * many row blocks a launch covers, each launch's XCD grid (and its padding), the tail plan.  The environment's
+ * developer switches are read as kpdi_set_problem reads them. */
+#define KPDI_PLAN_MAX_LAUNCHES 64
+typedef struct kpdi_plan {
+  int32_t form, tile;          /* kernel form (0 / 3) and its dictionary patterns per tile */
+  int32_t row_blocks;          /* 256-pattern blocks of the experimental set */
+  int32_t n_tiles, nsplit, rows_per_launch, launches;
+  int64_t round_rows;          /* dictionary patterns one full round of the chip covers */
+  int32_t n_main;              /* tiles of the main launch(es) */
+  int32_t tail_tiles, tail_units, tail_nsplit, fixed_draws; /* match.hip: quarter-tile tail launch, fixed hand-out */
+  int32_t tail_first, tail_shift;                           /* match16.hip f32: partial units from tile tail_first on */
+  int32_t n_launch_desc;
+  struct {
+    int32_t row_first, rows, xcd_rows, xcd_splits, rows_grid;
+  } launch[KPDI_PLAN_MAX_LAUNCHES];
+} kpdi_plan;
+int kpdi_plan_describe(int64_t m, int64_t n_chunk, int k_kept, int keep_n, int n_cu, int form, kpdi_plan *out);
+
 /* ---- device buffers for callers that keep data resident (bench.py) -------- */
 int kpdi_dev_alloc(kpdi_ctx *ctx, size_t bytes, void **d_out);
 int kpdi_dev_free(kpdi_ctx *ctx, void *d_ptr);
@@ -510,7 +535,7 @@ typedef struct kpdi_counters {
   double comm_ms;                /* RCCL all-gather of the per-rank best-k lists inside kpdi_finalize (incl. waiting for the
                                     slowest rank to arrive) */
   double fixed_ms;               /* per-sweep bookkeeping kernels around the match: list / bound / counter initialisation */
-  int32_t f64_certificate;       /* KPDI_COMPUTE_F64: 1 = statistical bound (default), 2 = worst-case bound (KPDI_F64_EPS=worstcase
+  int32_t f64_certificate;       /* KPDI_COMPUTE_F64: 2 = worst-case bound (default), 1 = statistical bound (KPDI_F64_EPS=statistical
                                     at kpdi_set_problem); 0 = not float64 arithmetic.  `uncertified_patterns == 0` is a proof only for 2 */
   int32_t gather_ranks;          /* lists merged by the last finalize: RCCL ranks or peer-copied group members, 0 = this context's own only */
 } kpdi_counters;

@@ -89,6 +89,19 @@ class H5ebsdInfo(C.Structure):
     ]
 
 
+class PlanLaunch(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("row_first", "rows", "xcd_rows", "xcd_splits", "rows_grid")]
+
+
+class Plan(C.Structure):
+    """kpdi_plan (include/kpdi.h): what the launch planner decides for a sweep."""
+    _fields_ = ([(n, C.c_int32) for n in ("form", "tile", "row_blocks", "n_tiles", "nsplit", "rows_per_launch", "launches")]
+                + [("round_rows", C.c_int64)]
+                + [(n, C.c_int32) for n in ("n_main", "tail_tiles", "tail_units", "tail_nsplit", "fixed_draws", "tail_first",
+                                            "tail_shift", "n_launch_desc")]
+                + [("launch", PlanLaunch * 64)])
+
+
 # every symbol include/kpdi.h declares: (restype, argtypes)
 _vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 SIGNATURES = {
@@ -128,6 +141,7 @@ SIGNATURES = {
     "kpdi_nelder_mead_selftest": (_i, [_vp, _i, _i, _vp, _vp, _vp, C.c_double, C.c_double, _i, _i, _vp]),
     "kpdi_orientation_similarity_map": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "kpdi_dtype_size": (_sz, [_i]),
+    "kpdi_plan_describe": (_i, [_i64, _i64, _i, _i, _i, _i, C.POINTER(Plan)]),
     "kpdi_h5ebsd_info_read": (_i, [C.c_char_p, C.c_char_p, C.POINTER(H5ebsdInfo)]),
     "kpdi_h5ebsd_read_patterns": (_i, [C.c_char_p, C.c_char_p, _vp, _sz]),
     "kpdi_h5ebsd_read_static_background": (_i, [C.c_char_p, C.c_char_p, _vp, _sz]),
@@ -234,6 +248,13 @@ def device_count():
 
 def version():
     return load().kpdi_version().decode()
+
+
+def plan_describe(m, n_chunk, k_kept=3600, keep_n=20, n_cu=256, form=-1):
+    """The launch plan of a sweep (csrc/plan.h) as a `Plan`; host arithmetic, needs no GPU."""
+    p = Plan()
+    check(load().kpdi_plan_describe(int(m), int(n_chunk), int(k_kept), int(keep_n), int(n_cu), int(form), C.byref(p)))
+    return p
 
 
 def dtype_code(dtype):

@@ -38,9 +38,9 @@ class DictionaryIndexingResult:
         self.scan_unit = scan_unit
         self.patterns_per_second = patterns_per_second
         self.comparisons_per_second = comparisons_per_second
-        # float64 arithmetic (`dtype=float64`): how the float32 screen was certified - {"mode": "statistical" |
-        # "worstcase" (KPDI_F64_EPS=worstcase), "uncertified_patterns": n}; a result is the exact float64 best-k for
-        # ANY data only with mode "worstcase" and 0 uncertified patterns (include/kpdi.h, KPDI_COMPUTE_F64); else None
+        # float64 arithmetic (`dtype=float64`): how the float32 screen was certified - {"mode": "worstcase" (the
+        # default) | "statistical" (KPDI_F64_EPS=statistical), "uncertified_patterns": n}; a result is the exact float64
+        # best-k for ANY data with mode "worstcase" and 0 uncertified patterns (include/kpdi.h, KPDI_COMPUTE_F64); else None
         self.float64_certificate = float64_certificate
 
     @property

@@ -44,8 +44,8 @@ class TestDictionaryIndexing:
                                                 signal_mask=signal_mask, rechunk=True)
         assert np.allclose(xmap.scores[:, 0], 1, atol=ATOL)
         assert xmap.scores.dtype == np.float64
-        # float64 arithmetic says how it was certified (statistical bound by default, 0 patterns left uncertified)
-        assert xmap.float64_certificate == {"mode": "statistical", "uncertified_patterns": 0}
+        # float64 arithmetic says how it was certified (the worst-case bound by default: a proof, 0 patterns left uncertified)
+        assert xmap.float64_certificate == {"mode": "worstcase", "uncertified_patterns": 0}
         g = load_golden("di_dummy.npz")
         ko.assert_topk_parity(xmap.scores, xmap.simulation_indices, g["ncc_sigmask_f64_it2__scores"],
                               g["ncc_sigmask_f64_it2__indices"], atol=ATOL)

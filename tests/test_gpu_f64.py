@@ -139,7 +139,8 @@ def test_near_ties_below_the_f32_resolution(monkeypatch, n_near):
     relative - their float32 scores cannot rank them, their float64 scores can.  Whatever the engine returns with
     `uncertified_patterns == 0` must BE the float64 best-20 (scores, indices, order); where the near-copies
     outnumber what the screening passes can rescore (300 of them against 32 + 3 x 32) it must SAY so.  With the
-    statistical bound (8 x the largest |f32 - f64| seen) and with the worst-case one (KPDI_F64_EPS=worstcase)."""
+    worst-case bound (the default: `f64_certificate == 2`, a proof for any data) and with the statistical one
+    (KPDI_F64_EPS=statistical: 8 x the largest |f32 - f64| seen)."""
     rng = np.random.default_rng(12)
     m, n, s = 24, 900, 24
     dic = rng.random((n, s, s), dtype=np.float32)
@@ -152,13 +153,13 @@ def test_near_ties_below_the_f32_resolution(monkeypatch, n_near):
         dic[d] = t
     exp = np.clip(base * 255 + rng.normal(0, 2, (m, s, s)), 0, 255).astype(np.uint8)
     ref_s, ref_i = oracle64(exp, dic, "ncc", 20)
-    for mode in (None, "worstcase"):
+    for mode in (None, "statistical"):
         if mode:
             monkeypatch.setenv("KPDI_F64_EPS", mode)
         scores, idx, cnt = engine64(exp, dic, "ncc", 20)
         # the bound in force is read from the environment by every kpdi_set_problem and reported (a process-wide
         # static used to make the second leg re-run the statistical bound silently)
-        assert cnt["f64_certificate"] == (2 if mode else 1), (mode, cnt["f64_certificate"])
+        assert cnt["f64_certificate"] == (1 if mode else 2), (mode, cnt["f64_certificate"])
         if n_near == 40:
             assert cnt["uncertified_patterns"] == 0 and cnt["rescore_extra_passes"] >= 1, (mode, cnt)
         else:
