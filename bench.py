@@ -377,6 +377,7 @@ def spawn_ranks(n_ranks, argv, script=None):
     reader = threading.Thread(target=lambda: line.append(procs[0].stdout.read()), daemon=True)
     reader.start()
     rc = 0
+    failed = ""
     live = set(range(n_ranks))
     while live and rc == 0:
         for r in sorted(live):
@@ -385,7 +386,8 @@ def spawn_ranks(n_ranks, argv, script=None):
                 live.discard(r)
                 if code != 0:
                     rc = code
-                    print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+                    failed = f"rank {r} exited with code {code}"
+                    print(f"bench.py: {failed}", file=sys.stderr)
         time.sleep(0.05)
     for r in live:  # a rank failed: stop exactly the processes started here
         procs[r].terminate()
@@ -398,13 +400,55 @@ def spawn_ranks(n_ranks, argv, script=None):
     if rc == 0 and line and line[0]:
         sys.stdout.buffer.write(line[0])
         sys.stdout.flush()
-    return rc
+        return 0
+    if os.environ.get("KPDI_BENCH_NO_FALLBACK") or "--single-process" in argv:
+        return rc or 1
+    # last step of the fallback chain (see main): the same job as ONE process driving every GPU through a kpdi_group
+    why = f"one process per GPU failed ({failed or 'no line from rank 0'})"
+    print(f"bench.py: {why} - retrying as ONE process over {n_ranks} GPUs", file=sys.stderr, flush=True)
+    env = dict(os.environ, KPDI_BENCH_FALLBACK_REASON=why)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, script] + list(argv) + ["--single-process"], env=env).returncode
+
+
+_JSON_FD = None  # the real stdout, kept aside for the ONE JSON line (set once per process)
 
 
 def main(argv=None, context_factory=None, group_factory=None):
+    """The bench line - with the last step of the multi-GPU fallback chain around it.  One process per GPU is the form
+    the driver launches; its gather falls back from RCCL to the host-staged one by itself (Communicator.attach).  If the
+    multi-process run still fails (a rank cannot create its context, the control plane breaks, a rank dies with an
+    exception) rank 0 runs the job again as ONE process driving every GPU through a kpdi_group (--single-process: RCCL
+    inside the process, else peer copies), the other ranks step aside, and the line says what happened
+    (`multi_gpu.gather_fallback_reason`).  $KPDI_BENCH_NO_FALLBACK=1 keeps the failure a failure."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    args = list(sys.argv[1:] if argv is None else argv)
+    try:
+        return _main(args, context_factory, group_factory)
+    except Exception as e:  # noqa: BLE001
+        if world <= 1 or os.environ.get("KPDI_BENCH_NO_FALLBACK") or "--single-process" in args:
+            raise
+        reason = f"one process per GPU failed on rank {rank} ({type(e).__name__}: {e})"
+        print("bench.py: " + reason + (" - stepping aside" if rank else f" - retrying as ONE process over {world} GPUs"),
+              file=sys.stderr, flush=True)
+        if rank != 0:
+            return 0  # (exit code 0: a launcher must not tear rank 0 down for it)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            os.environ.pop(k, None)
+        os.environ["KPDI_BENCH_FALLBACK_REASON"] = reason
+        if "--gpus" in args:
+            args[args.index("--gpus") + 1] = str(world)
+        else:
+            args += ["--gpus", str(world)]
+        return _main(args + ["--single-process"], context_factory, group_factory)
+
+
+def _main(argv, context_factory=None, group_factory=None):
     """`context_factory(device) -> engine context` / `group_factory(devices, gather) -> engine group` replace
     `kikuchipy_amd._lib.Context` / `_lib.Group` in the CPU rehearsal of the multi-rank / multi-device control flow
     (tests/_bench_worker.py, tests/test_bench_multirank.py); never set otherwise."""
+    global _JSON_FD
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -446,15 +490,17 @@ def main(argv=None, context_factory=None, group_factory=None):
 
     single = a.single_process and a.gpus > 1 and "WORLD_SIZE" not in os.environ
     if "WORLD_SIZE" not in os.environ and a.gpus > 1 and not single:
-        return spawn_ranks(a.gpus, sys.argv[1:] if argv is None else argv,
-                           script=os.environ.get("KPDI_BENCH_SCRIPT"))
+        return spawn_ranks(a.gpus, argv, script=os.environ.get("KPDI_BENCH_SCRIPT"))
 
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line
     # version banner through C stdio when a communicator is created, flushed at exit): keep the real
     # stdout aside for the JSON line and point file descriptor 1 - Python's and C's - at stderr.
     sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+    if _JSON_FD is None:
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+    json_fd = _JSON_FD
+    fallback_reason = os.environ.get("KPDI_BENCH_FALLBACK_REASON", "")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -494,8 +540,10 @@ def main(argv=None, context_factory=None, group_factory=None):
     lo, hi = shard_range(w["n"], rank, world)
     n_local = hi - lo
 
-    if os.environ.get("KPDI_BENCH_FAIL_RANK") == str(rank):  # tests: a rank that dies must fail the whole run
+    if os.environ.get("KPDI_BENCH_FAIL_RANK") == str(rank) and world > 1:  # tests: a rank that dies (fallback chain, step 3)
         sys.exit(3)
+    if os.environ.get("KPDI_BENCH_RAISE_RANK") == str(rank) and world > 1:  # tests: ... with an exception, under a launcher
+        raise RuntimeError("injected failure (KPDI_BENCH_RAISE_RANK)")
     metric = {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[w["metric"]]
     compute = {"f32": _lib.COMPUTE_F32, "f16x2": _lib.COMPUTE_F16X2, "f16": _lib.COMPUTE_F16}[a.compute]
 
@@ -657,7 +705,8 @@ def main(argv=None, context_factory=None, group_factory=None):
             "keep_n": w["keep_n"],
             "parallelism": f"dictionary sharded over {n_gpus} GPU(s)" + (
                 f", ONE process (kpdi_group), {cnt.get('gather', '?')} gather + merge" if single else
-                ", one process per GPU, RCCL all-gather merge" if world > 1 else ""),
+                (", one process per GPU, host-staged gather (RCCL unusable) + merge" if comm.gather == "host" else
+                 ", one process per GPU, RCCL all-gather merge") if world > 1 else ""),
             "hand_over": ("every step's result is collected before the next step is queued" if a.no_pipeline else
                           "the result of step i reaches host memory while step i + 1 runs (finalize_async / finalize_wait); "
                           "all K results are collected inside the timed region"),
@@ -724,7 +773,11 @@ def main(argv=None, context_factory=None, group_factory=None):
         same = all(p["result_sha256"] == per_rank[0]["result_sha256"] for p in per_rank)
         assert same, f"ranks disagree on the merged result: {[p['result_sha256'][:12] for p in per_rank]}"
         ranks_in_comm = sorted({p["comm_ranks"] for p in per_rank})
-        rccl = not single or cnt.get("gather") == "rccl"
+        host_gather = not single and comm.gather == "host"  # the fallback of Communicator.attach (RCCL unusable)
+        rccl = (not single and not host_gather) or cnt.get("gather") == "rccl"
+        if host_gather:
+            assert ranks_in_comm == [0], f"host-staged gather, yet RCCL communicators of sizes {ranks_in_comm} are attached"
+            assert cnt.get("gather_ranks") == n_gpus, f"{cnt.get('gather_ranks')} lists merged, expected {n_gpus}"
         if rccl:
             assert ranks_in_comm == [n_gpus], f"RCCL communicator sizes {ranks_in_comm}, expected {n_gpus} on every rank"
         if single:  # member 0 merged one list per member, however they reached it
@@ -738,7 +791,10 @@ def main(argv=None, context_factory=None, group_factory=None):
         out["multi_gpu"] = {
             "rccl_ranks": n_gpus if rccl else 0,  # ncclCommCount of every rank's communicator (asserted above)
             "processes": 1 if single else world,
-            "gather": "rccl" if rccl else "p2p (hipMemcpyPeerAsync into GPU 0)",
+            "gather": ("rccl" if rccl else
+                       "host-staged (kpdi_export_lists -> TCP control plane -> kpdi_import_lists; same merge kernel)" if host_gather
+                       else "p2p (hipMemcpyPeerAsync into GPU 0)"),
+            "gather_fallback_reason": (comm.gather_reason if host_gather else fallback_reason) or None,
             "lists_merged": int(cnt.get("gather_ranks", 0)) if single else world,
             "identical_result_on_every_rank": same if not single else None,  # (one process: one result)
             "allgather_ms_per_step": round(max(p["comm_ms"] for p in per_rank) / a.steps, 4),
@@ -753,7 +809,9 @@ def main(argv=None, context_factory=None, group_factory=None):
             "control_plane": ("none: one process, one host thread per GPU inside libkpdi (kpdi_group); data path: "
                               + ("ncclAllGather on an ncclCommInitAll communicator" if rccl else "peer copies") + " inside kpdi_group_finalize"
                               if single else
-                              "kikuchipy_amd.parallel.SocketGroup (TCP, loopback); data path: ncclAllGather inside kpdi_finalize"),
+                              "kikuchipy_amd.parallel.SocketGroup (TCP, loopback); data path: "
+                              + ("the ranks' lists over the same TCP star, merged by kpdi_finalize" if host_gather
+                                 else "ncclAllGather inside kpdi_finalize")),
         }
 
     # ---- configs[2] inside the default run: circular signal mask (K = 2819) + static and dynamic

@@ -66,6 +66,7 @@ typedef struct kpdi_ctx kpdi_ctx;
 #define KPDI_ENODEV (-3)  /* no usable GPU */
 #define KPDI_ECOMM (-4)   /* RCCL error */
 #define KPDI_ENOMEM (-5)
+#define KPDI_ETIMEOUT (-6) /* a collective did not complete in time (kpdi_comm_selftest) */
 
 /* similarity metric: "ncc" / "ndp" of EBSD._prepare_metric (signals/ebsd.py:3058-3061) */
 #define KPDI_METRIC_NCC 0 /* zero-mean + L2 normalise, then dot product */
@@ -376,6 +377,20 @@ int kpdi_set_experimental_h5ebsd(kpdi_ctx *ctx, const char *path, const char *sc
 #define KPDI_UNIQUE_ID_BYTES 128
 int kpdi_comm_unique_id(uint8_t *id_out /* KPDI_UNIQUE_ID_BYTES */);
 int kpdi_comm_init(kpdi_ctx *ctx, int rank, int nranks, const uint8_t *id);
+/* The fallback chain of a multi-process job (kikuchipy_amd/parallel.py: Communicator.attach; the sharding replaces the
+ * chunk loop of indexing/_dictionary_indexing.py:100-128, whose merge :120-128 is what the gather feeds):
+ *   kpdi_comm_selftest - ONE all-gather of n_bytes per rank, awaited for at most timeout_ms (KPDI_ETIMEOUT): a
+ *       communicator that bootstrapped can still hang in its first collective;
+ *   kpdi_comm_drop - forget (abort) the communicator, also while a kpdi_comm_init of this context hangs on another
+ *       thread: finalize then returns this context's own lists, or what kpdi_import_lists gave it;
+ *   kpdi_export_lists / kpdi_import_lists - the HOST-STAGED gather: every rank exports its own m x keep_n lists
+ *       (scores float, or double in KPDI_COMPUTE_F64; indices int32), the caller's transport all-gathers them
+ *       (M * keep_n * 8 bytes per rank: 0.66 MB at configs[1]), every rank imports the n_ranks lists (rank-major) and
+ *       its next kpdi_finalize[_f64 / _async] merges them with the kernel - and the total order - of the RCCL path. */
+int kpdi_comm_selftest(kpdi_ctx *ctx, int64_t n_bytes, int timeout_ms);
+int kpdi_comm_drop(kpdi_ctx *ctx);
+int kpdi_export_lists(kpdi_ctx *ctx, void *scores_out, int32_t *indices_out);
+int kpdi_import_lists(kpdi_ctx *ctx, const void *scores_all, const int32_t *indices_all, int n_ranks);
 
 /* ---- multi-GPU from ONE process: a group of contexts ----------------------------------------------------
  * The reference's call is one call in one interpreter (signals/ebsd.py:1827-1984; its loop over dictionary

@@ -156,6 +156,10 @@ SIGNATURES = {
     "kpdi_result_indices_i32": (_i, [_vp, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(_i64)]),
     "kpdi_comm_unique_id": (_i, [_vp]),
     "kpdi_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "kpdi_comm_selftest": (_i, [_vp, _i64, _i]),
+    "kpdi_comm_drop": (_i, [_vp]),
+    "kpdi_export_lists": (_i, [_vp, _vp, _vp]),
+    "kpdi_import_lists": (_i, [_vp, _vp, _vp, _i]),
     "kpdi_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "kpdi_dev_free": (_i, [_vp, _vp]),
     "kpdi_h2d": (_i, [_vp, _vp, _vp, _sz]),
@@ -337,6 +341,7 @@ class Context:
         self._projection_key = None  # simulations.ProjectedDictionary.configure
         self.result_token = 0     # bumped by every finalize()
         self._last_valid = False   # the last finalize() succeeded: its lists may still be resident in HBM
+        self._host_gather = None   # a parallel.Communicator whose ranks gather their lists over the control plane
 
     # -- lifetime
     def close(self):
@@ -618,6 +623,8 @@ class Context:
         if self._keep_n is None or int(keep_n) != self._keep_n:
             raise KpdiError(f"finalize(keep_n={keep_n}) but the context keeps {self._keep_n} entries per pattern "
                             "(set_problem / set_keep_n)")
+        if self._host_gather is not None:  # no usable RCCL communicator: the ranks' lists travel over the control plane
+            self._host_gather.gather_lists(self)
         m = self.n_experimental
         indices = np.empty((m, keep_n), dtype=np.int64)
         if self._compute == COMPUTE_F64:  # float64 arithmetic: the rescored scores (csrc/rescore.hip)
@@ -651,6 +658,8 @@ class Context:
             keep_n = self._keep_n
         if self._keep_n is None or int(keep_n) != self._keep_n:
             raise KpdiError(f"finalize_async(keep_n={keep_n}) but the context keeps {self._keep_n} entries per pattern")
+        if self._host_gather is not None:  # (the host-staged gather is synchronous; merge and hand-over still overlap)
+            self._host_gather.gather_lists(self)
         t = C.c_int(-1)
         check(self._f.finalize_async(self._h, C.byref(t)))
         self.result_token += 1
@@ -681,6 +690,30 @@ class Context:
         if buf.size != UNIQUE_ID_BYTES:
             raise KpdiError("unique id must be 128 bytes")
         check(self._f.comm_init(self._h, int(rank), int(nranks), _ptr(buf)))
+
+    def comm_selftest(self, n_bytes=1 << 20, timeout_ms=60000):
+        """One all-gather of `n_bytes` per rank, awaited for at most `timeout_ms` (raises KpdiError otherwise)."""
+        check(self._f.comm_selftest(self._h, int(n_bytes), int(timeout_ms)))
+
+    def comm_drop(self):
+        """Forget the RCCL communicator: `finalize` returns this context's own lists (or imported ones)."""
+        check(self._f.comm_drop(self._h))
+
+    def export_lists(self):
+        """This context's OWN running best-k lists: (scores (m, keep_n) float32 / float64, indices (m, keep_n) int32)."""
+        m = self.n_experimental
+        scores = np.empty((m, self._keep_n), dtype=np.float64 if self._compute == COMPUTE_F64 else np.float32)
+        indices = np.empty((m, self._keep_n), dtype=np.int32)
+        check(self._f.export_lists(self._h, _ptr(scores), _ptr(indices)))
+        return scores, indices
+
+    def import_lists(self, scores_all, indices_all):
+        """(n_ranks, m, keep_n) lists of all ranks: the next finalize merges THEM (host-staged gather)."""
+        s = np.ascontiguousarray(scores_all, dtype=np.float64 if self._compute == COMPUTE_F64 else np.float32)
+        i = np.ascontiguousarray(indices_all, dtype=np.int32)
+        if s.shape != i.shape or s.ndim != 3 or s.shape[1:] != (self.n_experimental, self._keep_n):
+            raise KpdiError(f"import_lists: lists of shape {s.shape} / {i.shape}, expected (n_ranks, {self.n_experimental}, {self._keep_n})")
+        check(self._f.import_lists(self._h, _ptr(s), _ptr(i), s.shape[0]))
 
     # -- device buffers
     def dev_alloc(self, nbytes):

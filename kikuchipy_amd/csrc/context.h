@@ -24,6 +24,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -97,6 +98,7 @@ struct Rccl {
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;  // (optional: older libraries lack it)
   std::string why;  // why the last load() failed
   bool load() {
     if (lib) return true;
@@ -131,6 +133,7 @@ struct Rccl {
     KPDI_SYM(GetErrorString, "ncclGetErrorString")
     KPDI_SYM(CommCount, "ncclCommCount")
 #undef KPDI_SYM
+    CommAbort = (decltype(CommAbort))dlsym(h, "ncclCommAbort");
     GetUniqueId = t.GetUniqueId;
     CommInitRank = t.CommInitRank;
     CommInitAll = t.CommInitAll;
@@ -285,6 +288,9 @@ struct kpdi_ctx {
   // comm
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
+  // kpdi_comm_drop has run: a kpdi_comm_init that is still inside ncclCommInitRank on another thread (it hung, its caller
+  // gave up) must not install its communicator when it finally returns
+  std::atomic<bool> comm_dropped{false};
   // in-process groups (group.hip): the members' lists peer-copied into gather_s / gather_i (gather64_*) of the ROOT
   // member instead of an RCCL all-gather; `p2p_ranks` > 0 = that many lists are waiting there for the next finalize
   int p2p_ranks = 0;

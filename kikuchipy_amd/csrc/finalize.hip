@@ -4,6 +4,9 @@
 // (one of the host translation units api.hip was split into in round 5: context.h holds what they share)
 #include "context.h"
 
+#include <chrono>
+#include <thread>
+
 using namespace kpdi;
 
 namespace kpdi {
@@ -230,15 +233,126 @@ int kpdi_comm_init(kpdi_ctx *c, int rank, int nranks, const uint8_t *id) {
   int rc = use_device(c);
   if (rc) return rc;
   if (!g_rccl.load()) return fail(KPDI_ECOMM, "cannot load librccl: %s", g_rccl.why.c_str());
+  c->comm_dropped = false;
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof uid);
-  ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, uid, rank);
-  if (r != ncclSuccess) {
-    c->comm = nullptr;
+  ncclComm_t comm = nullptr;
+  ncclResult_t r = g_rccl.CommInitRank(&comm, nranks, uid, rank);
+  if (r != ncclSuccess)
     return fail(KPDI_ECOMM, "ncclCommInitRank(rank %d of %d, device %d): %s", rank, nranks, c->device, g_rccl.GetErrorString(r));
+  if (c->comm_dropped) {  // the caller gave up on this call long ago (kpdi_comm_drop from another thread)
+    if (g_rccl.CommAbort) g_rccl.CommAbort(comm);
+    return fail(KPDI_ECOMM, "the communicator was dropped while ncclCommInitRank was still running");
   }
+  c->comm = comm;
   c->rank = rank;
   c->nranks = nranks;
+  return KPDI_OK;
+}
+
+// One all-gather of `n_bytes` per rank on the context's stream, awaited for at most `timeout_ms`: a communicator whose
+// bootstrap succeeded can still hang in its first collective (shared-memory segments, IPC handles, peer access) - better
+// found here, where the caller can still fall back (kpdi_comm_drop + kpdi_export_lists / kpdi_import_lists), than in
+// the finalize of a sweep.
+int kpdi_comm_selftest(kpdi_ctx *c, int64_t n_bytes, int timeout_ms) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!c->comm) return fail(KPDI_EINVAL, "no communicator attached (kpdi_comm_init)");
+  if (n_bytes < 4 || n_bytes > (1ll << 30) || timeout_ms < 1) return fail(KPDI_EINVAL, "kpdi_comm_selftest: bad size / timeout");
+  int rc = use_device(c);
+  if (rc) return rc;
+  const size_t n = (size_t)n_bytes / 4;
+  unsigned *d_send = nullptr, *d_recv = nullptr;
+  HIPCHK(hipMalloc(&d_send, n * 4));
+  HIPCHK(hipMalloc(&d_recv, n * 4 * c->nranks));
+  std::vector<unsigned> h(n, 0x5eed0000u + (unsigned)c->rank);
+  HIPCHK(hipMemcpyAsync(d_send, h.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  ncclResult_t r = g_rccl.AllGather(d_send, d_recv, n, ncclUint32, c->comm, c->stream);
+  if (r != ncclSuccess) return fail(KPDI_ECOMM, "RCCL all-gather (self-test): %s", g_rccl.GetErrorString(r));
+  hipEvent_t done = nullptr;
+  HIPCHK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(done, c->stream));
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipEventQuery(done);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) return fail(KPDI_EHIP, "self-test all-gather: %s", hipGetErrorString(q));
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) {
+      // (the buffers stay allocated: the collective may still touch them until the communicator is aborted)
+      return fail(KPDI_ETIMEOUT, "the first RCCL all-gather (%lld bytes per rank, %d ranks) did not complete within %d ms", (long long)n_bytes,
+                  c->nranks, timeout_ms);
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+  (void)hipEventDestroy(done);
+  std::vector<unsigned> got(n * c->nranks);
+  HIPCHK(hipMemcpy(got.data(), d_recv, got.size() * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(d_send);
+  (void)hipFree(d_recv);
+  for (int j = 0; j < c->nranks; ++j)
+    if (got[(size_t)j * n] != 0x5eed0000u + (unsigned)j || got[(size_t)j * n + n - 1] != 0x5eed0000u + (unsigned)j)
+      return fail(KPDI_ECOMM, "self-test all-gather: the block of rank %d arrived damaged", j);
+  return KPDI_OK;
+}
+
+// Forget the communicator (aborting whatever it still has in flight): finalize then hands out this context's own lists,
+// or the lists given to kpdi_import_lists.  Safe to call while a kpdi_comm_init of this context hangs on another thread.
+int kpdi_comm_drop(kpdi_ctx *c) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  c->comm_dropped = true;
+  ncclComm_t comm = c->comm;
+  c->comm = nullptr;
+  c->rank = 0;
+  c->nranks = 1;
+  if (comm) {
+    if (g_rccl.CommAbort) g_rccl.CommAbort(comm);
+    else if (g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+  }
+  return KPDI_OK;
+}
+
+// This context's OWN running best-k lists (no gather): m x keep_n scores - float, or double in KPDI_COMPUTE_F64 - and
+// their int32 dictionary indices (INT32_MAX = unfilled), in ranking order.
+int kpdi_export_lists(kpdi_ctx *c, void *scores_out, int32_t *indices_out) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!c->have_exp || !c->have_problem) return fail(KPDI_EINVAL, "nothing to export");
+  if (!scores_out || !indices_out) return fail(KPDI_EINVAL, "output pointer is NULL");
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (c->m == 0) return KPDI_OK;
+  rc = own_lists(c);
+  if (rc) return rc;
+  const size_t n = (size_t)c->m * c->keep_n;
+  const void *d_s = c->exact64 ? c->run64_s.p : c->run_s[c->run_cur].p;
+  const int *d_i = c->exact64 ? c->run64_i.as<int>() : c->run_i[c->run_cur].as<int>();
+  HIPCHK(hipMemcpyAsync(scores_out, d_s, n * (c->exact64 ? sizeof(double) : sizeof(float)), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(indices_out, d_i, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KPDI_OK;
+}
+
+// The lists of `n_ranks` contexts (rank-major: [n_ranks][m * keep_n], as kpdi_export_lists wrote them) take the place of
+// an all-gather: the NEXT finalize of this context merges them - same kernel, same total order - instead of its own.
+// The host-staged gather of a multi-process job whose RCCL communicator cannot be used (kikuchipy_amd.parallel).
+int kpdi_import_lists(kpdi_ctx *c, const void *scores_all, const int32_t *indices_all, int n_ranks) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!c->have_exp || !c->have_problem) return fail(KPDI_EINVAL, "nothing to merge into");
+  if (!scores_all || !indices_all || n_ranks < 1) return fail(KPDI_EINVAL, "kpdi_import_lists: bad arguments");
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (c->m == 0) return KPDI_OK;
+  const size_t n = (size_t)c->m * c->keep_n * n_ranks;
+  const size_t es = c->exact64 ? sizeof(double) : sizeof(float);
+  DevBuf &gs = c->exact64 ? c->gather64_s : c->gather_s;
+  DevBuf &gi = c->exact64 ? c->gather64_i : c->gather_i;
+  HIPCHK(hipStreamSynchronize(c->stream));  // (a merge of the previous finalize may still read the gather buffers)
+  HIPCHK(gs.reserve(n * es));
+  HIPCHK(gi.reserve(n * sizeof(int)));
+  HIPCHK(hipMemcpyAsync(gs.p, scores_all, n * es, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(gi.p, indices_all, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));  // the caller's buffers are free again
+  c->cnt.h2d_bytes += (double)(n * (es + sizeof(int)));
+  c->p2p_ranks = n_ranks;
   return KPDI_OK;
 }
 

@@ -11,6 +11,15 @@ per rank over xGMI inside `kpdi_finalize`, followed by the same (score desc,
 index asc) merge kernel used between chunks, so every rank ends with the
 bit-identical global result.
 
+Fallback chain of that exchange (`Communicator.attach`): RCCL all-gather -> when
+the communicator cannot be created on some rank, or its first all-gather does
+not complete in time (the ranks agree over the control plane), a HOST-STAGED
+gather of the same lists over the control plane (`gather_lists`: 0.66 MB per rank
+at configs[1], 6.4 MB at configs[3]) feeding the same merge kernel -> and
+`bench.py` additionally retries as ONE process driving every GPU
+(`--single-process`: a `kpdi_group`, in-process RCCL or peer copies).  Which
+gather ran, and why, is kept in `Communicator.gather` / `.gather_reason`.
+
 Refinement shards the other way: every rank refines a contiguous block of the
 map's patterns (they are independent), and the per-pattern results (9 doubles)
 are concatenated over the control plane (`Communicator.all_gather_rows`).
@@ -32,6 +41,7 @@ import json
 import os
 import socket
 import struct
+import threading
 import time
 
 import numpy as np
@@ -43,6 +53,26 @@ def _prefer_dmabuf_ipc():
     runtime initialises (the first call into libkpdi), so it is set when a multi-rank `Communicator` is made - the only
     place that needs it - and not as a side effect of importing this package (`setdefault`: the user's choice stands)."""
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def _call_with_timeout(fn, timeout):
+    """None when `fn()` returned within `timeout` seconds, else what went wrong as text.  A call that never returns
+    (a collective bootstrap waiting for a rank that has already failed) is left behind on its daemon thread."""
+    box = []
+
+    def run():
+        try:
+            fn()
+            box.append(None)
+        except Exception as e:  # noqa: BLE001 - whatever it is, the ranks must hear about it
+            box.append(f"{type(e).__name__}: {e}")
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(timeout)
+    if not box:
+        return f"no answer within {timeout:g} s"
+    return box[0]
 
 
 def shard_range(n_total, rank, world_size):
@@ -344,16 +374,65 @@ class Communicator:
             return array
         return np.concatenate([np.asarray(b) for b in self._all_gather(array)], axis=0)
 
+    gather = None         # "rccl" | "host": how the ranks' lists are gathered (set by the first attach)
+    gather_reason = ""    # why the host-staged gather was taken
+
     def attach(self, ctx):
-        """Create the RCCL communicator of `ctx` once (collective call: every rank must attach
-        its context in the same order).  The attachment is recorded ON the context - not by
-        `id(ctx)`, which CPython hands to the next context once this one is collected: a new
-        context then looked attached, skipped `kpdi_comm_init` and silently merged nothing."""
+        """Make `ctx` part of the job's gather, once (collective call: every rank must attach its context in the
+        same order).  RCCL first: rank 0's unique id travels over the control plane, every rank creates its
+        communicator (`kpdi_comm_init`) and runs one all-gather through it (`kpdi_comm_selftest`), each under a timeout
+        ($KPDI_COMM_TIMEOUT seconds, default 60), and the ranks tell each other how that went.  Unless it went well
+        everywhere, every rank drops its communicator and the lists are gathered over the control plane instead
+        (`gather_lists`, called by the context's `finalize`); $KPDI_GATHER=host goes there directly.
+        The attachment is recorded ON the context - not by `id(ctx)`, which CPython hands to the next context once
+        this one is collected: a new context then looked attached, skipped `kpdi_comm_init` and silently merged nothing."""
         if self.world_size == 1 or getattr(ctx, "_comm", None) is self:
             return
-        uid = self.exchange_unique_id(ctx.comm_unique_id)
-        ctx.comm_init(self.rank, self.world_size, uid)
+        mode, why = self._negotiate(ctx)
         ctx._comm = self
+        ctx._host_gather = self if mode == "host" else None
+        self.gather, self.gather_reason = mode, why
+
+    def _negotiate(self, ctx):
+        timeout = float(os.environ.get("KPDI_COMM_TIMEOUT", "60"))
+        payload = None
+        if self.rank == 0:
+            if os.environ.get("KPDI_GATHER", "").lower() == "host":
+                payload = b"E" + b"KPDI_GATHER=host"
+            else:
+                try:
+                    payload = b"U" + ctx.comm_unique_id()
+                except Exception as e:  # noqa: BLE001 - librccl missing, no device ...
+                    payload = b"E" + f"rank 0: {e}".encode()
+        msg = self._broadcast(payload, 0)
+        if msg[:1] != b"U":
+            return "host", msg[1:].decode()
+        uid = msg[1:]
+        status = _call_with_timeout(lambda: ctx.comm_init(self.rank, self.world_size, uid), timeout)
+        statuses = self.all_gather(status)
+        stage = "kpdi_comm_init"
+        if all(st is None for st in statuses):
+            n_bytes = int(os.environ.get("KPDI_COMM_SELFTEST_BYTES", str(1 << 20)))
+            status = _call_with_timeout(lambda: ctx.comm_selftest(n_bytes, int(timeout * 1000)), timeout + 5)
+            statuses = self.all_gather(status)
+            stage = "first all-gather"
+        bad = [r for r, st in enumerate(statuses) if st is not None]
+        if not bad:
+            return "rccl", ""
+        try:
+            ctx.comm_drop()  # (every rank: a communicator that only some ranks hold would hang the first finalize)
+        except Exception:  # noqa: BLE001
+            pass
+        # (a rank that failed outright says more than the ranks that then waited for it in vain)
+        told = [r for r in bad if not statuses[r].startswith("no answer")] or bad
+        return "host", f"{stage} failed on rank {told[0]} ({statuses[told[0]]})"
+
+    def gather_lists(self, ctx):
+        """The host-staged gather: every rank's own best-k lists (`kpdi_export_lists`) all-gathered over the control
+        plane and handed to `ctx` (`kpdi_import_lists`), whose finalize then merges them like all-gathered ones."""
+        scores, indices = ctx.export_lists()
+        parts = self.all_gather((scores, indices))
+        ctx.import_lists(np.stack([np.asarray(p[0]) for p in parts]), np.stack([np.asarray(p[1]) for p in parts]))
 
     def close(self):
         if self.group is not None:

@@ -41,6 +41,9 @@ for kw in (dict(metric="ncc", n_per_iteration=1300), dict(metric="ncc", n_per_it
     box = comm.all_gather((res.scores, res.simulation_indices))
     assert all(np.array_equal(b[0], box[0][0]) and np.array_equal(b[1], box[0][1]) for b in box)
 comm.barrier()
+expect = os.environ.get("KPDI_TEST_EXPECT_GATHER")
+if expect:
+    assert comm.gather == expect, (comm.gather, comm.gather_reason)
 if comm.rank == 0:
-    print("RCCL_WORKER_OK", comm.world_size)
+    print("RCCL_WORKER_OK", comm.world_size, "gather", comm.gather, "|", comm.gather_reason)
 comm.close()

@@ -25,6 +25,8 @@ class StandInContext:
         self.device = device
         self.comm = None
         self._comm = None  # set by Communicator.attach, as on the real context
+        self._host_gather = None  # ... when the ranks gather over the control plane (no usable "RCCL")
+        self._imported = None
         self.pushed = []
         self.mem = {}
         self.scores = None
@@ -100,11 +102,16 @@ class StandInContext:
         if self.scores is None:  # a rank that pushed nothing contributes empty lists
             self.scores = np.full((len(self.exp), self.keep_n), -np.inf, dtype=np.float32)
             self.idx = np.full((len(self.exp), self.keep_n), np.iinfo(np.int64).max, dtype=np.int64)
-        if self.comm is None:
+        if self._host_gather is not None:  # as _lib.Context.finalize: export -> control plane -> import -> merge
+            self._host_gather.gather_lists(self)
+        if self._imported is not None:
+            box, self._imported = self._imported, None
+        elif self.comm is None:
             return self.scores, self.idx
-        t0 = time.perf_counter()
-        box = self._comm.all_gather((self.scores, self.idx))
-        self.t["comm_ms"] += (time.perf_counter() - t0) * 1e3
+        else:
+            t0 = time.perf_counter()
+            box = self._comm.all_gather((self.scores, self.idx))
+            self.t["comm_ms"] += (time.perf_counter() - t0) * 1e3
         s = np.full_like(self.scores, -np.inf)
         i = np.full_like(self.idx, np.iinfo(np.int64).max)
         for s_r, i_r in box:
@@ -125,9 +132,47 @@ class StandInContext:
     def comm_unique_id():
         return bytes(range(128))
 
+    # $KPDI_TEST_COMM_FAULT = "<what>:<rank>" injects what a broken fabric does on the GPU box (tests/test_comm_fallback.py):
+    # init_error - kpdi_comm_init fails at once on that rank; init_hang - it never returns there (the other ranks then
+    # hang in their own bootstrap, as ncclCommInitRank does); collective_hang - the communicator comes up everywhere but
+    # that rank's first all-gather never completes
+    @staticmethod
+    def _fault(what, rank):
+        import os
+
+        spec = os.environ.get("KPDI_TEST_COMM_FAULT", "")
+        return spec == f"{what}:{rank}"
+
     def comm_init(self, rank, nranks, uid):
+        from kikuchipy_amd import _lib
+
         assert uid == bytes(range(128)), "the unique id did not travel from rank 0"
+        if self._fault("init_error", rank):
+            raise _lib.KpdiError("libkpdi error -4: ncclCommInitRank(rank %d of %d, device 0): unhandled system error" % (rank, nranks))
+        if self._fault("init_hang", rank) or any(self._fault("init_hang", r) or self._fault("init_error", r) for r in range(nranks)):
+            time.sleep(3600)  # a bootstrap that waits for a rank that will never arrive
         self.comm = (rank, nranks)
+
+    def comm_selftest(self, n_bytes=1 << 20, timeout_ms=60000):
+        from kikuchipy_amd import _lib
+
+        rank, nranks = self.comm
+        if any(self._fault("collective_hang", r) for r in range(nranks)):  # one rank missing: nobody's all-gather completes
+            time.sleep(timeout_ms / 1e3)
+            raise _lib.KpdiError(f"libkpdi error -6: the first RCCL all-gather ({n_bytes} bytes per rank, {nranks} ranks) did not "
+                                 f"complete within {timeout_ms} ms")
+
+    def comm_drop(self):
+        self.comm = None
+
+    def export_lists(self):
+        if self.scores is None:
+            self.scores = np.full((len(self.exp), self.keep_n), -np.inf, dtype=np.float32)
+            self.idx = np.full((len(self.exp), self.keep_n), np.iinfo(np.int64).max, dtype=np.int64)
+        return self.scores, self.idx
+
+    def import_lists(self, scores_all, indices_all):
+        self._imported = list(zip(np.asarray(scores_all), np.asarray(indices_all)))
 
     # -- "device memory"
     def dev_alloc(self, nbytes):
@@ -168,7 +213,8 @@ class StandInContext:
     def counters(self):
         kept = int(np.prod(self.sig)) if self.mask is None else int(np.count_nonzero(~self.mask))
         return dict(self.t, k_kept=kept, kpad=kept, match_grid=0, match_nsplit=0, match_form=-1,
-                    comm_ranks=self.comm[1] if self.comm else 0)
+                    comm_ranks=self.comm[1] if self.comm else 0,
+                    gather_ranks=self._host_gather.world_size if self._host_gather is not None else (self.comm[1] if self.comm else 0))
 
     def close(self):
         self.mem = {}

@@ -236,6 +236,54 @@ def test_rccl_path_single_rank(synth_inputs):
     assert np.array_equal(again[0], ref[0]) and np.array_equal(again[1], ref[1])
 
 
+def test_host_staged_gather_entry_points(synth_inputs):
+    """kpdi_export_lists / kpdi_import_lists / kpdi_comm_selftest / kpdi_comm_drop (the fallback of a multi-process job
+    whose RCCL communicator cannot be used): three "ranks" sweep their dictionary blocks on one GPU, their exported
+    lists imported into one context and merged by its finalize == the single sweep, bit for bit - in float32 and in
+    float64 arithmetic; a one-rank communicator passes its self-test and can be dropped."""
+    from kikuchipy_amd import _lib
+    from kikuchipy_amd.parallel import shard_range
+
+    exp, dic, g = synth_inputs
+    k, world = 20, 3
+    for compute in (_lib.COMPUTE_F32, _lib.COMPUTE_F64):
+        lists = []
+        with _lib.Context(0) as c:
+            c.set_problem(60, 60, None, _lib.METRIC_NCC, k, compute)
+            c.set_experimental(exp)
+            c.push_dictionary_chunk(dic, 0)
+            ref_s, ref_i = c.finalize(k)
+            for r in range(world):
+                lo, hi = shard_range(len(dic), r, world)
+                c.reset_topk()
+                c.push_dictionary_chunk(dic[lo:hi], lo)
+                lists.append(c.export_lists())
+            assert lists[0][0].dtype == (np.float64 if compute == _lib.COMPUTE_F64 else np.float32) and lists[0][1].dtype == np.int32
+            assert lists[1][1].min() >= shard_range(len(dic), 1, world)[0]  # a rank's own lists: global indices of ITS block
+            c.import_lists(np.stack([s for s, _ in lists]), np.stack([i for _, i in lists]))
+            s, i = c.finalize(k)
+            assert c.counters()["gather_ranks"] == world
+            assert np.array_equal(s, ref_s) and np.array_equal(i, ref_i)
+            s2, i2 = c.finalize(k)  # the imported lists were consumed: this rank's own again
+            assert np.array_equal(i2, lists[-1][1])
+            with pytest.raises(_lib.KpdiError, match="expected"):
+                c.import_lists(np.zeros((2, 3, k), np.float32), np.zeros((2, 3, k), np.int32))
+    with _lib.Context(0) as c:
+        with pytest.raises(_lib.KpdiError, match="no communicator"):
+            c.comm_selftest()
+        c.comm_init(0, 1, _lib.Context.comm_unique_id())
+        c.comm_selftest(1 << 16, 20000)
+        assert c.counters()["comm_ranks"] == 1
+        c.comm_drop()
+        assert c.counters()["comm_ranks"] == 0
+        out = run_engine(c, exp, dic, keep_n=k, chunk=1000)
+        with _lib.Context(0) as c2:
+            ref = run_engine(c2, exp, dic, keep_n=k, chunk=1000)
+        assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
+        c.comm_init(0, 1, _lib.Context.comm_unique_id())  # a dropped context can get a communicator again
+        c.comm_selftest(1 << 12, 20000)
+
+
 def test_sharded_sweep_equals_full_sweep(synth_inputs):
     """What N ranks do, on one GPU: each 'rank' sweeps only its dictionary block
     (kikuchipy_amd.parallel.shard_range); merging the per-rank lists with the
