@@ -155,7 +155,12 @@ def check_result(w, exp, dic, bg, mask, scores, indices, n_rows, large, compute=
     return out
 
 
-def rank_share_leg(_lib, make_context, device, key, n_ranks, d_dic, dic_host, reps, n_check, shard_range, per=12500):
+F16_RANDOM_OPERAND_CEILING_TFLOPS = 1740.0  # bare v_mfma_f32_32x32x16_f16 loop on random f16 operands (power-bound at
+#                                             ~1.7 GHz): profiles/r03_mfma_power_probe.txt
+
+
+def rank_share_leg(_lib, make_context, device, key, n_ranks, d_dic, dic_host, reps, n_check, shard_range, per=12500,
+                   compute="f32"):
     """One rank's share of an 8-GPU configuration, on this GPU, inside the default run (configs[3] /
     configs[4] are quoted on 8 GPUs; what ONE of them does is measurable here): rank 0's dictionary shard
     (`shard_range(n, 0, n_ranks)`), the whole experimental set, inputs resident, the step pipelined as the timed
@@ -164,8 +169,12 @@ def rank_share_leg(_lib, make_context, device, key, n_ranks, d_dic, dic_host, re
     configs[3]: the shard is the first 37 500 patterns of the dictionary already resident (`d_dic`, the same uniform
     float32 generator).  configs[4]: 62 500 patterns of 120 x 120 - one generated block of 12 500 and four copies of it
     with the pixels rotated by a different offset each (distinct, mutually uncorrelated patterns; 3.6 GB on the device,
-    0.7 GB generated)."""
+    0.7 GB generated).  `compute="f16"`: the arithmetic configs[4] NAMES (fp16 MFMA, f32 accumulate; the dictionary
+    resident as float16, 1.8 GB): checked against the float64-accumulated oracle over the same float16-stored
+    dictionary with the mode's documented bound (2e-3, tests/test_gpu_fullsize.py::test_config5_rank_share_f16)."""
     w = WORKLOADS[key]
+    f16 = compute == "f16"
+    dict_np = np.float16 if f16 else np.float32
     m, sy, sx, keep = w["m"], w["sy"], w["sx"], w["keep_n"]
     npix = sy * sx
     lo, hi = shard_range(w["n"], 0, n_ranks)
@@ -174,19 +183,21 @@ def rank_share_leg(_lib, make_context, device, key, n_ranks, d_dic, dic_host, re
     exp = rng.integers(0, 256, (m, sy, sx), dtype=np.uint8)
     c = make_context(device)
     try:
-        c.set_problem(sy, sx, None, {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[w["metric"]], keep, _lib.COMPUTE_F32)
+        c.set_problem(sy, sx, None, {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[w["metric"]], keep,
+                      _lib.COMPUTE_F16 if f16 else _lib.COMPUTE_F32)
         d_exp = c.dev_alloc(exp.nbytes)
         c.h2d(d_exp, exp)
         if d_dic is not None:  # a prefix of the resident dictionary
             blocks = lambda: [(0, dic_host[:n_shard])]  # noqa: E731
             d_shard = d_dic
         else:
-            base = rng.random((per, npix), dtype=np.float32)
+            base = rng.random((per, npix), dtype=np.float32).astype(dict_np)
             shift = lambda b: base if b == 0 else np.roll(base, 2477 * b, axis=1)  # noqa: E731
             blocks = lambda: ((b * per, shift(b)[:min(per, n_shard - b * per)]) for b in range(-(-n_shard // per)))  # noqa: E731
-            d_shard = c.dev_alloc(n_shard * npix * 4)
+            es = np.dtype(dict_np).itemsize
+            d_shard = c.dev_alloc(n_shard * npix * es)
             for at, blk in blocks():
-                c.h2d(d_shard + at * npix * 4, np.ascontiguousarray(blk))
+                c.h2d(d_shard + at * npix * es, np.ascontiguousarray(blk))
         c.set_profiling("match")
         pending = None
         scores = indices = None
@@ -198,7 +209,7 @@ def rank_share_leg(_lib, make_context, device, key, n_ranks, d_dic, dic_host, re
                 c.synchronize()
                 t0 = time.perf_counter()
             c.set_experimental_dev(d_exp, exp.dtype, m)
-            c.push_dictionary_chunk_dev(d_shard, np.float32, n_shard, lo)
+            c.push_dictionary_chunk_dev(d_shard, dict_np, n_shard, lo)
             ticket = c.finalize_async(keep)
             if pending is not None:
                 scores, indices = c.finalize_wait(pending)
@@ -207,10 +218,46 @@ def rank_share_leg(_lib, make_context, device, key, n_ranks, d_dic, dic_host, re
         c.synchronize()
         dt = (time.perf_counter() - t0) / reps
         cnt = c.counters()
+        c.set_profiling(True)  # (untimed: the preparation of the shard, which is 10 % of the float16 step)
+        c.reset_counters()
+        c.set_experimental_dev(d_exp, exp.dtype, m)
+        c.push_dictionary_chunk_dev(d_shard, dict_np, n_shard, lo)
+        c.finalize(keep)
+        prep_ms = c.counters()["prep_ms"]
     finally:
         c.close()
     match_ms = cnt["match_ms"] / reps
     tflops = cnt["match_flops"] / reps / (match_ms * 1e-3) / 1e12
+    if f16:
+        rec = {
+            "what": f"{w['name']}: rank 0's share of {n_ranks} ranks on ONE MI355X in the arithmetic configs[4] names - "
+                    f"fp16 MFMA, f32 accumulate (compute=f16, REDUCED PRECISION), dictionary resident as float16 "
+                    f"({n_shard * npix * 2 / 1e9:.1f} GB), K = {npix}; the whole experimental set x dictionary patterns "
+                    f"[{lo}, {hi}), results collected while the next step runs",
+            "shard_patterns": int(n_shard), "ms_per_step": round(dt * 1e3, 3),
+            "patterns_per_s_before_the_allgather": round(m / dt, 1),
+            "match_ms": round(match_ms, 3), "prep_ms": round(prep_ms, 3),
+            "match_tflops": round(tflops, 1), "match_frac": round(tflops / 2500.0, 4),
+            "match_frac_of_random_operand_ceiling": round(tflops / F16_RANDOM_OPERAND_CEILING_TFLOPS, 4),
+            "peaks": {"dense_f16_mfma_tflops": 2500.0, "random_operand_ceiling_tflops": F16_RANDOM_OPERAND_CEILING_TFLOPS,
+                      "ceiling_source": "profiles/r03_mfma_power_probe.txt (bare MFMA loop on random f16: power-bound)"},
+            "match_form": int(cnt.get("match_form", 0)),
+        }
+        if n_check:
+            from oracle import c_oracle
+
+            t0 = time.perf_counter()
+            rows = np.sort(np.random.default_rng(5).choice(m, n_check, replace=False))
+            rs, ri = c_oracle.rows_topk_f64(exp[rows], ((at, blk.astype(np.float32).reshape(-1, sy, sx)) for at, blk in blocks()),
+                                            np.arange(n_check), w["metric"], keep, None)
+            worst = float(np.abs(scores[rows] - rs).max())
+            assert worst < 2e-3, f"float16 share: max |dscore| {worst:.2e} against the float64-accumulated oracle (bound 2e-3)"
+            rec["check"] = {"rows": int(n_check), "oracle": "oracle/kpdi_oracle_c.c rows_topk_f64 over the whole (float16-stored) shard",
+                            "bound": 2e-3, "max_abs_score_diff": worst,
+                            "best_match_agreement": float(np.mean(indices[rows][:, 0] == ri[:, 0])),
+                            "index_agreement": float(np.mean(indices[rows] == ri)),
+                            "seconds": round(time.perf_counter() - t0, 2)}
+        return rec
     rec = {
         "what": f"{w['name']}: rank 0's share of {n_ranks} ranks on ONE MI355X (the whole experimental set x dictionary "
                 f"patterns [{lo}, {hi})), inputs resident, results collected while the next step runs",
@@ -234,6 +281,76 @@ def rank_share_leg(_lib, make_context, device, key, n_ranks, d_dic, dic_host, re
                         "index_agreement": float(np.mean(indices[rows] == ri)),
                         "seconds": round(time.perf_counter() - t0, 2)}
     return rec
+
+
+def plugin_seam_leg(exp, dic, keep_n, n_per_iteration, device, ref_scores, ref_indices):
+    """What a user of an UNMODIFIED kikuchipy gets: the reference's own loop
+    (indexing/_dictionary_indexing.py:94-128 and `_match_chunk`, :172-203 - restated here call for call, NumPy in place
+    of Dask's pass-through of NumPy results) driving this package's metric PLUGIN with a host-resident dictionary.  Per
+    chunk: one upload, one sweep, one synchronous hand-over of the chunk's best-k, then the reference's host merge
+    (hstack + argsort + take_along_axis).  Returns patterns/s and where the time goes."""
+    import kikuchipy_amd as kpa
+
+    m, n = len(exp), len(dic)
+    metric = kpa.NormalizedCrossCorrelationMetric(n_experimental_patterns=m, n_dictionary_patterns=n, device=device)
+    ctx = metric.context
+    t = {"upload": 0.0, "sweep_and_hand_over": 0.0, "host_merge": 0.0}
+    push, fin = ctx.push_dictionary_chunk, ctx.finalize
+
+    def timed(fn, key):
+        def run(*args, **kw):
+            t0 = time.perf_counter()
+            try:
+                return fn(*args, **kw)
+            finally:
+                t[key] += time.perf_counter() - t0
+        return run
+
+    ctx.push_dictionary_chunk = timed(push, "upload")
+    ctx.finalize = timed(fin, "sweep_and_hand_over")
+    best = None
+    for rep in range(3):
+        for k in t:
+            t[k] = 0.0
+        t_start = time.perf_counter()
+        experimental = metric.prepare_experimental(exp)                       # :70
+        dictionary = dic.reshape((n, -1))                                     # :71
+        keep = min(keep_n, n)                                                 # :67
+        n_iterations = int(np.ceil(n / n_per_iteration))                      # :68
+        indices = np.zeros((m, keep), dtype=np.int32)                         # :97
+        scores = np.full((m, keep), -metric.sign, dtype=metric.dtype)         # :98
+        starts = np.cumsum([0] + [n_per_iteration] * (n_iterations - 1))      # :100-104
+        ends = np.cumsum([n_per_iteration] * n_iterations)
+        ends[-1] = max(ends[-1], n)
+        for start, end in zip(starts, ends):
+            k_i = min(keep, end - start)
+            simulated = metric.prepare_dictionary(dictionary[start:end])      # :193
+            similarities = metric.match(experimental, simulated)              # :195
+            idx_i = similarities.argtopk(k_i, axis=-1).reshape((-1, k_i))     # :197-201
+            scores_i = similarities.topk(k_i, axis=-1).reshape((-1, k_i))
+            t0 = time.perf_counter()
+            idx_i = idx_i + start                                             # :118
+            all_scores = np.hstack((scores, scores_i))                        # :120-128
+            all_idx = np.hstack((indices, idx_i))
+            order = np.argsort(-all_scores, axis=1)[:, :keep]
+            scores = np.take_along_axis(all_scores, order, axis=1)
+            indices = np.take_along_axis(all_idx, order, axis=1)
+            t["host_merge"] += time.perf_counter() - t0
+        total = time.perf_counter() - t_start
+        if best is None or total < best[0]:
+            best = (total, dict(t))
+    ctx.close()
+    total, split = best
+    return {
+        "n_per_iteration": int(n_per_iteration), "iterations": int(n_iterations),
+        "patterns_per_s": round(m / total, 1), "ms_per_call": round(total * 1e3, 2),
+        "ms_upload": round(split["upload"] * 1e3, 2),
+        "ms_sweep_and_hand_over": round(split["sweep_and_hand_over"] * 1e3, 2),
+        "ms_reference_host_merge": round(split["host_merge"] * 1e3, 2),
+        "ms_other_host": round((total - sum(split.values())) * 1e3, 2),
+        "max_abs_score_diff_vs_the_timed_result": float(np.abs(scores - ref_scores).max()),
+        "index_agreement_with_the_timed_result": float(np.mean(indices == ref_indices)),
+    }
 
 
 def cpu_baseline(w, exp, dic, bg, mask, n_sample):
@@ -972,12 +1089,13 @@ def _main(argv, context_factory=None, group_factory=None):
 
     # ---- the 8-GPU configurations, as far as one GPU can show them: rank 0's share of configs[3] and of configs[4]
     if a.workload == "config2" and solo and a.compute == "f32" and not a.no_rank_shares and context_factory is None:
-        for key, n_ranks, reps, dd in (("config2", 4, 40, d_dic), ("config2", 8, 40, d_dic), ("config4", 8, 3, d_dic),
-                                       ("config5", 8, 3, None)):
-            name = f"{key}_share_of_{n_ranks}"
+        for key, n_ranks, reps, dd, cmp in (("config2", 4, 40, d_dic, "f32"), ("config2", 8, 40, d_dic, "f32"),
+                                            ("config4", 8, 3, d_dic, "f32"), ("config5", 8, 3, None, "f32"),
+                                            ("config5", 8, 8, None, "f16")):
+            name = f"{key}_share_of_{n_ranks}" + ("_f16" if cmp == "f16" else "")
             try:
                 rec = rank_share_leg(_lib, _lib.Context, device, key, n_ranks, dd if dict_np == np.float32 else None, dic,
-                                     reps, 0 if a.check_rows == 0 else 16, shard_range)
+                                     reps, 0 if a.check_rows == 0 else 16, shard_range, compute=cmp)
                 if key == "config2":  # strong scaling of the headline job before the all-gather: this step / (t_1 / N)
                     rec["step_over_even_share"] = round(rec["ms_per_step"] / (ms_per_step / n_ranks), 4)
                 out["extra"][name] = rec
@@ -1021,6 +1139,19 @@ def _main(argv, context_factory=None, group_factory=None):
             }
         except Exception as err:  # an informational leg must not cost the bench line
             out["extra"]["float64_mode_error"] = f"{type(err).__name__}: {err}"
+
+    if solo and not a.no_pcie and a.workload == "config2" and a.compute == "f32" and context_factory is None:
+        # informational: the drop-in seam itself - the reference's loop driving the metric plugin (host-resident dictionary)
+        for per in (3044, 25000):  # the tutorial's tenth of its dictionary; a quarter of this one
+            try:
+                out["extra"].setdefault("plugin_seam", {
+                    "what": "an UNMODIFIED kikuchipy's loop (indexing/_dictionary_indexing.py:94-128, :172-203, restated in "
+                            "bench.py) driving kikuchipy_amd.NormalizedCrossCorrelationMetric at configs[1], dictionary in host "
+                            "memory: per chunk one upload, one sweep, one synchronous hand-over, the reference's host merge. "
+                            "Best of 3 calls; the stand-alone driver (`value`) keeps the best-k on the device instead"})
+                out["extra"]["plugin_seam"][f"n_per_iteration_{per}"] = plugin_seam_leg(exp, dic, w["keep_n"], per, device, scores, indices)
+            except Exception as err:  # an informational leg must not cost the bench line
+                out["extra"]["plugin_seam_error"] = f"{type(err).__name__}: {err}"
 
     if solo and not a.no_generation:
         try:

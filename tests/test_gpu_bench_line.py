@@ -38,10 +38,21 @@ def test_default_bench_line_and_its_legs():
     failed = {k: v for k, v in out["extra"].items() if k.endswith("_error")}
     assert not failed, failed
     for leg in ("config3", "config2_share_of_4", "config2_share_of_8", "config4_share_of_8", "config5_share_of_8",
-                "float64_mode", "f16_mode", "split_f16_mode", "resident_dictionary", "dictionary_generation", "refinement"):
+                "config5_share_of_8_f16", "plugin_seam", "float64_mode", "f16_mode", "split_f16_mode", "resident_dictionary", "dictionary_generation", "refinement"):
         assert leg in out["extra"], leg
     for leg in ("config2_share_of_8", "config4_share_of_8", "config5_share_of_8"):
         assert out["extra"][leg]["check"]["index_agreement"] == 1.0
+    # the arithmetic configs[4] NAMES (fp16 MFMA, f32 accumulate, K = 14 400, float16-resident dictionary), in the driver's line
+    f16 = out["extra"]["config5_share_of_8_f16"]
+    assert f16["match_form"] == 2 and f16["shard_patterns"] == 62500 and "float16" in f16["what"]
+    assert f16["check"]["rows"] == 16 and f16["check"]["max_abs_score_diff"] < f16["check"]["bound"] == 2e-3
+    assert f16["check"]["best_match_agreement"] >= 0.9
+    assert 0.3 < f16["match_frac"] < 1.0 and f16["match_frac"] < f16["match_frac_of_random_operand_ceiling"] < 1.1
+    assert out["extra"]["float64_mode"]["certificate"] == "worstcase" and out["extra"]["float64_mode"]["uncertified_patterns"] == 0
+    for per in (3044, 25000):  # the drop-in seam: the reference's loop around the plugin gives the timed run's result
+        seam = out["extra"]["plugin_seam"][f"n_per_iteration_{per}"]
+        assert seam["patterns_per_s"] > 0 and seam["max_abs_score_diff_vs_the_timed_result"] < 1e-6, seam
+        assert seam["index_agreement_with_the_timed_result"] > 0.999
     # one rank's share of an 8-rank job takes between an eighth and a quarter of the whole step
     share = out["extra"]["config2_share_of_8"]
     assert 1.0 <= share["step_over_even_share"] < 2.0, share
