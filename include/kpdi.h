@@ -187,7 +187,17 @@ int kpdi_get_experimental(kpdi_ctx *ctx, void *patterns_out);
  * of the chunk is still running; it is ordered before every later call on the context);
  * uploads go through two staging buffers on a copy stream and overlap the sweep of the
  * previous piece / chunk - also with KPDI_COMPUTE_F64, whose look at a chunk's certification (and the extra screening
- * passes it may ask for) is left to the next call on the context. */
+ * passes it may ask for) is left to the next call on the context.
+ * SMALL CHUNKS ARE SWEPT TOGETHER.  The reference's call hands over `n_per_iteration` patterns per iteration - a tenth
+ * of the dictionary in its tutorial, 3044 patterns - and one such chunk fills three quarters of ONE tile round of the
+ * chip.  A pushed chunk of fewer than two tile rounds (8192 patterns against 4096 experimental ones) therefore only
+ * joins the context's pending rows (its raw patterns are copied device-to-device); they are prepared and matched as
+ * one launch set once three rounds' worth have come in, or when anything reads or ends the sweep (finalize,
+ * synchronize, counters, export; a new experimental set, problem or keep_n forgets them with the running lists), and the
+ * merge kernel translates rows of the coalesced matrix back to dictionary indices.  Chunks join in rising
+ * dictionary order, one dtype, at most 16 per sweep; anything else sweeps the pending rows first.  The result never
+ * depends on it (tests/test_gpu_engine.py); not in KPDI_COMPUTE_F64 nor for keep_n > 32; KPDI_NO_COALESCE=1 switches
+ * it off.  configs[1] pushed as 33 chunks of 3044: 26.6 -> 23.6 ms per call (one pass: 21.3; profiles/r05_group_chunks.txt). */
 int kpdi_push_dictionary_chunk(kpdi_ctx *ctx, const void *patterns, int dtype,
                                int64_t n_chunk, int64_t global_start);
 int kpdi_push_dictionary_chunk_dev(kpdi_ctx *ctx, const void *d_patterns, int dtype,
@@ -553,6 +563,7 @@ typedef struct kpdi_counters {
   int32_t f64_certificate;       /* KPDI_COMPUTE_F64: 2 = worst-case bound (default), 1 = statistical bound (KPDI_F64_EPS=statistical
                                     at kpdi_set_problem); 0 = not float64 arithmetic.  `uncertified_patterns == 0` is a proof only for 2 */
   int32_t gather_ranks;          /* lists merged by the last finalize: RCCL ranks or peer-copied group members, 0 = this context's own only */
+  int64_t coalesced_sweeps;      /* sweeps that took several small pushed chunks together (kpdi_push_dictionary_chunk: coalescing) */
 } kpdi_counters;
 /* sizeof(kpdi_counters) as the LIBRARY was built: a binding whose struct differs must refuse to call kpdi_get_counters
  * (the struct has grown between versions; kpdi_version() changes with it) */

@@ -68,6 +68,7 @@ class Counters(C.Structure):
         ("fixed_ms", C.c_double),
         ("f64_certificate", C.c_int32),
         ("gather_ranks", C.c_int32),
+        ("coalesced_sweeps", C.c_int64),
     ]
 
     def as_dict(self):
@@ -814,6 +815,7 @@ class Group(Context):
         self.root = self.members[0]
         self._keep = {}
         self._borrowed = []  # (ticket, array): host chunks the members' uploads may still be reading
+        self._host_gather = None
         self._keep_n = None
         self._compute = COMPUTE_F32
         self._projection_key = None

@@ -145,6 +145,7 @@ static int set_experimental_common(kpdi_ctx *c, const void *src, bool src_on_dev
   c->have_exp = true;
   c->exp_prepared = false;
   c->run_valid = false;
+  discard_pending(c);
   c->final_valid = false;
   return KPDI_OK;
 }
@@ -229,7 +230,7 @@ int kpdi_destroy(kpdi_ctx *c) {
                     &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps, &c->inv_map, &c->pre_scratch,
                     &c->mp_packed, &c->dcos, &c->rot, &c->proj_out,
                     &c->ref_raw, &c->ref_map, &c->ref_rowcol, &c->ref_pat, &c->ref_sqn, &c->ref_in, &c->ref_out,
-                    &c->ref_idx, &c->osm_idx, &c->osm_out, &c->stage[0], &c->stage[1]})
+                    &c->ref_idx, &c->osm_idx, &c->osm_out, &c->stage[0], &c->stage[1], &c->pending.raw})
     b->release();
   for (auto *l : {&c->ev_match, &c->ev_prep, &c->ev_merge, &c->ev_proj, &c->ev_pre, &c->ev_rescore})
     for (auto &pr : *l) {
@@ -260,6 +261,10 @@ int kpdi_synchronize(kpdi_ctx *c) {
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
   int rc = use_device(c);
   if (rc) return rc;
+  if (c->have_exp && c->have_problem) {
+    rc = flush_pending(c);  // "everything pushed has been swept"
+    if (rc) return rc;
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->result_stream) HIPCHK(hipStreamSynchronize(c->result_stream));
   return KPDI_OK;
@@ -335,6 +340,7 @@ int kpdi_set_problem(kpdi_ctx *c, int sy, int sx, const uint8_t *signal_mask, in
   c->have_problem = true;
   c->exp_prepared = false;
   c->run_valid = false;
+  discard_pending(c);
   c->final_valid = false;
   c->cnt.kpad = c->kpad;
   c->cnt.k_kept = c->k_kept;
@@ -347,6 +353,7 @@ int kpdi_set_keep_n(kpdi_ctx *c, int keep_n) {
   if (keep_n <= 0) return fail(KPDI_EINVAL, "keep_n must be >= 1");
   c->keep_n = keep_n;
   c->run_valid = false;
+  discard_pending(c);
   c->final_valid = false;
   return KPDI_OK;
 }
@@ -394,6 +401,7 @@ int kpdi_remove_static_background(kpdi_ctx *c, const float *static_bg, int opera
   c->pend.bg_max = *std::max_element(static_bg, static_bg + c->npix);
   c->exp_prepared = false;
   c->run_valid = false;
+  discard_pending(c);
   c->final_valid = false;
   return KPDI_OK;
 }
@@ -459,6 +467,7 @@ int kpdi_remove_dynamic_background(kpdi_ctx *c, int operation, int filter_domain
   c->pend.centre = centre;
   c->exp_prepared = false;
   c->run_valid = false;
+  discard_pending(c);
   c->final_valid = false;
   return KPDI_OK;
 }
@@ -484,6 +493,7 @@ int kpdi_reset_topk(kpdi_ctx *c) {
   int rc = use_device(c);
   if (rc) return rc;
   c->run_valid = false;
+  discard_pending(c);
   c->final_valid = false;
   return KPDI_OK;
 }
@@ -534,6 +544,10 @@ int kpdi_get_counters(kpdi_ctx *c, kpdi_counters *out) {
   if (!c || !out) return fail(KPDI_EINVAL, "NULL argument");
   int rc = use_device(c);
   if (rc) return rc;
+  if (c->have_exp && c->have_problem) {
+    rc = flush_pending(c);  // (the counters cover everything pushed)
+    if (rc) return rc;
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   rc = drain_events(c, c->ev_match, &c->cnt.match_ms);
   if (rc) return rc;

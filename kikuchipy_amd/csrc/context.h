@@ -193,6 +193,19 @@ struct kpdi_ctx {
   };
   std::vector<HeldChunk> held;
   std::vector<int> kept_pixels;  // host copy of pix_map: tells whether a new problem keeps the layout
+  // Small chunks waiting for ONE sweep (sweep.hip: "coalescing").  The reference's loop hands the metric a tenth of the
+  // dictionary per iteration (doc/tutorials/pattern_matching.ipynb:582); swept alone such a chunk fills three quarters
+  // of one tile round.  Their RAW patterns are appended here and prepared + matched together once a few rounds have
+  // come in (or when the result is asked for); the merge translates rows back to dictionary indices (IndexSegments).
+  struct PendingChunks {
+    kpdi::DevBuf raw;      // [capacity rows][npix] of `dtype`
+    int dtype = -1;
+    int64_t rows = 0, capacity = 0;
+    struct Segment {
+      int64_t row0, n, start;  // rows [row0, row0 + n) hold the dictionary patterns [start, start + n)
+    };
+    std::vector<Segment> seg;
+  } pending;
   // host-pointer pushes are cut into pieces whose upload (copy stream) overlaps the sweep of
   // the previous piece (compute stream): two staging buffers, events for hand-over
   kpdi::DevBuf stage[2];
@@ -382,8 +395,13 @@ int local_pass(kpdi_ctx *c, const float *y, int n_chunk, int n_tiles, int nsplit
 int prepare_chunk(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, float *out);
 void decide_form(kpdi_ctx *c, int64_t n_chunk);
 int check_chunk_args(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_start);
-int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start);
-int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_start, const void *raw = nullptr, int raw_dtype = 0);
+// `may_wait`: the chunk is a whole push of the caller's (not a piece of a larger upload) and may wait, if it is small, for
+// more chunks to be swept with (flush_pending: before anything reads or resets the running lists)
+int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start, bool may_wait = false);
+int flush_pending(kpdi_ctx *c);
+void discard_pending(kpdi_ctx *c);
+int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_start, const void *raw = nullptr, int raw_dtype = 0,
+                   const IndexSegments *seg = nullptr);
 int new_held_chunk(kpdi_ctx *c, int64_t n_chunk, int64_t global_start, float **out);
 void release_held(kpdi_ctx *c);
 

@@ -22,7 +22,9 @@ Rccl g_rccl;
 namespace kpdi {
 // this rank's running lists, made presentable: a rank that pushed nothing contributes empty lists
 int own_lists(kpdi_ctx *c) {
-  int rc = ensure_running(c);
+  int rc = flush_pending(c);  // (small chunks that were waiting for company: swept now)
+  if (rc) return rc;
+  rc = ensure_running(c);
   if (rc) return rc;
   if (c->run_empty && !c->exact64) {
     const size_t n0 = (size_t)c->m * c->keep_n;

@@ -132,6 +132,16 @@ bool gather_descriptors(const int *pix_map, int k, int npix, std::vector<unsigne
 hipError_t launch_split_f16(float *prepared, int n_rows_pad, int kpad, hipStream_t s);
 
 // ---- top-k merge (merge.hip) -------------------------------------------------
+// Several small dictionary chunks swept as ONE launch (sweep.hip: coalescing) sit row after row in one prepared matrix;
+// the match kernel then ranks by the ROW of that matrix, and the merge translates rows to dictionary indices: segment t
+// holds the rows [row0[t], row0[t + 1]) and a row r of it is dictionary pattern r + delta[t].  Rows and dictionary
+// indices both increase from segment to segment, so "lower row first" among equal scores is "lower index first".
+constexpr int INDEX_SEGMENTS = 16;
+struct IndexSegments {
+  int n = 0;                    // 0: the sources hold dictionary indices already
+  int row0[INDEX_SEGMENTS];     // first row of segment t (INT_MAX: unused)
+  int delta[INDEX_SEGMENTS];    // dictionary index of a row of segment t = row + delta[t]
+};
 struct MergeLaunch {
   int m;                // experimental patterns
   int k;                // entries to produce per pattern
@@ -147,6 +157,8 @@ struct MergeLaunch {
   int *out_idx;
   int out_stride;
   int out_offset;       // first output column
+  IndexSegments seg;    // seg.n > 0: the sources in `seg_sources` (bit j = source j) hold ROWS of a coalesced matrix
+  unsigned seg_sources = 0;
 };
 hipError_t launch_merge(const MergeLaunch &a, hipStream_t s);
 hipError_t launch_fill_topk(float *scores, int *idx, int64_t n, hipStream_t s);

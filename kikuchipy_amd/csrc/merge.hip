@@ -47,7 +47,17 @@ struct MergeArgs {
   float *out_s;
   int *out_i;
   int out_stride, out_offset;
+  IndexSegments seg;
+  unsigned seg_sources;
 };
+
+// row of a coalesced matrix -> dictionary index (kernels.h: IndexSegments); INT_MAX (no entry) stays
+__device__ __forceinline__ int segment_index(const MergeArgs &a, int row) {
+  int d = a.seg.delta[0];
+#pragma unroll
+  for (int t = 1; t < INDEX_SEGMENTS; ++t) d = row >= a.seg.row0[t] ? a.seg.delta[t] : d;
+  return row == INT_MAX ? row : row + d;
+}
 
 __global__ __launch_bounds__(256) void merge_kernel(MergeArgs a) {
   const int lane = threadIdx.x & 63;
@@ -64,8 +74,9 @@ __global__ __launch_bounds__(256) void merge_kernel(MergeArgs a) {
       for (int c = lane; c < count; c += 64) {
         const int l = c / len;
         const size_t e = (size_t)l * a.list_stride[j] + (c - l * len);
-        const int idx = pi[e];
+        int idx = pi[e];
         if (idx == INT_MAX) continue;
+        if ((a.seg_sources >> j) & 1u) idx = segment_index(a, idx);
         const unsigned long long key = topk_key(ps[e], idx);
         if (key < prev && key > best) best = key;
       }
@@ -111,7 +122,11 @@ __device__ __forceinline__ unsigned long long candidate_key(const MergeArgs &a, 
   // local + 0.5 is at least 1/64 away from an integer (and float holds it to 2^-9)
   const int l = (int)(((float)local + 0.5f) / (float)len);
   const size_t e = (size_t)m * stride + (size_t)l * list_stride + (local - l * len);
-  const int idx = pi[e];
+  int idx = pi[e];
+  if (a.seg_sources != 0) {  // (uniform over the launch)
+    const unsigned bit = in0 ? 1u : (in1 ? 2u : 4u);
+    idx = (a.seg_sources & bit) ? segment_index(a, idx) : idx;
+  }
   const unsigned long long key = topk_key(ps[e], idx);
   return (live && idx != INT_MAX) ? key : 0ull;
 }
@@ -212,6 +227,12 @@ hipError_t launch_merge(const MergeLaunch &l, hipStream_t s) {
   a.out_i = l.out_idx;
   a.out_stride = l.out_stride;
   a.out_offset = l.out_offset;
+  a.seg = l.seg;
+  a.seg_sources = l.seg.n > 0 ? l.seg_sources : 0u;
+  for (int t = std::max(l.seg.n, 0); t < INDEX_SEGMENTS; ++t) {
+    a.seg.row0[t] = INT_MAX;
+    a.seg.delta[t] = 0;
+  }
   int candidates = 0;
   for (int j = 0; j < l.n_src; ++j) candidates += l.src_lists[j] * l.src_len[j];
   const dim3 grid((l.m + 3) / 4), block(256);

@@ -374,13 +374,10 @@ int check_chunk_args(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_sta
   return KPDI_OK;
 }
 
-int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start) {
-  int rc = resolve_exact64(c);  // (before this chunk's preparation overwrites what extra passes of the last one would read)
-  if (rc) return rc;
-  rc = check_chunk_args(c, dtype, n_chunk, global_start);
-  if (rc) return rc;
-  if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
-  if (c->m == 0) return KPDI_OK;
+// prepare + sweep one raw chunk resident in device memory; `seg`: it is a coalesced matrix (rows -> dictionary indices)
+static int sweep_raw_chunk(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start,
+                           const IndexSegments *seg) {
+  int rc;
   decide_form(c, n_chunk);
   const int tile = dict_tile(c);
   const int n_pad = kpdi::round_up(n_chunk, tile);
@@ -412,7 +409,77 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
   if (rc) return rc;
   rc = prepare_chunk(c, d_patterns, dtype, n_chunk, c->dict_y.as<float>());
   if (rc) return rc;
-  return sweep_prepared(c, c->dict_y.as<float>(), n_chunk, global_start, d_patterns, dtype);
+  return sweep_prepared(c, c->dict_y.as<float>(), n_chunk, global_start, d_patterns, dtype, seg);
+}
+
+// ---- coalescing of small chunks (context.h: PendingChunks) ---------------------------------------------------------
+// A chunk may wait when it is a whole push of fewer than two tile rounds, in f32 / f16 arithmetic with a list that fits
+// one pass (float64 rescoring and bounded passes read the chunk's own raw patterns and indices: they sweep at once).
+// It is appended when the pending rows are of its dtype, come before it in the dictionary (rows and indices must rise
+// together: the match kernel breaks ties by row) and a segment is free; otherwise the pending rows are swept first.
+// Three rounds' worth of rows are swept as soon as they are there.  KPDI_NO_COALESCE=1: every chunk at once (A/B).
+static bool may_coalesce(const kpdi_ctx *c, int64_t n_chunk) {
+  if (c->sw.no_coalesce || c->exact64 || c->keep_n > kpdi::KMAX_LIMIT) return false;
+  return n_chunk < 2 * plan::round_rows(plan_env(c), c->m_pad / kpdi::TILE_EXP);
+}
+
+void discard_pending(kpdi_ctx *c) {
+  c->pending.rows = 0;
+  c->pending.seg.clear();
+}
+
+int flush_pending(kpdi_ctx *c) {
+  kpdi_ctx::PendingChunks &p = c->pending;
+  if (p.rows == 0) return KPDI_OK;
+  IndexSegments seg;
+  seg.n = (int)p.seg.size();
+  for (int t = 0; t < seg.n; ++t) {
+    seg.row0[t] = (int)p.seg[t].row0;
+    seg.delta[t] = (int)(p.seg[t].start - p.seg[t].row0);
+  }
+  const int64_t rows = p.rows, start = p.seg[0].start;
+  const bool one = seg.n == 1;  // a lone chunk: dictionary indices straight from the match kernel, as if it had not waited
+  discard_pending(c);
+  c->cnt.coalesced_sweeps += one ? 0 : 1;
+  return sweep_raw_chunk(c, p.raw.p, p.dtype, rows, one ? start : 0, one ? nullptr : &seg);
+}
+
+int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start, bool may_wait) {
+  int rc = resolve_exact64(c);  // (before this chunk's preparation overwrites what extra passes of the last one would read)
+  if (rc) return rc;
+  rc = check_chunk_args(c, dtype, n_chunk, global_start);
+  if (rc) return rc;
+  if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
+  if (c->m == 0) return KPDI_OK;
+  kpdi_ctx::PendingChunks &p = c->pending;
+  if (!may_wait || !may_coalesce(c, n_chunk)) {
+    rc = flush_pending(c);
+    return rc ? rc : sweep_raw_chunk(c, d_patterns, dtype, n_chunk, global_start, nullptr);
+  }
+  const size_t row_bytes = (size_t)c->npix * kpdi::dtype_size(dtype);
+  const int64_t round = plan::round_rows(plan_env(c), c->m_pad / kpdi::TILE_EXP);
+  if (p.rows > 0 && (p.dtype != dtype || (int)p.seg.size() == INDEX_SEGMENTS || p.rows + n_chunk > p.capacity ||
+                     global_start < p.seg.back().start + p.seg.back().n)) {
+    rc = flush_pending(c);
+    if (rc) return rc;
+  }
+  if (p.rows == 0) {
+    // room for what is swept together (three rounds) + the chunk that takes it there; at most 2 GiB
+    const int64_t want = std::min<int64_t>(5 * round, std::max<int64_t>((int64_t)((2ull << 30) / row_bytes), n_chunk));
+    if (p.raw.cap < (size_t)want * row_bytes) {
+      HIPCHK(hipStreamSynchronize(c->stream));  // (a sweep queued earlier may still read the buffer that is about to go)
+      HIPCHK(p.raw.reserve((size_t)want * row_bytes));
+    }
+    p.capacity = (int64_t)(p.raw.cap / row_bytes);
+    p.dtype = dtype;
+  }
+  HIPCHK(hipMemcpyAsync((char *)p.raw.p + (size_t)p.rows * row_bytes, d_patterns, (size_t)n_chunk * row_bytes, hipMemcpyDeviceToDevice,
+                        c->stream));
+  p.seg.push_back({p.rows, n_chunk, global_start});
+  p.rows += n_chunk;
+  c->final_valid = false;
+  if (p.rows >= 3 * round || p.rows + round / 4 > p.capacity) return flush_pending(c);
+  return KPDI_OK;
 }
 
 // One screening pass over a prepared chunk: the ranks [done, done + kp) of every pattern WITHIN this chunk ->
@@ -450,7 +517,8 @@ int local_pass(kpdi_ctx *c, const float *y, int n_chunk, int n_tiles, int nsplit
 }
 
 // every experimental pattern against one prepared chunk, merged into the running best-k
-int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_start, const void *raw, int raw_dtype) {
+int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_start, const void *raw, int raw_dtype,
+                   const IndexSegments *seg) {
   int rc = prepare_experimental(c);
   if (rc) return rc;
   rc = ensure_running(c);
@@ -491,10 +559,15 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
     ++ns;
   }
 
+  if (seg && (c->exact64 || k > kpdi::KMAX_LIMIT)) return fail(KPDI_EINVAL, "internal: coalesced chunks in a multi-pass sweep");
   if (k <= kpdi::KMAX_LIMIT) {
     const int len = kpdi::match_list_len(k);
     rc = run_match(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, len, global_start, nullptr, nullptr, true);
     if (rc) return rc;
+    if (seg) {  // the match launch(es) ranked ROWS of the coalesced matrix: sources from here on
+      mg.seg = *seg;
+      mg.seg_sources = ~0u << ns;
+    }
     mg.src_scores[ns] = c->part_s.as<float>();
     mg.src_idx[ns] = c->part_i.as<int>();
     const int lps = lists_per_split(c);
@@ -647,9 +720,11 @@ int kpdi_push_dictionary_chunk(kpdi_ctx *c, const void *patterns, int dtype, int
   // the sweep of the last piece may still be running on return (KPDI_COMPUTE_F64: with the look at its certification
   // left to the next call on the context, resolve_exact64)
   c->pend64.defer = true;
-  rc = staged_upload(c, patterns, (size_t)c->npix * es, upload_pieces(c, n_chunk, (size_t)c->npix * es),
+  const std::vector<int64_t> pieces = upload_pieces(c, n_chunk, (size_t)c->npix * es);
+  const bool one_piece = pieces.size() == 1;  // (pieces of a larger upload are sized for its pipeline: they sweep at once)
+  rc = staged_upload(c, patterns, (size_t)c->npix * es, pieces,
                      [&](const void *d_piece, int64_t n, int64_t offset) {
-                       return push_chunk_dev(c, d_piece, dtype, n, global_start + offset);
+                       return push_chunk_dev(c, d_piece, dtype, n, global_start + offset, one_piece);
                      });
   c->pend64.defer = false;
   return rc;
@@ -661,7 +736,7 @@ int kpdi_push_dictionary_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtyp
   if (!d_patterns) return fail(KPDI_EINVAL, "patterns pointer is NULL");
   int rc = use_device(c);
   if (rc) return rc;
-  return push_chunk_dev(c, d_patterns, dtype, n_chunk, global_start);
+  return push_chunk_dev(c, d_patterns, dtype, n_chunk, global_start, true);
 }
 
 // ---- dictionary generation --------------------------------------------------
@@ -715,6 +790,8 @@ int kpdi_sweep_held(kpdi_ctx *c) {
   int rc = use_device(c);
   if (rc) return rc;
   if (c->m == 0) return KPDI_OK;
+  rc = flush_pending(c);
+  if (rc) return rc;
   for (auto &h : c->held) {
     rc = sweep_prepared(c, h.y.as<float>(), h.n, h.start);
     if (rc) return rc;
@@ -754,7 +831,7 @@ int kpdi_push_rotations_chunk(kpdi_ctx *c, const double *rotations, int64_t n, i
   if (n > 0) HIPCHK(c->dict_raw.reserve((size_t)n * c->npix * sizeof(float)));
   rc = project_to_device(c, rotations, n, rescale, out_min, out_max, KPDI_F32, c->dict_raw.p);
   if (rc) return rc;
-  return push_chunk_dev(c, c->dict_raw.p, KPDI_F32, n, global_start);
+  return push_chunk_dev(c, c->dict_raw.p, KPDI_F32, n, global_start, true);
 }
 
 int kpdi_hold_rotations_chunk(kpdi_ctx *c, const double *rotations, int64_t n, int64_t global_start, int rescale,

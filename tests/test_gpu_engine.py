@@ -236,6 +236,94 @@ def test_rccl_path_single_rank(synth_inputs):
     assert np.array_equal(again[0], ref[0]) and np.array_equal(again[1], ref[1])
 
 
+def test_small_chunks_are_swept_together_and_nothing_changes(monkeypatch):
+    """Coalescing (csrc/sweep.hip): pushed chunks of less than two tile rounds wait for company and are prepared + matched
+    as ONE launch set; the merge translates rows of the coalesced matrix back to dictionary indices.  Whatever the order,
+    size, dtype or origin (host / device / generated) of the chunks the result is the single pass's, BIT FOR BIT; chunks
+    that cannot wait (float64 arithmetic, keep_n > 32, a start below what is pending, a 17th segment) are swept at once
+    or force the pending ones out first.  The reference's own call shape: `n_per_iteration` patterns per iteration
+    (indexing/_dictionary_indexing.py:100-128)."""
+    from kikuchipy_amd import _lib
+
+    rng = np.random.default_rng(77)
+    exp = rng.integers(0, 256, (700, 24, 20), dtype=np.uint8)
+    dic = rng.random((9000, 24, 20), dtype=np.float32)
+    dic[5000] = dic[17]  # ties across chunks: lower dictionary index first
+    dic[8999] = dic[17]
+    with _lib.Context(0) as c:
+        def sweep(pieces, keep_n=20, metric=_lib.METRIC_NCC, compute=_lib.COMPUTE_F32, dev=False, source=dic):
+            c.set_problem(24, 20, None, metric, keep_n, compute)
+            c.set_experimental(exp)
+            c.reset_counters()
+            d = None
+            if dev:
+                d = c.dev_alloc(source.nbytes)
+                c.h2d(d, source)
+            for a, b in pieces:
+                if dev:
+                    c.push_dictionary_chunk_dev(d + a * source[0].nbytes, source.dtype, b - a, a)
+                else:
+                    c.push_dictionary_chunk(source[a:b], a)
+            out = c.finalize(keep_n)
+            cnt = c.counters()
+            if dev:
+                c.dev_free(d)
+            return out, cnt
+
+        (ref_s, ref_i), cnt = sweep([(0, 9000)])
+        assert cnt["coalesced_sweeps"] == 0 and cnt["match_launches"] == 1
+        chunks = [(a, min(a + 700, 9000)) for a in range(0, 9000, 700)]
+        for dev in (False, True):
+            (s, i), cnt = sweep(chunks, dev=dev)
+            assert np.array_equal(s, ref_s) and np.array_equal(i, ref_i)
+            assert cnt["coalesced_sweeps"] >= 1 and cnt["match_launches"] < len(chunks), cnt
+            assert cnt["match_flops"] == 2.0 * 700 * 9000 * 480
+        # every other chunk first, then the rest: ascending runs coalesce, the step back forces a flush
+        order = chunks[0::2] + chunks[1::2]
+        (s, i), cnt = sweep(order)
+        assert np.array_equal(s, ref_s) and np.array_equal(i, ref_i) and cnt["coalesced_sweeps"] >= 2
+        (s, i), cnt = sweep(chunks[::-1])  # descending: nothing can wait for anything
+        assert np.array_equal(s, ref_s) and np.array_equal(i, ref_i) and cnt["match_launches"] == len(chunks)
+        tiny = [(a, a + 100) for a in range(0, 9000, 100)]  # 90 chunks: more than a coalesced matrix has segments
+        (s, i), cnt = sweep(tiny)
+        assert np.array_equal(s, ref_s) and np.array_equal(i, ref_i)
+        assert cnt["coalesced_sweeps"] == -(-90 // 16), cnt
+        # mixed dtypes (the uint16 chunks hold the same values scaled: ndp does not see the scale)
+        d16 = (dic * 1000).astype(np.uint16)
+        (r16_s, r16_i), _ = sweep([(0, 9000)], metric=_lib.METRIC_NDP, source=d16.astype(np.float32))
+        c.set_problem(24, 20, None, _lib.METRIC_NDP, 20, _lib.COMPUTE_F32)
+        c.set_experimental(exp)
+        for j, (a, b) in enumerate(chunks):
+            c.push_dictionary_chunk(d16[a:b] if j % 3 else d16[a:b].astype(np.float32), a)
+        s, i = c.finalize(20)
+        assert np.array_equal(s, r16_s) and np.array_equal(i, r16_i)
+        # arithmetic that reads a chunk's own raw patterns / ranks in bounded passes: swept at once, same result as ever
+        for kw in (dict(keep_n=40), dict(compute=_lib.COMPUTE_F64, keep_n=10)):
+            (a_s, a_i), cnt1 = sweep([(0, 9000)], **kw)
+            (b_s, b_i), cntn = sweep(chunks, **kw)
+            assert np.array_equal(a_i, b_i) and cntn["coalesced_sweeps"] == 0
+            assert np.array_equal(a_s, b_s) or kw.get("compute") == _lib.COMPUTE_F64 and np.abs(a_s - b_s).max() < 1e-14
+        # float16 arithmetic coalesces like float32
+        (a_s, a_i), _ = sweep([(0, 9000)], compute=_lib.COMPUTE_F16)
+        (b_s, b_i), cnt = sweep(chunks, compute=_lib.COMPUTE_F16)
+        assert np.array_equal(a_s, b_s) and np.array_equal(a_i, b_i) and cnt["coalesced_sweeps"] >= 1
+        # pending chunks belong to their sweep: a new experimental set forgets them, synchronize sweeps them
+        c.set_problem(24, 20, None, _lib.METRIC_NCC, 20, _lib.COMPUTE_F32)
+        c.set_experimental(exp)
+        c.push_dictionary_chunk(dic[:700], 0)
+        c.set_experimental(exp)
+        c.push_dictionary_chunk(dic[700:], 700)
+        c.push_dictionary_chunk(dic[:700], 0)
+        c.synchronize()
+        s, i = c.finalize(20)
+        assert np.array_equal(s, ref_s) and np.array_equal(i, ref_i)
+    monkeypatch.setenv("KPDI_NO_COALESCE", "1")
+    with _lib.Context(0) as c:
+        (s, i), cnt = sweep(chunks)
+        assert np.array_equal(s, ref_s) and np.array_equal(i, ref_i)
+        assert cnt["coalesced_sweeps"] == 0 and cnt["match_launches"] == len(chunks)
+
+
 def test_host_staged_gather_entry_points(synth_inputs):
     """kpdi_export_lists / kpdi_import_lists / kpdi_comm_selftest / kpdi_comm_drop (the fallback of a multi-process job
     whose RCCL communicator cannot be used): three "ranks" sweep their dictionary blocks on one GPU, their exported

@@ -106,9 +106,10 @@ def test_the_tutorial_call_on_eight_members_equals_the_single_sweep_at_full_size
     assert np.array_equal(got.scores, s1) and np.array_equal(got.simulation_indices, i1)
     assert np.array_equal(got_lazy.scores, s1) and np.array_equal(got_lazy.simulation_indices, i1)
     assert lazy.log == [3044] * 32 + [100000 - 32 * 3044]
-    # every member swept its quota, in 4 whole chunks + its 324 patterns of the last one (not 33 pieces of 380)
-    per = [(m["match_flops"], m["match_launches"]) for m in cnt["members"]]
-    assert per == [(2.0 * 4096 * 12500 * 3600, 5)] * 8, per
+    # every member took its quota as 4 whole chunks + its 324 patterns of the last one (not 33 pieces of 380) - and swept
+    # them TOGETHER (csrc/sweep.hip: small chunks wait for company): one launch set per member, as in a single-pass call
+    per = [(m["match_flops"], m["match_launches"], m["coalesced_sweeps"]) for m in cnt["members"]]
+    assert per == [(2.0 * 4096 * 12500 * 3600, 1, 1)] * 8, per
 
 
 def test_generated_chunks_on_a_group_equal_the_single_device():
