@@ -31,7 +31,12 @@
  * Degenerate patterns
  *  A pattern whose normalisation is undefined is DEGENERATE:
  *    ncc - zero variance over the kept pixels: a constant pattern (a dead or saturated detector frame); "constant" =
- *          centred sum of squares <= K (2^-20 mean)^2, i.e. constant to within the rounding of a float32 mean;
+ *          centred sum of squares <= K (2^-20 mean)^2, i.e. constant to within the rounding of a float32 mean (the mean of
+ *          K equal float32 values comes out up to ~8 ulp off, leaving residuals of that size).  This is a CONTRAST
+ *          FLOOR: a pattern whose RMS contrast is below 2^-20 = 9.5e-7 of its mean - uint16 data around 60 000 counts
+ *          with a standard deviation below 0.057 counts, or ONE pixel of 3600 differing by 1 count there - is treated as
+ *          constant although the reference would still correlate it (its float32 evaluation of such a pattern is itself
+ *          rounding noise: ulp(60 000) = 0.004 counts).  Real detector frames are 4-5 orders of magnitude above it;
  *    ndp - all kept pixels zero;
  *    either metric - NaN or +-inf among the kept pixels.
  *  The reference divides 0 by 0 there (similarity_metrics/_normalized_cross_correlation.py:228-233,

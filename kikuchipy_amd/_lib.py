@@ -770,12 +770,40 @@ def resolve_devices(devices):
     return out
 
 
+LAUNCHER_VARIABLES = ("WORLD_SIZE", "LOCAL_RANK", "SLURM_PROCID", "SLURM_LOCALID", "OMPI_COMM_WORLD_RANK", "PMI_RANK")
+_logged_defaults = set()
+
+
+def under_a_launcher():
+    """A launcher that starts one process per GPU (torchrun, srun, mpirun) has exported its variables: such a process
+    must not spread over every GPU by itself - its siblings would all do the same."""
+    return any(v in os.environ for v in LAUNCHER_VARIABLES)
+
+
 def default_devices():
-    """What a call that says nothing about devices runs on: $KPDI_DEVICES ("all" or ids like "0,1,2") if
-    set, else every visible GPU - the counterpart of the reference using every core of the host
-    (its Dask scheduler's default)."""
+    """What a call that says nothing about devices runs on: $KPDI_DEVICES ("all" or ids like "0,1,2") if set; else, in a
+    process started by a launcher (`under_a_launcher`), ONE GPU - the process's local rank ($LOCAL_RANK /
+    $SLURM_LOCALID modulo the visible devices); else every visible GPU - the counterpart of the reference using every
+    core of the host (its Dask scheduler's default).  What was chosen is logged once per choice
+    (`logging.getLogger("kikuchipy_amd")`, level INFO)."""
     env = os.environ.get("KPDI_DEVICES")
-    return resolve_devices(env if env else "all")
+    if env:
+        ids, why = resolve_devices(env), f"$KPDI_DEVICES={env}"
+    elif under_a_launcher():
+        local = os.environ.get("LOCAL_RANK") or os.environ.get("SLURM_LOCALID") or "0"
+        n = max(device_count(), 1)
+        ids = [int(local) % n if local.lstrip("-").isdigit() else 0]
+        why = ("a launcher's environment (" + ", ".join(v for v in LAUNCHER_VARIABLES if v in os.environ) +
+               "): one process per GPU is assumed; name devices= or set $KPDI_DEVICES to override")
+    else:
+        ids, why = resolve_devices("all"), "every visible GPU"
+    key = (tuple(ids), why)
+    if key not in _logged_defaults:
+        _logged_defaults.add(key)
+        import logging
+
+        logging.getLogger("kikuchipy_amd").info("no device named: running on GPU(s) %s (%s)", ids, why)
+    return ids
 
 
 def make_engine(device=0, devices=None, gather=None):

@@ -94,9 +94,10 @@ GROUP_MIN_COMPARISONS = 1 << 26
 def pick_devices(device, devices, comm, n_experimental, dictionary_size):
     """Which GPU(s) a `dictionary_indexing` call runs on -> (device, devices) for `make_engine`.
     `comm` (one process per GPU): the rank's own device.  `devices` given: those.  `device` given:
-    that one.  Neither: every visible GPU ($KPDI_DEVICES overrides) - the reference call uses every
-    core of the host without being asked (signals/ebsd.py:1827-1984 on Dask's default scheduler) -
-    unless the job is too small to be worth a group."""
+    that one.  Neither: every visible GPU ($KPDI_DEVICES overrides; ONE GPU in a process started by a
+    launcher, `_lib.default_devices`) - the reference call uses every core of the host without being
+    asked (signals/ebsd.py:1827-1984 on Dask's default scheduler) - unless the job is too small to be
+    worth a group."""
     from kikuchipy_amd import _lib
 
     if comm is not None:
@@ -169,6 +170,7 @@ def dictionary_indexing(
     comm=None,
     verbose=True,
     compute=None,
+    progress=None,
 ):
     """Index experimental patterns against a dictionary of simulated patterns.
 
@@ -204,6 +206,11 @@ def dictionary_indexing(
         per-device best-k lists merged by an in-process RCCL all-gather) - or one GPU when there is
         one, or when the job is tiny; $KPDI_DEVICES ("all" or ids like "0,1") overrides.  `devices="all"`
         / a list of ids / `device=i` say it explicitly.  Results do not depend on the choice.
+    progress
+        The reference shows a `tqdm` bar over the chunk loop (indexing/_dictionary_indexing.py:105).  None
+        (default): the same bar when `verbose`, the dictionary takes more than one iteration and tqdm is
+        importable; a callable: called as `progress(chunks_done, n_chunks)` after every pushed chunk; False:
+        nothing.  (A push returns when the chunk has been handed over - its sweep may still run.)
     comm
         `kikuchipy_amd.parallel.Communicator` to shard the dictionary over
         ranks (one process per GPU).  Every rank must pass the same arrays; each
@@ -267,7 +274,8 @@ def dictionary_indexing(
             )
 
     n_experimental_all = int(np.prod(nav_shape_exp)) if nav_shape_exp else 1
-    if isinstance(metric, str) and metric in METRICS:
+    own_engine = isinstance(metric, str) and metric in METRICS  # the metric - and its engine - are this call's own
+    if own_engine:
         device, devices = pick_devices(device, devices, comm, n_experimental_all, dict_size)
     metric = prepare_metric(metric, navigation_mask, signal_mask, dtype, rechunk, n_experimental_all,
                             dict_size, device=device, compute=compute, devices=devices)
@@ -291,10 +299,23 @@ def dictionary_indexing(
     from kikuchipy_amd.parallel import shard_range
 
     lo, hi = shard_range(dict_size, rank, world)
+    bounds = [] if resident is not None else chunk_bounds(dict_size, n_per_iteration)
+    bar = None
+    if progress is None and verbose and len(bounds) > 1 and rank == 0:
+        try:
+            from tqdm import tqdm
+
+            bar = tqdm(total=len(bounds))
+        except ImportError:
+            pass
     time_start = time.time()
     if resident is not None:
         ctx.sweep_held()
-    for start, end in ([] if resident is not None else chunk_bounds(dict_size, n_per_iteration)):
+    for n_done, (start, end) in enumerate(bounds, 1):
+        if bar is not None:
+            bar.update(1)
+        elif callable(progress):
+            progress(n_done, len(bounds))
         start, end = max(start, lo), min(end, hi)  # this rank's part of the chunk
         if start >= end:
             continue
@@ -311,12 +332,19 @@ def dictionary_indexing(
     uncertified_before = _uncertified(ctx) if f64 else 0
     scores, simulation_indices = ctx.finalize(keep_n)
     total_time = time.time() - time_start
+    if bar is not None:
+        bar.close()
     certificate = None
     if f64:
         from kikuchipy_amd import _lib
 
         certificate = {"mode": _lib.F64_CERTIFICATES.get(ctx.counters().get("f64_certificate", 0)),
                        "uncertified_patterns": _uncertified(ctx) - uncertified_before}
+    if own_engine and metric._ctx is not None:
+        # the engine was made for this call: its contexts, host threads and communicator go with it (a caller that
+        # wants them kept passes a metric instance, or indexes through an `EBSD`, which keeps its engines)
+        metric._ctx.close()
+        metric._ctx = None
     scores = scores.astype(metric.dtype, copy=False)
     pps = n_experimental / total_time
     cps = n_experimental * dict_size / total_time

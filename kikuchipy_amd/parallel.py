@@ -160,14 +160,25 @@ def _job_token(world_size, addr="", port=0):
     launcher's run id when it exports one (torchrun: TORCHELASTIC_RUN_ID; bench.py's own spawner:
     KPDI_JOB_ID) - else the rendezvous address itself, so that two jobs of equal size whose port
     ranges overlap still cannot join each other - and the world size."""
-    run = os.environ.get("KPDI_JOB_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or f"rendezvous-{addr}:{int(port)}"
+    run = (os.environ.get("KPDI_JOB_KEY") or os.environ.get("KPDI_JOB_ID") or os.environ.get("TORCHELASTIC_RUN_ID")
+           or f"rendezvous-{addr}:{int(port)}")
     return hashlib.sha256(f"{run}/{int(world_size)}".encode()).digest()[:16]
 
 
-def _rank_proof(token, rank, world_size):
-    """What a joining rank sends with its rank: shows that it knows the job token (the server's greeting alone would
-    let any local process that read it claim a rank)."""
-    return hmac.new(token, struct.pack("<ii", int(rank), int(world_size)), hashlib.sha256).digest()[:16]
+def _greeting(token):
+    """What rank 0 says first: the magic string and a DIGEST of the job token (never the token itself) - enough for a
+    rank of this job to recognise its server, useless for computing a proof."""
+    return _MAGIC + hashlib.sha256(b"kpdi-greeting" + token).digest()[:16]
+
+
+def _rank_proof(token, nonce, rank, world_size):
+    """A joining rank's answer to the server's challenge: HMAC(job token, nonce | rank | world size).  The token is
+    never on the wire, the nonce is fresh per connection: a process that only READS a greeting (or replays an old
+    answer) cannot claim a rank.  What the token is worth depends on the launcher: with $KPDI_JOB_ID /
+    $TORCHELASTIC_RUN_ID (or $KPDI_JOB_KEY) it is a secret of the job's processes; without them it is derived from
+    the rendezvous address and the world size - then this is collision avoidance between jobs, not authentication,
+    and the control plane should stay on the loopback interface (it binds MASTER_ADDR, 127.0.0.1 by default)."""
+    return hmac.new(token, nonce + struct.pack("<ii", int(rank), int(world_size)), hashlib.sha256).digest()[:16]
 
 
 _ACCEPT, _REJECT = b"\x01", b"\x00"
@@ -179,8 +190,9 @@ class SocketGroup:
     Rendezvous: rank 0 listens on MASTER_ADDR at the first free port of MASTER_PORT,
     MASTER_PORT + 1, ... (under `torch.distributed.run` MASTER_PORT itself is taken by the
     launcher's own store, so the first candidate is usually busy) and GREETS every connection with
-    a magic string + the job token; the other ranks walk the same candidates and only talk to a
-    server that greeted them correctly - they never write to a foreign server.  Every collective
+    a magic string + a digest of the job token + a fresh nonce; the other ranks walk the same candidates, only talk to a
+    server that greeted them correctly - they never write to a foreign server - and answer the nonce with an HMAC under
+    the token (`_rank_proof`).  Every collective
     goes through rank 0 (world sizes are <= 8 and the payloads are a 128-byte id, a timing, or a few
     result rows: latency of tens of microseconds on loopback, irrelevant next to a sweep)."""
 
@@ -236,11 +248,12 @@ class SocketGroup:
             conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             conn.settimeout(5.0)
             try:
-                conn.sendall(_MAGIC + token)
+                nonce = os.urandom(16)
+                conn.sendall(_greeting(token) + nonce)
                 hello = _recv_exact(conn, 8 + 16)
                 peer, world = struct.unpack("<ii", hello[:8])
                 ok = (world == self.world_size and 0 < peer < world and peer not in self._peers
-                      and hmac.compare_digest(hello[8:], _rank_proof(token, peer, world)))
+                      and hmac.compare_digest(hello[8:], _rank_proof(token, nonce, peer, world)))
                 conn.sendall(_ACCEPT if ok else _REJECT)  # the peer learns NOW, not at its first collective
             except (OSError, ConnectionError):
                 conn.close()  # a port scanner, a rank of another job that read the greeting and left
@@ -253,7 +266,7 @@ class SocketGroup:
 
     def _connect(self, addr, port, token):
         deadline = time.monotonic() + self.timeout
-        want = _MAGIC + token
+        want = _greeting(token)
         while True:
             for cand in range(port, port + _PORT_CANDIDATES):
                 s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
@@ -263,9 +276,10 @@ class SocketGroup:
                     # only OUR rank 0 speaks first; a foreign server stays silent -> timeout -> next
                     s.settimeout(0.5)
                     if _recv_exact(s, len(want)) == want:
+                        nonce = _recv_exact(s, 16)
                         s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                         s.settimeout(self.timeout)
-                        s.sendall(struct.pack("<ii", self.rank, self.world_size) + _rank_proof(token, self.rank, self.world_size))
+                        s.sendall(struct.pack("<ii", self.rank, self.world_size) + _rank_proof(token, nonce, self.rank, self.world_size))
                         if _recv_exact(s, 1) != _ACCEPT:
                             s.close()
                             raise PermissionError(f"rank {self.rank}: the rendezvous server on {addr}:{cand} rejected this rank "

@@ -78,6 +78,23 @@ class EBSD:
         self._ctx = None
         self._groups = {}  # device ids -> _lib.Group, kept from call to call (its communicator is made once)
 
+    # ------------------------------------------------------------------ engines
+    def close(self):
+        """Destroy the engines this signal keeps from call to call (its own context, its groups over several GPUs -
+        their host threads and communicators); they are made again when needed.  `with EBSD(...) as s:` calls it."""
+        for g in self._groups.values():
+            g.close()
+        self._groups = {}
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     # ------------------------------------------------------------------ shapes
     @property
     def _navigation_shape_rc(self):

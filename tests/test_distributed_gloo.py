@@ -110,8 +110,9 @@ def test_socket_group_wire_format_and_port_walk():
 
 
 def test_socket_group_rejects_what_is_not_a_rank_of_this_job(monkeypatch):
-    """A connector must PROVE it knows the job token (the greeting alone is readable by any local process), a rank
-    that is already taken is told at once, an absurd message length is refused, and a constructor that raises leaves an
+    """A connector must PROVE it knows the job token: the greeting carries only a digest of it and a fresh nonce, the
+    answer is an HMAC under the token (a process that reads the greeting, or replays an answer given to another nonce,
+    cannot claim a rank); a rank that is already taken is told at once, an absurd message length is refused, and a constructor that raises leaves an
     object whose __del__ is harmless."""
     import socket
     import struct
@@ -141,8 +142,18 @@ def test_socket_group_rejects_what_is_not_a_rank_of_this_job(monkeypatch):
         except OSError:
             import time
             time.sleep(0.05)
-    assert parallel._recv_exact(s, len(parallel._MAGIC) + 16) == parallel._MAGIC + token
+    greeting = parallel._recv_exact(s, len(parallel._MAGIC) + 16)
+    assert greeting == parallel._greeting(token) and token not in greeting  # the token itself is never on the wire
+    nonce1 = parallel._recv_exact(s, 16)
     s.sendall(struct.pack("<ii", 1, 3) + b"\x00" * 16)
+    assert parallel._recv_exact(s, 1) == parallel._REJECT
+    s.close()
+    # ... and one that replays a valid answer to ANOTHER connection's nonce
+    s = socket.create_connection(("127.0.0.1", port), timeout=5)
+    parallel._recv_exact(s, len(greeting))
+    nonce2 = parallel._recv_exact(s, 16)
+    assert nonce2 != nonce1
+    s.sendall(struct.pack("<ii", 1, 3) + parallel._rank_proof(token, nonce1, 1, 3))
     assert parallel._recv_exact(s, 1) == parallel._REJECT
     s.close()
     g1 = parallel.SocketGroup(1, 3, "127.0.0.1", port, timeout=30)   # the real rank 1 still gets in

@@ -66,6 +66,32 @@ def test_eight_in_process_shards_equal_the_single_sweep_at_full_size():
     ko.assert_topk_parity(s8[rows], i8[rows], rs, ri, atol=1e-5)
 
 
+def test_members_on_different_kernel_forms_still_merge_to_the_single_sweep():
+    """The "bit for bit" claim of include/kpdi.h rests on every f32 kernel form producing the same bits.  Here the members
+    of one group sweep shares whose sizes make the planner pick DIFFERENT forms (match16.hip's 256 x 256 tiles for
+    50 000 patterns, match.hip's 128 x 256 tiles + quarter-tile tail for 12 500, partial units for the odd rest) - the
+    counters say so - and the merged result is the single sweep's, bit for bit."""
+    from kikuchipy_amd import _lib
+
+    exp, dic = synth(2024, 4096, 100000)
+    s1, i1 = single(exp, dic, _lib.METRIC_NCC, 20, _lib.COMPUTE_F32)
+    sizes = [50000, 12500, 37397, 103]
+    starts = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    with _lib.Group([0] * 4) as g:
+        g.set_problem(60, 60, None, _lib.METRIC_NCC, 20, _lib.COMPUTE_F32)
+        g.set_experimental(exp, None)
+        d = []
+        for mem, a, n in zip(g.members, starts, sizes):
+            p = mem.dev_alloc(dic[a:a + n].nbytes)
+            mem.h2d(p, dic[a:a + n])
+            d.append(p)
+        g.push_dictionary_chunk_dev(d, np.float32, sizes, [int(a) for a in starts])
+        s, i = g.finalize(20)
+        forms = [m["match_form"] for m in g.counters()["members"]]
+    assert forms[0] == 3 and forms[1] == 0, forms  # (wide, classic; the others whatever the planner likes)
+    assert np.array_equal(s, s1) and np.array_equal(i, i1)
+
+
 class Lazy:
     """A Dask-like dictionary: sliced along axis 0, chunks materialised by `.compute()` inside the loop."""
 
@@ -91,13 +117,23 @@ def test_the_tutorial_call_on_eight_members_equals_the_single_sweep_at_full_size
 
     exp, dic = synth(2024, 4096, 100000)
     s1, i1 = single(exp, dic, _lib.METRIC_NCC, 20, _lib.COMPUTE_F32)
-    made = []
+    made, stats = [], []
     real = _lib.make_engine
-    _lib.make_engine = lambda *a, **k: made.append(real(*a, **k)) or made[-1]
+
+    def make(*a, **k):
+        eng = real(*a, **k)
+        close = eng.close
+        eng.close = lambda: (stats.append(eng.counters()), close())  # (the call closes the engine it made: look first)
+        made.append(eng)
+        return eng
+
+    _lib.make_engine = make
     try:
-        got = ka.dictionary_indexing(exp, dic, keep_n=20, n_per_iteration=3044, devices=[0] * 8, verbose=False)
-        grp = made[-1]
-        cnt = grp.counters()
+        calls = []
+        got = ka.dictionary_indexing(exp, dic, keep_n=20, n_per_iteration=3044, devices=[0] * 8, verbose=False,
+                                     progress=lambda done, total: calls.append((done, total)))
+        assert calls == [(j, 33) for j in range(1, 34)]
+        grp, cnt = made[-1], stats[-1]
         lazy = Lazy(dic, 3044)
         got_lazy = ka.dictionary_indexing(exp, lazy, keep_n=20, devices=[0] * 8, verbose=False)
     finally:

@@ -40,6 +40,37 @@ def test_resolve_devices(monkeypatch):
     assert _lib.default_devices() == [4]  # (a string names ids; a COUNT is the int form, devices=4)
 
 
+def test_default_devices_under_a_launcher(monkeypatch, caplog):
+    """A process started by a launcher (one process per GPU) that names no device stays on ONE GPU - its local rank's -
+    instead of opening a context on every GPU like its siblings would; $KPDI_DEVICES still overrides; the choice is
+    logged once."""
+    import logging
+
+    from kikuchipy_amd import _lib
+
+    for v in _lib.LAUNCHER_VARIABLES + ("KPDI_DEVICES",):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setattr(_lib, "device_count", lambda: 8)
+    _lib._logged_defaults.clear()
+    with caplog.at_level(logging.INFO, logger="kikuchipy_amd"):
+        assert _lib.default_devices() == list(range(8)) and not _lib.under_a_launcher()
+        assert _lib.default_devices() == list(range(8))
+        monkeypatch.setenv("WORLD_SIZE", "8")
+        monkeypatch.setenv("LOCAL_RANK", "5")
+        assert _lib.under_a_launcher() and _lib.default_devices() == [5]
+        monkeypatch.setenv("LOCAL_RANK", "11")  # more ranks than GPUs: they share
+        assert _lib.default_devices() == [3]
+        monkeypatch.delenv("LOCAL_RANK")
+        monkeypatch.delenv("WORLD_SIZE")
+        monkeypatch.setenv("SLURM_PROCID", "2")
+        monkeypatch.setenv("SLURM_LOCALID", "2")
+        assert _lib.default_devices() == [2]
+        monkeypatch.setenv("KPDI_DEVICES", "0,1")
+        assert _lib.default_devices() == [0, 1]
+    said = [r.getMessage() for r in caplog.records]
+    assert len(said) == 5 and "every visible GPU" in said[0] and "launcher" in said[1] and "KPDI_DEVICES" in said[-1]
+
+
 def test_pick_devices(monkeypatch):
     from kikuchipy_amd.indexing._dictionary_indexing import GROUP_MIN_COMPARISONS, pick_devices
 
@@ -79,6 +110,7 @@ def test_dictionary_indexing_over_a_group(monkeypatch, metric, keep_n, chunk, ma
                                  devices=[0, 0, 0], verbose=False)
     grp = made[-1]
     assert isinstance(grp, StandInGroup) and len(grp) == 3 and len(grp.threads_seen) > 1
+    assert grp._pool._shutdown  # the call made this engine itself: it closed it (threads, contexts, communicator)
     # every member swept its block of every chunk: contiguous, disjoint, covering the dictionary
     spans = sorted(sp for m in grp.members for sp in m.pushed)
     assert spans[0][0] == 0 and sum(n for _, n in spans) == len(dic)
