@@ -215,6 +215,10 @@ int kpdi_destroy(kpdi_ctx *c) {
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   release_held(c);
   c->pin_out.release();
+  for (auto &st : c->rot_stage) {
+    st.pin.release();
+    if (st.copied) (void)hipEventDestroy(st.copied);
+  }
   c->pend64.flag.release();
   if (c->pend64.ready) (void)hipEventDestroy(c->pend64.ready);
   for (auto &rs : c->slots) {

@@ -290,6 +290,13 @@ struct kpdi_ctx {
   int mp_npx = 0, mp_npy = 0;
   int64_t dc_npix = 0;
   kpdi::DevBuf mp_packed, dcos, rot, proj_out;
+  // rotations of pushed / held chunks go through a ring of page-locked slots (the caller's array may be a temporary:
+  // it is copied here on the host, 32 bytes per pattern) so that no push has to wait for the stream
+  struct RotStage {
+    kpdi::PinBuf pin;
+    hipEvent_t copied = nullptr;  // the upload out of this slot has run
+  } rot_stage[4];
+  int rot_next = 0;
 
   // refinement (refine.hip)
   bool have_ref = false;
@@ -400,6 +407,12 @@ int check_chunk_args(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_sta
 int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start, bool may_wait = false);
 int flush_pending(kpdi_ctx *c);
 void discard_pending(kpdi_ctx *c);
+// Where the next `n_chunk` rows of `dtype` (dictionary patterns from `global_start` on) would join the pending rows:
+// *slot = device address for their raw patterns, or nullptr when this chunk cannot wait (it is then swept at once).
+// What is pending may be swept first to make room / keep the order.  pending_commit() after the slot has been filled
+// (by work queued on the context's stream) makes the rows part of the pending matrix and sweeps it when it is due.
+int pending_slot(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_start, void **slot);
+int pending_commit(kpdi_ctx *c, int64_t n_chunk, int64_t global_start);
 int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_start, const void *raw = nullptr, int raw_dtype = 0,
                    const IndexSegments *seg = nullptr);
 int new_held_chunk(kpdi_ctx *c, int64_t n_chunk, int64_t global_start, float **out);
@@ -423,7 +436,8 @@ struct VarPc {
   int nrows, ncols;
   const double *om;
 };
+// `stay_async`: return without waiting for the stream (the rotations are staged through the context's pinned ring)
 int project_to_device(kpdi_ctx *c, const double *rotations, int64_t n, int rescale, double out_min, double out_max, int dtype_out,
-                      void *d_out, const VarPc *var = nullptr);
+                      void *d_out, const VarPc *var = nullptr, bool stay_async = false);
 
 }  // namespace kpdi

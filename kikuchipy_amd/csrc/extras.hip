@@ -8,14 +8,29 @@ using namespace kpdi;
 namespace kpdi {
 
 int project_to_device(kpdi_ctx *c, const double *rotations, int64_t n, int rescale, double out_min, double out_max,
-                      int dtype_out, void *d_out, const VarPc *var) {
+                      int dtype_out, void *d_out, const VarPc *var, bool stay_async) {
   if (!c->have_master) return fail(KPDI_EINVAL, "kpdi_set_master_pattern has not been called");
   if (!var && !c->have_dc) return fail(KPDI_EINVAL, "kpdi_set_detector has not been called");
   if (!rotations) return fail(KPDI_EINVAL, "rotations pointer is NULL");
   if (n <= 0 || n >= (int64_t)INT_MAX) return fail(KPDI_EINVAL, "need between 1 and 2^31-1 rotations per call");
   if (rescale && !(out_max > out_min)) return fail(KPDI_EINVAL, "rescale needs out_max > out_min");
   HIPCHK(c->rot.reserve((size_t)n * 7 * sizeof(double)));
-  HIPCHK(hipMemcpyAsync(c->rot.p, rotations, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  const size_t rot_bytes = (size_t)n * 4 * sizeof(double);
+  if (stay_async && !var) {
+    kpdi_ctx::RotStage &st = c->rot_stage[c->rot_next];
+    if (st.copied) HIPCHK(hipEventSynchronize(st.copied));  // (four pushes ago: long done)
+    if (st.pin.reserve(rot_bytes) == hipSuccess) {
+      c->rot_next = (c->rot_next + 1) % 4;
+      if (!st.copied) HIPCHK(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
+      memcpy(st.pin.p, rotations, rot_bytes);
+      HIPCHK(hipMemcpyAsync(c->rot.p, st.pin.p, rot_bytes, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipEventRecord(st.copied, c->stream));
+    } else {  // no page-locked memory to be had: the synchronous way
+      (void)hipGetLastError();
+      stay_async = false;
+    }
+  }
+  if (!stay_async || var) HIPCHK(hipMemcpyAsync(c->rot.p, rotations, rot_bytes, hipMemcpyHostToDevice, c->stream));
   c->cnt.h2d_bytes += (double)n * 4 * sizeof(double);
   kpdi::ProjectLaunch p{};
   p.rotations = c->rot.as<double>();
@@ -47,7 +62,7 @@ int project_to_device(kpdi_ctx *c, const double *rotations, int64_t n, int resca
   }
   // the rotations buffer may be a temporary of the caller's binding: it must have been read
   // before we return (pageable memory is staged synchronously, pinned memory is not)
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (!stay_async || var) HIPCHK(hipStreamSynchronize(c->stream));
   return KPDI_OK;
 }
 

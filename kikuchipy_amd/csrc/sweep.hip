@@ -451,16 +451,28 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
   if (rc) return rc;
   if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
   if (c->m == 0) return KPDI_OK;
-  kpdi_ctx::PendingChunks &p = c->pending;
-  if (!may_wait || !may_coalesce(c, n_chunk)) {
+  void *slot = nullptr;
+  if (may_wait) {
+    rc = pending_slot(c, dtype, n_chunk, global_start, &slot);
+    if (rc) return rc;
+  }
+  if (!slot) {
     rc = flush_pending(c);
     return rc ? rc : sweep_raw_chunk(c, d_patterns, dtype, n_chunk, global_start, nullptr);
   }
+  HIPCHK(hipMemcpyAsync(slot, d_patterns, (size_t)n_chunk * c->npix * kpdi::dtype_size(dtype), hipMemcpyDeviceToDevice, c->stream));
+  return pending_commit(c, n_chunk, global_start);
+}
+
+int pending_slot(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_start, void **slot) {
+  *slot = nullptr;
+  if (!c->have_exp || !c->have_problem || c->m == 0 || !may_coalesce(c, n_chunk)) return KPDI_OK;
+  kpdi_ctx::PendingChunks &p = c->pending;
   const size_t row_bytes = (size_t)c->npix * kpdi::dtype_size(dtype);
   const int64_t round = plan::round_rows(plan_env(c), c->m_pad / kpdi::TILE_EXP);
   if (p.rows > 0 && (p.dtype != dtype || (int)p.seg.size() == INDEX_SEGMENTS || p.rows + n_chunk > p.capacity ||
                      global_start < p.seg.back().start + p.seg.back().n)) {
-    rc = flush_pending(c);
+    int rc = flush_pending(c);
     if (rc) return rc;
   }
   if (p.rows == 0) {
@@ -473,8 +485,13 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
     p.capacity = (int64_t)(p.raw.cap / row_bytes);
     p.dtype = dtype;
   }
-  HIPCHK(hipMemcpyAsync((char *)p.raw.p + (size_t)p.rows * row_bytes, d_patterns, (size_t)n_chunk * row_bytes, hipMemcpyDeviceToDevice,
-                        c->stream));
+  *slot = (char *)p.raw.p + (size_t)p.rows * row_bytes;
+  return KPDI_OK;
+}
+
+int pending_commit(kpdi_ctx *c, int64_t n_chunk, int64_t global_start) {
+  kpdi_ctx::PendingChunks &p = c->pending;
+  const int64_t round = plan::round_rows(plan_env(c), c->m_pad / kpdi::TILE_EXP);
   p.seg.push_back({p.rows, n_chunk, global_start});
   p.rows += n_chunk;
   c->final_valid = false;
@@ -828,8 +845,20 @@ int kpdi_push_rotations_chunk(kpdi_ctx *c, const double *rotations, int64_t n, i
   if (c->have_dc && c->dc_npix != c->npix)
     return fail(KPDI_EINVAL, "detector has %lld pixels but the problem's signal shape has %d", (long long)c->dc_npix,
                 c->npix);
+  if (c->have_exp && c->m > 0 && n > 0 && check_chunk_args(c, KPDI_F32, n, global_start) == KPDI_OK) {
+    // a small chunk is SIMULATED straight into its place among the pending rows (no copy; sweep.hip: coalescing)
+    rc = resolve_exact64(c);
+    if (rc) return rc;
+    void *slot = nullptr;
+    rc = pending_slot(c, KPDI_F32, n, global_start, &slot);
+    if (rc) return rc;
+    if (slot) {
+      rc = project_to_device(c, rotations, n, rescale, out_min, out_max, KPDI_F32, slot, nullptr, true);
+      return rc ? rc : pending_commit(c, n, global_start);
+    }
+  }
   if (n > 0) HIPCHK(c->dict_raw.reserve((size_t)n * c->npix * sizeof(float)));
-  rc = project_to_device(c, rotations, n, rescale, out_min, out_max, KPDI_F32, c->dict_raw.p);
+  rc = project_to_device(c, rotations, n, rescale, out_min, out_max, KPDI_F32, c->dict_raw.p, nullptr, true);
   if (rc) return rc;
   return push_chunk_dev(c, c->dict_raw.p, KPDI_F32, n, global_start, true);
 }

@@ -63,6 +63,7 @@ for case in range(n_cases):
     chunk = int(rng.choice([n, max(1, n // 3), 100]))
     ctx.set_problem(sy, sx, sig, {"ncc": _lib.METRIC_NCC, "ndp": _lib.METRIC_NDP}[metric], k, mode)
     ctx.set_experimental(exp, nav)
+    ctx.set_dictionary_size(n if rng.random() < 0.6 else 0)  # (a group plans its chunk assignment with it; 0 = unknown)
     pre = ""
     if rng.random() < 0.25 and dt_e in (np.uint8, np.uint16) and sy >= 4 and sx >= 4:
         # recorded background removal, fused with the preparation at the first chunk; the oracle is then fed
