@@ -201,8 +201,9 @@ int kpdi_get_experimental(kpdi_ctx *ctx, void *patterns_out);
  * synchronize, counters, export; a new experimental set, problem or keep_n forgets them with the running lists), and the
  * merge kernel translates rows of the coalesced matrix back to dictionary indices.  Chunks join in rising
  * dictionary order, one dtype, at most 16 per sweep; anything else sweeps the pending rows first.  The result never
- * depends on it (tests/test_gpu_engine.py); not in KPDI_COMPUTE_F64 nor for keep_n > 32; KPDI_NO_COALESCE=1 switches
- * it off.  configs[1] pushed as 33 chunks of 3044: 26.6 -> 23.6 ms per call (one pass: 21.3; profiles/r05_group_chunks.txt). */
+ * depends on it (tests/test_gpu_engine.py); not in KPDI_COMPUTE_F64 (rescoring reads a chunk's own raw patterns);
+ * KPDI_NO_COALESCE=1 switches it off.  Chunks handed over to be HELD (kpdi_hold_*) wait the same way and become one
+ * resident chunk, eight rounds' worth at a time.  configs[1] pushed as 33 chunks of 3044: 26.6 -> 23.6 ms per call (one pass: 21.3; profiles/r05_group_chunks.txt). */
 int kpdi_push_dictionary_chunk(kpdi_ctx *ctx, const void *patterns, int dtype,
                                int64_t n_chunk, int64_t global_start);
 int kpdi_push_dictionary_chunk_dev(kpdi_ctx *ctx, const void *d_patterns, int dtype,

@@ -234,7 +234,7 @@ int kpdi_destroy(kpdi_ctx *c) {
                     &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps, &c->inv_map, &c->pre_scratch,
                     &c->mp_packed, &c->dcos, &c->rot, &c->proj_out,
                     &c->ref_raw, &c->ref_map, &c->ref_rowcol, &c->ref_pat, &c->ref_sqn, &c->ref_in, &c->ref_out,
-                    &c->ref_idx, &c->osm_idx, &c->osm_out, &c->stage[0], &c->stage[1], &c->pending.raw})
+                    &c->ref_idx, &c->osm_idx, &c->osm_out, &c->stage[0], &c->stage[1], &c->pending.raw, &c->pending_hold.raw})
     b->release();
   for (auto *l : {&c->ev_match, &c->ev_prep, &c->ev_merge, &c->ev_proj, &c->ev_pre, &c->ev_rescore})
     for (auto &pr : *l) {
@@ -267,6 +267,10 @@ int kpdi_synchronize(kpdi_ctx *c) {
   if (rc) return rc;
   if (c->have_exp && c->have_problem) {
     rc = flush_pending(c);  // "everything pushed has been swept"
+    if (rc) return rc;
+  }
+  if (c->have_problem) {
+    rc = flush_pending(c, true);  // ... and everything handed over to be held is prepared
     if (rc) return rc;
   }
   HIPCHK(hipStreamSynchronize(c->stream));

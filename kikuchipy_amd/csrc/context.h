@@ -190,6 +190,7 @@ struct kpdi_ctx {
   struct HeldChunk {
     kpdi::DevBuf y;
     int64_t n = 0, start = 0;
+    kpdi::IndexSegments seg;  // seg.n > 1: several small held chunks prepared as ONE matrix (rows -> dictionary indices)
   };
   std::vector<HeldChunk> held;
   std::vector<int> kept_pixels;  // host copy of pix_map: tells whether a new problem keeps the layout
@@ -205,7 +206,8 @@ struct kpdi_ctx {
       int64_t row0, n, start;  // rows [row0, row0 + n) hold the dictionary patterns [start, start + n)
     };
     std::vector<Segment> seg;
-  } pending;
+  } pending,       // pushed chunks: swept together
+    pending_hold;  // chunks to be held resident (kpdi_hold_*): prepared together into ONE held chunk
   // host-pointer pushes are cut into pieces whose upload (copy stream) overlaps the sweep of
   // the previous piece (compute stream): two staging buffers, events for hand-over
   kpdi::DevBuf stage[2];
@@ -405,14 +407,17 @@ int check_chunk_args(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_sta
 // `may_wait`: the chunk is a whole push of the caller's (not a piece of a larger upload) and may wait, if it is small, for
 // more chunks to be swept with (flush_pending: before anything reads or resets the running lists)
 int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start, bool may_wait = false);
-int flush_pending(kpdi_ctx *c);
-void discard_pending(kpdi_ctx *c);
+int flush_pending(kpdi_ctx *c, bool hold = false);
+void discard_pending(kpdi_ctx *c, bool hold = false);
 // Where the next `n_chunk` rows of `dtype` (dictionary patterns from `global_start` on) would join the pending rows:
 // *slot = device address for their raw patterns, or nullptr when this chunk cannot wait (it is then swept at once).
 // What is pending may be swept first to make room / keep the order.  pending_commit() after the slot has been filled
 // (by work queued on the context's stream) makes the rows part of the pending matrix and sweeps it when it is due.
-int pending_slot(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_start, void **slot);
-int pending_commit(kpdi_ctx *c, int64_t n_chunk, int64_t global_start);
+// `hold`: the chunk is to stay resident (the pending rows become one held chunk instead of being swept).
+int pending_slot(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_start, void **slot, bool hold = false);
+int pending_commit(kpdi_ctx *c, int64_t n_chunk, int64_t global_start, bool hold = false);
+// hold a raw chunk resident in device memory: it joins the pending rows when it is small, else it is prepared at once
+int hold_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start, bool may_wait);
 int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_start, const void *raw = nullptr, int raw_dtype = 0,
                    const IndexSegments *seg = nullptr);
 int new_held_chunk(kpdi_ctx *c, int64_t n_chunk, int64_t global_start, float **out);

@@ -413,23 +413,29 @@ static int sweep_raw_chunk(kpdi_ctx *c, const void *d_patterns, int dtype, int64
 }
 
 // ---- coalescing of small chunks (context.h: PendingChunks) ---------------------------------------------------------
-// A chunk may wait when it is a whole push of fewer than two tile rounds, in f32 / f16 arithmetic with a list that fits
-// one pass (float64 rescoring and bounded passes read the chunk's own raw patterns and indices: they sweep at once).
+// A chunk may wait when it is a whole push of fewer than two tile rounds, in f32 / f16 arithmetic (float64 rescoring
+// reads the chunk's own raw patterns: it sweeps at once).  Chunks to be HELD resident (kpdi_hold_*) wait the same way
+// and become one held chunk (eight rounds' worth at a time).
 // It is appended when the pending rows are of its dtype, come before it in the dictionary (rows and indices must rise
 // together: the match kernel breaks ties by row) and a segment is free; otherwise the pending rows are swept first.
 // Three rounds' worth of rows are swept as soon as they are there.  KPDI_NO_COALESCE=1: every chunk at once (A/B).
-static bool may_coalesce(const kpdi_ctx *c, int64_t n_chunk) {
-  if (c->sw.no_coalesce || c->exact64 || c->keep_n > kpdi::KMAX_LIMIT) return false;
-  return n_chunk < 2 * plan::round_rows(plan_env(c), c->m_pad / kpdi::TILE_EXP);
+static int64_t round_of(const kpdi_ctx *c) {
+  return c->have_exp && c->m_pad > 0 ? plan::round_rows(plan_env(c), c->m_pad / kpdi::TILE_EXP) : 4096;
 }
 
-void discard_pending(kpdi_ctx *c) {
-  c->pending.rows = 0;
-  c->pending.seg.clear();
+static bool may_coalesce(const kpdi_ctx *c, int64_t n_chunk, bool hold) {
+  if (c->sw.no_coalesce || (!hold && c->exact64)) return false;
+  return n_chunk < 2 * round_of(c);
 }
 
-int flush_pending(kpdi_ctx *c) {
-  kpdi_ctx::PendingChunks &p = c->pending;
+void discard_pending(kpdi_ctx *c, bool hold) {
+  kpdi_ctx::PendingChunks &p = hold ? c->pending_hold : c->pending;
+  p.rows = 0;
+  p.seg.clear();
+}
+
+int flush_pending(kpdi_ctx *c, bool hold) {
+  kpdi_ctx::PendingChunks &p = hold ? c->pending_hold : c->pending;
   if (p.rows == 0) return KPDI_OK;
   IndexSegments seg;
   seg.n = (int)p.seg.size();
@@ -439,7 +445,15 @@ int flush_pending(kpdi_ctx *c) {
   }
   const int64_t rows = p.rows, start = p.seg[0].start;
   const bool one = seg.n == 1;  // a lone chunk: dictionary indices straight from the match kernel, as if it had not waited
-  discard_pending(c);
+  discard_pending(c, hold);
+  if (hold) {  // the pending rows become ONE resident chunk
+    float *y = nullptr;
+    decide_form(c, rows);
+    int rc = new_held_chunk(c, rows, one ? start : 0, &y);
+    if (rc) return rc;
+    if (!one) c->held.back().seg = seg;
+    return prepare_chunk(c, p.raw.p, p.dtype, rows, y);
+  }
   c->cnt.coalesced_sweeps += one ? 0 : 1;
   return sweep_raw_chunk(c, p.raw.p, p.dtype, rows, one ? start : 0, one ? nullptr : &seg);
 }
@@ -464,22 +478,42 @@ int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chu
   return pending_commit(c, n_chunk, global_start);
 }
 
-int pending_slot(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_start, void **slot) {
+int hold_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start, bool may_wait) {
+  void *slot = nullptr;
+  int rc = KPDI_OK;
+  if (may_wait) {
+    rc = pending_slot(c, dtype, n_chunk, global_start, &slot, true);
+    if (rc) return rc;
+  }
+  if (slot) {
+    HIPCHK(hipMemcpyAsync(slot, d_patterns, (size_t)n_chunk * c->npix * kpdi::dtype_size(dtype), hipMemcpyDeviceToDevice, c->stream));
+    return pending_commit(c, n_chunk, global_start, true);
+  }
+  rc = flush_pending(c, true);  // (held chunks keep the order they were handed over in)
+  if (rc) return rc;
+  float *y = nullptr;
+  decide_form(c, n_chunk);
+  rc = new_held_chunk(c, n_chunk, global_start, &y);
+  return rc ? rc : prepare_chunk(c, d_patterns, dtype, n_chunk, y);
+}
+
+int pending_slot(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_start, void **slot, bool hold) {
   *slot = nullptr;
-  if (!c->have_exp || !c->have_problem || c->m == 0 || !may_coalesce(c, n_chunk)) return KPDI_OK;
-  kpdi_ctx::PendingChunks &p = c->pending;
+  if (!c->have_problem || !may_coalesce(c, n_chunk, hold)) return KPDI_OK;
+  if (!hold && (!c->have_exp || c->m == 0)) return KPDI_OK;
+  kpdi_ctx::PendingChunks &p = hold ? c->pending_hold : c->pending;
   const size_t row_bytes = (size_t)c->npix * kpdi::dtype_size(dtype);
-  const int64_t round = plan::round_rows(plan_env(c), c->m_pad / kpdi::TILE_EXP);
+  const int64_t round = round_of(c);
   if (p.rows > 0 && (p.dtype != dtype || (int)p.seg.size() == INDEX_SEGMENTS || p.rows + n_chunk > p.capacity ||
                      global_start < p.seg.back().start + p.seg.back().n)) {
-    int rc = flush_pending(c);
+    int rc = flush_pending(c, hold);
     if (rc) return rc;
   }
   if (p.rows == 0) {
-    // room for what is swept together (three rounds) + the chunk that takes it there; at most 2 GiB
-    const int64_t want = std::min<int64_t>(5 * round, std::max<int64_t>((int64_t)((2ull << 30) / row_bytes), n_chunk));
+    // room for what goes together (three rounds to be swept, eight to be held) + the chunk that takes it there; at most 2 GiB
+    const int64_t want = std::min<int64_t>((hold ? 10 : 5) * round, std::max<int64_t>((int64_t)((2ull << 30) / row_bytes), n_chunk));
     if (p.raw.cap < (size_t)want * row_bytes) {
-      HIPCHK(hipStreamSynchronize(c->stream));  // (a sweep queued earlier may still read the buffer that is about to go)
+      HIPCHK(hipStreamSynchronize(c->stream));  // (work queued earlier may still read the buffer that is about to go)
       HIPCHK(p.raw.reserve((size_t)want * row_bytes));
     }
     p.capacity = (int64_t)(p.raw.cap / row_bytes);
@@ -489,13 +523,13 @@ int pending_slot(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_start, 
   return KPDI_OK;
 }
 
-int pending_commit(kpdi_ctx *c, int64_t n_chunk, int64_t global_start) {
-  kpdi_ctx::PendingChunks &p = c->pending;
-  const int64_t round = plan::round_rows(plan_env(c), c->m_pad / kpdi::TILE_EXP);
+int pending_commit(kpdi_ctx *c, int64_t n_chunk, int64_t global_start, bool hold) {
+  kpdi_ctx::PendingChunks &p = hold ? c->pending_hold : c->pending;
+  const int64_t round = round_of(c);
   p.seg.push_back({p.rows, n_chunk, global_start});
   p.rows += n_chunk;
-  c->final_valid = false;
-  if (p.rows >= 3 * round || p.rows + round / 4 > p.capacity) return flush_pending(c);
+  if (!hold) c->final_valid = false;
+  if (p.rows >= (hold ? 8 : 3) * round || p.rows + round / 4 > p.capacity) return flush_pending(c, hold);
   return KPDI_OK;
 }
 
@@ -547,6 +581,8 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
   const int nsplit = plan::choose_nsplit(plan_env(c), uses16(c), row_blocks, n_tiles, &rows_per_launch);
   const int k = c->keep_n;
   if (c->exact64) {
+    if (seg) return fail(KPDI_EINVAL, "float64 arithmetic rescoring reads a chunk's own raw patterns: a dictionary held as coalesced chunks "
+                                      "keeps only the prepared form - push the chunks instead");
     if (!raw)
       return fail(KPDI_EINVAL, "float64 arithmetic rescoring reads the RAW dictionary patterns: resident (held) chunks keep "
                                "only the prepared form - push the chunks instead");
@@ -576,15 +612,18 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
     ++ns;
   }
 
-  if (seg && (c->exact64 || k > kpdi::KMAX_LIMIT)) return fail(KPDI_EINVAL, "internal: coalesced chunks in a multi-pass sweep");
+  // a coalesced matrix is ranked by ROW (index base 0): every list the chunk contributes - also the bounded passes'
+  // bounds, compared inside the match kernel - lives in row space until this merge translates it (rows and dictionary
+  // indices rise together, so "after (score, row)" is "after (score, index)")
+  const int64_t idx_base = seg ? 0 : global_start;
+  if (seg) {
+    mg.seg = *seg;
+    mg.seg_sources = ~0u << ns;
+  }
   if (k <= kpdi::KMAX_LIMIT) {
     const int len = kpdi::match_list_len(k);
-    rc = run_match(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, len, global_start, nullptr, nullptr, true);
+    rc = run_match(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, len, idx_base, nullptr, nullptr, true);
     if (rc) return rc;
-    if (seg) {  // the match launch(es) ranked ROWS of the coalesced matrix: sources from here on
-      mg.seg = *seg;
-      mg.seg_sources = ~0u << ns;
-    }
     mg.src_scores[ns] = c->part_s.as<float>();
     mg.src_idx[ns] = c->part_i.as<int>();
     const int lps = lists_per_split(c);
@@ -616,7 +655,7 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
     if (kk < k) HIPCHK(kpdi::launch_fill_topk(c->loc_s.as<float>(), c->loc_i.as<int>(), (int64_t)n, c->stream));
     for (int done = 0; done < kk;) {  // (the first pass is unbounded: up to 32 entries in every form)
       const int kp = std::min(done == 0 ? kpdi::KMAX_LIMIT : pass_entries(c), kk - done);
-      rc = local_pass(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, global_start, done, kp, k);
+      rc = local_pass(c, y, (int)n_chunk, n_tiles, nsplit, rows_per_launch, idx_base, done, kp, k);
       if (rc) return rc;
       done += kp;
     }
@@ -714,6 +753,7 @@ int new_held_chunk(kpdi_ctx *c, int64_t n_chunk, int64_t global_start, float **o
 }
 
 void release_held(kpdi_ctx *c) {
+  discard_pending(c, true);
   if (c->held.empty()) return;
   (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
@@ -764,6 +804,13 @@ int kpdi_hold_dictionary_chunk(kpdi_ctx *c, const void *patterns, int dtype, int
   if (rc) return rc;
   rc = use_device(c);
   if (rc) return rc;
+  if (n_chunk <= 192 * kpdi::TILE_DICT) {
+    // one upload piece: it may join the pending rows of small held chunks (hold_chunk_dev), else it is prepared at once
+    return staged_upload(c, patterns, (size_t)c->npix * kpdi::dtype_size(dtype), {n_chunk},
+                         [&](const void *d_piece, int64_t n, int64_t) { return hold_chunk_dev(c, d_piece, dtype, n, global_start, true); });
+  }
+  rc = flush_pending(c, true);  // (held chunks keep the order they were handed over in)
+  if (rc) return rc;
   float *y = nullptr;
   decide_form(c, n_chunk);
   rc = new_held_chunk(c, n_chunk, global_start, &y);
@@ -792,25 +839,23 @@ int kpdi_hold_dictionary_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtyp
   if (rc) return rc;
   rc = use_device(c);
   if (rc) return rc;
-  float *y = nullptr;
-  decide_form(c, n_chunk);
-  rc = new_held_chunk(c, n_chunk, global_start, &y);
-  if (rc) return rc;
-  return prepare_chunk(c, d_patterns, dtype, n_chunk, y);
+  return hold_chunk_dev(c, d_patterns, dtype, n_chunk, global_start, true);
 }
 
 int kpdi_sweep_held(kpdi_ctx *c) {
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
   if (!c->have_problem) return fail(KPDI_EINVAL, "kpdi_set_problem has not been called");
   if (!c->have_exp) return fail(KPDI_EINVAL, "kpdi_set_experimental has not been called");
-  if (c->held.empty()) return fail(KPDI_EINVAL, "no resident dictionary: kpdi_hold_dictionary_chunk has not been called");
   int rc = use_device(c);
   if (rc) return rc;
+  rc = flush_pending(c, true);  // (small chunks that were waiting to be held together)
+  if (rc) return rc;
+  if (c->held.empty()) return fail(KPDI_EINVAL, "no resident dictionary: kpdi_hold_dictionary_chunk has not been called");
   if (c->m == 0) return KPDI_OK;
   rc = flush_pending(c);
   if (rc) return rc;
   for (auto &h : c->held) {
-    rc = sweep_prepared(c, h.y.as<float>(), h.n, h.start);
+    rc = sweep_prepared(c, h.y.as<float>(), h.n, h.start, nullptr, 0, h.seg.n > 1 ? &h.seg : nullptr);
     if (rc) return rc;
   }
   return KPDI_OK;
@@ -826,6 +871,11 @@ int kpdi_release_held(kpdi_ctx *c) {
 
 int kpdi_held_size(kpdi_ctx *c, int64_t *n_patterns, int64_t *n_bytes) {
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (c->pending_hold.rows > 0) {  // (chunks that are still waiting to be prepared together count)
+    int rc = use_device(c);
+    if (!rc) rc = flush_pending(c, true);
+    if (rc) return rc;
+  }
   int64_t n = 0, bytes = 0;
   for (auto &h : c->held) {
     n += h.n;
@@ -873,14 +923,17 @@ int kpdi_hold_rotations_chunk(kpdi_ctx *c, const double *rotations, int64_t n, i
   if (c->have_dc && c->dc_npix != c->npix)
     return fail(KPDI_EINVAL, "detector has %lld pixels but the problem's signal shape has %d", (long long)c->dc_npix,
                 c->npix);
+  void *slot = nullptr;
+  rc = pending_slot(c, KPDI_F32, n, global_start, &slot, true);
+  if (rc) return rc;
+  if (slot) {  // a small chunk: simulated straight into its place among the rows that will be held together
+    rc = project_to_device(c, rotations, n, rescale, out_min, out_max, KPDI_F32, slot, nullptr, true);
+    return rc ? rc : pending_commit(c, n, global_start, true);
+  }
   HIPCHK(c->dict_raw.reserve((size_t)n * c->npix * sizeof(float)));
   rc = project_to_device(c, rotations, n, rescale, out_min, out_max, KPDI_F32, c->dict_raw.p);
   if (rc) return rc;
-  float *y = nullptr;
-  decide_form(c, n);
-  rc = new_held_chunk(c, n, global_start, &y);
-  if (rc) return rc;
-  return prepare_chunk(c, c->dict_raw.p, KPDI_F32, n, y);
+  return hold_chunk_dev(c, c->dict_raw.p, KPDI_F32, n, global_start, false);
 }
 
 }  // extern "C"

@@ -240,7 +240,7 @@ def test_small_chunks_are_swept_together_and_nothing_changes(monkeypatch):
     """Coalescing (csrc/sweep.hip): pushed chunks of less than two tile rounds wait for company and are prepared + matched
     as ONE launch set; the merge translates rows of the coalesced matrix back to dictionary indices.  Whatever the order,
     size, dtype or origin (host / device / generated) of the chunks the result is the single pass's, BIT FOR BIT; chunks
-    that cannot wait (float64 arithmetic, keep_n > 32, a start below what is pending, a 17th segment) are swept at once
+    that cannot wait (float64 arithmetic, a start below what is pending, a 17th segment) are swept at once
     or force the pending ones out first.  The reference's own call shape: `n_per_iteration` patterns per iteration
     (indexing/_dictionary_indexing.py:100-128)."""
     from kikuchipy_amd import _lib
@@ -297,11 +297,12 @@ def test_small_chunks_are_swept_together_and_nothing_changes(monkeypatch):
             c.push_dictionary_chunk(d16[a:b] if j % 3 else d16[a:b].astype(np.float32), a)
         s, i = c.finalize(20)
         assert np.array_equal(s, r16_s) and np.array_equal(i, r16_i)
-        # arithmetic that reads a chunk's own raw patterns / ranks in bounded passes: swept at once, same result as ever
-        for kw in (dict(keep_n=40), dict(compute=_lib.COMPUTE_F64, keep_n=10)):
+        # keep_n > 32 (bounded passes: the bounds live in row space until the merge) coalesces too; float64 arithmetic reads
+        # a chunk's own raw patterns: swept at once, same result as ever
+        for kw, together in ((dict(keep_n=40), True), (dict(compute=_lib.COMPUTE_F64, keep_n=10), False)):
             (a_s, a_i), cnt1 = sweep([(0, 9000)], **kw)
             (b_s, b_i), cntn = sweep(chunks, **kw)
-            assert np.array_equal(a_i, b_i) and cntn["coalesced_sweeps"] == 0
+            assert np.array_equal(a_i, b_i) and (cntn["coalesced_sweeps"] >= 1) == together
             assert np.array_equal(a_s, b_s) or kw.get("compute") == _lib.COMPUTE_F64 and np.abs(a_s - b_s).max() < 1e-14
         # float16 arithmetic coalesces like float32
         (a_s, a_i), _ = sweep([(0, 9000)], compute=_lib.COMPUTE_F16)

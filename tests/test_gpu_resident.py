@@ -57,6 +57,51 @@ def test_series_of_maps_equals_pushing_again(metric, keep_n, compute, masked):
         ka.dictionary_indexing(exp, resident, metric, keep_n, verbose=False)
 
 
+def test_small_held_chunks_are_prepared_together():
+    """Chunks handed over to be HELD that are smaller than two tile rounds (a lazy dictionary's Dask chunks usually are:
+    3044 patterns in the reference's tutorial) wait for each other and become ONE resident chunk - one launch set per
+    map instead of one per chunk - whose rows the merge maps back to dictionary indices.  Same result, bit for bit, as
+    pushing the chunks, for one-pass and multi-pass keep_n, host / device / generated chunks, any order."""
+    from kikuchipy_amd import _lib
+
+    rng = np.random.default_rng(9)
+    exp = rng.integers(0, 256, (300, 24, 20), dtype=np.uint8)
+    dic = rng.random((6000, 24, 20), dtype=np.float32)
+    dic[4100] = dic[33]
+    chunks = [(a, min(a + 450, 6000)) for a in range(0, 6000, 450)]
+    with _lib.Context(0) as c:
+        for keep_n, compute in ((20, _lib.COMPUTE_F32), (40, _lib.COMPUTE_F32), (8, _lib.COMPUTE_F16)):
+            c.set_problem(24, 20, None, _lib.METRIC_NCC, keep_n, compute)
+            c.set_experimental(exp)
+            c.push_dictionary_chunk(dic, 0)
+            ref = c.finalize(keep_n)
+            for order, dev in ((chunks, False), (chunks[::2] + chunks[1::2], True)):
+                c.release_held()
+                d = None
+                if dev:
+                    d = c.dev_alloc(dic.nbytes)
+                    c.h2d(d, dic)
+                for a, b in order:  # (held BEFORE the experimental set of the next map is known: set-up order is free)
+                    if dev:
+                        c.hold_dictionary_chunk_dev(d + a * dic[0].nbytes, dic.dtype, b - a, a)
+                    else:
+                        c.hold_dictionary_chunk(dic[a:b], a)
+                assert c.held_size()[0] == 6000
+                for _ in range(2):  # map after map
+                    c.set_experimental(exp)
+                    c.reset_counters()
+                    c.sweep_held()
+                    got = c.finalize(keep_n)
+                    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+                held_chunks = 1 if order is chunks else 2  # the step back in the dictionary closes the first group
+                if keep_n <= 32:  # (one match launch set per held chunk and map; bounded passes launch more)
+                    assert c.counters()["match_launches"] == held_chunks
+                if dev:
+                    c.dev_free(d)
+        c.release_held()
+        assert c.held_size() == (0, 0)
+
+
 def test_chunk_larger_than_one_upload_piece():
     """A held chunk is uploaded in pieces of 192 tiles and prepared piece by piece into one buffer."""
     from kikuchipy_amd import _lib
