@@ -1140,6 +1140,53 @@ def _main(argv, context_factory=None, group_factory=None):
         except Exception as err:  # an informational leg must not cost the bench line
             out["extra"]["float64_mode_error"] = f"{type(err).__name__}: {err}"
 
+    if solo and not a.no_rank_shares and a.workload == "config2" and a.compute == "f32" and context_factory is None:
+        try:
+            # informational: the reference's CHUNKED call shape (n_per_iteration = a tenth of the tutorial's dictionary, 3044
+            # patterns, doc/tutorials/pattern_matching.ipynb:582; loop indexing/_dictionary_indexing.py:100-128) on the resident
+            # inputs - one GPU taking all 33 chunks, and ONE member's pieces of the same call on a kpdi_group of 8 (the library's own
+            # assignment, csrc/group_assign.h); small chunks wait for company and are swept together (csrc/sweep.hip)
+            per, n_dev = 3044, 8
+            bounds = [(s0, min(s0 + per, w["n"])) for s0 in range(0, w["n"], per)]
+            loads = [0] * n_dev
+            mine = []
+            for s0, e0 in bounds:
+                for member, row0, rows in _lib.Group.assign_chunk(n_dev, w["n"], loads, e0 - s0):
+                    if member == 0:
+                        mine.append((s0 + row0, rows))
+            cc = _lib.Context(device)
+            cc.set_problem(w["sy"], w["sx"], mask, metric, w["keep_n"], compute)
+            row_bytes = w["sy"] * w["sx"] * np.dtype(dict_np).itemsize
+
+            def chunked(pieces, reps=6):
+                for r in range(reps + 2):
+                    if r == 2:
+                        cc.reset_counters()
+                        cc.synchronize()
+                        t0 = time.perf_counter()
+                    cc.set_experimental_dev(d_exp, exp.dtype, w["m"])
+                    for s0, rows in pieces:
+                        cc.push_dictionary_chunk_dev(d_dic + s0 * row_bytes, dict_np, rows, s0)
+                    res = cc.finalize(w["keep_n"])
+                return (time.perf_counter() - t0) / reps * 1e3, res, cc.counters()
+
+            t_all, (s_c, i_c), cnt_c = chunked([(s0, e0 - s0) for s0, e0 in bounds])
+            t_mem, _, cnt_m = chunked(mine)
+            cc.close()
+            out["extra"]["chunked_call"] = {
+                "what": f"configs[1] pushed as {len(bounds)} chunks of {per} patterns (the reference's n_per_iteration loop), raw inputs "
+                        "resident: one GPU taking every chunk, and member 0's pieces of the same call on a kpdi_group of 8",
+                "ms_per_call_one_gpu": round(t_all, 3), "patterns_per_s_one_gpu": round(w["m"] / t_all * 1e3, 1),
+                "ms_per_step_single_pass": round(ms_per_step, 3),
+                "sweeps_per_call": int(cnt_c["match_launches"] // 6), "coalesced_sweeps_per_call": int(cnt_c["coalesced_sweeps"] // 6),
+                "identical_to_the_single_pass": bool(np.array_equal(s_c, scores) and np.array_equal(i_c, indices)),
+                "group_member_pieces": len(mine), "group_member_patterns": int(sum(r for _, r in mine)),
+                "group_member_ms": round(t_mem, 3), "group_member_over_even_share": round(t_mem / (t_all / n_dev), 4),
+                "group_member_sweeps": int(cnt_m["match_launches"] // 6),
+            }
+        except Exception as err:  # an informational leg must not cost the bench line
+            out["extra"]["chunked_call_error"] = f"{type(err).__name__}: {err}"
+
     if solo and not a.no_pcie and a.workload == "config2" and a.compute == "f32" and context_factory is None:
         # informational: the drop-in seam itself - the reference's loop driving the metric plugin (host-resident dictionary)
         for per in (3044, 25000):  # the tutorial's tenth of its dictionary; a quarter of this one

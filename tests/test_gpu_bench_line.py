@@ -38,7 +38,7 @@ def test_default_bench_line_and_its_legs():
     failed = {k: v for k, v in out["extra"].items() if k.endswith("_error")}
     assert not failed, failed
     for leg in ("config3", "config2_share_of_4", "config2_share_of_8", "config4_share_of_8", "config5_share_of_8",
-                "config5_share_of_8_f16", "plugin_seam", "float64_mode", "f16_mode", "split_f16_mode", "resident_dictionary", "dictionary_generation", "refinement"):
+                "config5_share_of_8_f16", "chunked_call", "plugin_seam", "float64_mode", "f16_mode", "split_f16_mode", "resident_dictionary", "dictionary_generation", "refinement"):
         assert leg in out["extra"], leg
     for leg in ("config2_share_of_8", "config4_share_of_8", "config5_share_of_8"):
         assert out["extra"][leg]["check"]["index_agreement"] == 1.0
@@ -49,6 +49,9 @@ def test_default_bench_line_and_its_legs():
     assert f16["check"]["best_match_agreement"] >= 0.9
     assert 0.3 < f16["match_frac"] < 1.0 and f16["match_frac"] < f16["match_frac_of_random_operand_ceiling"] < 1.1
     assert out["extra"]["float64_mode"]["certificate"] == "worstcase" and out["extra"]["float64_mode"]["uncertified_patterns"] == 0
+    ch = out["extra"]["chunked_call"]  # the reference's chunked call: same result, small chunks swept together, a member near its even share
+    assert ch["identical_to_the_single_pass"] and ch["coalesced_sweeps_per_call"] >= 1 and ch["sweeps_per_call"] < 33
+    assert ch["group_member_patterns"] == 12500 and ch["group_member_sweeps"] == 1 and ch["group_member_over_even_share"] < 1.25
     for per in (3044, 25000):  # the drop-in seam: the reference's loop around the plugin gives the timed run's result
         seam = out["extra"]["plugin_seam"][f"n_per_iteration_{per}"]
         assert seam["patterns_per_s"] > 0 and seam["max_abs_score_diff_vs_the_timed_result"] < 1e-6, seam
