@@ -302,6 +302,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
 
     int stage = 0;
     int tiles_done = 0, refresh_at = 0;
+#ifdef KPDI16_EPI_STATS  // developer build: per tile, what the epilogue of ONE wave did (tools/probes/one_step.py; profiles/r05_f32_tile_time.txt)
+    int st_hot = 0, st_iter = 0, st_cand = 0;
+    unsigned long long st_t0 = 0;
+#endif
 #ifdef KPDI16_TIME_EPI  // developer build (tools/build_variant.sh + tools/probes/one_step.py): where the cycles between tiles go
     unsigned long long epi_cycles = 0, epi_drain = 0;
     const unsigned long long kern_t0 = __builtin_readcyclecounter();
@@ -427,6 +431,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
         }
 #ifdef KPDI16_TIME_EPI
       epi_drain += __builtin_readcyclecounter() - epi_t0;
+#endif
+#ifdef KPDI16_EPI_STATS
+      st_hot = st_iter = st_cand = 0;
+      st_t0 = __builtin_readcyclecounter();
 #endif
       {
         // ---- epilogue of the tile.  Steady state (per column group): the 64 accumulator registers are
@@ -564,8 +572,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
             unsigned pm = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) pm |= acc[cg][rt][r] >= thr_raw ? (1u << r) : 0u;
+#ifdef KPDI16_EPI_STATS
+            ++st_hot;
+#endif
 #pragma unroll 1
             while (__builtin_amdgcn_ballot_w64(pm != 0) != 0) {
+#ifdef KPDI16_EPI_STATS
+              ++st_iter;
+              st_cand += __builtin_popcountll(__builtin_amdgcn_ballot_w64(pm != 0));
+#endif
               if (pm != 0) {
                 const int r = __builtin_ctz(pm);
                 pm &= pm - 1;
@@ -650,6 +665,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
         }
 #ifdef KPDI16_TIME_EPI
         epi_cycles += __builtin_readcyclecounter() - epi_t0;
+#endif
+#ifdef KPDI16_EPI_STATS
+        {
+          const unsigned long long dt = __builtin_readcyclecounter() - st_t0;
+          if (blockIdx.x == 100 && lane == 0 && wv == 0)
+            printf("tile %d: %llu cycles, %d hot blocks of 16, %d loop iterations, %d candidates of the wave, first_fast %d\n", tiles_done, dt,
+                   st_hot, st_iter, st_cand, (int)first_fast);
+        }
 #endif
         ++tiles_done;
         t0 = t1;
