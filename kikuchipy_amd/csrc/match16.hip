@@ -306,6 +306,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
     int st_hot = 0, st_iter = 0, st_cand = 0;
     unsigned long long st_t0 = 0;
 #endif
+#ifdef KPDI16_EPI_FINE  // developer build: cycles of the three parts of a block's epilogue (same tools, same record)
+    unsigned long long fine_screen = 0, fine_pm = 0, fine_loop = 0;
+    int fine_blocks = 0;
+#endif
 #ifdef KPDI16_TIME_EPI  // developer build (tools/build_variant.sh + tools/probes/one_step.py): where the cycles between tiles go
     unsigned long long epi_cycles = 0, epi_drain = 0;
     const unsigned long long kern_t0 = __builtin_readcyclecounter();
@@ -528,6 +532,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
           for (int rt = 0; rt < 4; ++rt) {
             if (first_tile) continue;
             if (F32 && rt >= rt_n) continue;
+#ifdef KPDI16_EPI_FINE
+            const unsigned long long f0 = __builtin_readcyclecounter();
+#endif
             float m = acc[cg][rt][0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[cg][rt][r]);
@@ -569,9 +576,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
             // cycles of scalar dependency stalls each, 16 x 16 times per tile: 2 % of the kernel, profiles/r03_epilogue_cycles.txt);
             // then ONE loop, as long as any lane has a bit left: lowest bit -> register (a 16-way select) -> append.  Bits
             // are taken in ascending register order = ascending dictionary index, like the per-register form.
+#ifdef KPDI16_EPI_FINE
+            const unsigned long long f1 = __builtin_readcyclecounter();
+#endif
             unsigned pm = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) pm |= acc[cg][rt][r] >= thr_raw ? (1u << r) : 0u;
+#ifdef KPDI16_EPI_FINE
+            asm volatile("" : "+v"(pm));
+            const unsigned long long f2 = __builtin_readcyclecounter();
+#endif
 #ifdef KPDI16_EPI_STATS
             ++st_hot;
 #endif
@@ -606,6 +620,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
                 }
               }
             }
+#ifdef KPDI16_EPI_FINE
+            {
+              const unsigned long long f3 = __builtin_readcyclecounter();
+              fine_screen += f1 - f0;
+              fine_pm += f2 - f1;
+              fine_loop += f3 - f2;
+              ++fine_blocks;
+            }
+#endif
             }
           }
           if (__builtin_amdgcn_ballot_w64(overflow) == 0) {
@@ -682,6 +705,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
         if (t0 >= n_units) break;
       }
     }
+#ifdef KPDI16_EPI_FINE
+    if (blockIdx.x == 100 && lane == 0)
+      printf("wave %d: %d hot blocks: screen %llu, mask %llu, loop %llu cycles per hot block\n", wv, fine_blocks, fine_screen / fine_blocks,
+             fine_pm / fine_blocks, fine_loop / fine_blocks);
+#endif
 #ifdef KPDI16_TIME_EPI
     if ((blockIdx.x == 0 || blockIdx.x == 100) && lane == 0)
       printf("block %d wave %d: %d tiles, %llu cycles between tiles (%llu of them waiting for the last MFMAs) of %llu in the tile loop "
