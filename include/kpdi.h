@@ -435,7 +435,9 @@ int kpdi_import_lists(kpdi_ctx *ctx, const void *scores_all, const int32_t *indi
  * member 0 (xGMI between devices) - which also works when several members share ONE device (RCCL refuses duplicate
  * devices), so the whole multi-device code path runs on a 1-GPU box.  KPDI_GATHER_AUTO: $KPDI_GATHER = "rccl" | "p2p"
  * if set, else P2P when a device appears twice, else RCCL (falling back to P2P, with the reason kept for
- * kpdi_group_describe, if the communicator cannot be created).  A group of one device gathers nothing.
+ * kpdi_group_describe, if the communicator cannot be created or its first all-gather - a small one, run by
+ * kpdi_group_create on every member at once under $KPDI_COMM_TIMEOUT seconds, default 60 - does not complete; with
+ * KPDI_GATHER_RCCL asked for by name that is an error instead).  A group of one device gathers nothing.
  * Calls other than the chunk pushes are synchronous with respect to the members' host work (they return when every
  * member's call has) and, like the per-context calls, asynchronous with respect to the GPUs.  One thread at a time
  * drives a group.

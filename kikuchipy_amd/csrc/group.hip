@@ -165,6 +165,32 @@ int join_workers(kpdi_group *g) {
 
 int bad_group() { return kpdi::fail_msg(KPDI_EINVAL, "group is NULL"); }
 
+// One small all-gather through the members' new communicator, every member on a thread of its own, each under a timeout
+// ($KPDI_COMM_TIMEOUT seconds, default 60): a communicator whose bootstrap succeeded can still hang in its first
+// collective (peer access, IPC handles) - found here, where the group can still take the peer-copy gather, not in the
+// finalize of the first sweep.  The multi-process form does the same in Communicator.attach (kikuchipy_amd/parallel.py).
+int comm_selftest_all(kpdi_group *g, std::string *why) {
+  double seconds = 60.0;
+  if (const char *e = getenv("KPDI_COMM_TIMEOUT")) seconds = std::max(0.001, atof(e));
+  const int timeout_ms = (int)std::min(seconds * 1000.0, 2.0e9);
+  std::vector<int> rc(g->n, 0);
+  std::vector<std::string> err(g->n);
+  std::vector<std::thread> th;
+  for (int i = 0; i < g->n; ++i)
+    th.emplace_back([&, i] {
+      rc[i] = getenv("KPDI_GROUP_SELFTEST_FAIL") ? kpdi::fail_msg(KPDI_ECOMM, "injected failure (KPDI_GROUP_SELFTEST_FAIL)")
+                                                 : kpdi_comm_selftest(g->ctx[i], 65536, timeout_ms);
+      if (rc[i]) err[i] = kpdi::thread_error();
+    });
+  for (auto &t : th) t.join();
+  for (int i = 0; i < g->n; ++i)
+    if (rc[i]) {
+      *why = member_error(g, i, err[i]);
+      return rc[i];
+    }
+  return KPDI_OK;
+}
+
 // a new sweep starts: nobody has taken anything yet
 void reset_loads(kpdi_group *g) { g->load.assign(g->n, 0); }
 
@@ -285,13 +311,24 @@ int kpdi_group_create(const int *device_ids, int n_dev, int gather, kpdi_group *
     else if (duplicates) mode = KPDI_GATHER_P2P, note = " (a device appears twice: RCCL refuses duplicate devices)";
     else {
       // a communicator of the process's own: no unique id to pass around, no sockets, no environment
-      if (kpdi::comm_init_all(g->ctx.data(), n_dev) == KPDI_OK) mode = KPDI_GATHER_RCCL;
-      else mode = KPDI_GATHER_P2P, note = std::string(" (RCCL unavailable: ") + kpdi::thread_error() + ")";
+      if (kpdi::comm_init_all(g->ctx.data(), n_dev) == KPDI_OK) {
+        std::string why;
+        if (comm_selftest_all(g.get(), &why) == KPDI_OK) {
+          mode = KPDI_GATHER_RCCL;
+        } else {  // (every member drops: a communicator that only some members hold would hang the first finalize)
+          for (kpdi_ctx *c : g->ctx) (void)kpdi_comm_drop(c);
+          mode = KPDI_GATHER_P2P, note = " (RCCL's first all-gather failed: " + why + ")";
+        }
+      } else {
+        mode = KPDI_GATHER_P2P, note = std::string(" (RCCL unavailable: ") + kpdi::thread_error() + ")";
+      }
     }
   } else if (mode == KPDI_GATHER_RCCL) {
-    const int rc = kpdi::comm_init_all(g->ctx.data(), n_dev);  // (also with one device: keeps the path testable)
+    int rc = kpdi::comm_init_all(g->ctx.data(), n_dev);  // (also with one device: keeps the path testable)
+    std::string e = rc ? kpdi::thread_error() : "";
+    if (!rc) rc = comm_selftest_all(g.get(), &e);  // asked for by name: a failure is an error, not a fallback
     if (rc) {
-      const std::string e = kpdi::thread_error();
+      for (kpdi_ctx *c : g->ctx) (void)kpdi_comm_drop(c);
       destroy_members();
       return kpdi::fail_msg(rc, "KPDI_GATHER_RCCL: %s%s", e.c_str(),
                             duplicates ? " - several members share a device; use KPDI_GATHER_P2P for that" : "");

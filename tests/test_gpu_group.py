@@ -304,6 +304,21 @@ def test_in_process_rccl_communicator_with_one_member():
         _lib.Group([0, 0], gather="rccl")  # RCCL refuses duplicate devices: the message says what to use instead
 
 
+def test_a_group_tries_its_rccl_communicator_before_it_relies_on_it(monkeypatch):
+    """kpdi_group_create runs one small all-gather through a new communicator (every member on a thread of its own, under
+    $KPDI_COMM_TIMEOUT): asked for by name, a failure is an error that names the member; chosen automatically (distinct
+    devices - not reachable on a one-GPU box), the group takes the peer-copy gather instead and says why."""
+    from kikuchipy_amd import _lib
+
+    monkeypatch.setenv("KPDI_GROUP_SELFTEST_FAIL", "1")
+    with pytest.raises(_lib.KpdiError, match=r"device 0 \(group member 0 of 1\): injected failure"):
+        _lib.Group([0], gather="rccl")
+    monkeypatch.delenv("KPDI_GROUP_SELFTEST_FAIL")
+    monkeypatch.setenv("KPDI_COMM_TIMEOUT", "20")
+    with _lib.Group([0], gather="rccl") as g:  # (the real self-test, one rank)
+        assert g.gather == "rccl"
+
+
 def test_pipelined_series_of_maps_on_a_group():
     """finalize_async / finalize_wait on a group: map i's merged result is collected after map i + 1 has been
     queued on every member (what bench.py --single-process does); device-resident inputs per member."""
