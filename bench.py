@@ -286,71 +286,94 @@ def rank_share_leg(_lib, make_context, device, key, n_ranks, d_dic, dic_host, re
 def plugin_seam_leg(exp, dic, keep_n, n_per_iteration, device, ref_scores, ref_indices):
     """What a user of an UNMODIFIED kikuchipy gets: the reference's own loop
     (indexing/_dictionary_indexing.py:94-128 and `_match_chunk`, :172-203 - restated here call for call, NumPy in place
-    of Dask's pass-through of NumPy results) driving this package's metric PLUGIN with a host-resident dictionary.  Per
-    chunk: one upload, one sweep, one synchronous hand-over of the chunk's best-k, then the reference's host merge
-    (hstack + argsort + take_along_axis).  Returns patterns/s and where the time goes."""
+    of Dask's pass-through of NumPy results) driving this package's metric PLUGIN with a host-resident dictionary.
+    Two forms, same result: the plugin as it ships - after the first chunk it sweeps the chunks the loop is about to ask
+    for ahead of it, on a thread of its own, while the loop runs the reference's host merge
+    (similarity_metrics._LookAhead) - and with $KPDI_SEAM_LOOKAHEAD=0: per chunk one upload, one sweep, one synchronous
+    hand-over, then the host merge (where the time goes is only separable there).  Best of 3 calls each."""
     import kikuchipy_amd as kpa
 
     m, n = len(exp), len(dic)
-    metric = kpa.NormalizedCrossCorrelationMetric(n_experimental_patterns=m, n_dictionary_patterns=n, device=device)
-    ctx = metric.context
-    t = {"upload": 0.0, "sweep_and_hand_over": 0.0, "host_merge": 0.0}
-    push, fin = ctx.push_dictionary_chunk, ctx.finalize
 
-    def timed(fn, key):
-        def run(*args, **kw):
-            t0 = time.perf_counter()
-            try:
-                return fn(*args, **kw)
-            finally:
-                t[key] += time.perf_counter() - t0
-        return run
+    def one_form(lookahead):
+        os.environ["KPDI_SEAM_LOOKAHEAD"] = "1" if lookahead else "0"
+        metric = kpa.NormalizedCrossCorrelationMetric(n_experimental_patterns=m, n_dictionary_patterns=n, device=device)
+        ctx = metric.context
+        t = {"upload": 0.0, "sweep_and_hand_over": 0.0, "host_merge": 0.0}
+        push, fin = ctx.push_dictionary_chunk, ctx.finalize
 
-    ctx.push_dictionary_chunk = timed(push, "upload")
-    ctx.finalize = timed(fin, "sweep_and_hand_over")
-    best = None
-    for rep in range(3):
-        for k in t:
-            t[k] = 0.0
-        t_start = time.perf_counter()
-        experimental = metric.prepare_experimental(exp)                       # :70
-        dictionary = dic.reshape((n, -1))                                     # :71
-        keep = min(keep_n, n)                                                 # :67
-        n_iterations = int(np.ceil(n / n_per_iteration))                      # :68
-        indices = np.zeros((m, keep), dtype=np.int32)                         # :97
-        scores = np.full((m, keep), -metric.sign, dtype=metric.dtype)         # :98
-        starts = np.cumsum([0] + [n_per_iteration] * (n_iterations - 1))      # :100-104
-        ends = np.cumsum([n_per_iteration] * n_iterations)
-        ends[-1] = max(ends[-1], n)
-        for start, end in zip(starts, ends):
-            k_i = min(keep, end - start)
-            simulated = metric.prepare_dictionary(dictionary[start:end])      # :193
-            similarities = metric.match(experimental, simulated)              # :195
-            idx_i = similarities.argtopk(k_i, axis=-1).reshape((-1, k_i))     # :197-201
-            scores_i = similarities.topk(k_i, axis=-1).reshape((-1, k_i))
-            t0 = time.perf_counter()
-            idx_i = idx_i + start                                             # :118
-            all_scores = np.hstack((scores, scores_i))                        # :120-128
-            all_idx = np.hstack((indices, idx_i))
-            order = np.argsort(-all_scores, axis=1)[:, :keep]
-            scores = np.take_along_axis(all_scores, order, axis=1)
-            indices = np.take_along_axis(all_idx, order, axis=1)
-            t["host_merge"] += time.perf_counter() - t0
-        total = time.perf_counter() - t_start
-        if best is None or total < best[0]:
-            best = (total, dict(t))
-    ctx.close()
-    total, split = best
-    return {
-        "n_per_iteration": int(n_per_iteration), "iterations": int(n_iterations),
-        "patterns_per_s": round(m / total, 1), "ms_per_call": round(total * 1e3, 2),
-        "ms_upload": round(split["upload"] * 1e3, 2),
-        "ms_sweep_and_hand_over": round(split["sweep_and_hand_over"] * 1e3, 2),
-        "ms_reference_host_merge": round(split["host_merge"] * 1e3, 2),
-        "ms_other_host": round((total - sum(split.values())) * 1e3, 2),
-        "max_abs_score_diff_vs_the_timed_result": float(np.abs(scores - ref_scores).max()),
-        "index_agreement_with_the_timed_result": float(np.mean(indices == ref_indices)),
-    }
+        def timed(fn, key):
+            def run(*args, **kw):
+                t0 = time.perf_counter()
+                try:
+                    return fn(*args, **kw)
+                finally:
+                    t[key] += time.perf_counter() - t0
+            return run
+
+        if not lookahead:  # (with the look-ahead most of these calls run on its thread, beside the host merge)
+            ctx.push_dictionary_chunk = timed(push, "upload")
+            ctx.finalize = timed(fin, "sweep_and_hand_over")
+        best = None
+        for rep in range(3):
+            for k in t:
+                t[k] = 0.0
+            hits0 = metric.lookahead_hits
+            t_start = time.perf_counter()
+            experimental = metric.prepare_experimental(exp)                       # :70
+            dictionary = dic.reshape((n, -1))                                     # :71
+            keep = min(keep_n, n)                                                 # :67
+            n_iterations = int(np.ceil(n / n_per_iteration))                      # :68
+            indices = np.zeros((m, keep), dtype=np.int32)                         # :97
+            scores = np.full((m, keep), -metric.sign, dtype=metric.dtype)         # :98
+            starts = np.cumsum([0] + [n_per_iteration] * (n_iterations - 1))      # :100-104
+            ends = np.cumsum([n_per_iteration] * n_iterations)
+            ends[-1] = max(ends[-1], n)
+            for start, end in zip(starts, ends):
+                k_i = min(keep, end - start)
+                simulated = metric.prepare_dictionary(dictionary[start:end])      # :193
+                similarities = metric.match(experimental, simulated)              # :195
+                idx_i = similarities.argtopk(k_i, axis=-1).reshape((-1, k_i))     # :197-201
+                scores_i = similarities.topk(k_i, axis=-1).reshape((-1, k_i))
+                t0 = time.perf_counter()
+                idx_i = idx_i + start                                             # :118
+                all_scores = np.hstack((scores, scores_i))                        # :120-128
+                all_idx = np.hstack((indices, idx_i))
+                order = np.argsort(-all_scores, axis=1)[:, :keep]
+                scores = np.take_along_axis(all_scores, order, axis=1)
+                indices = np.take_along_axis(all_idx, order, axis=1)
+                t["host_merge"] += time.perf_counter() - t0
+            total = time.perf_counter() - t_start
+            if best is None or total < best[0]:
+                best = (total, dict(t), metric.lookahead_hits - hits0)
+        metric.close()
+        total, split, hits = best
+        r = {"patterns_per_s": round(m / total, 1), "ms_per_call": round(total * 1e3, 2),
+             "ms_reference_host_merge": round(split["host_merge"] * 1e3, 2),
+             "max_abs_score_diff_vs_the_timed_result": float(np.abs(scores - ref_scores).max()),
+             "index_agreement_with_the_timed_result": float(np.mean(indices == ref_indices))}
+        if lookahead:
+            r["chunks_served_from_the_lookahead"] = int(hits)
+        else:
+            r.update({"ms_upload": round(split["upload"] * 1e3, 2),
+                      "ms_sweep_and_hand_over": round(split["sweep_and_hand_over"] * 1e3, 2),
+                      "ms_other_host": round((total - sum(split.values())) * 1e3, 2)})
+        return r, scores, indices
+
+    saved = os.environ.get("KPDI_SEAM_LOOKAHEAD")
+    try:
+        on, s_on, i_on = one_form(True)
+        off, s_off, i_off = one_form(False)
+    finally:
+        if saved is None:
+            os.environ.pop("KPDI_SEAM_LOOKAHEAD", None)
+        else:
+            os.environ["KPDI_SEAM_LOOKAHEAD"] = saved
+    out = {"n_per_iteration": int(n_per_iteration), "iterations": int(np.ceil(n / n_per_iteration))}
+    out.update(on)
+    out["without_lookahead"] = off
+    out["identical_with_and_without_lookahead"] = bool(np.array_equal(s_on, s_off) and np.array_equal(i_on, i_off))
+    return out
 
 
 def cpu_baseline(w, exp, dic, bg, mask, n_sample):
@@ -1194,8 +1217,9 @@ def _main(argv, context_factory=None, group_factory=None):
                 out["extra"].setdefault("plugin_seam", {
                     "what": "an UNMODIFIED kikuchipy's loop (indexing/_dictionary_indexing.py:94-128, :172-203, restated in "
                             "bench.py) driving kikuchipy_amd.NormalizedCrossCorrelationMetric at configs[1], dictionary in host "
-                            "memory: per chunk one upload, one sweep, one synchronous hand-over, the reference's host merge. "
-                            "Best of 3 calls; the stand-alone driver (`value`) keeps the best-k on the device instead"})
+                            "memory.  The plugin sweeps the chunks the loop is about to ask for ahead of it, beside the reference's "
+                            "host merge (`without_lookahead`: per chunk one upload, one sweep, one synchronous hand-over, then the "
+                            "host merge).  Best of 3 calls; the stand-alone driver (`value`) keeps the best-k on the device instead"})
                 out["extra"]["plugin_seam"][f"n_per_iteration_{per}"] = plugin_seam_leg(exp, dic, w["keep_n"], per, device, scores, indices)
             except Exception as err:  # an informational leg must not cost the bench line
                 out["extra"]["plugin_seam_error"] = f"{type(err).__name__}: {err}"

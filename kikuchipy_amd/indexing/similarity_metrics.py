@@ -24,6 +24,9 @@ in float64 from the raw patterns and certified (`compute="f64"`, csrc/rescore.hi
 """
 
 import abc
+import os
+import queue
+import threading
 import warnings
 
 import numpy as np
@@ -143,6 +146,99 @@ class Similarities:
         return self._run(k)[0]
 
 
+class _LookAhead:
+    """The sweeps of the dictionary chunks the reference's loop is ABOUT to ask for, run ahead of it on a thread of
+    their own (the drop-in seam).
+
+    The loop of indexing/_dictionary_indexing.py:105-128 hands the metric one chunk at a time - `dictionary[start:end]`,
+    a VIEW of the caller's array for a NumPy dictionary - and merges the chunk's best-k on the host before it slices the
+    next one, so a metric that only works when asked leaves the GPU idle during every host merge and the host idle
+    during every upload and sweep.  After the first chunk of a call the next ones are predictable: same number of rows,
+    adjacent in the same buffer, up to `n_dictionary_patterns` rows in all.  The worker uploads and sweeps them in that
+    order - the upload of chunk j + 1 overlapping the sweep of chunk j (`finalize_async` / `finalize_wait`) - and
+    `take()` hands a result over when the loop asks for exactly that chunk (same address, rows and k).  A request
+    for anything else cancels the look-ahead (its results are dropped) and is served the ordinary way.  At most two
+    finished results wait (+ two chunks in flight): that is all a wrong guess can waste.  Same calls into the
+    engine per chunk as without it, so the results are the same bit for bit ($KPDI_SEAM_LOOKAHEAD=0 switches it off).
+    """
+
+    def __init__(self, ctx, owner, first_row, rows, total_rows, sig_shape, k):
+        self._ctx = ctx
+        self._flat = owner.reshape(-1)  # (a view: the owner is C-contiguous; keeps the caller's buffer alive)
+        self._row_elems = int(np.prod(sig_shape))
+        self._sig_shape = tuple(sig_shape)
+        self._rows, self._total, self._k = int(rows), int(total_rows), int(k)
+        self._next = int(first_row)        # next row the CONSUMER will ask for
+        self._results = queue.Queue(maxsize=2)
+        self._stop = False
+        self._thread = threading.Thread(target=self._run, args=(int(first_row),), daemon=True, name="kpdi-lookahead")
+        self._thread.start()
+
+    def _chunk(self, row):
+        n = min(self._rows, self._total - row)
+        a = self._flat[row * self._row_elems:(row + n) * self._row_elems]
+        return a.reshape((n,) + self._sig_shape)
+
+    def _run(self, row):
+        ctx, pending = self._ctx, None
+        try:
+            while row < self._total and not self._stop:
+                chunk = self._chunk(row)
+                k_run = min(self._k, len(chunk))
+                ctx.set_keep_n(k_run)
+                ctx.set_dictionary_size(0)
+                ctx.push_dictionary_chunk(chunk, 0)
+                ticket = ctx.finalize_async(k_run)
+                if pending is not None:
+                    self._put((pending[1], ctx.finalize_wait(pending[0])))
+                pending = (ticket, row)
+                row += len(chunk)
+            if pending is not None:
+                res = ctx.finalize_wait(pending[0])  # (always collected: the slot must be free for whoever comes next)
+                self._put((pending[1], res))
+        except BaseException as e:  # noqa: BLE001 - handed to the consumer, which raises it in the caller's thread
+            self._put((None, e))
+
+    def _put(self, item):
+        while not self._stop:  # (a cancelled look-ahead drops what it has: nobody will ask)
+            try:
+                return self._results.put(item, timeout=0.1)
+            except queue.Full:
+                pass
+
+    @property
+    def exhausted(self):
+        return self._next >= self._total
+
+    def expects(self, patterns, k):
+        """Whether `patterns` is exactly the chunk whose result comes next."""
+        if self.exhausted or int(k) != self._k:
+            return False
+        want = self._chunk(self._next)
+        return (patterns.shape == want.shape and patterns.dtype == want.dtype and patterns.flags.c_contiguous
+                and patterns.ctypes.data == want.ctypes.data)
+
+    def take(self):
+        row, res = self._results.get()
+        if row is None:
+            raise res
+        assert row == self._next
+        self._next += min(self._rows, self._total - row)
+        if self.exhausted:
+            self._thread.join()
+        return res
+
+    def cancel(self):
+        """Stop running ahead; wait until the worker has left the engine (its results are dropped)."""
+        self._stop = True
+        while self._thread.is_alive():
+            try:
+                self._results.get(timeout=0.05)
+            except queue.Empty:
+                pass
+        self._thread.join()
+
+
 class _HipMetric(SimilarityMetric):
     _allowed_dtypes = [np.float32, np.float64]
     _sign = 1
@@ -178,6 +274,9 @@ class _HipMetric(SimilarityMetric):
         self._ctx = context
         self._engine_m = 0
         self._problem = None
+        self._lookahead = None
+        self._rows_seen = 0   # dictionary rows the loop has asked for since prepare_experimental
+        self.lookahead_hits = 0  # chunks that were served from the look-ahead (diagnostics, tests)
 
     # ------------------------------------------------------------------ engine
     @property
@@ -214,18 +313,74 @@ class _HipMetric(SimilarityMetric):
         ctx = self.context
         n = patterns.shape[0]
         k_run = min(k, n)
-        ctx.set_keep_n(k_run)
-        # (inside the reference's loop every chunk is a sweep of its own, collected at once: a group cuts it over its
-        # members only when the pieces are worth a launch each - the rule for an unannounced dictionary size)
-        ctx.set_dictionary_size(0)
-        ctx.push_dictionary_chunk(patterns, 0)
-        scores, indices = ctx.finalize(k_run)
+        la, self._lookahead = self._lookahead, None
+        if la is not None and la.expects(patterns, k):
+            scores, indices = la.take()  # swept while the caller was merging the previous chunk (_LookAhead)
+            self.lookahead_hits += 1
+            if not la.exhausted:
+                self._lookahead = la
+        else:
+            if la is not None:
+                la.cancel()
+            ctx.set_keep_n(k_run)
+            # (inside the reference's loop every chunk is a sweep of its own, collected at once: a group cuts it over its
+            # members only when the pieces are worth a launch each - the rule for an unannounced dictionary size)
+            ctx.set_dictionary_size(0)
+            ctx.push_dictionary_chunk(patterns, 0)
+            scores, indices = ctx.finalize(k_run)
+            self._lookahead = self._start_lookahead(patterns, k)
+        self._rows_seen += n
         scores = scores.astype(self.dtype, copy=False)
         if k_run < k:
             pad = ((0, 0), (0, k - k_run))
             scores = np.pad(scores, pad, constant_values=-np.inf)
             indices = np.pad(indices, pad, constant_values=0)
         return scores, indices
+
+    def _start_lookahead(self, patterns, k):
+        """A `_LookAhead` over the chunks behind `patterns` - the chunk just served the ordinary way - or None when they
+        cannot be predicted: not a view into a larger C-contiguous array of the same dtype, nothing left of the
+        `n_dictionary_patterns` rows, float64 arithmetic or a group of devices (no pipelined hand-over of single chunks)."""
+        ctx = self.context
+        if os.environ.get("KPDI_SEAM_LOOKAHEAD", "1") == "0" or hasattr(ctx, "members") or not hasattr(ctx, "finalize_async"):
+            return None
+        total, n = self.n_dictionary_patterns, patterns.shape[0]
+        if total is None or self.effective_compute == "f64" or not patterns.flags.c_contiguous or n < 1:
+            return None
+        first, seen = self._rows_seen, self._rows_seen + n  # rows of the dictionary: this chunk = [first, seen)
+        if seen >= total:
+            return None
+        owner = patterns
+        while isinstance(owner.base, np.ndarray):
+            owner = owner.base
+        if owner is patterns or owner.dtype != patterns.dtype or not owner.flags.c_contiguous:
+            return None
+        row_bytes = patterns[0].nbytes
+        off = patterns.ctypes.data - owner.ctypes.data
+        if row_bytes == 0 or off < 0 or off % row_bytes:
+            return None
+        row0 = off // row_bytes - first  # the dictionary's row 0 within the owner
+        if row0 < 0 or (row0 + total) * row_bytes > owner.nbytes:
+            return None  # (the rest of the dictionary would lie outside this buffer: not the layout the loop slices)
+        return _LookAhead(self.context, owner, row0 + seen, n, row0 + total, patterns.shape[1:], k)
+
+    def _cancel_lookahead(self):
+        la, self._lookahead = self._lookahead, None
+        if la is not None:
+            la.cancel()
+
+    def close(self):
+        """Stop a look-ahead that is still running (a loop that was abandoned half-way) and close the engine."""
+        self._cancel_lookahead()
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self._cancel_lookahead()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
     # ------------------------------------------------------------------ plugin API
     def __call__(self, experimental, dictionary):
@@ -240,6 +395,8 @@ class _HipMetric(SimilarityMetric):
         and normalisation (_normalized_cross_correlation.py:88-128) run on the GPU
         when the first dictionary chunk arrives."""
         self.raise_error_if_invalid()
+        self._cancel_lookahead()  # (a new call of the loop: nothing of the last one is wanted any more)
+        self._rows_seen = 0
         if np.dtype(self.dtype) == np.float64 and self.effective_compute != "f64":
             warnings.warn(
                 f"dtype=float64 with compute={self.effective_compute!r}: the metric is evaluated in that arithmetic "

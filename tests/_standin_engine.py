@@ -120,7 +120,8 @@ class StandInContext:
 
     def finalize_async(self, keep_n=None):
         self._pending = getattr(self, "_pending", {})
-        ticket = len(self._pending)
+        assert len(self._pending) < 2, "two results are already pending (as the engine: two result slots)"
+        ticket = self._tickets = getattr(self, "_tickets", 0) + 1
         self._pending[ticket] = self.finalize(keep_n)  # (the stand-in has nothing to overlap: it finishes here)
         return ticket
 

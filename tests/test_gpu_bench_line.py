@@ -56,6 +56,8 @@ def test_default_bench_line_and_its_legs():
         seam = out["extra"]["plugin_seam"][f"n_per_iteration_{per}"]
         assert seam["patterns_per_s"] > 0 and seam["max_abs_score_diff_vs_the_timed_result"] < 1e-6, seam
         assert seam["index_agreement_with_the_timed_result"] > 0.999
+        assert seam["identical_with_and_without_lookahead"] and seam["chunks_served_from_the_lookahead"] == seam["iterations"] - 1
+        assert seam["without_lookahead"]["ms_upload"] > 0
     # one rank's share of an 8-rank job takes between an eighth and a quarter of the whole step
     share = out["extra"]["config2_share_of_8"]
     assert 1.0 <= share["step_over_even_share"] < 2.0, share

@@ -99,3 +99,84 @@ def test_seam_with_the_gpu_engine(name):
     finally:
         for c in ctxs:
             c.close()
+
+
+# ---- the look-ahead of the plugin (similarity_metrics._LookAhead): the chunks the reference's loop is about to ask for are
+# swept ahead of it; anything else cancels it.  CPU, stand-in engine.
+def _lookahead_metric(n_exp, n_dict, keep_n=5):
+    import kikuchipy_amd as kpa
+    from _standin_engine import StandInContext
+
+    m = kpa.NormalizedCrossCorrelationMetric(context=StandInContext(0))
+    return ko.plugin_prepare_metric(m, n_exp, None, None, np.dtype("float32"), n_dict)
+
+
+def test_lookahead_serves_the_chunks_of_the_loop_and_changes_nothing(monkeypatch):
+    rng = np.random.default_rng(5)
+    exp = rng.integers(0, 256, (6, 12, 10)).astype(np.uint8)
+    dic = rng.random((103, 12, 10)).astype(np.float32)  # 11 chunks of 10 rows; the last one holds 3 < keep_n
+    out = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("KPDI_SEAM_LOOKAHEAD", on)
+        m = _lookahead_metric(6, 103)
+        s, i, _ = ko.plugin_loop(m, exp, (6,), dic, 5, 10)
+        out[on] = (s, i, m.lookahead_hits)
+        assert m._lookahead is None  # (the worker has left when the last chunk was handed over)
+        m.close()
+    assert out["1"][2] == 10 and out["0"][2] == 0  # every chunk but the first came from the look-ahead
+    assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
+    # a second call of the loop on the same metric starts over (prepare_experimental resets the row count)
+    monkeypatch.setenv("KPDI_SEAM_LOOKAHEAD", "1")
+    m = _lookahead_metric(6, 103)
+    a = ko.plugin_loop(m, exp, (6,), dic, 5, 10)
+    b = ko.plugin_loop(m, exp, (6,), dic, 5, 25)
+    assert m.lookahead_hits == 10 + 4 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    m.close()
+
+
+def test_lookahead_is_dropped_when_the_loop_asks_for_something_else():
+    rng = np.random.default_rng(6)
+    exp = rng.integers(0, 256, (4, 12, 10)).astype(np.uint8)
+    dic = rng.random((60, 12, 10)).astype(np.float32)
+    m = _lookahead_metric(4, 60)
+    e = m.prepare_experimental(exp)
+    flat = dic.reshape((60, -1))
+
+    def best(rows, k=3):
+        sim = m.match(e, m.prepare_dictionary(rows))
+        return sim.topk(k, axis=-1), sim.argtopk(k, axis=-1)
+
+    first = best(flat[0:10])
+    assert m._lookahead is not None and m.lookahead_hits == 0
+    skipped = best(flat[30:40])          # not the adjacent chunk: cancelled, served the ordinary way
+    assert m.lookahead_hits == 0
+    other_k = best(flat[40:50], k=2)     # (the chunk behind [30, 40) - but with another k: not what was swept ahead)
+    assert m.lookahead_hits == 0
+    copy = best(flat[10:20].copy())      # same values, another buffer: not a view of the dictionary - no prediction from it
+    assert m._lookahead is None and m.lookahead_hits == 0
+    m.close()
+    # each result is what a fresh metric returns for that chunk alone
+    for rows, k, got in ((flat[0:10], 3, first), (flat[30:40], 3, skipped), (flat[40:50], 2, other_k), (flat[10:20], 3, copy)):
+        m2 = _lookahead_metric(4, 60)
+        e2 = m2.prepare_experimental(exp)
+        sim = m2.match(e2, m2.prepare_dictionary(rows.copy()))
+        assert np.array_equal(sim.topk(k, axis=-1), got[0]) and np.array_equal(sim.argtopk(k, axis=-1), got[1])
+        m2.close()
+
+
+def test_lookahead_stays_inside_the_callers_buffer_and_ends_with_close():
+    rng = np.random.default_rng(7)
+    exp = rng.integers(0, 256, (3, 12, 10)).astype(np.uint8)
+    big = rng.random((50, 12, 10)).astype(np.float32)
+    m = _lookahead_metric(3, 40)         # the metric is told of 40 dictionary rows ...
+    e = m.prepare_experimental(exp)
+    tail = big[30:].reshape((20, -1))    # ... but this buffer ends 20 rows behind the first chunk's start
+    m.match(e, m.prepare_dictionary(tail[0:10])).topk(2, axis=-1)
+    assert m._lookahead is None          # rows [10, 40) of "the dictionary" would lie outside `big`: nothing is predicted
+    m2 = _lookahead_metric(3, 40)
+    e2 = m2.prepare_experimental(exp)
+    m2.match(e2, m2.prepare_dictionary(big.reshape((50, -1))[0:10])).topk(2, axis=-1)
+    la = m2._lookahead
+    assert la is not None                # running ahead over rows [10, 40) ...
+    m2.close()                           # ... until the loop is abandoned: the worker leaves the engine
+    assert not la._thread.is_alive() and m2._lookahead is None
