@@ -191,6 +191,13 @@ def main():
         # the engine was driven as the seam promises: prepared once, one push per chunk, chunk starts 0 (the loop adds them)
         n_chunks = int(np.ceil(dic.shape[0] / n_per))
         assert len(engine.pushed) == n_chunks and all(start == 0 for start, _ in engine.pushed), (name, engine.pushed)
+        # the plugin's look-ahead (similarity_metrics._LookAhead) predicts the REAL loop's slices: every chunk of a NumPy
+        # dictionary but the first was swept ahead - also of the lazy case here, whose `dask.array.from_array` over an
+        # in-memory array hands out VIEWS of that array from `.compute()` (a dictionary that is really computed arrives
+        # in fresh arrays and is not predicted); float64 arithmetic (no pipelined hand-over) is never predicted
+        want_hits = n_chunks - 1 if dtype != np.float64 else 0
+        assert m.lookahead_hits == want_hits, (name, m.lookahead_hits, want_hits)
+        print(f"{name}: {n_chunks} chunk(s), {m.lookahead_hits} served from the look-ahead")
         assert [n for _, n in engine.pushed] == [min(n_per, dic.shape[0] - c * n_per) for c in range(n_chunks)], name
         out[f"{name}__scores"] = rs
         out[f"{name}__indices"] = ri
