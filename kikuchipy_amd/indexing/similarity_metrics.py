@@ -24,10 +24,12 @@ in float64 from the raw patterns and certified (`compute="f64"`, csrc/rescore.hi
 """
 
 import abc
+import atexit
 import os
 import queue
 import threading
 import warnings
+import weakref
 
 import numpy as np
 
@@ -146,6 +148,20 @@ class Similarities:
         return self._run(k)[0]
 
 
+_LIVE_LOOKAHEADS = weakref.WeakSet()
+
+
+@atexit.register
+def _cancel_lookaheads_at_exit():
+    # (a loop abandoned half-way leaves a worker inside the engine: it must have left before the interpreter tears the
+    # HIP runtime down under it)
+    for la in list(_LIVE_LOOKAHEADS):
+        try:
+            la.cancel()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 class _LookAhead:
     """The sweeps of the dictionary chunks the reference's loop is ABOUT to ask for, run ahead of it on a thread of
     their own (the drop-in seam).
@@ -172,6 +188,7 @@ class _LookAhead:
         self._results = queue.Queue(maxsize=2)
         self._stop = False
         self._thread = threading.Thread(target=self._run, args=(int(first_row),), daemon=True, name="kpdi-lookahead")
+        _LIVE_LOOKAHEADS.add(self)
         self._thread.start()
 
     def _chunk(self, row):
