@@ -180,3 +180,33 @@ def test_lookahead_stays_inside_the_callers_buffer_and_ends_with_close():
     assert la is not None                # running ahead over rows [10, 40) ...
     m2.close()                           # ... until the loop is abandoned: the worker leaves the engine
     assert not la._thread.is_alive() and m2._lookahead is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric_name", ["ncc", "ndp"])
+def test_lookahead_on_the_gpu_engine_serves_the_loop_and_changes_nothing(monkeypatch, metric_name):
+    """The real engine behind the plugin in the (restated) reference loop: 8 chunks of 700 rows + one of 100, a signal
+    mask, keep_n = 20 - every chunk but the first comes from the look-ahead (pipelined finalize_async / finalize_wait on
+    the worker thread), bit for bit what the same loop returns with the look-ahead switched off."""
+    import kikuchipy_amd as kpa
+
+    rng = np.random.default_rng(11)
+    exp = rng.integers(0, 256, (300, 20, 20)).astype(np.uint8)
+    dic = rng.random((5700, 20, 20)).astype(np.float32)
+    sm = np.zeros((20, 20), dtype=bool)
+    sm[:3] = True
+    cls = {"ncc": kpa.NormalizedCrossCorrelationMetric, "ndp": kpa.NormalizedDotProductMetric}[metric_name]
+    out = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("KPDI_SEAM_LOOKAHEAD", on)
+        m = ko.plugin_prepare_metric(cls(device=0), 300, None, sm, np.dtype("float32"), 5700)
+        try:
+            s_, i_, _ = ko.plugin_loop(m, exp, (300,), dic, 20, 700)
+            out[on] = (s_, i_, m.lookahead_hits)
+        finally:
+            m.close()
+    assert out["1"][2] == 8 and out["0"][2] == 0
+    assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
+    # ... and what the oracle returns for the same call: north_star's 1e-5
+    rs, ri = ko.dictionary_indexing(exp, dic, metric_name, 20, 700, None, sm, np.float32)
+    ko.assert_topk_parity(out["1"][0], out["1"][1], rs, ri, atol=1e-5)
