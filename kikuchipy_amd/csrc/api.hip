@@ -234,7 +234,7 @@ int kpdi_destroy(kpdi_ctx *c) {
                     &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps, &c->inv_map, &c->pre_scratch,
                     &c->mp_packed, &c->dcos, &c->rot, &c->proj_out,
                     &c->ref_raw, &c->ref_map, &c->ref_rowcol, &c->ref_pat, &c->ref_sqn, &c->ref_in, &c->ref_out,
-                    &c->ref_idx, &c->osm_idx, &c->osm_out, &c->stage[0], &c->stage[1], &c->pending.raw, &c->pending_hold.raw})
+                    &c->ref_idx, &c->osm_idx, &c->osm_out, &c->stage[0], &c->stage[1], &c->pending.raw, &c->pending.raw_b, &c->pending_hold.raw})
     b->release();
   for (auto *l : {&c->ev_match, &c->ev_prep, &c->ev_merge, &c->ev_proj, &c->ev_pre, &c->ev_rescore})
     for (auto &pr : *l) {
@@ -245,7 +245,9 @@ int kpdi_destroy(kpdi_ctx *c) {
   for (int b = 0; b < 2; ++b) {
     if (c->stage_filled[b]) (void)hipEventDestroy(c->stage_filled[b]);
     if (c->stage_free[b]) (void)hipEventDestroy(c->stage_free[b]);
+    if (c->pending.consumed[b]) (void)hipEventDestroy(c->pending.consumed[b]);
   }
+  if (c->pending.filled) (void)hipEventDestroy(c->pending.filled);
   if (c->copy_stream) {
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipStreamDestroy(c->copy_stream);

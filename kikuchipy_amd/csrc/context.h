@@ -200,6 +200,17 @@ struct kpdi_ctx {
   // come in (or when the result is asked for); the merge translates rows back to dictionary indices (IndexSegments).
   struct PendingChunks {
     kpdi::DevBuf raw;      // [capacity rows][npix] of `dtype`
+    // Pushed chunks only: a SECOND buffer, filled while the rows of the first are still waiting for their preparation
+    // kernel - so that a host chunk can be uploaded STRAIGHT into its rows on the copy stream (no staging buffer, no
+    // device-to-device copy queued behind the sweeps on the compute stream: that copy held the staging buffers until the
+    // sweep in front of it had finished, and the uploads of a chunked call ran after its sweeps instead of beside them).
+    kpdi::DevBuf raw_b;
+    int cur = 0;                                        // 0: `raw` is being filled, 1: `raw_b`
+    hipEvent_t consumed[2] = {nullptr, nullptr};        // behind the preparation kernel that read buffer i (compute stream)
+    bool consumed_set[2] = {false, false};
+    hipEvent_t filled = nullptr;                        // behind the last upload into the current buffer (copy stream)
+    bool filled_pending = false;                        // ... which the next flush has to wait for
+    kpdi::DevBuf &buf() { return cur ? raw_b : raw; }
     int dtype = -1;
     int64_t rows = 0, capacity = 0;
     struct Segment {

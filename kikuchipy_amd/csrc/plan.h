@@ -24,7 +24,7 @@ struct Switches {
   double odd_wide = FORM_ODD_SPLIT_WIDE, odd_classic = FORM_ODD_SPLIT_CLASSIC;
   double wide_launch = FORM_WIDE_LAUNCH, fixed_frac = 0.8;
   bool xcd_grid = true, xcd_pad = true, no_tail = false, one_stream = false, tail_stream2 = false;
-  bool f64_statistical = false, f64_sync = false, no_coalesce = false;
+  bool f64_statistical = false, f64_sync = false, no_coalesce = false, no_direct_upload = false;
   long upload_tiles = 0;
   void read() {
     *this = Switches{};
@@ -44,6 +44,7 @@ struct Switches {
     if (const char *e = getenv("KPDI_F64_EPS")) f64_statistical = !strcmp(e, "statistical");
     f64_sync = getenv("KPDI_F64_SYNC") != nullptr;
     no_coalesce = getenv("KPDI_NO_COALESCE") != nullptr;
+    no_direct_upload = getenv("KPDI_NO_DIRECT_UPLOAD") != nullptr;
     if (const char *e = getenv("KPDI_UPLOAD_TILES")) upload_tiles = atol(e);
   }
 };

@@ -376,7 +376,7 @@ int check_chunk_args(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_sta
 
 // prepare + sweep one raw chunk resident in device memory; `seg`: it is a coalesced matrix (rows -> dictionary indices)
 static int sweep_raw_chunk(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start,
-                           const IndexSegments *seg) {
+                           const IndexSegments *seg, hipEvent_t raw_consumed = nullptr) {
   int rc;
   decide_form(c, n_chunk);
   const int tile = dict_tile(c);
@@ -409,6 +409,7 @@ static int sweep_raw_chunk(kpdi_ctx *c, const void *d_patterns, int dtype, int64
   if (rc) return rc;
   rc = prepare_chunk(c, d_patterns, dtype, n_chunk, c->dict_y.as<float>());
   if (rc) return rc;
+  if (raw_consumed) HIPCHK(hipEventRecord(raw_consumed, c->stream));  // (the raw rows may be overwritten from here on)
   return sweep_prepared(c, c->dict_y.as<float>(), n_chunk, global_start, d_patterns, dtype, seg);
 }
 
@@ -455,7 +456,19 @@ int flush_pending(kpdi_ctx *c, bool hold) {
     return prepare_chunk(c, p.raw.p, p.dtype, rows, y);
   }
   c->cnt.coalesced_sweeps += one ? 0 : 1;
-  return sweep_raw_chunk(c, p.raw.p, p.dtype, rows, one ? start : 0, one ? nullptr : &seg);
+  // rows uploaded on the copy stream (kpdi_push_dictionary_chunk) must have arrived; the buffer is handed to the
+  // preparation kernel and the OTHER one takes what is pushed next
+  if (p.filled_pending) {
+    HIPCHK(hipStreamWaitEvent(c->stream, p.filled, 0));
+    p.filled_pending = false;
+  }
+  const int b = p.cur;
+  const void *raw = p.buf().p;
+  if (!p.consumed[b]) HIPCHK(hipEventCreateWithFlags(&p.consumed[b], hipEventDisableTiming));
+  p.cur ^= 1;
+  p.capacity = 0;  // (of the buffer that is filled next: pending_slot sizes it)
+  p.consumed_set[b] = true;
+  return sweep_raw_chunk(c, raw, p.dtype, rows, one ? start : 0, one ? nullptr : &seg, p.consumed[b]);
 }
 
 int push_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start, bool may_wait) {
@@ -509,17 +522,18 @@ int pending_slot(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_start, 
     int rc = flush_pending(c, hold);
     if (rc) return rc;
   }
+  kpdi::DevBuf &rb = p.buf();
   if (p.rows == 0) {
     // room for what goes together (three rounds to be swept, eight to be held) + the chunk that takes it there; at most 2 GiB
     const int64_t want = std::min<int64_t>((hold ? 10 : 5) * round, std::max<int64_t>((int64_t)((2ull << 30) / row_bytes), n_chunk));
-    if (p.raw.cap < (size_t)want * row_bytes) {
+    if (rb.cap < (size_t)want * row_bytes) {
       HIPCHK(hipStreamSynchronize(c->stream));  // (work queued earlier may still read the buffer that is about to go)
-      HIPCHK(p.raw.reserve((size_t)want * row_bytes));
+      HIPCHK(rb.reserve((size_t)want * row_bytes));
     }
-    p.capacity = (int64_t)(p.raw.cap / row_bytes);
+    p.capacity = (int64_t)(rb.cap / row_bytes);
     p.dtype = dtype;
   }
-  *slot = (char *)p.raw.p + (size_t)p.rows * row_bytes;
+  *slot = (char *)rb.p + (size_t)p.rows * row_bytes;
   return KPDI_OK;
 }
 
@@ -779,6 +793,42 @@ int kpdi_push_dictionary_chunk(kpdi_ctx *c, const void *patterns, int dtype, int
   c->pend64.defer = true;
   const std::vector<int64_t> pieces = upload_pieces(c, n_chunk, (size_t)c->npix * es);
   const bool one_piece = pieces.size() == 1;  // (pieces of a larger upload are sized for its pipeline: they sweep at once)
+  if (one_piece && c->have_exp && c->m > 0 && !c->sw.no_direct_upload) {
+    // A small chunk that may wait for company (coalescing, above) is uploaded STRAIGHT into its rows of the pending buffer
+    // on the copy stream: nothing of it is queued on the compute stream until the rows are swept, so the uploads of a
+    // chunked call run beside the sweeps of the chunks before them.  (Through a staging buffer + a device-to-device copy
+    // on the compute stream - the path below - the copy sat behind the previous sweep, held its staging buffer until then
+    // and the next upload waited for it: configs[1] as 33 chunks from host memory took uploads + sweeps, 60 ms.)
+    rc = resolve_exact64(c);
+    if (rc) return rc;
+    rc = check_chunk_args(c, dtype, n_chunk, global_start);
+    if (rc) return rc;
+    void *slot = nullptr;
+    rc = pending_slot(c, dtype, n_chunk, global_start, &slot);
+    if (rc) return rc;
+    if (slot) {
+      kpdi_ctx::PendingChunks &p = c->pending;
+      if (!c->copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+          HIPCHK(hipEventCreateWithFlags(&c->stage_filled[b], hipEventDisableTiming));
+          HIPCHK(hipEventCreateWithFlags(&c->stage_free[b], hipEventDisableTiming));
+          HIPCHK(hipEventRecord(c->stage_free[b], c->stream));
+        }
+      }
+      if (!p.filled) HIPCHK(hipEventCreateWithFlags(&p.filled, hipEventDisableTiming));
+      // (the rows this buffer held before have been read by their preparation kernel)
+      if (p.consumed_set[p.cur]) HIPCHK(hipStreamWaitEvent(c->copy_stream, p.consumed[p.cur], 0));
+      HIPCHK(hipMemcpyAsync(slot, patterns, (size_t)n_chunk * c->npix * es, hipMemcpyHostToDevice, c->copy_stream));
+      HIPCHK(hipEventRecord(p.filled, c->copy_stream));
+      p.filled_pending = true;
+      c->cnt.h2d_bytes += (double)n_chunk * c->npix * es;
+      rc = pending_commit(c, n_chunk, global_start);  // (sweeps the pending rows when enough of them are there)
+      HIPCHK(hipStreamSynchronize(c->copy_stream));   // the caller's buffer is free again
+      c->pend64.defer = false;
+      return rc;
+    }
+  }
   rc = staged_upload(c, patterns, (size_t)c->npix * es, pieces,
                      [&](const void *d_piece, int64_t n, int64_t offset) {
                        return push_chunk_dev(c, d_piece, dtype, n, global_start + offset, one_piece);
