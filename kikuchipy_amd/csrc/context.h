@@ -426,7 +426,7 @@ void discard_pending(kpdi_ctx *c, bool hold = false);
 // (by work queued on the context's stream) makes the rows part of the pending matrix and sweeps it when it is due.
 // `hold`: the chunk is to stay resident (the pending rows become one held chunk instead of being swept).
 int pending_slot(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_start, void **slot, bool hold = false);
-int pending_commit(kpdi_ctx *c, int64_t n_chunk, int64_t global_start, bool hold = false);
+int pending_commit(kpdi_ctx *c, int64_t n_chunk, int64_t global_start, bool hold = false, bool eager = false);
 // hold a raw chunk resident in device memory: it joins the pending rows when it is small, else it is prepared at once
 int hold_chunk_dev(kpdi_ctx *c, const void *d_patterns, int dtype, int64_t n_chunk, int64_t global_start, bool may_wait);
 int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_start, const void *raw = nullptr, int raw_dtype = 0,

@@ -24,7 +24,7 @@ struct Switches {
   double odd_wide = FORM_ODD_SPLIT_WIDE, odd_classic = FORM_ODD_SPLIT_CLASSIC;
   double wide_launch = FORM_WIDE_LAUNCH, fixed_frac = 0.8;
   bool xcd_grid = true, xcd_pad = true, no_tail = false, one_stream = false, tail_stream2 = false;
-  bool f64_statistical = false, f64_sync = false, no_coalesce = false, no_direct_upload = false;
+  bool f64_statistical = false, f64_sync = false, no_coalesce = false, no_direct_upload = false, no_coalesce_wait = false;
   long upload_tiles = 0;
   void read() {
     *this = Switches{};
@@ -45,6 +45,7 @@ struct Switches {
     f64_sync = getenv("KPDI_F64_SYNC") != nullptr;
     no_coalesce = getenv("KPDI_NO_COALESCE") != nullptr;
     no_direct_upload = getenv("KPDI_NO_DIRECT_UPLOAD") != nullptr;
+    no_coalesce_wait = getenv("KPDI_NO_COALESCE_WAIT") != nullptr;
     if (const char *e = getenv("KPDI_UPLOAD_TILES")) upload_tiles = atol(e);
   }
 };

@@ -524,8 +524,8 @@ int pending_slot(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_start, 
   }
   kpdi::DevBuf &rb = p.buf();
   if (p.rows == 0) {
-    // room for what goes together (three rounds to be swept, eight to be held) + the chunk that takes it there; at most 2 GiB
-    const int64_t want = std::min<int64_t>((hold ? 10 : 5) * round, std::max<int64_t>((int64_t)((2ull << 30) / row_bytes), n_chunk));
+    // room for what goes together (up to eight rounds) + the chunk that takes it there; at most 2 GiB
+    const int64_t want = std::min<int64_t>(10 * round, std::max<int64_t>((int64_t)((2ull << 30) / row_bytes), n_chunk));
     if (rb.cap < (size_t)want * row_bytes) {
       HIPCHK(hipStreamSynchronize(c->stream));  // (work queued earlier may still read the buffer that is about to go)
       HIPCHK(rb.reserve((size_t)want * row_bytes));
@@ -537,13 +537,23 @@ int pending_slot(kpdi_ctx *c, int dtype, int64_t n_chunk, int64_t global_start, 
   return KPDI_OK;
 }
 
-int pending_commit(kpdi_ctx *c, int64_t n_chunk, int64_t global_start, bool hold) {
+int pending_commit(kpdi_ctx *c, int64_t n_chunk, int64_t global_start, bool hold, bool eager) {
   kpdi_ctx::PendingChunks &p = hold ? c->pending_hold : c->pending;
   const int64_t round = round_of(c);
   p.seg.push_back({p.rows, n_chunk, global_start});
   p.rows += n_chunk;
   if (!hold) c->final_valid = false;
-  if (p.rows >= (hold ? 8 : 3) * round || p.rows + round / 4 > p.capacity) return flush_pending(c, hold);
+  bool flush = p.rows + round / 4 > p.capacity || p.rows >= 8 * round;
+  if (!flush && !hold && p.rows >= 3 * round) {
+    // Three rounds are worth a launch set.  A chunk that came over the host link (`eager`) is swept at once: its sweep
+    // runs beside the uploads that follow, and whatever is still pending when the last chunk has arrived is swept with
+    // nothing left to hide behind.  Rows that were already on the device (resident or simulated chunks: the pushes only
+    // queue work) gain nothing from an early sweep while the GPU is still busy with the one before - they wait for
+    // company up to eight rounds: fewer launch ramps, less round padding.
+    flush = eager || c->sw.no_coalesce_wait || hipStreamQuery(c->stream) == hipSuccess;
+    (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error)
+  }
+  if (flush) return flush_pending(c, hold);
   return KPDI_OK;
 }
 
@@ -823,7 +833,7 @@ int kpdi_push_dictionary_chunk(kpdi_ctx *c, const void *patterns, int dtype, int
       HIPCHK(hipEventRecord(p.filled, c->copy_stream));
       p.filled_pending = true;
       c->cnt.h2d_bytes += (double)n_chunk * c->npix * es;
-      rc = pending_commit(c, n_chunk, global_start);  // (sweeps the pending rows when enough of them are there)
+      rc = pending_commit(c, n_chunk, global_start, false, true);  // (sweeps the pending rows when enough of them are there)
       HIPCHK(hipStreamSynchronize(c->copy_stream));   // the caller's buffer is free again
       c->pend64.defer = false;
       return rc;
