@@ -292,6 +292,7 @@ class _HipMetric(SimilarityMetric):
         self._engine_m = 0
         self._problem = None
         self._lookahead = None
+        self._lookahead_off = False  # set by a wrong guess, until the next prepare_experimental
         self._rows_seen = 0   # dictionary rows the loop has asked for since prepare_experimental
         self.lookahead_hits = 0  # chunks that were served from the look-ahead (diagnostics, tests)
 
@@ -339,6 +340,7 @@ class _HipMetric(SimilarityMetric):
         else:
             if la is not None:
                 la.cancel()
+                self._lookahead_off = True  # a wrong guess: this is not the loop the look-ahead was made for (until the next call)
             ctx.set_keep_n(k_run)
             # (inside the reference's loop every chunk is a sweep of its own, collected at once: a group cuts it over its
             # members only when the pieces are worth a launch each - the rule for an unannounced dictionary size)
@@ -359,7 +361,8 @@ class _HipMetric(SimilarityMetric):
         cannot be predicted: not a view into a larger C-contiguous array of the same dtype, nothing left of the
         `n_dictionary_patterns` rows, float64 arithmetic or a group of devices (no pipelined hand-over of single chunks)."""
         ctx = self.context
-        if os.environ.get("KPDI_SEAM_LOOKAHEAD", "1") == "0" or hasattr(ctx, "members") or not hasattr(ctx, "finalize_async"):
+        if self._lookahead_off or os.environ.get("KPDI_SEAM_LOOKAHEAD", "1") == "0" or hasattr(ctx, "members") \
+                or not hasattr(ctx, "finalize_async"):
             return None
         total, n = self.n_dictionary_patterns, patterns.shape[0]
         if total is None or self.effective_compute == "f64" or not patterns.flags.c_contiguous or n < 1:
@@ -413,6 +416,7 @@ class _HipMetric(SimilarityMetric):
         when the first dictionary chunk arrives."""
         self.raise_error_if_invalid()
         self._cancel_lookahead()  # (a new call of the loop: nothing of the last one is wanted any more)
+        self._lookahead_off = False
         self._rows_seen = 0
         if np.dtype(self.dtype) == np.float64 and self.effective_compute != "f64":
             warnings.warn(

@@ -148,12 +148,16 @@ def test_lookahead_is_dropped_when_the_loop_asks_for_something_else():
 
     first = best(flat[0:10])
     assert m._lookahead is not None and m.lookahead_hits == 0
-    skipped = best(flat[30:40])          # not the adjacent chunk: cancelled, served the ordinary way
-    assert m.lookahead_hits == 0
-    other_k = best(flat[40:50], k=2)     # (the chunk behind [30, 40) - but with another k: not what was swept ahead)
-    assert m.lookahead_hits == 0
-    copy = best(flat[10:20].copy())      # same values, another buffer: not a view of the dictionary - no prediction from it
+    skipped = best(flat[30:40])          # not the adjacent chunk: cancelled, served the ordinary way ...
+    assert m.lookahead_hits == 0 and m._lookahead is None  # ... and nothing more is guessed during this call of the loop
+    other_k = best(flat[40:50], k=2)
+    copy = best(flat[10:20].copy())      # (same values, another buffer)
     assert m._lookahead is None and m.lookahead_hits == 0
+    e = m.prepare_experimental(exp)      # the next call of the loop starts over
+    again = best(flat[0:10])
+    assert m._lookahead is not None
+    nxt = best(flat[10:20])
+    assert m.lookahead_hits == 1 and np.array_equal(again[0], first[0]) and np.array_equal(nxt[0], copy[0])
     m.close()
     # each result is what a fresh metric returns for that chunk alone
     for rows, k, got in ((flat[0:10], 3, first), (flat[30:40], 3, skipped), (flat[40:50], 2, other_k), (flat[10:20], 3, copy)):
