@@ -787,6 +787,48 @@ void release_held(kpdi_ctx *c) {
 
 }  // namespace kpdi
 
+namespace {
+
+// A small host chunk that may wait for company (coalescing, above) is uploaded STRAIGHT into its rows of the pending buffer
+// on the copy stream: nothing of it is queued on the compute stream until the rows are swept, so the uploads of a chunked
+// call run beside the sweeps of the chunks before them.  (Through a staging buffer + a device-to-device copy on the compute
+// stream - staged_upload below - the copy sat behind the previous sweep, held its staging buffer until then and the next
+// upload waited for it: configs[1] as 33 chunks from host memory took uploads + sweeps, 60 ms.)  *done = false: the chunk
+// cannot wait (no slot); nothing has happened and the caller takes the staged path.
+static int direct_upload(kpdi_ctx *c, const void *patterns, int dtype, size_t es, int64_t n_chunk, int64_t global_start, bool *done) {
+  *done = false;
+  int rc = resolve_exact64(c);
+  if (rc) return rc;
+  rc = check_chunk_args(c, dtype, n_chunk, global_start);
+  if (rc) return rc;
+  void *slot = nullptr;
+  rc = pending_slot(c, dtype, n_chunk, global_start, &slot);
+  if (rc || !slot) return rc;
+  kpdi_ctx::PendingChunks &p = c->pending;
+  if (!c->copy_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+      HIPCHK(hipEventCreateWithFlags(&c->stage_filled[b], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&c->stage_free[b], hipEventDisableTiming));
+      HIPCHK(hipEventRecord(c->stage_free[b], c->stream));
+    }
+  }
+  if (!p.filled) HIPCHK(hipEventCreateWithFlags(&p.filled, hipEventDisableTiming));
+  // (the rows this buffer held before have been read by their preparation kernel)
+  if (p.consumed_set[p.cur]) HIPCHK(hipStreamWaitEvent(c->copy_stream, p.consumed[p.cur], 0));
+  HIPCHK(hipMemcpyAsync(slot, patterns, (size_t)n_chunk * c->npix * es, hipMemcpyHostToDevice, c->copy_stream));
+  HIPCHK(hipEventRecord(p.filled, c->copy_stream));
+  p.filled_pending = true;
+  *done = true;
+  c->cnt.h2d_bytes += (double)n_chunk * c->npix * es;
+  rc = pending_commit(c, n_chunk, global_start, false, true);  // (sweeps the pending rows when enough of them are there)
+  const hipError_t e = hipStreamSynchronize(c->copy_stream);   // the caller's buffer is free again
+  if (!rc && e != hipSuccess) return fail(KPDI_EHIP, "upload of a dictionary chunk: %s", hipGetErrorString(e));
+  return rc;
+}
+
+}  // namespace
+
 extern "C" {
 
 int kpdi_push_dictionary_chunk(kpdi_ctx *c, const void *patterns, int dtype, int64_t n_chunk, int64_t global_start) {
@@ -804,37 +846,9 @@ int kpdi_push_dictionary_chunk(kpdi_ctx *c, const void *patterns, int dtype, int
   const std::vector<int64_t> pieces = upload_pieces(c, n_chunk, (size_t)c->npix * es);
   const bool one_piece = pieces.size() == 1;  // (pieces of a larger upload are sized for its pipeline: they sweep at once)
   if (one_piece && c->have_exp && c->m > 0 && !c->sw.no_direct_upload) {
-    // A small chunk that may wait for company (coalescing, above) is uploaded STRAIGHT into its rows of the pending buffer
-    // on the copy stream: nothing of it is queued on the compute stream until the rows are swept, so the uploads of a
-    // chunked call run beside the sweeps of the chunks before them.  (Through a staging buffer + a device-to-device copy
-    // on the compute stream - the path below - the copy sat behind the previous sweep, held its staging buffer until then
-    // and the next upload waited for it: configs[1] as 33 chunks from host memory took uploads + sweeps, 60 ms.)
-    rc = resolve_exact64(c);
-    if (rc) return rc;
-    rc = check_chunk_args(c, dtype, n_chunk, global_start);
-    if (rc) return rc;
-    void *slot = nullptr;
-    rc = pending_slot(c, dtype, n_chunk, global_start, &slot);
-    if (rc) return rc;
-    if (slot) {
-      kpdi_ctx::PendingChunks &p = c->pending;
-      if (!c->copy_stream) {
-        HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        for (int b = 0; b < 2; ++b) {
-          HIPCHK(hipEventCreateWithFlags(&c->stage_filled[b], hipEventDisableTiming));
-          HIPCHK(hipEventCreateWithFlags(&c->stage_free[b], hipEventDisableTiming));
-          HIPCHK(hipEventRecord(c->stage_free[b], c->stream));
-        }
-      }
-      if (!p.filled) HIPCHK(hipEventCreateWithFlags(&p.filled, hipEventDisableTiming));
-      // (the rows this buffer held before have been read by their preparation kernel)
-      if (p.consumed_set[p.cur]) HIPCHK(hipStreamWaitEvent(c->copy_stream, p.consumed[p.cur], 0));
-      HIPCHK(hipMemcpyAsync(slot, patterns, (size_t)n_chunk * c->npix * es, hipMemcpyHostToDevice, c->copy_stream));
-      HIPCHK(hipEventRecord(p.filled, c->copy_stream));
-      p.filled_pending = true;
-      c->cnt.h2d_bytes += (double)n_chunk * c->npix * es;
-      rc = pending_commit(c, n_chunk, global_start, false, true);  // (sweeps the pending rows when enough of them are there)
-      HIPCHK(hipStreamSynchronize(c->copy_stream));   // the caller's buffer is free again
+    bool done = false;
+    rc = direct_upload(c, patterns, dtype, es, n_chunk, global_start, &done);
+    if (rc || done) {
       c->pend64.defer = false;
       return rc;
     }
