@@ -25,6 +25,8 @@ timeout 900 python tools/rank_share_probe.py $O/rank_share_config5_f16_dict16.js
 timeout 300 python tools/group_chunk_probe.py $O/group_chunks.txt > /dev/null 2>&1
 KPDI_NO_COALESCE=1 timeout 300 python tools/group_chunk_probe.py $O/group_chunks_nocoalesce.txt > /dev/null 2>&1
 timeout 300 python tools/f64_probe.py $O/f64_bounds.txt > /dev/null 2>&1
+# ---- the stand-alone driver as a user calls it (host dictionary; one pass, a quarter, the tutorial's chunking), both upload paths
+{ echo "# shipped"; timeout 300 python tools/standalone_call_probe.py 2>/dev/null | grep "n_per_iteration="; echo "# KPDI_NO_DIRECT_UPLOAD=1"; KPDI_NO_DIRECT_UPLOAD=1 timeout 300 python tools/standalone_call_probe.py 2>/dev/null | grep "n_per_iteration="; } > $O/standalone_call.txt
 (cd /tmp && export TMPDIR=/tmp
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_config5_f16 -o b -- python $R/bench.py --workload config5 --steps 2 --warmup 1 --no-cpu-baseline --compute f16 --check-rows 0 --no-traffic > /dev/null 2>&1)
 )
