@@ -299,7 +299,12 @@ class _HipMetric(SimilarityMetric):
     # ------------------------------------------------------------------ engine
     @property
     def context(self):
-        """The libkpdi context (created on first use: needs a GPU)."""
+        """The libkpdi context (created on first use: needs a GPU).  Asking for it ends a look-ahead that is still
+        running: the engine is then the caller's alone."""
+        self._cancel_lookahead()
+        return self._engine()
+
+    def _engine(self):
         if self._ctx is None:
             self._ctx = _lib.make_engine(self._device, self._devices)
         return self._ctx
@@ -317,7 +322,7 @@ class _HipMetric(SimilarityMetric):
             raise ValueError(
                 f"The signal mask shape {sm.shape} and the detector shape {tuple(sig_shape)} must be identical"
             )
-        self.context.set_problem(sig_shape[0], sig_shape[1], sm, self._metric_code, keep_n,
+        self._engine().set_problem(sig_shape[0], sig_shape[1], sm, self._metric_code, keep_n,
                                  self.COMPUTE_MODES[self.effective_compute])
         self._problem = tuple(sig_shape)
 
@@ -328,7 +333,7 @@ class _HipMetric(SimilarityMetric):
         announces `k`, so the loop's `.reshape((-1, k))` is a no-op on it); a NumPy result cannot change shape behind
         the loop's back, so the missing columns are returned as entries that can never be selected - score -inf -
         which the host merge of :120-128 drops (`keep_n <= dictionary size`, :67, guarantees enough real ones)."""
-        ctx = self.context
+        ctx = self._engine()
         n = patterns.shape[0]
         k_run = min(k, n)
         la, self._lookahead = self._lookahead, None
@@ -360,7 +365,7 @@ class _HipMetric(SimilarityMetric):
         """A `_LookAhead` over the chunks behind `patterns` - the chunk just served the ordinary way - or None when they
         cannot be predicted: not a view into a larger C-contiguous array of the same dtype, nothing left of the
         `n_dictionary_patterns` rows, float64 arithmetic or a group of devices (no pipelined hand-over of single chunks)."""
-        ctx = self.context
+        ctx = self._engine()
         if self._lookahead_off or os.environ.get("KPDI_SEAM_LOOKAHEAD", "1") == "0" or hasattr(ctx, "members") \
                 or not hasattr(ctx, "finalize_async"):
             return None
@@ -382,7 +387,7 @@ class _HipMetric(SimilarityMetric):
         row0 = off // row_bytes - first  # the dictionary's row 0 within the owner
         if row0 < 0 or (row0 + total) * row_bytes > owner.nbytes:
             return None  # (the rest of the dictionary would lie outside this buffer: not the layout the loop slices)
-        return _LookAhead(self.context, owner, row0 + seen, n, row0 + total, patterns.shape[1:], k)
+        return _LookAhead(ctx, owner, row0 + seen, n, row0 + total, patterns.shape[1:], k)
 
     def _cancel_lookahead(self):
         la, self._lookahead = self._lookahead, None
@@ -435,8 +440,8 @@ class _HipMetric(SimilarityMetric):
             n = max(int(np.prod(patterns.shape[:-2])), 1)
         patterns = patterns.reshape((n,) + sig_shape)
         self._set_problem(sig_shape, 1)
-        self.context.set_experimental(patterns, self.navigation_mask)
-        self._engine_m = self.context.n_experimental
+        self._engine().set_experimental(patterns, self.navigation_mask)
+        self._engine_m = self._engine().n_experimental
         n_pix = int(np.prod(sig_shape))
         if self.signal_mask is not None:
             n_pix = int((~np.asarray(self.signal_mask, dtype=bool)).sum())
