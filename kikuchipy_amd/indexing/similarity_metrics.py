@@ -178,8 +178,9 @@ class _LookAhead:
     engine per chunk as without it, so the results are the same bit for bit ($KPDI_SEAM_LOOKAHEAD=0 switches it off).
     """
 
-    def __init__(self, ctx, owner, first_row, rows, total_rows, sig_shape, k):
+    def __init__(self, ctx, owner, first_row, rows, total_rows, sig_shape, k, pipelined=True):
         self._ctx = ctx
+        self._pipelined = pipelined  # False (float64 arithmetic: no finalize_async): one chunk at a time, still beside the host merge
         self._flat = owner.reshape(-1)  # (a view: the owner is C-contiguous; keeps the caller's buffer alive)
         self._row_elems = int(np.prod(sig_shape))
         self._sig_shape = tuple(sig_shape)
@@ -205,6 +206,10 @@ class _LookAhead:
                 ctx.set_keep_n(k_run)
                 ctx.set_dictionary_size(0)
                 ctx.push_dictionary_chunk(chunk, 0)
+                if not self._pipelined:
+                    self._put((row, ctx.finalize(k_run)))
+                    row += len(chunk)
+                    continue
                 ticket = ctx.finalize_async(k_run)
                 if pending is not None:
                     self._put((pending[1], ctx.finalize_wait(pending[0])))
@@ -364,13 +369,14 @@ class _HipMetric(SimilarityMetric):
     def _start_lookahead(self, patterns, k):
         """A `_LookAhead` over the chunks behind `patterns` - the chunk just served the ordinary way - or None when they
         cannot be predicted: not a view into a larger C-contiguous array of the same dtype, nothing left of the
-        `n_dictionary_patterns` rows, float64 arithmetic or a group of devices (no pipelined hand-over of single chunks)."""
+        `n_dictionary_patterns` rows, a group of devices.  (float64 arithmetic has no pipelined hand-over: its look-ahead
+        sweeps one chunk at a time - still beside the caller's host merge.)"""
         ctx = self._engine()
         if self._lookahead_off or os.environ.get("KPDI_SEAM_LOOKAHEAD", "1") == "0" or hasattr(ctx, "members") \
                 or not hasattr(ctx, "finalize_async"):
             return None
         total, n = self.n_dictionary_patterns, patterns.shape[0]
-        if total is None or self.effective_compute == "f64" or not patterns.flags.c_contiguous or n < 1:
+        if total is None or not patterns.flags.c_contiguous or n < 1:
             return None
         first, seen = self._rows_seen, self._rows_seen + n  # rows of the dictionary: this chunk = [first, seen)
         if seen >= total:
@@ -387,7 +393,8 @@ class _HipMetric(SimilarityMetric):
         row0 = off // row_bytes - first  # the dictionary's row 0 within the owner
         if row0 < 0 or (row0 + total) * row_bytes > owner.nbytes:
             return None  # (the rest of the dictionary would lie outside this buffer: not the layout the loop slices)
-        return _LookAhead(ctx, owner, row0 + seen, n, row0 + total, patterns.shape[1:], k)
+        return _LookAhead(ctx, owner, row0 + seen, n, row0 + total, patterns.shape[1:], k,
+                          pipelined=self.effective_compute != "f64")
 
     def _cancel_lookahead(self):
         la, self._lookahead = self._lookahead, None

@@ -194,8 +194,8 @@ def main():
         # the plugin's look-ahead (similarity_metrics._LookAhead) predicts the REAL loop's slices: every chunk of a NumPy
         # dictionary but the first was swept ahead - also of the lazy case here, whose `dask.array.from_array` over an
         # in-memory array hands out VIEWS of that array from `.compute()` (a dictionary that is really computed arrives
-        # in fresh arrays and is not predicted); float64 arithmetic (no pipelined hand-over) is never predicted
-        want_hits = n_chunks - 1 if dtype != np.float64 else 0
+        # in fresh arrays and is not predicted); float64 arithmetic too (one chunk at a time: it has no pipelined hand-over)
+        want_hits = n_chunks - 1
         assert m.lookahead_hits == want_hits, (name, m.lookahead_hits, want_hits)
         print(f"{name}: {n_chunks} chunk(s), {m.lookahead_hits} served from the look-ahead")
         assert [n for _, n in engine.pushed] == [min(n_per, dic.shape[0] - c * n_per) for c in range(n_chunks)], name

@@ -187,11 +187,12 @@ def test_lookahead_stays_inside_the_callers_buffer_and_ends_with_close():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("metric_name", ["ncc", "ndp"])
-def test_lookahead_on_the_gpu_engine_serves_the_loop_and_changes_nothing(monkeypatch, metric_name):
+@pytest.mark.parametrize("metric_name,dtype", [("ncc", "float32"), ("ndp", "float32"), ("ncc", "float64")])
+def test_lookahead_on_the_gpu_engine_serves_the_loop_and_changes_nothing(monkeypatch, metric_name, dtype):
     """The real engine behind the plugin in the (restated) reference loop: 8 chunks of 700 rows + one of 100, a signal
     mask, keep_n = 20 - every chunk but the first comes from the look-ahead (pipelined finalize_async / finalize_wait on
-    the worker thread), bit for bit what the same loop returns with the look-ahead switched off."""
+    the worker thread; float64 arithmetic: one synchronous sweep at a time there), bit for bit what the same loop returns
+    with the look-ahead switched off."""
     import kikuchipy_amd as kpa
 
     rng = np.random.default_rng(11)
@@ -203,7 +204,7 @@ def test_lookahead_on_the_gpu_engine_serves_the_loop_and_changes_nothing(monkeyp
     out = {}
     for on in ("1", "0"):
         monkeypatch.setenv("KPDI_SEAM_LOOKAHEAD", on)
-        m = ko.plugin_prepare_metric(cls(device=0), 300, None, sm, np.dtype("float32"), 5700)
+        m = ko.plugin_prepare_metric(cls(device=0), 300, None, sm, np.dtype(dtype), 5700)
         try:
             s_, i_, _ = ko.plugin_loop(m, exp, (300,), dic, 20, 700)
             out[on] = (s_, i_, m.lookahead_hits)
@@ -211,6 +212,9 @@ def test_lookahead_on_the_gpu_engine_serves_the_loop_and_changes_nothing(monkeyp
             m.close()
     assert out["1"][2] == 8 and out["0"][2] == 0
     assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
-    # ... and what the oracle returns for the same call: north_star's 1e-5
-    rs, ri = ko.dictionary_indexing(exp, dic, metric_name, 20, 700, None, sm, np.float32)
-    ko.assert_topk_parity(out["1"][0], out["1"][1], rs, ri, atol=1e-5)
+    # ... and what the oracle returns for the same call: north_star's 1e-5 (float64 arithmetic: 1e-12, one chunk at a time
+    # on the look-ahead's thread - no pipelined hand-over there)
+    assert out["1"][0].dtype == np.dtype(dtype)
+    rs, ri = ko.dictionary_indexing(exp, dic, metric_name, 20, 700, None, sm, np.dtype(dtype).type)
+    ko.assert_topk_parity(out["1"][0], out["1"][1], rs, ri, atol=1e-5 if dtype == "float32" else 1e-12,
+                          tie=2e-5 if dtype == "float32" else 1e-11)
