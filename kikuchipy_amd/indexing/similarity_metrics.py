@@ -219,6 +219,11 @@ class _LookAhead:
                 res = ctx.finalize_wait(pending[0])  # (always collected: the slot must be free for whoever comes next)
                 self._put((pending[1], res))
         except BaseException as e:  # noqa: BLE001 - handed to the consumer, which raises it in the caller's thread
+            if pending is not None:  # (a result slot of the engine must not stay taken)
+                try:
+                    ctx.finalize_wait(pending[0])
+                except Exception:  # noqa: BLE001
+                    pass
             self._put((None, e))
 
     def _put(self, item):
