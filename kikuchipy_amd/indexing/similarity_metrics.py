@@ -219,9 +219,9 @@ class _LookAhead:
                 res = ctx.finalize_wait(pending[0])  # (always collected: the slot must be free for whoever comes next)
                 self._put((pending[1], res))
         except BaseException as e:  # noqa: BLE001 - handed to the consumer, which raises it in the caller's thread
-            if pending is not None:  # (a result slot of the engine must not stay taken)
+            if pending is not None:  # the chunk before the failing one is still good (and its result slot must not stay taken)
                 try:
-                    ctx.finalize_wait(pending[0])
+                    self._put((pending[1], ctx.finalize_wait(pending[0])))
                 except Exception:  # noqa: BLE001
                     pass
             self._put((None, e))

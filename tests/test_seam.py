@@ -186,6 +186,38 @@ def test_lookahead_stays_inside_the_callers_buffer_and_ends_with_close():
     assert not la._thread.is_alive() and m2._lookahead is None
 
 
+def test_lookahead_hands_a_failure_to_the_chunk_it_belongs_to():
+    """A sweep that fails on the look-ahead's thread is raised in the caller's thread when the loop asks for THAT chunk -
+    the chunks before it are served - and the engine is usable afterwards (no result slot left taken)."""
+    import kikuchipy_amd as kpa
+    from _standin_engine import StandInContext
+
+    class Failing(StandInContext):
+        pushes = 0
+
+        def push_dictionary_chunk(self, patterns, global_start):
+            Failing.pushes += 1
+            if Failing.pushes == 3:
+                raise RuntimeError("third chunk refused")
+            return super().push_dictionary_chunk(patterns, global_start)
+
+    rng = np.random.default_rng(8)
+    exp = rng.integers(0, 256, (3, 12, 10)).astype(np.uint8)
+    dic = rng.random((50, 12, 10)).astype(np.float32)
+    flat = dic.reshape((50, -1))
+    m = ko.plugin_prepare_metric(kpa.NormalizedCrossCorrelationMetric(context=Failing(0)), 3, None, None, np.dtype("float32"), 50)
+    e = m.prepare_experimental(exp)
+    best = lambda rows: m.match(e, m.prepare_dictionary(rows)).topk(2, axis=-1)  # noqa: E731
+    best(flat[0:10])
+    best(flat[10:20])                       # from the look-ahead
+    with pytest.raises(RuntimeError, match="third chunk refused"):
+        best(flat[20:30])                   # the worker's failure, here
+    assert m.lookahead_hits == 1 and m._lookahead is None
+    e = m.prepare_experimental(exp)         # the engine still works
+    assert best(flat[0:10]).shape == (3, 2)
+    m.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("metric_name,dtype", [("ncc", "float32"), ("ndp", "float32"), ("ncc", "float64")])
 def test_lookahead_on_the_gpu_engine_serves_the_loop_and_changes_nothing(monkeypatch, metric_name, dtype):
