@@ -1224,6 +1224,32 @@ def _main(argv, context_factory=None, group_factory=None):
             except Exception as err:  # an informational leg must not cost the bench line
                 out["extra"]["plugin_seam_error"] = f"{type(err).__name__}: {err}"
 
+    if solo and not a.no_pcie and a.workload == "config2" and a.compute == "f32" and context_factory is None:
+        # informational: the stand-alone driver as a USER calls it - kikuchipy_amd.dictionary_indexing(exp, dictionary in host
+        # memory, n_per_iteration=...) - engine made and closed by the call; wall time of the whole call, best of 3
+        try:
+            import kikuchipy_amd as kpa
+
+            leg = {"what": "kikuchipy_amd.dictionary_indexing(4096 patterns, 100 000-pattern dictionary in HOST memory, metric='ncc', "
+                           "keep_n=20, n_per_iteration=...) as a user calls it: one engine per call (created, fed over the host "
+                           "link, closed); wall time of the whole call, best of 3 after a warm-up call"}
+            for per in (None, 3044):
+                best_t, res = None, None
+                for rep in range(4):
+                    t0 = time.perf_counter()
+                    res = kpa.dictionary_indexing(exp, dic, metric=w["metric"], keep_n=w["keep_n"], n_per_iteration=per,
+                                                  device=device, verbose=False)
+                    dt = time.perf_counter() - t0
+                    if rep and (best_t is None or dt < best_t):
+                        best_t = dt
+                leg["single_pass" if per is None else f"n_per_iteration_{per}"] = {
+                    "ms_per_call": round(best_t * 1e3, 2), "patterns_per_s": round(w["m"] / best_t, 1),
+                    "identical_to_the_timed_result": bool(np.array_equal(res.scores, scores)
+                                                          and np.array_equal(res.simulation_indices, indices))}
+            out["extra"]["standalone_call"] = leg
+        except Exception as err:  # an informational leg must not cost the bench line
+            out["extra"]["standalone_call_error"] = f"{type(err).__name__}: {err}"
+
     if solo and not a.no_generation:
         try:
             # informational: the dictionary is SIMULATED on the device inside the step

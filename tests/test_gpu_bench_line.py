@@ -58,6 +58,9 @@ def test_default_bench_line_and_its_legs():
         assert seam["index_agreement_with_the_timed_result"] > 0.999
         assert seam["identical_with_and_without_lookahead"] and seam["chunks_served_from_the_lookahead"] == seam["iterations"] - 1
         assert seam["without_lookahead"]["ms_upload"] > 0
+    sa = out["extra"]["standalone_call"]  # the user's call: same result, chunked or not; the chunked call within 1.5 x the single pass
+    assert sa["single_pass"]["identical_to_the_timed_result"] and sa["n_per_iteration_3044"]["identical_to_the_timed_result"]
+    assert sa["n_per_iteration_3044"]["ms_per_call"] < 1.5 * sa["single_pass"]["ms_per_call"]
     # one rank's share of an 8-rank job takes between an eighth and a quarter of the whole step
     share = out["extra"]["config2_share_of_8"]
     assert 1.0 <= share["step_over_even_share"] < 2.0, share
