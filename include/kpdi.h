@@ -30,15 +30,13 @@
  *
  * Degenerate patterns
  *  A pattern whose normalisation is undefined is DEGENERATE:
- *    ncc - zero variance over the kept pixels: a constant pattern (a dead or saturated detector frame); "constant" =
- *          centred sum of squares <= K (2^-20 mean)^2, i.e. constant to within the rounding of a float32 mean (the mean of
- *          K equal float32 values comes out up to ~8 ulp off, leaving residuals of that size).  This is a CONTRAST
- *          FLOOR: a pattern whose RMS contrast is below 2^-20 = 9.5e-7 of its mean - uint16 data around 60 000 counts
- *          with a standard deviation below 0.057 counts, or ONE pixel of 3600 differing by 1 count there - is treated as
- *          constant although the reference would still correlate it (its float32 evaluation of such a pattern is itself
- *          rounding noise: ulp(60 000) = 0.004 counts).  Real detector frames are 4-5 orders of magnitude above it;
+ *    ncc - a CONSTANT pattern (a dead or saturated detector frame): all kept pixels EQUAL.  The test is exact (minimum
+ *          == maximum of the pixels as read, after the cast to the compute dtype's float32) - there is no contrast floor:
+ *          uint16 data around 60 000 counts with ONE pixel of 3600 off by one count is an ordinary pattern and correlates
+ *          as in the reference (tests/test_gpu_degenerate.py::test_no_contrast_floor);
  *    ndp - all kept pixels zero;
- *    either metric - NaN or +-inf among the kept pixels.
+ *    either metric - NaN or +-inf among the kept pixels, or a sum of squares that is not a positive finite float32
+ *          (overflow; differences so small that their squares underflow).
  *  The reference divides 0 by 0 there (similarity_metrics/_normalized_cross_correlation.py:228-233,
  *  _normalized_dot_product.py:181-194): the prepared row is NaN, every score of it is NaN, and Dask's topk ranks NaN
  *  FIRST (dask/array/chunk.py:167-258) - a degenerate dictionary pattern becomes every experimental pattern's best
@@ -526,6 +524,9 @@ typedef struct kpdi_plan {
   int32_t n_main;              /* tiles of the main launch(es) */
   int32_t tail_tiles, tail_units, tail_nsplit, fixed_draws; /* match.hip: quarter-tile tail launch, fixed hand-out */
   int32_t tail_first, tail_shift;                           /* match16.hip f32: partial units from tile tail_first on */
+  int32_t perm_rounds, perm_stride; /* match16.hip: round j < perm_rounds of split sp takes tile sp + nsplit * ((j * perm_stride)
+                                       mod perm_rounds) - a low-discrepancy walk, so that the order of the dictionary
+                                       (sampler order, sorted by score) does not matter to the fused top-k; 0 = natural order */
   int32_t n_launch_desc;
   struct {
     int32_t row_first, rows, xcd_rows, xcd_splits, rows_grid;
@@ -572,6 +573,11 @@ typedef struct kpdi_counters {
                                     at kpdi_set_problem); 0 = not float64 arithmetic.  `uncertified_patterns == 0` is a proof only for 2 */
   int32_t gather_ranks;          /* lists merged by the last finalize: RCCL ranks or peer-copied group members, 0 = this context's own only */
   int64_t coalesced_sweeps;      /* sweeps that took several small pushed chunks together (kpdi_push_dictionary_chunk: coalescing) */
+  /* what the fused top-k of match16.hip did (collected at profiling level 1 only; per-lane lists: one per lane and 32
+   * experimental patterns of a wave tile): lists that ran, candidates that passed the shared bound and were appended to
+   * a lane's buffer, buffers that overflowed (the list is then built from the tile directly: the slow path), first
+   * tiles that took that path because the bound was not complete in time */
+  int64_t epi_lists, epi_appended, epi_overflows, epi_direct_first;
 } kpdi_counters;
 /* sizeof(kpdi_counters) as the LIBRARY was built: a binding whose struct differs must refuse to call kpdi_get_counters
  * (the struct has grown between versions; kpdi_version() changes with it) */

@@ -69,6 +69,10 @@ class Counters(C.Structure):
         ("f64_certificate", C.c_int32),
         ("gather_ranks", C.c_int32),
         ("coalesced_sweeps", C.c_int64),
+        ("epi_lists", C.c_int64),
+        ("epi_appended", C.c_int64),
+        ("epi_overflows", C.c_int64),
+        ("epi_direct_first", C.c_int64),
     ]
 
     def as_dict(self):
@@ -99,7 +103,7 @@ class Plan(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("form", "tile", "row_blocks", "n_tiles", "nsplit", "rows_per_launch", "launches")]
                 + [("round_rows", C.c_int64)]
                 + [(n, C.c_int32) for n in ("n_main", "tail_tiles", "tail_units", "tail_nsplit", "fixed_draws", "tail_first",
-                                            "tail_shift", "n_launch_desc")]
+                                            "tail_shift", "perm_rounds", "perm_stride", "n_launch_desc")]
                 + [("launch", PlanLaunch * 64)])
 
 
@@ -375,6 +379,7 @@ class Context:
                                       int(keep_n)))
         self._keep_n = int(keep_n)
         self._compute = int(compute)
+        self._detector = (int(sy), int(sx))
 
     def set_keep_n(self, keep_n):
         check(self._f.set_keep_n(self._h, int(keep_n)))
@@ -406,6 +411,7 @@ class Context:
         nm = _mask_bytes(navigation_mask)
         check(self._f.set_experimental_dev(self._h, C.c_void_p(d_ptr), dtype_code(dtype), int(m_all),
                                                _ptr(nm)))
+        self._exp_shape, self._exp_dtype = (int(m_all),) + getattr(self, "_detector", (-1,)), np.dtype(dtype)
 
     @property
     def n_experimental(self):

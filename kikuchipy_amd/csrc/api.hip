@@ -575,6 +575,14 @@ int kpdi_get_counters(kpdi_ctx *c, kpdi_counters *out) {
   if (rc) return rc;
   rc = drain_events(c, c->ev_fixed, &c->cnt.fixed_ms);
   if (rc) return rc;
+  if (c->epi_stats.p) {
+    unsigned long long st[4];
+    HIPCHK(hipMemcpy(st, c->epi_stats.p, sizeof st, hipMemcpyDeviceToHost));
+    c->cnt.epi_lists = (int64_t)st[0];
+    c->cnt.epi_appended = (int64_t)st[1];
+    c->cnt.epi_overflows = (int64_t)st[2];
+    c->cnt.epi_direct_first = (int64_t)st[3];
+  }
   c->cnt.f64_certificate = c->exact64 ? (c->sw.f64_statistical ? 1 : 2) : 0;
   c->cnt.comm_ranks = 0;
   if (c->comm) {
@@ -592,6 +600,7 @@ int kpdi_reset_counters(kpdi_ctx *c) {
   if (rc) return rc;
   const int kpad = c->cnt.kpad, kk = c->cnt.k_kept, gr = c->cnt.gather_ranks;
   c->cnt = kpdi_counters{};
+  if (c->epi_stats.p) HIPCHK(hipMemsetAsync(c->epi_stats.p, 0, 4 * sizeof(unsigned long long), c->stream));
   c->cnt.kpad = kpad;
   c->cnt.k_kept = kk;
   c->cnt.gather_ranks = gr;

@@ -231,6 +231,7 @@ struct kpdi_ctx {
   // top-k state
   kpdi::DevBuf part_s, part_i;       // partial lists of one match launch
   kpdi::DevBuf tail_s, tail_i;       // partial lists of the quarter-tile tail launch (match.hip: ROWT = 1)
+  kpdi::DevBuf epi_stats;            // 4 x u64: what the epilogues of match16.hip did (profiling level 1; kpdi_counters.epi_*)
   kpdi::DevBuf list16;               // float16 form: home of the per-lane lists during a launch (match16.hip)
   int tail_nsplit = 0;         // lists per pattern / 2 of the last run_match's tail launch, 0 = none
   kpdi::DevBuf run_s[2], run_i[2];   // running best-k ping-pong

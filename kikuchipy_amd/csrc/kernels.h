@@ -79,6 +79,8 @@ struct MatchLaunch {
   int row_tiles = 4;   // 4: units of work = 128-pattern tiles; 1: the tail form - 32-pattern units (f32 only)
   int row_base = 0;    // tail form: dictionary row (of this chunk) of unit 0, a multiple of 32; `n_tiles` counts units
   int tail_first = 0, tail_shift = 0;  // float32 form of match16.hip: partial units for the tiles from tail_first on
+  int perm_rounds = 0, perm_stride = 1;  // match16.hip: order of a workgroup's tiles (match_device.h: MatchArgs)
+  unsigned long long *epi_stats = nullptr;  // match16.hip: 4 device counters of what the epilogues did, or nullptr
 };
 constexpr unsigned THRESHOLD_NONE = 0x007fffffu;  // key of -inf
 constexpr int BOUND_SLOTS = 32;

@@ -115,11 +115,17 @@ __device__ __forceinline__ T *chunk_base(T *base, int chunk) {
 // increasing dictionary index) into the lane's list: first a screen with plain compares (bit r of
 // `hot` = some lane of register r reaches the threshold), then only those registers go through the
 // loop with the scalar register index (match.hip: scan_tile, FORM = 2).
-template <int KMAX, bool BOUNDED, bool F32 = false>
+// LEX: candidates may arrive in any order of dictionary index (the permuted tile order): thresholds are non-strict
+// against a list's last entry and the insertion decides by (score, index).  !LEX (the 32-entry lists of the 8-wave
+// form, which have no register to spare for it - tools/check_mfma_loops.py): natural tile order, strict thresholds,
+// list_insert's arrival-order tie rule.
+template <int KMAX, bool BOUNDED, bool F32 = false, bool LEX = true>
 __device__ __forceinline__ void scan16(f32x16 (&acc)[4], float (&best)[KMAX], int (&best_idx)[KMAX], float gthr,
                                        float ub, int ub_idx, int row0, int n_valid, int idx_base, int rt_n = 4) {
   constexpr float unscale = F32 ? 1.f : 0x1p-24f;  // float16 operands are stored scaled by 2^12 each
-  float thr = fmaxf(gthr, next_up(best[KMAX - 1]));
+  // (non-strict against the list's last entry: tiles arrive in a permuted order, so an equal score with a LOWER index
+  // may still come - the insertion decides by (score, index))
+  float thr = fmaxf(gthr, LEX ? best[KMAX - 1] : next_up(best[KMAX - 1]));
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
     if (F32 && rt >= rt_n) continue;  // a partial unit of the float32 form's tail
@@ -134,11 +140,16 @@ __device__ __forceinline__ void scan16(f32x16 (&acc)[4], float (&best)[KMAX], in
       const float v = acc[rt][r] * unscale + 0.f;  // -0 -> +0 so that ties compare as the merge does
       const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
       const int idx = idx_base + lrow;
-      bool ok = lrow < n_valid && v >= thr;
+      bool ok = lrow < n_valid && v >= thr && (!LEX || ranks_before(v, idx, best[KMAX - 1], best_idx[KMAX - 1]));
       if (BOUNDED) ok = ok && (v < ub || (v == ub && idx > ub_idx));
       if (ok) {
-        list_insert<KMAX>(best, best_idx, v, idx);
-        thr = fmaxf(gthr, next_up(best[KMAX - 1]));
+        if (LEX) {
+          list_insert_lex<KMAX>(best, best_idx, v, idx);
+          thr = fmaxf(gthr, best[KMAX - 1]);
+        } else {
+          list_insert<KMAX>(best, best_idx, v, idx);
+          thr = fmaxf(gthr, next_up(best[KMAX - 1]));
+        }
       }
     }
   }
@@ -163,6 +174,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
   static_assert(!F32 || WAVES == 4, "the float32 form runs one wave per SIMD");
   typedef Geo<WAVES> G;
   constexpr int NCG = G::NCG;
+  constexpr bool LEX = !(KMAX == 32 && WAVES == 8);  // (scan16 above)
   constexpr int BLOCK16 = G::DBLOCK, STAGE16 = G::STAGE, NSTAGE16 = G::NSTAGE, KSTEPS16 = G::KS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -256,7 +268,28 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
 #define KPDI16_UNIT_TILE(u) ((u) < tail_first ? (u) : tail_first + (((u) - tail_first) >> tail_shift))
 #define KPDI16_UNIT_ROW(u) ((u) < tail_first ? 0 : ((((u) - tail_first) & ((1 << tail_shift) - 1)) * (F16_TILE >> tail_shift)))
 #define KPDI16_UNIT_RT(u) ((u) < tail_first ? 4 : (4 >> tail_shift))
-  int t0 = sp, t1 = sp + a.nsplit, t2 = sp + 2 * a.nsplit;
+  // ORDER of this workgroup's units: the whole-tile rounds [0, perm_rounds) in a low-discrepancy walk over the
+  // dictionary (round j: tile sp + nsplit * ((j * perm_stride) mod perm_rounds); the same for every row block, so the
+  // workgroups of an XCD still stream the same tiles together), then the remaining rounds in natural order.  A
+  // dictionary in the order a sampler emits it - or sorted by score, the hostile case - then looks to the shared bound
+  // like a shuffled one: after the first rounds it holds samples from all over the dictionary, and a tile whose every
+  // row beats everything seen so far happens O(log rounds) times instead of every round (bench.py:
+  // extra.structured_config2.dictionary_sorted_ascending: match 0.76 -> of the f32 peak with the natural order).
+  const int perm_rounds = a.perm_rounds, perm_stride = a.perm_stride;
+  int seq_round = 0, seq_pos = 0;
+  auto next_unit = [&]() {
+    int u;
+    if (seq_round < perm_rounds) {
+      u = sp + a.nsplit * seq_pos;
+      seq_pos += perm_stride;
+      if (seq_pos >= perm_rounds) seq_pos -= perm_rounds;
+    } else {
+      u = sp + a.nsplit * seq_round;
+    }
+    ++seq_round;
+    return u;
+  };
+  int t0 = next_unit(), t1 = next_unit(), t2 = next_unit();
   if (t0 < n_units) {
     const int last_tile = n_tiles - 1;
     int ld_pos = 0, ld_step = 0, ld_stage = 0;
@@ -492,6 +525,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
           }
         }
 #endif
+        // index of a built list's last entry (a candidate that TIES with it passes only with a lower index: tiles
+        // arrive in a permuted order); lists are rarely built before the end - then nothing is loaded
+        int lidx[NCG];
+        {
+          bool built = false;
+#pragma unroll
+          for (int cg = 0; cg < NCG; ++cg) {
+            lidx[cg] = INT_MAX;
+            built = built || last[cg] > -INFINITY;
+          }
+          if (LEX && __builtin_amdgcn_ballot_w64(built) != 0) {
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg)
+              lidx[cg] = chunk_base(home_i + cg * KMAX * 64, (KMAX - 1) / 16)[((KMAX - 1) % 16) * 64 + ulane];
+          }
+        }
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) {
 #ifdef KPDI16_NO_EPILOGUE  // (the MFMAs are asm volatile: they stay)
@@ -510,7 +559,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
             ub_cg = a.bound_score[m_lane + 32 * cg];
             ubi_cg = a.bound_idx[m_lane + 32 * cg];
           }
-          const float thr = fmaxf(g[cg], next_up(last[cg]));
+          const float thr = fmaxf(g[cg], LEX ? last[cg] : next_up(last[cg]));
           const float thr_raw = F32 ? thr : thr * 0x1p24f;  // exact: the float16 form's accumulators hold 2^24 * score
           float *bs = buf_s + cg * CAND_CAP * 64;
           int *bi = buf_i + cg * CAND_CAP * 64;
@@ -556,7 +605,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
               const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
               const float v = acc[cg][rt][r] * unscale + 0.f;  // -0 -> +0 so that ties compare as the merge does
               const int idx = idx_base + lrow;
-              bool ok = acc[cg][rt][r] >= thr_raw && lrow < n_valid;
+              bool ok = acc[cg][rt][r] >= thr_raw && lrow < n_valid && (!LEX || v > last[cg] || idx < lidx[cg]);
               if (BOUNDED) ok = ok && (v < ub_cg || (v == ub_cg && idx > ubi_cg));
               if (ok) {
                 if (c < cap) {
@@ -604,7 +653,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
                 const int lrow = row0 + rt * 32 + (r & 3) + 8 * (r >> 2);
                 const float v = raw * unscale + 0.f;  // -0 -> +0 so that ties compare as the merge does
                 const int idx = idx_base + lrow;
-                bool ok = lrow < n_valid;
+                bool ok = lrow < n_valid && (!LEX || v > last[cg] || idx < lidx[cg]);
                 if (BOUNDED) ok = ok && (v < ub_cg || (v == ub_cg && idx > ubi_cg));
                 if (ok) {
                   if (c < cap) {
@@ -661,11 +710,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
               if (i < cnt[cg]) {
                 const float v = bs[i * 64 + ulane];
                 const int id = bi[i * 64 + ulane];
-                if (v > best[KMAX - 1]) list_insert<KMAX>(best, bidx, v, id);
+                if (LEX) {
+                  if (ranks_before(v, id, best[KMAX - 1], bidx[KMAX - 1])) list_insert_lex<KMAX>(best, bidx, v, id);
+                } else if (v > best[KMAX - 1]) {
+                  list_insert<KMAX>(best, bidx, v, id);
+                }
+              }
+            }
+            if (LEX && a.epi_stats) {  // (developer counters, profiling level 1: what was appended before this list was built)
+              const unsigned app = wave_sum_u32((unsigned)cnt[cg]);
+              if (lane == 0) {
+                atomicAdd(a.epi_stats + 1, (unsigned long long)app);
+                atomicAdd(a.epi_stats + (first_tile ? 3 : 2), 1ull);
               }
             }
             cnt[cg] = 0;
-            scan16<KMAX, BOUNDED, F32>(acc[cg], best, bidx, g[cg], ub_cg, ubi_cg, row0, n_valid, idx_base, rt_n);
+            scan16<KMAX, BOUNDED, F32, LEX>(acc[cg], best, bidx, g[cg], ub_cg, ubi_cg, row0, n_valid, idx_base, rt_n);
 #pragma unroll
             for (int q = 0; q < (KMAX + 15) / 16; ++q) {
               float *ps = chunk_base(hs, q);
@@ -700,7 +760,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
         ++tiles_done;
         t0 = t1;
         t1 = t2;
-        t2 += a.nsplit;
+        t2 = next_unit();
         --ld_pos;
         if (t0 >= n_units) break;
       }
@@ -753,7 +813,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-          hot |= __builtin_amdgcn_ballot_w64(vs[e] >= tf && vs[e] > best[KMAX - 1]) != 0 ? (1u << e) : 0u;
+          hot |= __builtin_amdgcn_ballot_w64(vs[e] >= tf && (LEX ? ranks_before(vs[e], ids[e], best[KMAX - 1], bidx[KMAX - 1])
+                                                                 : vs[e] > best[KMAX - 1])) != 0 ? (1u << e) : 0u;
 #pragma unroll 1
         while (hot != 0) {
           const int e = __builtin_ctz(hot);
@@ -765,7 +826,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
             v = e == q ? vs[q] : v;
             id = e == q ? ids[q] : id;
           }
-          if (v >= tf && v > best[KMAX - 1]) list_insert<KMAX>(best, bidx, v, id);
+          if (LEX) {
+            if (v >= tf && ranks_before(v, id, best[KMAX - 1], bidx[KMAX - 1])) list_insert_lex<KMAX>(best, bidx, v, id);
+          } else if (v >= tf && v > best[KMAX - 1]) {
+            list_insert<KMAX>(best, bidx, v, id);
+          }
+        }
+      }
+      if (LEX && a.epi_stats) {
+        const unsigned app = wave_sum_u32((unsigned)cnt[cg]);
+        if (lane == 0) {
+          atomicAdd(a.epi_stats, 64ull);
+          atomicAdd(a.epi_stats + 1, (unsigned long long)app);
         }
       }
       const size_t o = ((size_t)(m_lane + 32 * cg) * lists + (size_t)list_id) * KMAX;
@@ -788,7 +860,7 @@ size_t match16_scratch_bytes(int grid, int waves, int list_len) {
 }
 
 template <int KMAX, bool BOUNDED, int WAVES, bool F32 = false>
-static hipError_t launch16_t(const MatchArgs &args, int grid, void *scratch, hipStream_t s) {
+static hipError_t launch16_t(const MatchArgs &args_in, int grid, void *scratch, hipStream_t s) {
   // (the attribute belongs to the function ON A DEVICE: remembered per device, not per process - a second context
   // on another GPU would otherwise launch a 144 KB kernel without it)
   static unsigned long long attr_set = 0;
@@ -800,6 +872,8 @@ static hipError_t launch16_t(const MatchArgs &args, int grid, void *scratch, hip
     if (e != hipSuccess) return e;
     attr_set |= 1ull << (dev & 63);
   }
+  MatchArgs args = args_in;
+  if (KMAX == 32 && WAVES == 8) args.perm_rounds = 0;  // (!LEX instantiations: natural order, match16_kernel)
   // scratch: scores of all lists, then their indices
   float *ls = (float *)scratch;
   int *li = (int *)(ls + scratch16_entries(grid, WAVES, KMAX));
@@ -866,6 +940,9 @@ hipError_t launch_match16(const MatchLaunch &a, int waves, void *list_scratch, h
   g.tile_ctr = a.tile_ctr;
   g.tile_groups = 1;
   g.fixed_draws = 1 << 30;
+  g.perm_rounds = a.perm_rounds;
+  g.perm_stride = a.perm_stride;
+  g.epi_stats = a.epi_stats;
   g.tail_first = a.operand_form == 3 && a.tail_shift > 0 ? a.tail_first : a.n_tiles;
   g.tail_shift = a.operand_form == 3 ? a.tail_shift : 0;
   g.xcd_rows = a.xcd_rows;

@@ -34,6 +34,12 @@ struct MatchArgs {
   unsigned *gthr;      // [m_pad][BOUND_SLOTS] published list ranks (monotone keys), see shared_bound()
   int bound_rank;      // which entry (1-based) of its list a workgroup lane publishes
   int bound_grouped;   // 1: all 32 slots are in use and bound_rank == 1 (grouped form)
+  // match16.hip: ORDER of a workgroup's tiles.  Round j < perm_rounds of split sp takes tile sp + nsplit * ((j *
+  // perm_stride) mod perm_rounds) - a low-discrepancy walk over the dictionary (perm_stride ~ 0.618 perm_rounds, coprime;
+  // plan.h: tile_order_stride) - the rounds from perm_rounds on (partial units, an incomplete last round) follow in
+  // natural order.  perm_rounds = 0: natural order throughout.
+  int perm_rounds, perm_stride;
+  unsigned long long *epi_stats;  // nullptr, or 4 counters of what the epilogues did (kpdi_counters.epi_*)
 };
 
 // Block id -> (row block of the launch, dictionary split).  Block b runs on XCD b % 8 (observed, used for
@@ -191,6 +197,32 @@ __device__ __forceinline__ void list_insert(float (&s)[KMAX], int (&id)[KMAX], f
   }
   id[0] = blend(above[0], idx, id[0]);
   s[0] = fmaxf(s[0], v);
+}
+
+// Does candidate (v, idx) rank before (s, id)?  Score descending, dictionary index ascending: the engine's total order.
+__device__ __forceinline__ bool ranks_before(float v, int idx, float s, int id) { return v > s || (v == s && idx < id); }
+
+// list_insert for candidates that arrive in ANY order of dictionary index (match16.hip walks the dictionary's tiles in
+// a permuted order): the position is decided by (score, index), so equal scores end up lower index first whatever the
+// arrival order.  Precondition: ranks_before(v, idx, s[KMAX - 1], id[KMAX - 1]).
+template <int KMAX>
+__device__ __forceinline__ void list_insert_lex(float (&s)[KMAX], int (&id)[KMAX], float v, int idx) {
+  int above[KMAX];  // all ones where (v, idx) ranks before entry j (monotone in j: 0..0 1..1)
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) above[j] = ranks_before(v, idx, s[j], id[j]) ? -1 : 0;
+#pragma unroll
+  for (int j = KMAX - 1; j >= 1; --j) {
+    id[j] = blend(above[j], blend(above[j - 1], id[j - 1], idx), id[j]);
+    s[j] = __builtin_amdgcn_fmed3f(s[j - 1], s[j], v);
+  }
+  id[0] = blend(above[0], idx, id[0]);
+  s[0] = fmaxf(s[0], v);
+}
+
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += (unsigned)__shfl_xor((int)v, o, 64);
+  return v;
 }
 
 // smallest float above f (f finite or -inf)

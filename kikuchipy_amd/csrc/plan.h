@@ -25,6 +25,7 @@ struct Switches {
   double wide_launch = FORM_WIDE_LAUNCH, fixed_frac = 0.8;
   bool xcd_grid = true, xcd_pad = true, no_tail = false, one_stream = false, tail_stream2 = false;
   bool f64_statistical = false, f64_sync = false, no_coalesce = false, no_direct_upload = false, no_coalesce_wait = false;
+  bool natural_order = false;
   long upload_tiles = 0;
   void read() {
     *this = Switches{};
@@ -47,6 +48,7 @@ struct Switches {
     no_direct_upload = getenv("KPDI_NO_DIRECT_UPLOAD") != nullptr;
     no_coalesce_wait = getenv("KPDI_NO_COALESCE_WAIT") != nullptr;
     if (const char *e = getenv("KPDI_UPLOAD_TILES")) upload_tiles = atol(e);
+    if (const char *e = getenv("KPDI_TILE_ORDER")) natural_order = !strcmp(e, "natural");
   }
 };
 
@@ -129,6 +131,49 @@ inline double wide_tail(const Env &e, int n_tiles, int nsplit, int *shift) {
       const double cost = (double)(((left << sh) + nsplit - 1) / nsplit) / (1 << sh) * (sh == 1 ? FORM_WIDE_HALF : FORM_WIDE_QUARTER);
       if (cost < best - 1e-9) best = cost, *shift = sh;
     }
+  return best;
+}
+
+// match16.hip: the order in which a workgroup walks its whole-tile rounds (match_device.h: MatchArgs.perm_*): round j
+// takes round-slot (j * stride) mod rounds, stride ~ 0.618 rounds and coprime to it - the first visits are spread over
+// the whole dictionary whichever way it is ordered, so a dictionary in sampler order (or sorted by score) costs the
+// fused top-k O(log rounds) "everything in this tile is a candidate" tiles instead of one per round.  Returns the
+// stride; *rounds = 0 (natural order) when there are fewer than 3 whole rounds or KPDI_TILE_ORDER=natural.
+inline int tile_order_stride(const Env &e, int whole_tiles, int nsplit, int *rounds) {
+  *rounds = 0;
+  const int r = nsplit > 0 ? whole_tiles / nsplit : 0;
+  if (r < 3 || e.sw.natural_order) return 1;
+  auto gcd = [](int a, int b) {
+    while (b) {
+      const int t = a % b;
+      a = b;
+      b = t;
+    }
+    return a;
+  };
+  // among the strides in [r / 2, 3 r / 4] coprime to r: the one whose walk 0, s, 2 s, ... (mod r) sets the fewest running
+  // maxima - what a dictionary sorted by rising score shows a workgroup (a falling one shows its best tile first) - and,
+  // among equals, the one closest to the golden section (an integer stride near 0.618 r can degenerate: r = 1184, s =
+  // 733 sets 59 maxima, the best stride 11).  r <= 2048 is searched; beyond, the golden stride is taken as it is.
+  const double golden = 0.6180339887 * r;
+  int best = 1, best_records = 1 << 30;
+  double best_dist = 1e30;
+  for (int s = std::max(1, r / 2); s <= std::min(r - 1, 3 * r / 4 + 1); ++s) {
+    if (gcd(s, r) != 1) continue;
+    int records = 0;
+    if (r <= 2048) {
+      records = 1;
+      for (int j = 1, p = 0, mx = 0; j < r; ++j) {
+        p += s;
+        if (p >= r) p -= r;
+        if (p > mx) mx = p, ++records;
+      }
+    }
+    const double dist = std::abs(s - golden);
+    if (records < best_records || (records == best_records && dist < best_dist)) best = s, best_records = records, best_dist = dist;
+  }
+  if (best_records == (1 << 30)) return 1;  // (no coprime stride in the window: r = 4 -> 3 is found, r = 3 -> 2; never here)
+  *rounds = r;
   return best;
 }
 

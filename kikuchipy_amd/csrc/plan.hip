@@ -43,6 +43,7 @@ extern "C" int kpdi_plan_describe(int64_t m, int64_t n_chunk, int k_kept, int ke
     out->n_main = n_tiles;
     (void)plan::wide_tail(e, n_tiles, nsplit, &out->tail_shift);
     out->tail_first = n_tiles - n_tiles % nsplit;
+    out->perm_stride = plan::tile_order_stride(e, out->tail_shift > 0 ? out->tail_first : n_tiles, nsplit, &out->perm_rounds);
   }
   for (int r0 = 0, j = 0; r0 < row_blocks; r0 += rpl, ++j) {
     if (j >= KPDI_PLAN_MAX_LAUNCHES) {

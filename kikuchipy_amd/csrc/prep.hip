@@ -32,7 +32,7 @@
 // cannot carry the constant.
 //
 // A DEGENERATE pattern - zero variance (`ncc`) / all zeros (`ndp`) / NaN or inf among its kept pixels; 0/0 = NaN in
-// the reference - becomes an all-zero row: it scores exactly 0 against everything (prep_device.h: degenerate_norm2,
+// the reference - becomes an all-zero row: it scores exactly 0 against everything (prep_device.h: degenerate_pattern,
 // include/kpdi.h "Degenerate patterns").
 #include "prep_device.h"
 
@@ -63,10 +63,16 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const T *raw, int np
   const int nslab = kpad / TILE_K;
   const int tid = threadIdx.x;
 
-  float s = 0.f;
-  for (int c = tid; c < k; c += PREP_THREADS) s += (float)p[pix_map ? pix_map[c] : c];
+  float s = 0.f, lo = INFINITY, hi = -INFINITY;
+  for (int c = tid; c < k; c += PREP_THREADS) {
+    const float x = (float)p[pix_map ? pix_map[c] : c];
+    s += x;
+    lo = fminf(lo, x);
+    hi = fmaxf(hi, x);
+  }
   float mean = 0.f;
   if (metric != KPDI_METRIC_NDP) mean = block_sum(s, red) / (float)k;
+  if (metric == KPDI_METRIC_NCC) block_minmax_n<PREP_THREADS>(lo, hi, red);
   float q = 0.f;
   for (int c = tid; c < k; c += PREP_THREADS) {
     const float d = (float)p[pix_map ? pix_map[c] : c] - mean;
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const T *raw, int np
   q = block_sum(q, red);
   const bool centred = metric == NORM_NDP_CENTRED;
   const float norm2 = centred ? q + (float)k * mean * mean : q;
-  const bool degenerate = degenerate_norm2(norm2, centred ? 0.f : mean, k);  // -> an all-zero row (prep_device.h)
+  const bool degenerate = degenerate_pattern(norm2, lo, hi, metric == KPDI_METRIC_NCC);  // -> an all-zero row (prep_device.h)
   const float inv = degenerate ? 0.f : 1.f / sqrtf(norm2);
   const float cval = degenerate ? 0.f : sqrtf((float)k) * mean * inv;
   if (degenerate) mean = 0.f;
@@ -100,11 +106,13 @@ __device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], flo
   const int nslab = kpad / TILE_K;
   float mean = 0.f;
   if (metric != KPDI_METRIC_NDP) mean = wave_sum(s) / (float)k;
-  float q2 = 0.f;
+  float q2 = 0.f, lo = INFINITY, hi = -INFINITY;
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES; ++i) {
     const int c = lane + 64 * i;
     if (c < k) {
+      lo = fminf(lo, v[i]);
+      hi = fmaxf(hi, v[i]);
       v[i] -= mean;
       q2 += v[i] * v[i];
     } else {
@@ -112,9 +120,13 @@ __device__ __forceinline__ void normalise_and_store(float (&v)[WAVE_VALUES], flo
     }
   }
   q2 = wave_sum(q2);
+  if (metric == KPDI_METRIC_NCC) {
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+  }
   const bool centred = metric == NORM_NDP_CENTRED;
   const float norm2 = centred ? q2 + (float)k * mean * mean : q2;
-  const bool degenerate = degenerate_norm2(norm2, centred ? 0.f : mean, k);  // -> an all-zero row (prep_device.h)
+  const bool degenerate = degenerate_pattern(norm2, lo, hi, metric == KPDI_METRIC_NCC);  // -> an all-zero row (prep_device.h)
   const float inv = degenerate ? 0.f : 1.f / sqrtf(norm2);
   const float cval = degenerate ? 0.f : sqrtf((float)k) * mean * inv;
   if (degenerate) {
@@ -306,13 +318,28 @@ __global__ __launch_bounds__(256 * NP) void prep16_block4_kernel(const T *raw, i
     __syncthreads();
     return (red[4 * g] + red[4 * g + 1]) + (red[4 * g + 2] + red[4 * g + 3]);
   };
+  // minimum / maximum over the 4 waves of a group (the exact test for a constant pattern, prep_device.h)
+  auto group_minmax = [&](float &lo, float &hi) {
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    __syncthreads();
+    if ((tid & 63) == 0) red[wave] = lo;
+    __syncthreads();
+    lo = fminf(fminf(red[4 * g], red[4 * g + 1]), fminf(red[4 * g + 2], red[4 * g + 3]));
+    __syncthreads();
+    if ((tid & 63) == 0) red[wave] = hi;
+    __syncthreads();
+    hi = fmaxf(fmaxf(red[4 * g], red[4 * g + 1]), fmaxf(red[4 * g + 2], red[4 * g + 3]));
+  };
   float mean = 0.f;
   if (metric != KPDI_METRIC_NDP) mean = group_total(s) / (float)k;
-  float q2 = 0.f;
+  float q2 = 0.f, lo = INFINITY, hi = -INFINITY;
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES; ++i) {
     const int c = VW * (t + 256 * (i / VW)) + (i % VW);
     if (c < k) {
+      lo = fminf(lo, v[i]);
+      hi = fmaxf(hi, v[i]);
       v[i] -= mean;
       q2 += v[i] * v[i];
     } else {
@@ -320,7 +347,8 @@ __global__ __launch_bounds__(256 * NP) void prep16_block4_kernel(const T *raw, i
     }
   }
   q2 = group_total(q2);
-  const bool degenerate = degenerate_norm2(q2, mean, k);  // -> an all-zero row (prep_device.h)
+  if (metric == KPDI_METRIC_NCC) group_minmax(lo, hi);
+  const bool degenerate = degenerate_pattern(q2, lo, hi, metric == KPDI_METRIC_NCC);  // -> an all-zero row (prep_device.h)
   const float inv = degenerate ? 0.f : 4096.f / sqrtf(q2);  // float16 operands are stored scaled by 2^12
   if (degenerate) {
 #pragma unroll
@@ -398,13 +426,28 @@ __global__ __launch_bounds__(PREP16_THREADS) void prep32_block4_kernel(const T *
     __syncthreads();
     return (red[4 * g] + red[4 * g + 1]) + (red[4 * g + 2] + red[4 * g + 3]);
   };
+  // minimum / maximum over the 4 waves of a group (the exact test for a constant pattern, prep_device.h)
+  auto group_minmax = [&](float &lo, float &hi) {
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    __syncthreads();
+    if ((tid & 63) == 0) red[wave] = lo;
+    __syncthreads();
+    lo = fminf(fminf(red[4 * g], red[4 * g + 1]), fminf(red[4 * g + 2], red[4 * g + 3]));
+    __syncthreads();
+    if ((tid & 63) == 0) red[wave] = hi;
+    __syncthreads();
+    hi = fmaxf(fmaxf(red[4 * g], red[4 * g + 1]), fmaxf(red[4 * g + 2], red[4 * g + 3]));
+  };
   float mean = 0.f;
   if (metric != KPDI_METRIC_NDP) mean = group_total(s) / (float)k;
-  float q2 = 0.f;
+  float q2 = 0.f, lo = INFINITY, hi = -INFINITY;
 #pragma unroll
   for (int i = 0; i < WAVE_VALUES; ++i) {
     const int c = 4 * (t + 256 * (i / 4)) + (i & 3);
     if (c < k) {
+      lo = fminf(lo, v[i]);
+      hi = fmaxf(hi, v[i]);
       v[i] -= mean;
       q2 += v[i] * v[i];
     } else {
@@ -412,9 +455,10 @@ __global__ __launch_bounds__(PREP16_THREADS) void prep32_block4_kernel(const T *
     }
   }
   q2 = group_total(q2);
+  if (metric == KPDI_METRIC_NCC) group_minmax(lo, hi);
   const bool centred = metric == NORM_NDP_CENTRED;
   const float norm2 = centred ? q2 + (float)k * mean * mean : q2;
-  const bool degenerate = degenerate_norm2(norm2, centred ? 0.f : mean, k);  // -> an all-zero row (prep_device.h)
+  const bool degenerate = degenerate_pattern(norm2, lo, hi, metric == KPDI_METRIC_NCC);  // -> an all-zero row (prep_device.h)
   const float inv = degenerate ? 0.f : 1.f / sqrtf(norm2);
   const float cval = degenerate ? 0.f : sqrtf((float)k) * mean * inv;
   if (degenerate) {

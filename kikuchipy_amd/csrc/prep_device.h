@@ -10,18 +10,19 @@ namespace kpdi {
 constexpr int NORM_NDP_CENTRED = 2;  // internal value of the `metric` argument: `ndp` in its centred form (prep.hip)
 
 // ---- degenerate patterns (include/kpdi.h, "Degenerate patterns") ---------------------------------------------------
-// A pattern whose normalisation is undefined is DEGENERATE: `ncc` - a constant pattern (dead or saturated detector
-// frame: zero variance; "constant" = centred sum of squares <= K (2^-20 mean)^2, i.e. constant to within the rounding
-// of a float32 mean), `ndp` - an all-zero pattern, either metric - NaN or inf among the kept pixels.  The reference
-// divides 0 by 0 there (similarity_metrics/_normalized_cross_correlation.py:228-233, _normalized_dot_product.py:181-194)
-// and ranks the resulting NaN FIRST (dask/array/chunk.py:167-258).  Here such a pattern is prepared as the all-zero
-// row: its score against every pattern is exactly +0 ("no correlation"), on the experimental and on the dictionary
-// side, in every arithmetic.  `norm2` = sum of squares the row is divided by the root of; `mean` = the mean that was
-// removed (0 for `ndp`).
+// A pattern whose normalisation is undefined is DEGENERATE: `ncc` - a CONSTANT pattern (dead or saturated detector
+// frame): all kept pixels equal, tested EXACTLY (minimum == maximum of the pixels as read - no tolerance: one pixel
+// of 3600 off by one count at 60 000 counts is an ordinary pattern and correlates as in the reference); `ndp` - an
+// all-zero pattern; either metric - NaN or inf among the kept pixels, or a sum of squares that is not a positive
+// finite number.  The reference divides 0 by 0 there (similarity_metrics/_normalized_cross_correlation.py:228-233,
+// _normalized_dot_product.py:181-194) and ranks the resulting NaN FIRST (dask/array/chunk.py:167-258).  Here such a
+// pattern is prepared as the all-zero row: its score against every pattern is exactly +0 ("no correlation"), on the
+// experimental and on the dictionary side, in every arithmetic.  `norm2` = sum of squares the row is divided by the
+// root of; `lo` / `hi` = minimum / maximum of the kept pixels before the mean is removed; `ncc` = the metric removes
+// the mean and divides by the centred norm.
 template <typename F>
-__host__ __device__ inline bool degenerate_norm2(F norm2, F mean, int k) {
-  const F tol = mean * (F)9.5367431640625e-07;  // 2^-20
-  return !(norm2 > (F)k * tol * tol && norm2 < (F)__builtin_inff());  // (NaN fails both comparisons)
+__host__ __device__ inline bool degenerate_pattern(F norm2, F lo, F hi, bool ncc) {
+  return !(norm2 > (F)0 && norm2 < (F)__builtin_inff()) || (ncc && lo == hi);  // (NaN fails both comparisons)
 }
 constexpr int PREP_THREADS = 256;
 constexpr int WAVE_VALUES = 64;  // values per lane of the wave-per-pattern kernels (K <= 4096)
@@ -30,6 +31,39 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// minimum and maximum over a workgroup of NT threads; `red`: NT / 64 floats (used twice)
+template <int NT>
+__device__ __forceinline__ void block_minmax_n(float &lo, float &hi, float *red) {
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();  // protect `red` from the previous use
+  if ((threadIdx.x & 63) == 0) red[w] = lo;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) t = fminf(t, red[i]);
+  lo = t;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = hi;
+  __syncthreads();
+  t = red[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) t = fmaxf(t, red[i]);
+  hi = t;
 }
 
 // sum over a workgroup of NT threads; `red`: NT / 64 floats
@@ -137,6 +171,16 @@ __device__ __forceinline__ float group_sum(float v, float *red) {
   return block_sum_n<NT>(v, red);
 }
 
+template <int NT>
+__device__ __forceinline__ void group_minmax(float &lo, float &hi, float *red) {
+  if (NT == 64) {
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+  } else {
+    block_minmax_n<NT>(lo, hi, red);
+  }
+}
+
 // H16: the kernel was instantiated FOR the float16 form (split & 0xff == 2) / for the other two forms: with one
 // body for all three, the float16 stores' address arithmetic - unrolled 16 times - raised the f32 kernels
 // from 170-204 to 256 registers and the masked f32 preparation from 0.79 to 1.33 ms.
@@ -149,11 +193,13 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[NV], float 
   const int nslab = kpad / TILE_K;
   float mean = 0.f;
   if (metric != KPDI_METRIC_NDP) mean = group_sum<NT>(s, red) / (float)k;
-  float q2 = 0.f;
+  float q2 = 0.f, lo = INFINITY, hi = -INFINITY;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = 4 * (lane + NT * (i / 4)) + (i & 3);
     if (c < k) {
+      lo = fminf(lo, v[i]);
+      hi = fmaxf(hi, v[i]);
       v[i] -= mean;
       q2 += v[i] * v[i];
     } else {
@@ -161,9 +207,10 @@ __device__ __forceinline__ void normalise_and_store_quads(float (&v)[NV], float 
     }
   }
   q2 = group_sum<NT>(q2, red);
+  if (metric == KPDI_METRIC_NCC) group_minmax<NT>(lo, hi, red);
   const bool centred = metric == NORM_NDP_CENTRED;
   const float norm2 = centred ? q2 + (float)k * mean * mean : q2;
-  const bool degenerate = degenerate_norm2(norm2, centred ? 0.f : mean, k);  // (uniform over the NT threads of the row)
+  const bool degenerate = degenerate_pattern(norm2, lo, hi, metric == KPDI_METRIC_NCC);  // (uniform over the NT threads of the row)
   const float inv = degenerate ? 0.f : 1.f / sqrtf(norm2);
   const float cval = degenerate ? 0.f : sqrtf((float)k) * mean * inv;
   if (degenerate) {  // 0 x NaN is NaN: the row is written as zeros

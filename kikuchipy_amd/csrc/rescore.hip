@@ -61,14 +61,20 @@ __global__ __launch_bounds__(RESCORE_THREADS) void rescore_kernel(RescoreLaunch 
   __syncthreads();
   const double mx = centre ? ((red[0] + red[1]) + (red[2] + red[3])) / (double)a.k : 0.0;
   __syncthreads();
-  double q = 0.0, r1 = 0.0;
+  // (x0 = the first kept pixel: sum (x - x0)^2 is EXACTLY zero for a constant pattern and for no other - the exact
+  // test of include/kpdi.h "Degenerate patterns"; an all-zero pattern under `ndp` has sxx == 0)
+  const double x0 = raw_value(a.exp_raw, a.exp_dtype, xrow + (a.pix_map ? a.pix_map[0] : 0));
+  double q = 0.0, r1 = 0.0, qc = 0.0;
   for (int i = tid; i < a.k; i += RESCORE_THREADS) {
-    const double v = raw_value(a.exp_raw, a.exp_dtype, xrow + (a.pix_map ? a.pix_map[i] : i)) - mx;
+    const double raw = raw_value(a.exp_raw, a.exp_dtype, xrow + (a.pix_map ? a.pix_map[i] : i));
+    const double v = raw - mx;
     q += v * v;
     r1 += v;
+    qc += (raw - x0) * (raw - x0);
   }
   q = wave_sum_f64(q);
   r1 = wave_sum_f64(r1);
+  qc = wave_sum_f64(qc);
   if (lane == 0) {
     red[wave] = q;
     diff_red[wave] = 0.f;
@@ -80,6 +86,9 @@ __global__ __launch_bounds__(RESCORE_THREADS) void rescore_kernel(RescoreLaunch 
   __syncthreads();
   if (tid == 0) xstat[2] = (red[0] + red[1]) + (red[2] + red[3]);  // sum of the centred pixels: ~1e-13, not 0
   __syncthreads();
+  if (lane == 0) red[wave] = qc;
+  __syncthreads();
+  const bool x_constant = centre && !((red[0] + red[1]) + (red[2] + red[3]) > 0.0);  // (NaN: not > 0 -> degenerate)
   const double sxx = xstat[1], sx_res = xstat[2];
   // ---- candidates: ONE pass over a dictionary row.  With y0 = its first kept pixel (a shift that keeps the
   // one-pass variance free of cancellation) and x' = x - mean(x):
@@ -111,8 +120,9 @@ __global__ __launch_bounds__(RESCORE_THREADS) void rescore_kernel(RescoreLaunch 
       if (centre) sxy -= (s1 / (double)a.k) * sx_res;
       // degenerate patterns (zero variance / all zeros / NaN or inf in the data: include/kpdi.h) score exactly 0, as
       // in the f32 path, which prepares them as all-zero rows; the reference divides 0 by 0 there
-      const double my = centre ? y0 + s1 / (double)a.k : 0.0;
-      const bool degenerate = degenerate_norm2(sxx, mx, a.k) || degenerate_norm2(syy, my, a.k);
+      // (s2 = sum (y - y0)^2: exactly zero for a constant dictionary pattern, and only then)
+      const bool degenerate = x_constant || (centre && !(s2 > 0.0)) || degenerate_pattern(sxx, 0.0, 1.0, false) ||
+                              degenerate_pattern(syy, 0.0, 1.0, false);
       score = degenerate ? 0.0 : sxy / (sqrt(sxx) * sqrt(syy));
       if (!(score == score)) score = 0.0;
       if (score > -INFINITY) worst = fmaxf(worst, fabsf((float)(score - (double)s32)));

@@ -216,6 +216,18 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
     (void)plan::wide_tail(plan_env(c), n_main, nsplit, &ml.tail_shift);
     ml.tail_first = n_main - n_main % nsplit;
   }
+  if (f16) {
+    // whole-tile rounds are walked in a permuted order (plan.h: tile_order_stride); partial units stay last
+    const int whole = (c->wide32 && ml.tail_shift > 0) ? ml.tail_first : n_main;
+    ml.perm_stride = plan::tile_order_stride(plan_env(c), whole, nsplit, &ml.perm_rounds);
+    if (c->profiling == 1) {  // every phase bracketed = the developer level: the epilogues count what they do
+      if (!c->epi_stats.p) {
+        HIPCHK(c->epi_stats.reserve(4 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(c->epi_stats.p, 0, 4 * sizeof(unsigned long long), c->stream));
+      }
+      ml.epi_stats = c->epi_stats.as<unsigned long long>();
+    }
+  }
   ml.bound_rank = pl.bound_rank;
   ml.bound_grouped = pl.bound_grouped;
   ml.gthr = c->gthr.as<unsigned>();

@@ -55,33 +55,33 @@ ALLOWED_DTYPES = (np.dtype(np.float32), np.dtype(np.float64))
 # every score of it is NaN, and Dask's `topk` ranks NaN FIRST (`dask/array/chunk.py:167-258`: NaN sorts as the largest
 # value) - a degenerate DICTIONARY pattern becomes everybody's best match, a degenerate experimental pattern gets
 # arbitrary indices with NaN scores.  SURVEY.md 8(a) puts that out of contract and asks the engine to document what it
-# does instead; the ENGINE'S RULE (include/kpdi.h "Degenerate patterns", csrc/prep_device.h: degenerate_norm2), which
+# does instead; the ENGINE'S RULE (include/kpdi.h "Degenerate patterns", csrc/prep_device.h: degenerate_pattern), which
 # the oracle applies with `degenerate="zero"` (the default: it is the engine's checker): the row becomes ALL ZEROS, so
 # its score against every pattern is exactly 0 - "no correlation" - on either side, and ranks among the real scores
 # like any other 0 (ties: lower dictionary index first).  `degenerate="reference"` leaves the reference's NaN.
-DEGENERATE_REL = 2.0**-20  # `ncc`: "constant" = centred sum of squares <= K (2^-20 mean)^2 (the rounding of a float32 mean)
-
-
-def degenerate_rows(norm2, mean, k):
+def degenerate_rows(norm2, constant=None):
     """Rows whose normalisation is undefined (see above): `norm2` (n,) the sum of squares a row is divided by the root
-    of, `mean` (n,) the mean that was removed (0 for `ndp`)."""
+    of - not a positive finite number (all zeros, NaN / inf in the data); `constant` (n,) bool, `ncc` only: all kept
+    pixels of the row are EQUAL (minimum == maximum, an exact test: no contrast floor - one pixel off by one count on a
+    60 000-count background is an ordinary pattern, `_normalized_cross_correlation.py:228-233` correlates it)."""
     with np.errstate(invalid="ignore", over="ignore"):
-        tol = np.asarray(mean, dtype=np.float64) * DEGENERATE_REL
         norm2 = np.asarray(norm2, dtype=np.float64)
-        return ~((norm2 > k * tol * tol) & (norm2 < np.inf))
+        bad = ~((norm2 > 0) & (norm2 < np.inf))
+    return bad if constant is None else bad | np.asarray(constant, dtype=bool)
 
 
 def zero_mean_normalize(patterns, degenerate="zero"):
     """indexing/similarity_metrics/_normalized_cross_correlation.py:228-233
     (`_zero_mean_normalize_patterns_numpy`); in place on a private copy."""
     with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        constant = np.min(patterns, axis=1) == np.max(patterns, axis=1)
         patterns_mean = np.mean(patterns, axis=1, keepdims=True)
         patterns -= patterns_mean
         norm2 = np.sum(np.square(patterns), axis=1, keepdims=True)
         patterns_norm = np.sqrt(norm2)
         patterns /= patterns_norm
     if degenerate == "zero":
-        patterns[degenerate_rows(norm2[:, 0], patterns_mean[:, 0], patterns.shape[1])] = 0
+        patterns[degenerate_rows(norm2[:, 0], constant)] = 0
     return patterns
 
 
@@ -92,7 +92,7 @@ def normalize(patterns, degenerate="zero"):
         norm2 = np.sum(np.square(patterns), axis=1)
         out = patterns / np.sqrt(norm2)[..., np.newaxis]
     if degenerate == "zero":
-        out[degenerate_rows(norm2, 0.0, patterns.shape[1])] = 0
+        out[degenerate_rows(norm2)] = 0
     return out
 
 

@@ -26,13 +26,13 @@ void kpdi_c_set_threads(int n) {
   if (n > 0) omp_set_num_threads(n);
 }
 
-/* Degenerate patterns - zero variance (ncc) / all zeros (ndp) / NaN or inf among the pixels: the reference divides 0 by
- * 0 (NaN, ranked first by Dask's topk); the ENGINE's documented rule (include/kpdi.h, "Degenerate patterns";
- * csrc/prep_device.h: degenerate_norm2), which this checker follows: the row becomes all zeros, every score of it is
- * exactly 0.  norm2 = the sum of squares the row is divided by the root of, mean = the mean removed (0 for ndp). */
-static int degenerate_norm2(double norm2, double mean, int64_t k) {
-  const double tol = mean * 9.5367431640625e-07; /* 2^-20 */
-  return !(norm2 > (double)k * tol * tol && norm2 < INFINITY);
+/* Degenerate patterns - a constant pattern (ncc) / all zeros (ndp) / NaN or inf among the pixels: the reference divides
+ * 0 by 0 (NaN, ranked first by Dask's topk); the ENGINE's documented rule (include/kpdi.h, "Degenerate patterns";
+ * csrc/prep_device.h: degenerate_pattern), which this checker follows: the row becomes all zeros, every score of it is
+ * exactly 0.  norm2 = the sum of squares the row is divided by the root of; constant = (ncc only) all kept pixels are
+ * EQUAL - an exact test, no contrast floor. */
+static int degenerate_pattern(double norm2, int constant) {
+  return !(norm2 > 0.0 && norm2 < INFINITY) || constant;
 }
 
 /* rows: n x k, in place.  metric 0 = ncc (subtract mean first), 1 = ndp. */
@@ -41,6 +41,11 @@ void kpdi_c_normalize(float *rows, int64_t n, int64_t k, int metric) {
   for (int64_t r = 0; r < n; ++r) {
     float *p = rows + r * k;
     float mean = 0.f;
+    float lo = p[0], hi = p[0];
+    for (int64_t i = 1; i < k; ++i) {
+      lo = p[i] < lo ? p[i] : lo;
+      hi = p[i] > hi ? p[i] : hi;
+    }
     if (metric == 0) {
       double s = 0.0;
       for (int64_t i = 0; i < k; ++i) s += p[i];
@@ -49,7 +54,7 @@ void kpdi_c_normalize(float *rows, int64_t n, int64_t k, int metric) {
     }
     double q = 0.0;
     for (int64_t i = 0; i < k; ++i) q += (double)p[i] * (double)p[i];
-    if (degenerate_norm2(q, mean, k)) {
+    if (degenerate_pattern(q, metric == 0 && lo == hi)) {
       for (int64_t i = 0; i < k; ++i) p[i] = 0.f;
       continue;
     }
@@ -174,9 +179,12 @@ void kpdi_c_prepare_f32(const float *raw, int64_t n, int64_t k_in, const int64_t
     const float *p = raw + r * k_in;
     float *o = out + r * k;
     double s = 0.0;
+    float lo = INFINITY, hi = -INFINITY;
     for (int64_t i = 0; i < k; ++i) {
       o[i] = p[pix_map ? pix_map[i] : i];
       s += o[i];
+      lo = o[i] < lo ? o[i] : lo;
+      hi = o[i] > hi ? o[i] : hi;
     }
     const float mean = metric == 0 ? (float)(s / (double)k) : 0.f;
     double q = 0.0;
@@ -184,7 +192,7 @@ void kpdi_c_prepare_f32(const float *raw, int64_t n, int64_t k_in, const int64_t
       o[i] -= mean;
       q += (double)o[i] * o[i];
     }
-    if (degenerate_norm2(q, mean, k)) {
+    if (degenerate_pattern(q, metric == 0 && lo == hi)) {
       for (int64_t i = 0; i < k; ++i) o[i] = 0.f;
       continue;
     }
@@ -230,14 +238,20 @@ void kpdi_c_prepare_f64(const float *raw, int64_t n, int64_t k_in, const int64_t
     const float *p = raw + r * k_in;
     float *o = out + r * k;
     double s = 0.0;
-    for (int64_t i = 0; i < k; ++i) s += p[pix_map ? pix_map[i] : i];
+    float lo = INFINITY, hi = -INFINITY;
+    for (int64_t i = 0; i < k; ++i) {
+      const float x = p[pix_map ? pix_map[i] : i];
+      s += x;
+      lo = x < lo ? x : lo;
+      hi = x > hi ? x : hi;
+    }
     const double mean = metric == 0 ? s / (double)k : 0.0;
     double q = 0.0;
     for (int64_t i = 0; i < k; ++i) {
       const double d = (double)p[pix_map ? pix_map[i] : i] - mean;
       q += d * d;
     }
-    if (degenerate_norm2(q, mean, k)) {
+    if (degenerate_pattern(q, metric == 0 && lo == hi)) {
       for (int64_t i = 0; i < k; ++i) o[i] = 0.f;
       continue;
     }

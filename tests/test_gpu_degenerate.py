@@ -1,6 +1,7 @@
 """Degenerate patterns: defined (include/kpdi.h "Degenerate patterns"), implemented (csrc/prep_device.h:
-degenerate_norm2, csrc/rescore.hip), tested against the oracle, which states the same rule
-(oracle/kpdi_oracle.py: degenerate_rows).
+degenerate_pattern, csrc/rescore.hip), tested against the oracle, which states the same rule
+(oracle/kpdi_oracle.py: degenerate_rows) - and, for patterns that are NEARLY constant, against the reference's own
+arithmetic (`degenerate="reference"`): the rule is an exact test for "all kept pixels equal", not a contrast floor.
 
 Constant / all-zero / saturated patterns (dead detector frames are ordinary in real maps) and NaN / inf pixels, on the
 experimental AND on the dictionary side, inside 256-row tiles of ordinary patterns, every arithmetic, one and several
@@ -153,3 +154,47 @@ def test_what_the_reference_does_instead():
     # the engine's rule on the same data: no NaN, the degenerate pattern is not anybody's best match
     rs, ri = ko.dictionary_indexing(exp[:8], dic, keep_n=5)
     assert np.isfinite(rs).all() and not np.isin(ri[ordinary, 0], [0]).any()
+
+
+def faint_patterns(dtype, base, n=40, seed=8):
+    """Patterns on a `base`-count background with ONE to three pixels off by one count: RMS contrast ~1e-7 of the mean,
+    far below round 5's floor (2^-20), yet the reference correlates them (a centred delta)."""
+    rng = np.random.default_rng(seed)
+    p = np.full((n, SY, SX), base, dtype=dtype)
+    for r in range(n):
+        for _ in range(1 + r % 3):
+            y, x = rng.integers(SY), rng.integers(SX)
+            p[r, y, x] = p[r, y, x] + 1 if r % 2 else p[r, y, x] - 1
+    return p
+
+
+@pytest.mark.parametrize("compute", ["f32", "f64"])
+@pytest.mark.parametrize("dtype,base", [(np.uint16, 60000), (np.uint8, 200), (np.float32, 60000.0)])
+def test_no_contrast_floor(dtype, base, compute):
+    """uint16 at ~60 000 counts with a single pixel off by one must correlate LIKE THE REFERENCE
+    (similarity_metrics/_normalized_cross_correlation.py:228-233 evaluated by the oracle with degenerate="reference",
+    i.e. no rule of this library applied), on the experimental and on the dictionary side; an exactly constant frame
+    among them stays degenerate (score 0)."""
+    exp = faint_patterns(dtype, base)
+    exp[7] = base  # exactly constant: degenerate
+    rng = np.random.default_rng(4)
+    dic = rng.random((600, SY, SX)).astype(np.float32)
+    faint_d = faint_patterns(np.float32, 60000.0, n=20, seed=9)
+    dic[100:120] = faint_d
+    keep_n = 10
+    scores, idx = run(exp, dic, "ncc", keep_n, compute)
+    assert np.isfinite(scores).all()
+    # the reference's arithmetic, nothing else: float32 (or float64) zero-mean-normalise, matrix product, top-k
+    odt = np.float64 if compute == "f64" else np.float32
+    with np.errstate(invalid="ignore", divide="ignore"):
+        e = ko.zero_mean_normalize(exp.reshape(len(exp), -1).astype(odt), degenerate="reference")
+        d = ko.zero_mean_normalize(dic.reshape(len(dic), -1).astype(odt), degenerate="reference")
+    ordinary = np.setdiff1d(np.arange(len(exp)), [7])
+    assert np.isfinite(e[ordinary]).all() and np.isfinite(d).all(), "the reference itself is well defined on these"
+    sim = (e[ordinary].astype(np.float64) @ d.astype(np.float64).T).astype(np.float32)
+    ri, rs = ko.topk_desc(sim, keep_n)
+    tol = 1e-5 if compute == "f32" else 1e-6
+    ko.assert_topk_parity(scores[ordinary], idx[ordinary], rs, ri, atol=tol)
+    # the faint dictionary patterns are real candidates: a delta correlates +-1 / 0.5 / ... with another delta
+    assert np.abs(scores[ordinary]).max() > 0.3
+    assert np.array_equal(scores[7], np.zeros(keep_n)) and np.array_equal(idx[7], np.arange(keep_n))

@@ -291,3 +291,27 @@ def test_dynamic_background_reference_known_answers():
             assert np.allclose(out[0, 0], ans, atol=1e-4)
         else:
             assert np.abs(out[0, 0].astype(np.int64) - ans.astype(np.int64)).max() <= 1
+
+
+def test_degenerate_rule_is_exact_not_a_contrast_floor():
+    """include/kpdi.h "Degenerate patterns": only an EXACTLY constant pattern is degenerate for `ncc`.  One pixel of
+    480 off by one count on a 60 000-count background (RMS contrast 1e-6 of the mean) must come out of the oracle's
+    default rule exactly as out of the reference's arithmetic (_normalized_cross_correlation.py:228-233), in the
+    Python and in the C restatement."""
+    from oracle import c_oracle
+
+    p = np.full((6, 480), 60000.0, dtype=np.float32)
+    for r in range(5):
+        p[r, 7 * r + 3] += 1.0
+    ref = ko.zero_mean_normalize(p.copy(), degenerate="reference")
+    got = ko.zero_mean_normalize(p.copy())
+    assert np.isfinite(ref[:5]).all() and np.array_equal(got[:5], ref[:5])
+    assert np.abs(got[:5]).max() > 0.99  # a centred delta
+    assert not got[5].any()              # the exactly constant row: all zeros
+    c = c_oracle.prepare_f64(p.reshape(6, 24, 20), "ncc", None)
+    # (float64 keeps the 1 / 480 of the mean that float32 rounds away: 2e-3 per pixel)
+    assert np.allclose(c[:5], ref[:5], atol=3e-3) and np.abs(c[:5]).max() > 0.99 and not c[5].any()
+    z = np.zeros((2, 480), dtype=np.float32)
+    z[0, 3] = 1e-3
+    n = ko.normalize(z)
+    assert n[0, 3] == 1.0 and not n[1].any()

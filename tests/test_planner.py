@@ -7,6 +7,8 @@ blocks a launch covers, each launch's XCD grid, the tail of the last round.  Inv
 patterns: every row block is covered exactly once, padded grids hold at most 9/8 of the rows, no launch is without
 tiles, the tail units cover exactly the tiles the main rounds leave."""
 
+import math
+
 import numpy as np
 import pytest
 
@@ -63,6 +65,20 @@ def check(p, m, n, form):
         assert p.tail_shift in (0, 1, 2)
         if p.tail_first == p.n_tiles:
             assert p.tail_shift == 0
+        # the ORDER of a workgroup's whole-tile rounds: a permutation (stride coprime to the rounds) that spreads the first
+        # visits over the dictionary; partial units and an incomplete last round stay behind it, in natural order
+        whole = p.tail_first if p.tail_shift else p.n_tiles
+        if p.perm_rounds:
+            r, st = p.perm_rounds, p.perm_stride
+            assert r == whole // p.nsplit >= 3 and 1 <= st < r and math.gcd(st, r) == 1
+            order = [(j * st) % r for j in range(r)]
+            assert sorted(order) == list(range(r))
+            if r >= 8:  # the running maximum of the walk (= what a dictionary sorted by score shows a workgroup) rises rarely
+                records = sum(1 for j in range(r) if order[j] == max(order[:j + 1]))
+                assert records <= 1 + 1.5 * math.log2(r), (r, st, records)
+                assert order[0] == 0  # (a dictionary sorted by FALLING score shows its best tile first)
+        else:
+            assert whole // p.nsplit < 3 and p.perm_stride == 1
     assert p.round_rows == max(1, N_CU // row_blocks) * 256
 
 
@@ -101,6 +117,10 @@ def test_switches_reach_the_planner(monkeypatch):
     p = _lib.plan_describe(4096, 100000)
     assert (p.launch[0].xcd_rows, p.launch[0].xcd_splits, p.launch[0].rows_grid) == (0, 0, 16)
     monkeypatch.delenv("KPDI_XCD_GRID")
+    assert _lib.plan_describe(4096, 100000).perm_rounds == 24
+    monkeypatch.setenv("KPDI_TILE_ORDER", "natural")
+    assert _lib.plan_describe(4096, 100000).perm_rounds == 0
+    monkeypatch.delenv("KPDI_TILE_ORDER")
     monkeypatch.setenv("KPDI_XCD_PAD", "0")
     p = _lib.plan_describe(40000, 37500)
     assert p.launch[4].rows_grid == 29
