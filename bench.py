@@ -602,6 +602,8 @@ def _main(argv, context_factory=None, group_factory=None):
                     help="experimental rows of the timed result that are checked against the C oracle over the whole "
                          "dictionary before the line is printed (default: 64; 32 for the large workloads; 0 = no check)")
     ap.add_argument("--no-config3", action="store_true", help="skip the configs[2] leg of the default run")
+    ap.add_argument("--no-structured", action="store_true",
+                    help="skip the informational leg on physically structured data (bench_structured.py)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-pointer sweep")
     ap.add_argument("--no-rank-shares", action="store_true",
                     help="skip the informational legs that run ONE rank's share of the 8-GPU configurations (configs[3], configs[4])")
@@ -1015,6 +1017,21 @@ def _main(argv, context_factory=None, group_factory=None):
             raise
         except Exception as err:  # an informational leg must not cost the bench line
             out["extra"]["config3_error"] = f"{type(err).__name__}: {err}"
+
+    # ---- configs[1]'s size on PHYSICALLY STRUCTURED data (bench_structured.py): a grain map of projections of the Ni master
+    # pattern against an orientation-ordered dictionary (the reference's own benchmark shape,
+    # benchmarks/indexing/test_dictionary_indexing.py:30-63), and that dictionary sorted by score both ways
+    if a.workload == "config2" and solo and a.compute == "f32" and not a.no_structured and context_factory is None:
+        try:
+            import bench_structured
+
+            out["extra"]["structured_config2"] = bench_structured.leg(
+                _lib, device, reps=max(3, min(a.steps, 8)), n_check=0 if a.check_rows == 0 else 64,
+                baseline_frac=out["extra"].get("config3", {}).get("match_frac"))
+        except AssertionError:
+            raise
+        except Exception as err:  # an informational leg must not cost the bench line
+            out["extra"]["structured_config2_error"] = f"{type(err).__name__}: {err}"
 
     if solo and not a.no_pcie:
         try:

@@ -193,9 +193,8 @@ def summarize(ms, cnt, m, reps):
 
 def leg(_lib, device, reps=8, n_check=64, m=4096, sy=60, sx=60, keep_n=20, hostile=True, baseline_frac=None):
     """bench.py's `extra.structured_config2`."""
-    from bench import circular_mask  # (the same window as configs[2])
-
-    mask = circular_mask(sy, sx)
+    yy, xx = np.ogrid[:sy, :sx]  # `~Window("circular", (sy, sx)).astype(bool)` (filters/window.py:249-269), as configs[2]
+    mask = np.sqrt((yy - sy // 2) ** 2 + (xx - sx // 2) ** 2) > max(sy // 2, sx // 2)
     c = _lib.Context(device)
     try:
         t_build = time.perf_counter()
@@ -221,8 +220,8 @@ def leg(_lib, device, reps=8, n_check=64, m=4096, sy=60, sx=60, keep_n=20, hosti
             "build_seconds": round(t_build, 2),
         }
         out.update(summarize(ms, cnt, m, reps))
-        if baseline_frac:
-            out["match_frac_over_random_data"] = round(out["match_frac"] / baseline_frac, 4)
+        if baseline_frac:  # (configs[2]: the same pipeline on i.i.d. random patterns, this run)
+            out["match_frac_on_random_data"] = baseline_frac
         if n_check:
             out["check"] = check(exp, bg, mask, pre, dic, scores, indices, keep_n, n_check)
         if hostile:

@@ -527,6 +527,8 @@ typedef struct kpdi_plan {
   int32_t perm_rounds, perm_stride; /* match16.hip: round j < perm_rounds of split sp takes tile sp + nsplit * ((j * perm_stride)
                                        mod perm_rounds) - a low-discrepancy walk, so that the order of the dictionary
                                        (sampler order, sorted by score) does not matter to the fused top-k; 0 = natural order */
+  int32_t tail_gemm_rows;           /* match16.hip f32: dictionary rows behind the whole rounds that tailgemm.hip takes as a kernel of
+                                       its own (32 x 128 workgroups, scores -> select -> a merge source); then tail_shift = 0 */
   int32_t n_launch_desc;
   struct {
     int32_t row_first, rows, xcd_rows, xcd_splits, rows_grid;
@@ -577,7 +579,10 @@ typedef struct kpdi_counters {
    * experimental patterns of a wave tile): lists that ran, candidates that passed the shared bound and were appended to
    * a lane's buffer, buffers that overflowed (the list is then built from the tile directly: the slow path), first
    * tiles that took that path because the bound was not complete in time */
-  int64_t epi_lists, epi_appended, epi_overflows, epi_direct_first;
+  int64_t epi_lists;
+  int64_t epi_appended;
+  int64_t epi_overflows;
+  int64_t epi_direct_first;
 } kpdi_counters;
 /* sizeof(kpdi_counters) as the LIBRARY was built: a binding whose struct differs must refuse to call kpdi_get_counters
  * (the struct has grown between versions; kpdi_version() changes with it) */

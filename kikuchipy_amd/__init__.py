@@ -27,6 +27,8 @@ from kikuchipy_amd.simulations import ProjectedDictionary  # noqa: E402,F401
 from kikuchipy_amd.io import load  # noqa: E402,F401
 from kikuchipy_amd import filters  # noqa: E402,F401
 
+from kikuchipy_amd._lib import clear_engine_cache  # noqa: E402,F401
+
 __all__ = [
     "DictionaryIndexingResult",
     "DictionaryXmap",
@@ -39,6 +41,7 @@ __all__ = [
     "NormalizedCrossCorrelationMetric",
     "NormalizedDotProductMetric",
     "SimilarityMetric",
+    "clear_engine_cache",
     "dictionary_indexing",
     "filters",
     "load",

@@ -5,8 +5,10 @@ The library is built in-tree by `make -C kikuchipy_amd/csrc` (or
 package: if the library is missing, or no gfx950 GPU is visible, calls raise.
 """
 
+import atexit
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -103,7 +105,7 @@ class Plan(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("form", "tile", "row_blocks", "n_tiles", "nsplit", "rows_per_launch", "launches")]
                 + [("round_rows", C.c_int64)]
                 + [(n, C.c_int32) for n in ("n_main", "tail_tiles", "tail_units", "tail_nsplit", "fixed_draws", "tail_first",
-                                            "tail_shift", "perm_rounds", "perm_stride", "n_launch_desc")]
+                                            "tail_shift", "perm_rounds", "perm_stride", "tail_gemm_rows", "n_launch_desc")]
                 + [("launch", PlanLaunch * 64)])
 
 
@@ -697,6 +699,7 @@ class Context:
         if buf.size != UNIQUE_ID_BYTES:
             raise KpdiError("unique id must be 128 bytes")
         check(self._f.comm_init(self._h, int(rank), int(nranks), _ptr(buf)))
+        self._has_comm = True  # (such an engine is never kept for another call: release_engine)
 
     def comm_selftest(self, n_bytes=1 << 20, timeout_ms=60000):
         """One all-gather of `n_bytes` per rank, awaited for at most `timeout_ms` (raises KpdiError otherwise)."""
@@ -822,6 +825,73 @@ def make_engine(device=0, devices=None, gather=None):
     return Group(ids, gather=gather)
 
 
+# ---- engines that outlive the call that made them --------------------------------------------------------------------
+# `kikuchipy_amd.dictionary_indexing(..., metric="ncc")` makes its own engine.  Creating one (context, streams, the first
+# allocation of the prepared matrices and staging buffers) and destroying it (hipFree synchronises) was 6-7 ms of every
+# such call - a quarter of a 30 ms call at configs[1].  The engine of a finished call is therefore kept, idle, ONE per set
+# of devices, and handed to the next call that names the same devices (its device buffers stay allocated: they are sized
+# for the job before).  `clear_engine_cache()` closes them; KPDI_ENGINE_CACHE=0 switches the cache off.
+_ENGINE_POOL = {}
+_ENGINE_POOL_LOCK = threading.Lock()
+
+
+def _engine_key(device, devices, gather):
+    ids = resolve_devices(devices)
+    return (tuple(ids) if ids is not None else (int(device),), gather)
+
+
+def acquire_engine(device=0, devices=None, gather=None):
+    """`make_engine`, or the idle engine an earlier call released for the same devices."""
+    key = _engine_key(device, devices, gather)
+    engine = None
+    if os.environ.get("KPDI_ENGINE_CACHE", "1") != "0":
+        with _ENGINE_POOL_LOCK:
+            engine = _ENGINE_POOL.pop(key, None)
+    if engine is not None and hasattr(engine, "_h") and not (engine._h and engine._h.value):
+        engine = None  # (closed behind the pool's back)
+    if engine is None:
+        engine = make_engine(device, devices, gather)
+    engine._pool_key = key
+    return engine
+
+
+def release_engine(engine):
+    """The call that acquired `engine` has finished with it, successfully: keep it for the next one (held chunks
+    released, profiling off), or close it when the cache is off, holds one already, or the engine was given a
+    communicator (that belongs to the job that attached it)."""
+    key = getattr(engine, "_pool_key", None)
+    keep = key is not None and os.environ.get("KPDI_ENGINE_CACHE", "1") != "0" and getattr(engine, "_host_gather", None) is None \
+        and not getattr(engine, "_has_comm", False)
+    if keep:
+        try:
+            if hasattr(engine, "release_held"):
+                engine.release_held()
+            engine.set_profiling(False)
+            getattr(engine, "_keep", {}).clear()
+            with _ENGINE_POOL_LOCK:
+                if key not in _ENGINE_POOL:
+                    _ENGINE_POOL[key] = engine
+                    return
+        except Exception:  # noqa: BLE001 - an engine that cannot be tidied up is not kept
+            pass
+    engine.close()
+
+
+def clear_engine_cache():
+    """Close the idle engines `dictionary_indexing` calls left behind (and free their device memory)."""
+    with _ENGINE_POOL_LOCK:
+        engines = list(_ENGINE_POOL.values())
+        _ENGINE_POOL.clear()
+    for e in engines:
+        try:
+            e.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+atexit.register(clear_engine_cache)
+
+
 class Group(Context):
     """Several GPUs behind the interface of one `Context` (`kpdi_group`, include/kpdi.h): the
     experimental set is replicated, every dictionary chunk is block-assigned to the members,
@@ -919,17 +989,36 @@ class Group(Context):
         super().synchronize()
         self._drop_consumed(True)
 
-    def finalize(self, keep_n=None):
+    def _after_finalize(self, ok):
+        """Borrowed host chunks after a finalize: the C call joins its members' host work before anything is gathered, so
+        after a SUCCESSFUL return every chunk has been read and all may go.  After an exception the call may have failed
+        before that join (a Python-side check, an allocation): queued uploads may still be reading the arrays - only what
+        the library reports as consumed is dropped (use-after-free otherwise)."""
+        if ok:
+            self._drop_consumed(True)
+            return
         try:
-            return super().finalize(keep_n)
+            self._drop_consumed()
+        except KpdiError:
+            pass
+
+    def finalize(self, keep_n=None):
+        ok = False
+        try:
+            res = super().finalize(keep_n)
+            ok = True
+            return res
         finally:
-            self._drop_consumed(True)  # (the group joins its members' host work before anything is gathered)
+            self._after_finalize(ok)
 
     def finalize_async(self, keep_n=None):
+        ok = False
         try:
-            return super().finalize_async(keep_n)
+            res = super().finalize_async(keep_n)
+            ok = True
+            return res
         finally:
-            self._drop_consumed(True)
+            self._after_finalize(ok)
 
     # -- what differs from a single context
     def set_problem(self, sy, sx, signal_mask=None, metric=METRIC_NCC, keep_n=20, compute=COMPUTE_F32):

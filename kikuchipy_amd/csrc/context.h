@@ -234,6 +234,9 @@ struct kpdi_ctx {
   kpdi::DevBuf epi_stats;            // 4 x u64: what the epilogues of match16.hip did (profiling level 1; kpdi_counters.epi_*)
   kpdi::DevBuf list16;               // float16 form: home of the per-lane lists during a launch (match16.hip)
   int tail_nsplit = 0;         // lists per pattern / 2 of the last run_match's tail launch, 0 = none
+  int tail_lists = 0;          // lists per pattern in tail_s / tail_i after the last run_match (0 = none): 2 * tail_nsplit
+                               // (match.hip's tail launch) or 1 (tailgemm.hip)
+  kpdi::DevBuf tail_scores;          // tailgemm.hip: scores of the last partial round, [rows][m_pad]
   kpdi::DevBuf run_s[2], run_i[2];   // running best-k ping-pong
   int run_cur = 0;
   bool run_valid = false;
@@ -247,6 +250,7 @@ struct kpdi_ctx {
   } presetup;
   struct MatchPlan {
     int tail_tiles = 0, n_main = 0, fixed_draws = 3, bound_rank = 1, bound_grouped = 0, tail_units = 0, tail_nsplit = 0;
+    int gemm_rows = 0;  // float32 form of match16.hip: dictionary rows behind the whole rounds that tailgemm.hip takes (0 = none)
   } preplan;
   bool final_valid = false;       // `final_idx` points at the lists kpdi_finalize handed out last
   const int *final_idx = nullptr;
@@ -325,6 +329,7 @@ struct kpdi_ctx {
   // kpdi_comm_drop has run: a kpdi_comm_init that is still inside ncclCommInitRank on another thread (it hung, its caller
   // gave up) must not install its communicator when it finally returns
   std::atomic<bool> comm_dropped{false};
+  void *selftest_left[2] = {nullptr, nullptr};  // device buffers of a kpdi_comm_selftest that timed out, freed by kpdi_comm_drop
   // in-process groups (group.hip): the members' lists peer-copied into gather_s / gather_i (gather64_*) of the ROOT
   // member instead of an RCCL all-gather; `p2p_ranks` > 0 = that many lists are waiting there for the next finalize
   int p2p_ranks = 0;

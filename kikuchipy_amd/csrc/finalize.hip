@@ -263,34 +263,47 @@ int kpdi_comm_selftest(kpdi_ctx *c, int64_t n_bytes, int timeout_ms) {
   int rc = use_device(c);
   if (rc) return rc;
   const size_t n = (size_t)n_bytes / 4;
-  unsigned *d_send = nullptr, *d_recv = nullptr;
-  HIPCHK(hipMalloc(&d_send, n * 4));
-  HIPCHK(hipMalloc(&d_recv, n * 4 * c->nranks));
+  // buffers and event of the test: freed on EVERY way out - except after a time-out, where the collective may still touch
+  // the buffers: they pass to the context and go when kpdi_comm_drop has aborted the communicator
+  struct Scratch {
+    kpdi_ctx *c;
+    unsigned *send = nullptr, *recv = nullptr;
+    hipEvent_t done = nullptr;
+    bool keep = false;
+    ~Scratch() {
+      if (done) (void)hipEventDestroy(done);
+      if (keep) {
+        c->selftest_left[0] = send;
+        c->selftest_left[1] = recv;
+      } else {
+        if (send) (void)hipFree(send);
+        if (recv) (void)hipFree(recv);
+      }
+    }
+  } sc{c};
+  HIPCHK(hipMalloc(&sc.send, n * 4));
+  HIPCHK(hipMalloc(&sc.recv, n * 4 * c->nranks));
   std::vector<unsigned> h(n, 0x5eed0000u + (unsigned)c->rank);
-  HIPCHK(hipMemcpyAsync(d_send, h.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(sc.send, h.data(), n * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  ncclResult_t r = g_rccl.AllGather(d_send, d_recv, n, ncclUint32, c->comm, c->stream);
+  ncclResult_t r = g_rccl.AllGather(sc.send, sc.recv, n, ncclUint32, c->comm, c->stream);
   if (r != ncclSuccess) return fail(KPDI_ECOMM, "RCCL all-gather (self-test): %s", g_rccl.GetErrorString(r));
-  hipEvent_t done = nullptr;
-  HIPCHK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-  HIPCHK(hipEventRecord(done, c->stream));
+  HIPCHK(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(sc.done, c->stream));
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
-    const hipError_t q = hipEventQuery(done);
+    const hipError_t q = hipEventQuery(sc.done);
     if (q == hipSuccess) break;
     if (q != hipErrorNotReady) return fail(KPDI_EHIP, "self-test all-gather: %s", hipGetErrorString(q));
     if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) {
-      // (the buffers stay allocated: the collective may still touch them until the communicator is aborted)
+      sc.keep = true;
       return fail(KPDI_ETIMEOUT, "the first RCCL all-gather (%lld bytes per rank, %d ranks) did not complete within %d ms", (long long)n_bytes,
                   c->nranks, timeout_ms);
     }
     std::this_thread::sleep_for(std::chrono::microseconds(200));
   }
-  (void)hipEventDestroy(done);
   std::vector<unsigned> got(n * c->nranks);
-  HIPCHK(hipMemcpy(got.data(), d_recv, got.size() * 4, hipMemcpyDeviceToHost));
-  (void)hipFree(d_send);
-  (void)hipFree(d_recv);
+  HIPCHK(hipMemcpy(got.data(), sc.recv, got.size() * 4, hipMemcpyDeviceToHost));
   for (int j = 0; j < c->nranks; ++j)
     if (got[(size_t)j * n] != 0x5eed0000u + (unsigned)j || got[(size_t)j * n + n - 1] != 0x5eed0000u + (unsigned)j)
       return fail(KPDI_ECOMM, "self-test all-gather: the block of rank %d arrived damaged", j);
@@ -309,6 +322,10 @@ int kpdi_comm_drop(kpdi_ctx *c) {
   if (comm) {
     if (g_rccl.CommAbort) g_rccl.CommAbort(comm);
     else if (g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+  }
+  for (void *&p : c->selftest_left) {  // (what a timed-out self-test left behind: nothing touches it any more)
+    if (p && use_device(c) == KPDI_OK) (void)hipFree(p);
+    p = nullptr;
   }
   return KPDI_OK;
 }

@@ -29,7 +29,18 @@ constexpr double FORM_WIDE_GAIN_K = 0.02;
 // (KPDI_FORM_WIDE_LAUNCH overrides it for fitting runs of tools/form_probe.py; after the first tile's candidates left the
 // buffers - launch 0.20 -> 0.166 ms - 1.0 and 0.9 leave the grid's worst point and mean regret where they are, 0.8 adds a 7 % miss)
 constexpr double FORM_WIDE_LAUNCH = 1.1;
+// Round 6 (profiles/r06_form_choice.json, 80 shapes, with the last partial round on tailgemm.hip): for sweeps of ONE launch
+// (M <= 4096 here) the wide kernel now wins from 12 500 dictionary patterns up - one rank's share of configs[1] at N = 8
+// 2.92 vs 3.01 ms, at N = 4 5.57 vs 5.67 - which the constant above (fitted when a launch cost 0.2 ms and the tail a quarter
+// round) hid; 0.6 gets every single-launch shape of the grid right (worst 0.6 %).  Sweeps of several launches (M = 10 000:
+// 32 + 8 row blocks) keep 1.1: with 0.6 the grid's worst point was 14 % (10 000 x 37 500, wide chosen, its second launch
+// a quarter full).
+constexpr double FORM_WIDE_LAUNCH_SINGLE = 0.6;
 // ... its partial units (halves / quarters of a tile) cost this much more per row than whole tiles
 constexpr double FORM_WIDE_HALF = 1.1;
 constexpr double FORM_WIDE_QUARTER = 1.25;
+// tailgemm.hip in place of the partial units: one round of its 32 x 128 workgroups over the chip, and the fixed cost of its
+// two launches (the GEMM and the select pass), in tile-times of the wide kernel (first guess; fitted below)
+constexpr double FORM_TAIL_GEMM_UNIT = 0.08;
+constexpr double FORM_TAIL_GEMM_LAUNCH = 0.02;
 }  // namespace kpdi

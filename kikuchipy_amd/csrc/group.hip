@@ -525,10 +525,19 @@ int hold_chunk(kpdi_group *g, int64_t n_chunk, J job) {
   if (rc) return rc;
   const std::vector<kpdi::ChunkPiece> pieces =
       kpdi::group_assign_chunk(g->n, g->n_total, g->n_total > 0 ? 1 : min_piece(g), g->held.data(), n_chunk);
-  std::vector<const kpdi::ChunkPiece *> mine(g->n, nullptr);
-  // (a member appears at most once: pieces of one chunk go to distinct members)
-  for (const kpdi::ChunkPiece &pc : pieces) mine[pc.member] = &pc;
-  return run_all(g, [&](int i, kpdi_ctx *c) { return mine[i] ? job(c, *mine[i]) : (int)KPDI_OK; });
+  // A member may take SEVERAL pieces of one chunk: what exceeds the announced dictionary size goes whole to the
+  // least-loaded member (group_assign.h), which may hold an earlier, non-adjacent piece already - e.g. a chunk of 6
+  // against an announced size of 4 on two members: (0: 0-1) (1: 2-3) (0: 4-5).  Every piece of a member runs in its job,
+  // in row order.
+  std::vector<std::vector<const kpdi::ChunkPiece *>> mine(g->n);
+  for (const kpdi::ChunkPiece &pc : pieces) mine[pc.member].push_back(&pc);
+  return run_all(g, [&](int i, kpdi_ctx *c) {
+    for (const kpdi::ChunkPiece *pc : mine[i]) {
+      const int r = job(c, *pc);
+      if (r) return r;
+    }
+    return (int)KPDI_OK;
+  });
 }
 
 }  // namespace

@@ -105,6 +105,30 @@ hipError_t launch_match16(const MatchLaunch &a, int waves, void *list_scratch, h
 size_t match16_scratch_bytes(int grid, int waves, int list_len);
 int match_blocks_per_cu();
 
+// ---- the last partial round of a float32 sweep on match16.hip's operands, as a kernel of its own (tailgemm.hip)
+struct TailGemmLaunch {
+  const float *dict;  // prepared dictionary chunk (operand form 3), whole matrix
+  const float *exp;   // prepared experimental matrix (form 3)
+  int kpad;           // floats per prepared row (a multiple of 24)
+  int tile_first;     // dictionary tile (256 patterns) that holds row group 0
+  int row_groups;     // 32-row groups to compute, from row tile_first * 256 on
+  int m_pad;
+  float *scores;      // out: [row_groups * 32][m_pad]
+};
+hipError_t launch_tail_gemm(const TailGemmLaunch &a, hipStream_t s);
+struct TailSelectLaunch {
+  const float *scores;  // [rows ...][m_pad] of launch_tail_gemm
+  int rows;             // valid rows (dictionary patterns) of it
+  int m, m_pad;
+  int idx_first;        // dictionary index (or coalesced row) of row 0
+  const unsigned *gthr; // the shared bound, final for this chunk
+  int bound_grouped, list_len;
+  float *out_scores;    // [m][tail_select_lists()][list_len]
+  int *out_idx;
+};
+hipError_t launch_tail_select(const TailSelectLaunch &a, hipStream_t s);
+int tail_select_lists();  // sorted lists per pattern it writes
+
 // ---- pattern preparation (prep.hip): cast -> gather rows/pixels -> normalise --
 struct PrepLaunch {
   const void *raw;     // (n_rows_in, npix) of `dtype`

@@ -26,6 +26,7 @@ struct Switches {
   bool xcd_grid = true, xcd_pad = true, no_tail = false, one_stream = false, tail_stream2 = false;
   bool f64_statistical = false, f64_sync = false, no_coalesce = false, no_direct_upload = false, no_coalesce_wait = false;
   bool natural_order = false;
+  int tail_gemm = -1;  // KPDI_TAIL_GEMM: 0 never, 1 whenever possible, else by cost
   long upload_tiles = 0;
   void read() {
     *this = Switches{};
@@ -49,6 +50,7 @@ struct Switches {
     no_coalesce_wait = getenv("KPDI_NO_COALESCE_WAIT") != nullptr;
     if (const char *e = getenv("KPDI_UPLOAD_TILES")) upload_tiles = atol(e);
     if (const char *e = getenv("KPDI_TILE_ORDER")) natural_order = !strcmp(e, "natural");
+    if (const char *e = getenv("KPDI_TAIL_GEMM")) tail_gemm = atoi(e);
   }
 };
 
@@ -132,6 +134,23 @@ inline double wide_tail(const Env &e, int n_tiles, int nsplit, int *shift) {
       if (cost < best - 1e-9) best = cost, *shift = sh;
     }
   return best;
+}
+
+// match16.hip, float32 form: the last partial round as a kernel of its own (tailgemm.hip: 32 rows x 128 experimental
+// patterns per workgroup, deep load pipeline, scores to a small matrix, a select pass behind it) instead of partial units
+// inside the main kernel.  Worth it when few tiles are left per row block - one tile per 16 workgroups costs 0.31
+// tile-times as a quarter-unit round and ~0.1 here.  Returns its cost in tile-times (1e30: not possible) for the
+// dictionary rows [tail_first * 256, n_chunk); KPDI_TAIL_GEMM=0 / 1 forces it off / on.
+inline double wide_gemm_tail(const Env &e, int row_blocks, int n_tiles, int nsplit, int64_t n_chunk, int *rows) {
+  *rows = 0;
+  const int left = n_tiles % nsplit;
+  if (left == 0 || e.sw.tail_gemm == 0 || e.sw.no_tail) return 1e30;
+  const int64_t r = n_chunk - (int64_t)(n_tiles - left) * F16_TILE;
+  if (r <= 0 || r * row_blocks * TILE_EXP > (64ll << 20)) return 1e30;  // (the score matrix: at most 256 MB)
+  const int64_t wgs = (r + 31) / 32 * row_blocks * 2;
+  const int64_t rounds = (wgs + e.n_cu - 1) / e.n_cu;
+  *rows = (int)r;
+  return e.sw.tail_gemm == 1 ? 0.0 : rounds * FORM_TAIL_GEMM_UNIT + FORM_TAIL_GEMM_LAUNCH;
 }
 
 // match16.hip: the order in which a workgroup walks its whole-tile rounds (match_device.h: MatchArgs.perm_*): round j
@@ -224,8 +243,13 @@ inline bool prefer_wide(const Env &e, int row_blocks, int k_kept, int64_t n_chun
   // 0.27 ms against 0.1 ms, measured on one rank's share of configs[1] at N = 8)
   // (fitted between K = 2819 and 14 400: no extrapolation below)
   const double gain = FORM_WIDE_GAIN + FORM_WIDE_GAIN_K * std::max(-0.3, 1.0 - 3600.0 / std::max(k_kept, 1));
-  const double wide = ((row_blocks + rpl - 1) / rpl) * ((t256 / nsw + wide_tail(e, t256, nsw, &shift)) * 2.0 / gain + e.sw.wide_launch) *
-                      (nsw % 8 == 0 ? 1.0 : FORM_WIDE_ODD);
+  int gemm_rows = 0;
+  const double tail = std::min(wide_tail(e, t256, nsw, &shift), wide_gemm_tail(e, row_blocks, t256, nsw, n_chunk, &gemm_rows));
+  const int launches_w = (row_blocks + rpl - 1) / rpl;
+  // (a sweep of ONE launch pays the wide kernel's launch once and nothing else; the constant of sweeps of several launches
+  // also carries what their last, partly filled launch loses - form_model.h)
+  const double launch = launches_w == 1 && e.sw.wide_launch == FORM_WIDE_LAUNCH ? FORM_WIDE_LAUNCH_SINGLE : e.sw.wide_launch;
+  const double wide = launches_w * ((t256 / nsw + tail) * 2.0 / gain + launch) * (nsw % 8 == 0 ? 1.0 : FORM_WIDE_ODD);
   return wide < classic;
 }
 

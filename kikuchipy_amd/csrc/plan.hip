@@ -30,7 +30,6 @@ extern "C" int kpdi_plan_describe(int64_t m, int64_t n_chunk, int k_kept, int ke
   out->launches = (row_blocks + rpl - 1) / rpl;
   out->round_rows = plan::round_rows(e, row_blocks);
   const bool bounded = keep_n > KMAX_LIMIT;  // (passes after the first are bounded; the first pass plans like a plain sweep)
-  (void)bounded;
   if (!wide) {
     out->tail_tiles = plan::classic_tail_tiles(e, n_tiles, nsplit, row_blocks <= rpl, false);
     out->n_main = n_tiles - out->tail_tiles;
@@ -41,9 +40,15 @@ extern "C" int kpdi_plan_describe(int64_t m, int64_t n_chunk, int k_kept, int ke
     }
   } else {
     out->n_main = n_tiles;
-    (void)plan::wide_tail(e, n_tiles, nsplit, &out->tail_shift);
+    const double inside = plan::wide_tail(e, n_tiles, nsplit, &out->tail_shift);
     out->tail_first = n_tiles - n_tiles % nsplit;
-    out->perm_stride = plan::tile_order_stride(e, out->tail_shift > 0 ? out->tail_first : n_tiles, nsplit, &out->perm_rounds);
+    int rows = 0;
+    if (!bounded && plan::wide_gemm_tail(e, row_blocks, n_tiles, nsplit, n_chunk, &rows) < inside && rows > 0) {
+      out->tail_gemm_rows = rows;  // (sweep.hip: match_setup)
+      out->n_main = out->tail_first;
+      out->tail_shift = 0;
+    }
+    out->perm_stride = plan::tile_order_stride(e, (out->tail_shift > 0 || rows > 0) ? out->tail_first : n_tiles, nsplit, &out->perm_rounds);
   }
   for (int r0 = 0, j = 0; r0 < row_blocks; r0 += rpl, ++j) {
     if (j >= KPDI_PLAN_MAX_LAUNCHES) {

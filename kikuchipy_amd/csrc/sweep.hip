@@ -148,6 +148,17 @@ static int match_setup(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int ro
   if (allow_tail && c->compute == KPDI_COMPUTE_F32 && !c->wide32)
     pl->tail_tiles = plan::classic_tail_tiles(plan_env(c), n_tiles, nsplit, row_blocks <= rows_per_launch, bounded);
   pl->n_main = n_tiles - pl->tail_tiles;
+  if (allow_tail && c->compute == KPDI_COMPUTE_F32 && c->wide32 && !bounded) {
+    // float32 form of match16.hip: the last partial round inside the kernel (halves / quarters of a tile) or as a kernel
+    // of its own (tailgemm.hip), whichever the model prices lower
+    int shift = 0, rows = 0;
+    const double inside = plan::wide_tail(plan_env(c), n_tiles, nsplit, &shift);
+    const double own = plan::wide_gemm_tail(plan_env(c), row_blocks, n_tiles, nsplit, n_chunk, &rows);
+    if (rows > 0 && own < inside) {
+      pl->gemm_rows = rows;
+      pl->n_main = n_tiles - n_tiles % nsplit;
+    }
+  }
   {
     // the published ranks are only comparable under one plan: (re)initialise when it changes
     int used;
@@ -177,6 +188,7 @@ static int match_setup(kpdi_ctx *c, int n_chunk, int n_tiles, int nsplit, int ro
 int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int nsplit, int rows_per_launch,
               int list_len, int64_t global_start, const float *bound_s, const int *bound_i, bool allow_tail) {
   c->tail_nsplit = 0;
+  c->tail_lists = 0;
   MatchPlan pl;
   const kpdi_ctx::MatchSetup &ps = c->presetup;
   if (ps.valid && ps.n_chunk == n_chunk && ps.n_tiles == n_tiles && ps.nsplit == nsplit && ps.rows_per_launch == rows_per_launch &&
@@ -212,7 +224,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   ml.bound_score = bound_s;
   ml.bound_idx = bound_i;
   ml.operand_form = operand_form(c);
-  if (c->wide32) {  // (float32 form only: the same guards in the float16 schedule cost its 32-cycle MFMAs 10 %)
+  if (c->wide32 && pl.gemm_rows == 0) {  // (float32 form only: the same guards in the float16 schedule cost its 32-cycle MFMAs 10 %)
     (void)plan::wide_tail(plan_env(c), n_main, nsplit, &ml.tail_shift);
     ml.tail_first = n_main - n_main % nsplit;
   }
@@ -316,6 +328,37 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
       }
       c->tail_nsplit = ns_t;
+      c->tail_lists = 2 * ns_t;
+    }
+    if (pl.gemm_rows > 0) {
+      // the rows behind the whole rounds: scores by tailgemm.hip, then - the shared bound is final now - the few that reach
+      // it become one sorted list per pattern, a merge source of its own
+      const int rows = pl.gemm_rows, groups = (rows + 31) / 32;
+      HIPCHK(c->tail_scores.reserve((size_t)groups * 32 * c->m_pad * sizeof(float)));
+      HIPCHK(c->tail_s.reserve((size_t)c->m_pad * kpdi::tail_select_lists() * list_len * sizeof(float)));
+      HIPCHK(c->tail_i.reserve((size_t)c->m_pad * kpdi::tail_select_lists() * list_len * sizeof(int)));
+      kpdi::TailGemmLaunch tg;
+      tg.dict = dict_y;
+      tg.exp = c->exp_x.as<float>();
+      tg.kpad = c->kpad;
+      tg.tile_first = n_main;
+      tg.row_groups = groups;
+      tg.m_pad = c->m_pad;
+      tg.scores = c->tail_scores.as<float>();
+      HIPCHK(kpdi::launch_tail_gemm(tg, c->stream));
+      kpdi::TailSelectLaunch ts;
+      ts.scores = tg.scores;
+      ts.rows = rows;
+      ts.m = c->m;
+      ts.m_pad = c->m_pad;
+      ts.idx_first = (int)global_start + n_main * kpdi::F16_TILE;
+      ts.gthr = c->gthr.as<unsigned>();
+      ts.bound_grouped = pl.bound_grouped;
+      ts.list_len = list_len;
+      ts.out_scores = c->tail_s.as<float>();
+      ts.out_idx = c->tail_i.as<int>();
+      HIPCHK(kpdi::launch_tail_select(ts, c->stream));
+      c->tail_lists = kpdi::tail_select_lists();
     }
   }
   c->cnt.match_launches += 1;
@@ -668,12 +711,12 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
     mg.src_row_stride[ns] = lps * nsplit * len;
     mg.src_list_stride[ns] = len;
     ++ns;
-    if (c->tail_nsplit > 0) {
+    if (c->tail_lists > 0) {
       mg.src_scores[ns] = c->tail_s.as<float>();
       mg.src_idx[ns] = c->tail_i.as<int>();
-      mg.src_lists[ns] = 2 * c->tail_nsplit;
+      mg.src_lists[ns] = c->tail_lists;
       mg.src_len[ns] = len;
-      mg.src_row_stride[ns] = 2 * c->tail_nsplit * len;
+      mg.src_row_stride[ns] = c->tail_lists * len;
       mg.src_list_stride[ns] = len;
       ++ns;
     }

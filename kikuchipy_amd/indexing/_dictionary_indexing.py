@@ -281,6 +281,24 @@ def dictionary_indexing(
                             dict_size, device=device, compute=compute, devices=devices)
     if not isinstance(metric, _HipMetric):
         raise ValueError("the stand-alone driver runs the GPU metrics of kikuchipy_amd only")
+    if own_engine:
+        metric._pooled_engine = True  # its engine: the idle one an earlier call left, if any (_lib.acquire_engine)
+    try:
+        return _run(experimental, dictionary, metric, keep_n, n_per_iteration, resident, dict_size, nav_shape_exp,
+                    n_experimental_all, step_sizes, dictionary_rotations, phase_name, scan_unit, verbose, progress, comm,
+                    own_engine)
+    except BaseException:
+        if own_engine and metric._ctx is not None:
+            # the engine was made for this call and the call failed half-way: its contexts, host threads and communicator
+            # go with it now, not when the garbage collector finds the metric (a healthy one is kept: _lib.release_engine)
+            ctx, metric._ctx = metric._ctx, None
+            ctx.close()
+        raise
+
+
+def _run(experimental, dictionary, metric, keep_n, n_per_iteration, resident, dict_size, nav_shape_exp, n_experimental_all,
+         step_sizes, dictionary_rotations, phase_name, scan_unit, verbose, progress, comm, own_engine):
+    """The sweep of `dictionary_indexing` once its arguments are checked and its metric is made."""
 
     # ---- indexing/_dictionary_indexing.py:66-128
     keep_n = min(keep_n, dict_size)
@@ -309,31 +327,33 @@ def dictionary_indexing(
         except ImportError:
             pass
     time_start = time.time()
-    if resident is not None:
-        ctx.sweep_held()
-    for n_done, (start, end) in enumerate(bounds, 1):
-        if bar is not None:
-            bar.update(1)
-        elif callable(progress):
-            progress(n_done, len(bounds))
-        start, end = max(start, lo), min(end, hi)  # this rank's part of the chunk
-        if start >= end:
-            continue
-        chunk = dictionary[start:end]
-        if hasattr(chunk, "push_to_engine"):
-            # simulated on the device from (master pattern, detector, rotations): the chunk
-            # never exists on the host (kikuchipy_amd.simulations.ProjectedDictionary)
-            chunk.push_to_engine(ctx, start)
-            continue
-        if _is_lazy(chunk):
-            chunk = chunk.compute()
-        ctx.push_dictionary_chunk(np.asarray(chunk), start)
     f64 = metric.effective_compute == "f64"
-    uncertified_before = _uncertified(ctx) if f64 else 0
-    scores, simulation_indices = ctx.finalize(keep_n)
+    try:
+        if resident is not None:
+            ctx.sweep_held()
+        for n_done, (start, end) in enumerate(bounds, 1):
+            start, end = max(start, lo), min(end, hi)  # this rank's part of the chunk
+            if start < end:
+                chunk = dictionary[start:end]
+                if hasattr(chunk, "push_to_engine"):
+                    # simulated on the device from (master pattern, detector, rotations): the chunk
+                    # never exists on the host (kikuchipy_amd.simulations.ProjectedDictionary)
+                    chunk.push_to_engine(ctx, start)
+                else:
+                    if _is_lazy(chunk):
+                        chunk = chunk.compute()
+                    ctx.push_dictionary_chunk(np.asarray(chunk), start)
+            # AFTER the chunk has been handed over (or found to belong to another rank); rank 0 only, like the bar
+            if bar is not None:
+                bar.update(1)
+            elif callable(progress) and rank == 0:
+                progress(n_done, len(bounds))
+        uncertified_before = _uncertified(ctx) if f64 else 0
+        scores, simulation_indices = ctx.finalize(keep_n)
+    finally:
+        if bar is not None:
+            bar.close()
     total_time = time.time() - time_start
-    if bar is not None:
-        bar.close()
     certificate = None
     if f64:
         from kikuchipy_amd import _lib
@@ -341,10 +361,13 @@ def dictionary_indexing(
         certificate = {"mode": _lib.F64_CERTIFICATES.get(ctx.counters().get("f64_certificate", 0)),
                        "uncertified_patterns": _uncertified(ctx) - uncertified_before}
     if own_engine and metric._ctx is not None:
-        # the engine was made for this call: its contexts, host threads and communicator go with it (a caller that
-        # wants them kept passes a metric instance, or indexes through an `EBSD`, which keeps its engines)
-        metric._ctx.close()
-        metric._ctx = None
+        # the engine was made for this call: it is handed back - kept, idle, for the next call on the same devices, or
+        # closed with its contexts, host threads and communicator (_lib.release_engine; a caller that wants an engine of
+        # its own passes a metric instance, or indexes through an `EBSD`, which keeps its engines)
+        from kikuchipy_amd import _lib
+
+        engine, metric._ctx = metric._ctx, None
+        _lib.release_engine(engine)
     scores = scores.astype(metric.dtype, copy=False)
     pps = n_experimental / total_time
     cps = n_experimental * dict_size / total_time

@@ -176,6 +176,15 @@ class _LookAhead:
     for anything else cancels the look-ahead (its results are dropped) and is served the ordinary way.  At most two
     finished results wait (+ two chunks in flight): that is all a wrong guess can waste.  Same calls into the
     engine per chunk as without it, so the results are the same bit for bit ($KPDI_SEAM_LOOKAHEAD=0 switches it off).
+
+    HAZARD, and what guards it.  The worker reads rows of the caller's buffer that `match()` has not been handed yet.
+    The reference's loop never writes to the dictionary, but a CUSTOM loop around the metric may fill or update a
+    pre-allocated buffer chunk by chunk - the look-ahead would then have swept stale rows.  Every chunk is therefore
+    fingerprinted when the worker reads it (`_fingerprint`: 4096 evenly spaced 8-byte words, ~20 us), and `take()` only
+    hands a result over if the chunk `match()` was given still has that fingerprint; otherwise the look-ahead is
+    cancelled and the chunk is swept the ordinary way.  A sampled fingerprint sees a refilled or rescaled chunk, not a
+    single modified pixel between samples: a loop that edits its dictionary in place at that granularity must set
+    $KPDI_SEAM_LOOKAHEAD=0 (or pass a read-only array - `flags.writeable = False` - and keep it so).
     """
 
     def __init__(self, ctx, owner, first_row, rows, total_rows, sig_shape, k, pipelined=True):
@@ -197,34 +206,44 @@ class _LookAhead:
         a = self._flat[row * self._row_elems:(row + n) * self._row_elems]
         return a.reshape((n,) + self._sig_shape)
 
+    @staticmethod
+    def _fingerprint(chunk):
+        """4096 evenly spaced 8-byte words of a C-contiguous chunk (all of it when it is smaller), as bytes."""
+        raw = chunk.reshape(-1).view(np.uint8)
+        words = raw[:raw.size - raw.size % 8].view(np.uint64)
+        if words.size <= 4096:
+            return raw.tobytes()
+        return words[::words.size // 4096][:4096].tobytes() + raw[-8:].tobytes()
+
     def _run(self, row):
         ctx, pending = self._ctx, None
         try:
             while row < self._total and not self._stop:
                 chunk = self._chunk(row)
+                fp = self._fingerprint(chunk)  # (what the worker saw: compared with what match() is handed, take())
                 k_run = min(self._k, len(chunk))
                 ctx.set_keep_n(k_run)
                 ctx.set_dictionary_size(0)
                 ctx.push_dictionary_chunk(chunk, 0)
                 if not self._pipelined:
-                    self._put((row, ctx.finalize(k_run)))
+                    self._put((row, ctx.finalize(k_run), fp))
                     row += len(chunk)
                     continue
                 ticket = ctx.finalize_async(k_run)
                 if pending is not None:
-                    self._put((pending[1], ctx.finalize_wait(pending[0])))
-                pending = (ticket, row)
+                    self._put((pending[1], ctx.finalize_wait(pending[0]), pending[2]))
+                pending = (ticket, row, fp)
                 row += len(chunk)
             if pending is not None:
                 res = ctx.finalize_wait(pending[0])  # (always collected: the slot must be free for whoever comes next)
-                self._put((pending[1], res))
+                self._put((pending[1], res, pending[2]))
         except BaseException as e:  # noqa: BLE001 - handed to the consumer, which raises it in the caller's thread
             if pending is not None:  # the chunk before the failing one is still good (and its result slot must not stay taken)
                 try:
-                    self._put((pending[1], ctx.finalize_wait(pending[0])))
+                    self._put((pending[1], ctx.finalize_wait(pending[0]), pending[2]))
                 except Exception:  # noqa: BLE001
                     pass
-            self._put((None, e))
+            self._put((None, e, None))
 
     def _put(self, item):
         while not self._stop:  # (a cancelled look-ahead drops what it has: nobody will ask)
@@ -245,11 +264,16 @@ class _LookAhead:
         return (patterns.shape == want.shape and patterns.dtype == want.dtype and patterns.flags.c_contiguous
                 and patterns.ctypes.data == want.ctypes.data)
 
-    def take(self):
-        row, res = self._results.get()
+    def take(self, patterns):
+        """The result of the chunk that comes next - `patterns`, as `expects()` has established - or None when its rows
+        are no longer what the worker read (the caller wrote to its buffer in between): the look-ahead is then over."""
+        row, res, fp = self._results.get()
         if row is None:
             raise res
         assert row == self._next
+        if fp != self._fingerprint(patterns):
+            self.cancel()
+            return None
         self._next += min(self._rows, self._total - row)
         if self.exhausted:
             self._thread.join()
@@ -316,7 +340,9 @@ class _HipMetric(SimilarityMetric):
 
     def _engine(self):
         if self._ctx is None:
-            self._ctx = _lib.make_engine(self._device, self._devices)
+            # (a metric made by `dictionary_indexing` for one call takes the idle engine an earlier call left: _lib.acquire_engine)
+            make = _lib.acquire_engine if getattr(self, "_pooled_engine", False) else _lib.make_engine
+            self._ctx = make(self._device, self._devices)
         return self._ctx
 
     @property
@@ -347,8 +373,14 @@ class _HipMetric(SimilarityMetric):
         n = patterns.shape[0]
         k_run = min(k, n)
         la, self._lookahead = self._lookahead, None
+        served = None
         if la is not None and la.expects(patterns, k):
-            scores, indices = la.take()  # swept while the caller was merging the previous chunk (_LookAhead)
+            served = la.take(patterns)  # swept while the caller was merging the previous chunk (_LookAhead)
+            if served is None:
+                self._lookahead_off = True  # the caller writes to its dictionary between calls: no running ahead (until the next call)
+                la = None
+        if served is not None:
+            scores, indices = served
             self.lookahead_hits += 1
             if not la.exhausted:
                 self._lookahead = la

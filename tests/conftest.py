@@ -64,3 +64,16 @@ def gpu_available():
         return _lib.device_count() > 0
     except Exception:
         return False
+
+
+@pytest.fixture(autouse=True)
+def _no_engine_left_behind():
+    """`dictionary_indexing` keeps the engine of a finished call for the next one (kikuchipy_amd._lib: engine pool); a test
+    must not inherit another test's engine (stand-ins, patched factories, environment switches read at creation)."""
+    yield
+    try:
+        from kikuchipy_amd import _lib
+
+        _lib.clear_engine_cache()
+    except Exception:  # noqa: BLE001 - the library may be unbuildable in a test of exactly that
+        pass

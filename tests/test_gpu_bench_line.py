@@ -40,6 +40,13 @@ def test_default_bench_line_and_its_legs():
     for leg in ("config3", "config2_share_of_4", "config2_share_of_8", "config4_share_of_8", "config5_share_of_8",
                 "config5_share_of_8_f16", "chunked_call", "plugin_seam", "float64_mode", "f16_mode", "split_f16_mode", "resident_dictionary", "dictionary_generation", "refinement"):
         assert leg in out["extra"], leg
+    # physically structured data (grain map x orientation-ordered Ni dictionary) runs like random data; a dictionary sorted
+    # by score (the hostile order for a threshold-screened top-k) stays above 0.8 of the peak
+    st = out["extra"]["structured_config2"]
+    assert st["kept_pixels"] == 2819 and st["check"]["index_agreement"] > 0.99 and st["check"]["max_abs_score_diff"] < 1e-5
+    assert st["match_frac"] >= 0.87 and st["match_frac"] >= out["extra"]["config3"]["match_frac"] - 0.02, st
+    assert st["dictionary_sorted_ascending"]["match_frac"] >= 0.80 and st["dictionary_sorted_descending"]["match_frac"] >= 0.87
+    assert st["dictionary_sorted_ascending"]["scores_identical_to_sampler_order"]
     for leg in ("config2_share_of_8", "config4_share_of_8", "config5_share_of_8"):
         assert out["extra"][leg]["check"]["index_agreement"] == 1.0
     # the arithmetic configs[4] NAMES (fp16 MFMA, f32 accumulate, K = 14 400, float16-resident dictionary), in the driver's line

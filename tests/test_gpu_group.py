@@ -463,3 +463,30 @@ def test_background_removal_over_a_group():
     with _lib.Group([0] * 4) as g:
         a = _pattern.remove_dynamic_background(few, contexts=g.members)
     assert np.array_equal(a, _pattern.remove_dynamic_background(few, device=0))
+
+
+def test_a_held_chunk_larger_than_the_announced_dictionary_keeps_every_row():
+    """with a stale / too small announced size the assignment names a member TWICE for one chunk (the
+    overflow goes whole to the least-loaded member: csrc/group_assign.h) - `Group.assign_chunk(2, 4, [0, 0], 6)` =
+    [(0, 0, 2), (1, 2, 2), (0, 4, 2)] - and the hold path used to keep only the member's last piece: rows silently left
+    the resident dictionary.  Every piece must be held."""
+    from kikuchipy_amd import _lib
+
+    assert _lib.Group.assign_chunk(2, 4, [0, 0], 6) == [(0, 0, 2), (1, 2, 2), (0, 4, 2)]
+    dic = patterns(3, 900)
+    exp = patterns(4, 40, dtype=np.uint8)
+    with _lib.Context(0) as c:
+        c.set_problem(12, 10, None, _lib.METRIC_NCC, 10)
+        c.set_experimental(exp)
+        c.push_dictionary_chunk(dic, 0)
+        want = c.finalize(10)
+    with _lib.Group([0, 0, 0]) as g:
+        g.set_problem(12, 10, None, _lib.METRIC_NCC, 10)
+        g.set_dictionary_size(500)             # announced: 500; held below: 900 (in two chunks, the second beyond it)
+        g.set_experimental(exp)
+        g.hold_dictionary_chunk(dic[:700], 0)  # 500 by quota + 200 overflow: a member holds two non-adjacent pieces
+        g.hold_dictionary_chunk(dic[700:], 700)
+        assert g.held_size()[0] == 900
+        g.sweep_held()
+        got = g.finalize(10)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])

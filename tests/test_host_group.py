@@ -110,7 +110,16 @@ def test_dictionary_indexing_over_a_group(monkeypatch, metric, keep_n, chunk, ma
                                  devices=[0, 0, 0], verbose=False)
     grp = made[-1]
     assert isinstance(grp, StandInGroup) and len(grp) == 3 and len(grp.threads_seen) > 1
-    assert grp._pool._shutdown  # the call made this engine itself: it closed it (threads, contexts, communicator)
+    # the call made this engine itself: it handed it back - kept idle for the next call on the same devices - and
+    # clear_engine_cache() closes it (threads, contexts, communicator)
+    assert not grp._pool._shutdown and _lib._ENGINE_POOL[((0, 0, 0), None)] is grp
+    again = ka.dictionary_indexing(exp, dic, metric, keep_n, n_per_iteration=chunk, navigation_mask=nav, signal_mask=sig,
+                                   devices=[0, 0, 0], verbose=False)
+    assert made[-1] is grp and np.array_equal(again.simulation_indices, got.simulation_indices)  # ... which it served
+    for m in grp.members:
+        del m.pushed[len(m.pushed) // 2:]  # (the second call pushed the same spans again)
+    ka.clear_engine_cache()
+    assert grp._pool._shutdown and not _lib._ENGINE_POOL
     # every member swept its block of every chunk: contiguous, disjoint, covering the dictionary
     spans = sorted(sp for m in grp.members for sp in m.pushed)
     assert spans[0][0] == 0 and sum(n for _, n in spans) == len(dic)

@@ -63,11 +63,17 @@ def check(p, m, n, form):
         # match16.hip f32: whole rounds up to tail_first, then halves / quarters of the remaining tiles
         assert p.tail_first % p.nsplit == 0 and 0 <= p.n_tiles - p.tail_first < p.nsplit
         assert p.tail_shift in (0, 1, 2)
+        # the last partial round: inside the kernel (partial units) or as tailgemm.hip's own launch over exactly the rows left
+        if p.tail_gemm_rows:
+            assert p.tail_shift == 0 and p.n_main == p.tail_first < p.n_tiles
+            assert p.tail_gemm_rows == n - p.tail_first * 256 > 0
+        else:
+            assert p.n_main == p.n_tiles
         if p.tail_first == p.n_tiles:
             assert p.tail_shift == 0
         # the ORDER of a workgroup's whole-tile rounds: a permutation (stride coprime to the rounds) that spreads the first
         # visits over the dictionary; partial units and an incomplete last round stay behind it, in natural order
-        whole = p.tail_first if p.tail_shift else p.n_tiles
+        whole = p.tail_first if (p.tail_shift or p.tail_gemm_rows) else p.n_tiles
         if p.perm_rounds:
             r, st = p.perm_rounds, p.perm_stride
             assert r == whole // p.nsplit >= 3 and 1 <= st < r and math.gcd(st, r) == 1
@@ -93,7 +99,13 @@ def test_known_plans_of_the_benchmark_configurations():
     p = _lib.plan_describe(4096, 100000)          # configs[1] whole: the wide kernel, 16 x 16 workgroups, XCD grid 2 x 4
     assert (p.form, p.n_tiles, p.nsplit, p.rows_per_launch, p.launches) == (3, 391, 16, 16, 1)
     assert (p.launch[0].xcd_rows, p.launch[0].xcd_splits) == (2, 4)
-    p = _lib.plan_describe(4096, 12500)           # one rank's share at N = 8: match.hip, 6 rounds + a 7-unit tail
+    # one rank's share at N = 8: the wide kernel's three whole rounds (walked 0, 2, 1) + its last 212 rows on tailgemm.hip
+    p = _lib.plan_describe(4096, 12500)
+    assert (p.form, p.n_tiles, p.nsplit, p.n_main, p.tail_shift, p.tail_gemm_rows) == (3, 49, 16, 48, 0, 212)
+    assert (p.perm_rounds, p.perm_stride) == (3, 2)
+    p = _lib.plan_describe(4096, 25000)           # ... at N = 4: six rounds + 424 rows
+    assert (p.form, p.n_main, p.tail_gemm_rows) == (3, 96, 424)
+    p = _lib.plan_describe(4096, 12500, form=0)   # match.hip, when asked for: 6 rounds + a 7-unit tail launch
     assert (p.form, p.n_tiles, p.nsplit, p.tail_tiles, p.tail_units) == (0, 98, 16, 2, 7)
     p = _lib.plan_describe(40000, 37500)          # configs[3] share: 157 row blocks = 4 x 32 + 29, the last grid padded
     assert (p.form, p.rows_per_launch, p.launches) == (3, 32, 5)
@@ -111,7 +123,7 @@ def test_switches_reach_the_planner(monkeypatch):
     p = _lib.plan_describe(4096, 12500, form=0)
     assert p.tail_tiles == 0 and p.n_main == p.n_tiles
     p = _lib.plan_describe(4096, 12500, form=3)
-    assert p.tail_shift == 0
+    assert p.tail_shift == 0 and p.tail_gemm_rows == 0
     monkeypatch.delenv("KPDI_NO_TAIL")
     monkeypatch.setenv("KPDI_XCD_GRID", "0")
     p = _lib.plan_describe(4096, 100000)
@@ -121,6 +133,13 @@ def test_switches_reach_the_planner(monkeypatch):
     monkeypatch.setenv("KPDI_TILE_ORDER", "natural")
     assert _lib.plan_describe(4096, 100000).perm_rounds == 0
     monkeypatch.delenv("KPDI_TILE_ORDER")
+    assert _lib.plan_describe(4096, 12500).tail_gemm_rows == 212
+    monkeypatch.setenv("KPDI_TAIL_GEMM", "0")
+    p = _lib.plan_describe(4096, 12500, form=3)
+    assert p.tail_gemm_rows == 0 and p.tail_shift == 2
+    monkeypatch.setenv("KPDI_TAIL_GEMM", "1")
+    assert _lib.plan_describe(4096, 100000).tail_gemm_rows == 100000 - 384 * 256
+    monkeypatch.delenv("KPDI_TAIL_GEMM")
     monkeypatch.setenv("KPDI_XCD_PAD", "0")
     p = _lib.plan_describe(40000, 37500)
     assert p.launch[4].rows_grid == 29

@@ -168,6 +168,41 @@ def test_lookahead_is_dropped_when_the_loop_asks_for_something_else():
         m2.close()
 
 
+def test_lookahead_never_serves_rows_the_caller_has_rewritten():
+    """a CUSTOM loop that refills a pre-allocated dictionary buffer between `match()` calls must not be
+    served what the look-ahead swept before the rows changed: every chunk is fingerprinted when the worker reads it and
+    checked against what `match()` is handed; on a mismatch the chunk is swept the ordinary way and nothing more is
+    guessed during that call."""
+    rng = np.random.default_rng(8)
+    exp = rng.integers(0, 256, (4, 12, 10)).astype(np.uint8)
+    buf = rng.random((40, 12, 10)).astype(np.float32)
+    m = _lookahead_metric(4, 40)
+    e = m.prepare_experimental(exp)
+    flat = buf.reshape((40, -1))
+
+    def best(rows, k=3):
+        sim = m.match(e, m.prepare_dictionary(rows))
+        return sim.topk(k, axis=-1), sim.argtopk(k, axis=-1)
+
+    best(flat[0:10])
+    la = m._lookahead
+    assert la is not None
+    while la._results.qsize() < 1:   # the worker has swept rows [10, 20) (as they were) ...
+        pass
+    flat[10:20] = rng.random((10, 120)).astype(np.float32)  # ... and now the caller refills them
+    got = best(flat[10:20])
+    assert m.lookahead_hits == 0 and m._lookahead is None and m._lookahead_off
+    m2 = _lookahead_metric(4, 40)
+    e2 = m2.prepare_experimental(exp)
+    sim = m2.match(e2, m2.prepare_dictionary(flat[10:20].copy()))
+    assert np.array_equal(sim.topk(3, axis=-1), got[0]) and np.array_equal(sim.argtopk(3, axis=-1), got[1])
+    nxt = best(flat[20:30])          # the rest of this call is served the ordinary way
+    assert m.lookahead_hits == 0 and m._lookahead is None
+    m.close()
+    m2.close()
+    assert nxt[0].shape == (4, 3)
+
+
 def test_lookahead_stays_inside_the_callers_buffer_and_ends_with_close():
     rng = np.random.default_rng(7)
     exp = rng.integers(0, 256, (3, 12, 10)).astype(np.uint8)

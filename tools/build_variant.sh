@@ -8,7 +8,7 @@ mkdir -p ../../build/variants
 obj=../../build/variants/${src%.hip}_$tag.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off "$@" -c $src -o $obj
 objs=""
-for f in api plan sweep exact64 finalize extras group match match16 prep merge preproc project refine osm h5ebsd rescore; do  # (the Makefile's OBJS)
+for f in api plan sweep exact64 finalize extras group match match16 tailgemm prep merge preproc project refine osm h5ebsd rescore; do  # (the Makefile's OBJS)
   if [ "$f.hip" == "$src" ]; then objs="$objs $obj"; else objs="$objs $f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../../build/variants/libkpdi_$tag.so -ldl
