@@ -460,7 +460,7 @@ def measure_traffic(a, kernel_substring):
         return {"traffic": None, "traffic_note": "not measured: this process is itself running under a profiler"}
     sub = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", a.workload,
            "--compute", a.compute, "--no-cpu-baseline", "--no-pcie", "--no-generation", "--no-config3", "--no-rank-shares",
-           "--check-rows", "0", "--no-traffic"]
+           "--no-structured", "--check-rows", "0", "--no-traffic"]
     t0 = time.perf_counter()
     per_counter = {}
     tmp = tempfile.mkdtemp(prefix="kpdi_traffic_", dir="/tmp")

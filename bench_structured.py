@@ -135,8 +135,8 @@ def timed_sweeps(_lib, c, d_exp, exp, bg_f32, d_dic, n, keep_n, reps):
     c.synchronize()
     dt = (time.perf_counter() - t0) / reps
     cnt = c.counters()
-    # untimed: two more steps at profiling level 1, where the epilogues of the match kernel count what they do
-    c.set_profiling(True)
+    # untimed: two more steps at profiling level 3, where the epilogues of the match kernel count what they do
+    c.set_profiling("epilogue")
     c.reset_counters()
     for _ in range(2):
         c.set_experimental_dev(d_exp, exp.dtype, len(exp))
@@ -182,7 +182,7 @@ def summarize(ms, cnt, m, reps):
            "match_tflops": round(tf, 2), "match_frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
            "match_form": int(cnt.get("match_form", 0))}
     if cnt.get("epi_lists"):
-        # (kpdi_counters.epi_*: what the fused top-k's epilogues did in two untimed launches at profiling level 1; a "list" is
+        # (kpdi_counters.epi_*: what the fused top-k's epilogues did in two untimed launches at profiling level 3; a "list" is
         # one lane's share of 32 experimental patterns x the dictionary rows its wave sees: 64 candidates per tile)
         el = max(cnt["epi_launches"], 1)
         rec["candidates_appended_per_lane_list"] = round(cnt["epi_appended"] / cnt["epi_lists"], 3)

@@ -546,7 +546,8 @@ int kpdi_d2h(kpdi_ctx *ctx, void *dst, const void *d_src, size_t bytes);
  * kpdi_set_profiling(ctx, level): 0 off; 1 every phase of a sweep (preparation, match, merge, all-gather, ...) is
  * bracketed by HIP events on the context's stream; 2 only the match launches (and the all-gather) are - an event
  * record between two kernels leaves the GPU idle for ~6 us, 0.05 ms per step with level 1, which a 3 ms step
- * notices.  kpdi_get_counters() synchronises and sums the events. */
+ * notices; 3 = level 1 + the fused top-k of match16.hip counts what its epilogues do (kpdi_counters.epi_*: a few
+ * thousand atomics per launch, ~50 us - a developer level).  kpdi_get_counters() synchronises and sums the events. */
 typedef struct kpdi_counters {
   double match_ms;      /* sum of match-kernel durations (HIP events) */
   int64_t match_launches;

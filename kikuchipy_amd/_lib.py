@@ -745,7 +745,7 @@ class Context:
     def set_profiling(self, on=True):
         """False / 0: off; True / 1: every phase of a sweep is bracketed by HIP events; "match" / 2: only the match
         launches (and the all-gather) are - an event record between two kernels idles the GPU for ~6 us."""
-        check(self._f.set_profiling(self._h, 2 if on == "match" else int(on)))
+        check(self._f.set_profiling(self._h, {"match": 2, "epilogue": 3}.get(on, int(on) if not isinstance(on, str) else -1)))
 
     def counters(self):
         c = Counters()
@@ -867,6 +867,7 @@ def release_engine(engine):
             if hasattr(engine, "release_held"):
                 engine.release_held()
             engine.set_profiling(False)
+            engine.reset_counters()  # (the next call's counters are its own)
             getattr(engine, "_keep", {}).clear()
             with _ENGINE_POOL_LOCK:
                 if key not in _ENGINE_POOL:

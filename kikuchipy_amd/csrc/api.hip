@@ -545,7 +545,8 @@ int kpdi_d2h(kpdi_ctx *c, void *dst, const void *d_src, size_t bytes) {
 
 int kpdi_set_profiling(kpdi_ctx *c, int on) {
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
-  if (on < 0 || on > 2) return fail(KPDI_EINVAL, "profiling level %d (0 off, 1 every phase, 2 match launches only)", on);
+  if (on < 0 || on > 3)
+    return fail(KPDI_EINVAL, "profiling level %d (0 off, 1 every phase, 2 match launches only, 3 every phase + the epilogue counters)", on);
   c->profiling = on;
   return KPDI_OK;
 }

@@ -231,7 +231,7 @@ struct kpdi_ctx {
   // top-k state
   kpdi::DevBuf part_s, part_i;       // partial lists of one match launch
   kpdi::DevBuf tail_s, tail_i;       // partial lists of the quarter-tile tail launch (match.hip: ROWT = 1)
-  kpdi::DevBuf epi_stats;            // 4 x u64: what the epilogues of match16.hip did (profiling level 1; kpdi_counters.epi_*)
+  kpdi::DevBuf epi_stats;            // 4 x u64: what the epilogues of match16.hip did (profiling level 3; kpdi_counters.epi_*)
   kpdi::DevBuf list16;               // float16 form: home of the per-lane lists during a launch (match16.hip)
   int tail_nsplit = 0;         // lists per pattern / 2 of the last run_match's tail launch, 0 = none
   int tail_lists = 0;          // lists per pattern in tail_s / tail_i after the last run_match (0 = none): 2 * tail_nsplit
@@ -339,7 +339,9 @@ struct kpdi_ctx {
   // measurement: 0 off; 1 every phase bracketed by HIP events; 2 the match launches (and the all-gather) only - an event
   // record between two kernels costs ~6 us of idle GPU (profiles/r04_share_timeline.txt: 71 us per 3 ms step with level 1)
   int profiling = 0;
-  bool timed(const void *list) const { return profiling == 1 || (profiling == 2 && (list == &ev_match || list == &ev_comm)); }
+  bool timed(const void *list) const {
+    return profiling == 1 || profiling == 3 || (profiling == 2 && (list == &ev_match || list == &ev_comm));
+  }
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_match, ev_prep, ev_merge, ev_proj, ev_pre, ev_rescore, ev_comm, ev_fixed;
   std::vector<hipEvent_t> ev_pool;
   kpdi_counters cnt{};

@@ -177,6 +177,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
   constexpr bool LEX = !(KMAX == 32 && WAVES == 8);  // (scan16 above)
   constexpr int BLOCK16 = G::DBLOCK, STAGE16 = G::STAGE, NSTAGE16 = G::NSTAGE, KSTEPS16 = G::KS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef KPDI16_TIME_PHASES  // developer build: cycles of a launch's phases (tools/probes/one_step.py; profiles/r06_launch_phases.txt)
+  const unsigned long long ph_t0 = __builtin_readcyclecounter();
+  unsigned long long ph_prologue = 0, ph_first_loop = 0, ph_first_epi = 0, ph_loop_end = 0, ph_epi_t0 = 0;
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0 .. WAVES - 1
@@ -212,14 +216,23 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
   float *home_s = ls_scores + (((size_t)blockIdx.x * WAVES + wv) * NCG) * KMAX * 64;
   int *home_i = ls_idx + (((size_t)blockIdx.x * WAVES + wv) * NCG) * KMAX * 64;
   const unsigned ulane = (unsigned)lane;
+  // A list's home holds nothing until the list has been BUILT (a full candidate buffer, a first tile without a bound:
+  // wave-uniform events) - bit cg of `built` says so, and an unbuilt list is the empty list wherever it is wanted.  (The
+  // homes used to be initialised here: 160 stores per lane, 42 MB from the whole chip at once at the start of every
+  // launch, and as much to load at its end - part of what a launch of this kernel costs beyond its tiles.)
+  // (the 32-entry lists of the 8-wave form - !LEX - keep the initialised homes: that instantiation has no register to
+  // spare, tools/check_mfma_loops.py)
+  unsigned built = LEX ? 0u : ~0u;
+  if (!LEX) {
 #pragma unroll
-  for (int c = 0; c < (NCG * KMAX + 15) / 16; ++c) {
-    float *ps = chunk_base(home_s, c);
-    int *pi = chunk_base(home_i, c);
+    for (int c = 0; c < (NCG * KMAX + 15) / 16; ++c) {
+      float *ps = chunk_base(home_s, c);
+      int *pi = chunk_base(home_i, c);
 #pragma unroll
-    for (int j = 16 * c; j < NCG * KMAX && j < 16 * c + 16; ++j) {
-      ps[(j - 16 * c) * 64 + ulane] = -INFINITY;
-      pi[(j - 16 * c) * 64 + ulane] = INT_MAX;
+      for (int j = 16 * c; j < NCG * KMAX && j < 16 * c + 16; ++j) {
+        ps[(j - 16 * c) * 64 + ulane] = -INFINITY;
+        pi[(j - 16 * c) * 64 + ulane] = INT_MAX;
+      }
     }
   }
   // candidate buffers behind the lists: [((wg * WAVES + wave) * NCG + cg) * CAND_CAP + slot][lane]
@@ -322,6 +335,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
     KPDI16_CURSOR_ADVANCE();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef KPDI16_TIME_PHASES
+    ph_prologue = __builtin_readcyclecounter() - ph_t0;
+#endif
 
     // rows of this wave in a unit: 32 * rt_n consecutive rows from unit row + wr * 32 * rt_n
     auto fa_base = [&](int u) { return (unsigned)((KPDI16_UNIT_ROW(u) + wr * 32 * KPDI16_UNIT_RT(u)) * 32) + fa_lane; };
@@ -447,6 +463,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
 #ifdef KPDI16_TIME_EPI
       const unsigned long long epi_t0 = __builtin_readcyclecounter();
 #endif
+#ifdef KPDI16_TIME_PHASES
+      ph_epi_t0 = __builtin_readcyclecounter();
+      if (tiles_done == 0) ph_first_loop = ph_epi_t0 - ph_t0 - ph_prologue;
+#endif
       // the last MFMAs (8 passes) must have written the accumulators before they are read
       // (the pipe retires MFMAs in order: ONE wait covers all of them; the empty statements only tie every accumulator to
       // this point - 16 x 24 wait states per tile were spent here before)
@@ -528,18 +548,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
         // index of a built list's last entry (a candidate that TIES with it passes only with a lower index: tiles
         // arrive in a permuted order); lists are rarely built before the end - then nothing is loaded
         int lidx[NCG];
-        {
-          bool built = false;
 #pragma unroll
-          for (int cg = 0; cg < NCG; ++cg) {
-            lidx[cg] = INT_MAX;
-            built = built || last[cg] > -INFINITY;
-          }
-          if (LEX && __builtin_amdgcn_ballot_w64(built) != 0) {
-#pragma unroll
-            for (int cg = 0; cg < NCG; ++cg)
-              lidx[cg] = chunk_base(home_i + cg * KMAX * 64, (KMAX - 1) / 16)[((KMAX - 1) % 16) * 64 + ulane];
-          }
+        for (int cg = 0; cg < NCG; ++cg) {
+          lidx[cg] = INT_MAX;
+          if (LEX && ((built >> cg) & 1)) lidx[cg] = chunk_base(home_i + cg * KMAX * 64, (KMAX - 1) / 16)[((KMAX - 1) % 16) * 64 + ulane];
         }
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) {
@@ -695,15 +707,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
             int bidx[KMAX];
             float *hs = home_s + cg * KMAX * 64;
             int *hi = home_i + cg * KMAX * 64;
+            if (!LEX || ((built >> cg) & 1)) {
 #pragma unroll
-            for (int q = 0; q < (KMAX + 15) / 16; ++q) {
-              const float *ps = chunk_base(hs, q);
-              const int *pi = chunk_base(hi, q);
+              for (int q = 0; q < (KMAX + 15) / 16; ++q) {
+                const float *ps = chunk_base(hs, q);
+                const int *pi = chunk_base(hi, q);
 #pragma unroll
-              for (int j = 16 * q; j < KMAX && j < 16 * q + 16; ++j) {
-                best[j] = ps[(j - 16 * q) * 64 + ulane];
-                bidx[j] = pi[(j - 16 * q) * 64 + ulane];
+                for (int j = 16 * q; j < KMAX && j < 16 * q + 16; ++j) {
+                  best[j] = ps[(j - 16 * q) * 64 + ulane];
+                  bidx[j] = pi[(j - 16 * q) * 64 + ulane];
+                }
               }
+            } else {  // (never built: the empty list)
+#pragma unroll
+              for (int j = 0; j < KMAX; ++j) {
+                best[j] = -INFINITY;
+                bidx[j] = INT_MAX;
+              }
+              if (LEX) built |= 1u << cg;
             }
 #pragma unroll 1
             for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt[cg]) != 0; ++i) {
@@ -717,7 +738,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
                 }
               }
             }
-            if (LEX && a.epi_stats) {  // (developer counters, profiling level 1: what was appended before this list was built)
+            if (LEX && a.epi_stats) {  // (developer counters, profiling level 3: what was appended before this list was built)
               const unsigned app = wave_sum_u32((unsigned)cnt[cg]);
               if (lane == 0) {
                 atomicAdd(a.epi_stats + 1, (unsigned long long)app);
@@ -757,6 +778,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
                    st_hot, st_iter, st_cand, (int)first_fast);
         }
 #endif
+#ifdef KPDI16_TIME_PHASES
+        if (tiles_done == 0) ph_first_epi = __builtin_readcyclecounter() - ph_epi_t0;
+        ph_loop_end = __builtin_readcyclecounter() - ph_t0;
+#endif
         ++tiles_done;
         t0 = t1;
         t1 = t2;
@@ -786,14 +811,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
     for (int cg = 0; cg < NCG; ++cg) {
       float best[KMAX];
       int bidx[KMAX];
+      if (!LEX || ((built >> cg) & 1)) {
 #pragma unroll
-      for (int q = 0; q < (KMAX + 15) / 16; ++q) {
-        const float *ps = chunk_base(home_s + cg * KMAX * 64, q);
-        const int *pi = chunk_base(home_i + cg * KMAX * 64, q);
+        for (int q = 0; q < (KMAX + 15) / 16; ++q) {
+          const float *ps = chunk_base(home_s + cg * KMAX * 64, q);
+          const int *pi = chunk_base(home_i + cg * KMAX * 64, q);
 #pragma unroll
-        for (int j = 16 * q; j < KMAX && j < 16 * q + 16; ++j) {
-          best[j] = ps[(j - 16 * q) * 64 + ulane];
-          bidx[j] = pi[(j - 16 * q) * 64 + ulane];
+          for (int j = 16 * q; j < KMAX && j < 16 * q + 16; ++j) {
+            best[j] = ps[(j - 16 * q) * 64 + ulane];
+            bidx[j] = pi[(j - 16 * q) * 64 + ulane];
+          }
+        }
+      } else {  // (never built: the empty list + the buffered candidates below)
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+          best[j] = -INFINITY;
+          bidx[j] = INT_MAX;
         }
       }
       // a candidate below the bound has KMAX better ones somewhere among the pattern's lists
@@ -804,32 +837,39 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
         const int *pi = chunk_base(buf_i + (cg * CAND_CAP + base) * 64, 0);
         f32x16 vs;
         int ids[16];
-        unsigned hot = 0;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const bool in = base + e < cnt[cg];
           vs[e] = in ? ps[e * 64 + ulane] : -INFINITY;
           ids[e] = in ? pi[e * 64 + ulane] : INT_MAX;
         }
+        // Which of a lane's 16 candidates may still enter its list: a bit mask per lane; then ONE loop, as long as any
+        // lane has a bit left, in which every lane inserts ITS next candidate (lowest bit = arrival order -> a 16-way
+        // select).  A handful of a lane's ~10 buffered candidates reach the final bound, so the loop runs 3 - 5 times;
+        // walking the 16 slots wave-wide (one insertion per slot in which ANY lane had a candidate - nearly all of them)
+        // ran 16+ insertions of ~250 instructions per column group: most of the 55 us a launch spent behind its last tile
+        // (profiles/r06_launch_phases.txt).
+        unsigned pm = 0;
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-          hot |= __builtin_amdgcn_ballot_w64(vs[e] >= tf && (LEX ? ranks_before(vs[e], ids[e], best[KMAX - 1], bidx[KMAX - 1])
-                                                                 : vs[e] > best[KMAX - 1])) != 0 ? (1u << e) : 0u;
+          pm |= (vs[e] >= tf && (LEX ? ranks_before(vs[e], ids[e], best[KMAX - 1], bidx[KMAX - 1]) : vs[e] > best[KMAX - 1])) ? (1u << e) : 0u;
 #pragma unroll 1
-        while (hot != 0) {
-          const int e = __builtin_ctz(hot);
-          hot &= hot - 1;
-          float v = vs[0];
-          int id = ids[0];
+        while (__builtin_amdgcn_ballot_w64(pm != 0) != 0) {
+          if (pm != 0) {
+            const int e = __builtin_ctz(pm);
+            pm &= pm - 1;
+            float v = vs[0];
+            int id = ids[0];
 #pragma unroll
-          for (int q = 1; q < 16; ++q) {  // (wave-uniform e: scalar compares)
-            v = e == q ? vs[q] : v;
-            id = e == q ? ids[q] : id;
-          }
-          if (LEX) {
-            if (v >= tf && ranks_before(v, id, best[KMAX - 1], bidx[KMAX - 1])) list_insert_lex<KMAX>(best, bidx, v, id);
-          } else if (v >= tf && v > best[KMAX - 1]) {
-            list_insert<KMAX>(best, bidx, v, id);
+            for (int q = 1; q < 16; ++q) {
+              v = e == q ? vs[q] : v;
+              id = e == q ? ids[q] : id;
+            }
+            if (LEX) {
+              if (ranks_before(v, id, best[KMAX - 1], bidx[KMAX - 1])) list_insert_lex<KMAX>(best, bidx, v, id);
+            } else if (v > best[KMAX - 1]) {
+              list_insert<KMAX>(best, bidx, v, id);
+            }
           }
         }
       }
@@ -848,6 +888,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
       }
     }
   }
+#ifdef KPDI16_TIME_PHASES
+  {
+    const unsigned long long end = __builtin_readcyclecounter() - ph_t0;
+    if ((blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 255) && lane == 0 && wv == 0)
+      printf("block %d: prologue %llu, first tile's steps %llu, first epilogue %llu, tile loop ends at %llu, final stage %llu, kernel %llu cycles "
+             "(100 MHz ticks x ?; s_memtime)\n", (int)blockIdx.x, ph_prologue, ph_first_loop, ph_first_epi, ph_loop_end, end - ph_loop_end, end);
+  }
+#endif
 }
 
 // floats (and as many ints) the kernel keeps per launch: the lists and the candidate buffers behind them

@@ -165,7 +165,43 @@ __global__ __launch_bounds__(256) void merge_cached_kernel(MergeArgs a) {
   unsigned long long keys[NK];
 #pragma unroll
   for (int i = 0; i < NK; ++i) keys[i] = candidate_key(a, m, lane + 64 * i, end0, end1, end2);
+  // Most candidate slots hold nothing (a partial list of the match kernel keeps one or two entries of its 20): the k
+  // selection rounds below scan every slot of a lane, 24 x k compare-selects per lane - the kernel was VALU-issue-bound on
+  // them (4096 waves x 5000 instructions: 38 us at configs[1]).  The real candidates are first packed into the wave's
+  // part of LDS (ballot + prefix count), at most CK per lane; the rounds then scan ceil(n / 64) keys.  More than 64 CK of
+  // them (long lists, many sources): the rounds run over the registers as before.  The order of candidates is immaterial
+  // (keys are totally ordered): the result is the same bit for bit.
+  constexpr int CK = NK < 8 ? NK : 8;
+  __shared__ unsigned long long packed[4][64 * CK];
+  unsigned long long *mine = packed[threadIdx.x >> 6];
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < NK; ++i) {
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(keys[i] != 0ull);
+    const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+    if (keys[i] != 0ull && pos < 64 * CK) mine[pos] = keys[i];
+    n += __builtin_popcountll(b);
+  }
   unsigned long long prev = ~0ull;
+#ifdef KPDI_MERGE_NO_COMPACT  // (developer build: the rounds over the registers, always)
+  n = 64 * CK + 1;
+#endif
+  if (n <= 64 * CK) {
+    unsigned long long ck[CK];
+#pragma unroll
+    for (int j = 0; j < CK; ++j) ck[j] = lane + 64 * j < n ? mine[lane + 64 * j] : 0ull;  // (this wave's own writes: no barrier)
+    const int per_lane = (n + 63) >> 6;
+    for (int r = 0; r < a.k; ++r) {
+      unsigned long long best = 0ull;
+#pragma unroll
+      for (int j = 0; j < CK; ++j)
+        if (j < per_lane && ck[j] < prev && ck[j] > best) best = ck[j];
+      best = wave_max_key(best);
+      if (lane == 0) store_rank(a, m, r, best);
+      prev = best;  // 0 once the candidates are exhausted: nothing is below it
+    }
+    return;
+  }
   for (int r = 0; r < a.k; ++r) {
     unsigned long long best = 0ull;
 #pragma unroll

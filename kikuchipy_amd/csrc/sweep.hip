@@ -232,7 +232,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
     // whole-tile rounds are walked in a permuted order (plan.h: tile_order_stride); partial units stay last
     const int whole = (c->wide32 && ml.tail_shift > 0) ? ml.tail_first : n_main;
     ml.perm_stride = plan::tile_order_stride(plan_env(c), whole, nsplit, &ml.perm_rounds);
-    if (c->profiling == 1) {  // every phase bracketed = the developer level: the epilogues count what they do
+    if (c->profiling == 3) {  // the developer level: the epilogues count what they do (~50 us of atomics per launch)
       if (!c->epi_stats.p) {
         HIPCHK(c->epi_stats.reserve(4 * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(c->epi_stats.p, 0, 4 * sizeof(unsigned long long), c->stream));

@@ -11,11 +11,13 @@
 // So the left-over rows get what small units need - a DEEP pipeline - here:
 //   * workgroup = 32 dictionary rows x 128 experimental patterns (wave w: one 32 x 32 accumulator against column group w),
 //     so 212 left-over rows x 4096 patterns are 7 x 32 = 224 workgroups: the whole chip, one round;
-//   * a step = the 24 pixels of one (tile, step) block of the plane-major operands (prep_device.h: half_slot, form 3):
-//     3 x 1 KB of the dictionary tile + 12 x 1 KB of the experimental tile = 16 lane-linear LDS-DMA pieces (one a
-//     repeat), four per wave;
-//   * a ring of EIGHT 16 KB stages, loads running SEVEN steps ahead (7 x 768 cycles of matrix work hide the latency), one
-//     `s_waitcnt vmcnt` + one barrier per step, the fragments of step s + 1 read while the MFMAs of step s run;
+//   * a step = the 24 pixels of one (tile, step) block of the plane-major operands (prep_device.h: half_slot, form 3): a wave
+//     loads what IT needs - 3 x 1 KB of its column group + 3 x 1 KB of the dictionary rows - into its own part of LDS, six
+//     lane-linear LDS-DMA pieces per step.  The dictionary pieces are thereby loaded four times per workgroup (from L2:
+//     9 KB per step) - and NO wave ever waits for another: no barrier in the kernel (one per step cost a quarter of the
+//     matrix pipe's time: 64.8 -> us for 212 rows, profiles/r06_tail_kernel.txt);
+//   * a ring of SIX stages of 4 x 6 KB, loads running FIVE steps ahead (5 x 768 cycles of matrix work hide the latency),
+//     one `s_waitcnt vmcnt` per step, the fragments of step s + 1 read while the MFMAs of step s run;
 //   * NO fused top-k: the 32 x 128 scores go to a small matrix S[row][pattern] (212 x 4096 floats = 3.5 MB); by then the
 //     main kernel has finished and the shared rejection bound of every pattern is FINAL, so tail_select_kernel (one
 //     thread per pattern, coalesced over patterns) passes a handful of the rows to a sorted list that joins the merge
@@ -30,7 +32,8 @@
 
 namespace kpdi {
 
-constexpr int TG_STAGES = 8, TG_AHEAD = 7, TG_STAGE = 16384, TG_BLOCK = F16_TILE * F16_STEP * 2;  // 24 KB (tile, step) block
+constexpr int TG_STAGES = 6, TG_AHEAD = 5, TG_WAVE = 6144, TG_STAGE = 4 * TG_WAVE, TG_BLOCK = F16_TILE * F16_STEP * 2;  // 24 KB (tile, step) block
+constexpr int TG_PIECES = 6;  // LDS-DMA pieces per wave and step
 constexpr int TG_COLS = 128;  // experimental patterns per workgroup
 
 struct TailGemmArgs {
@@ -53,21 +56,15 @@ __global__ __launch_bounds__(256, 1) void tail_gemm_kernel(TailGemmArgs a) {
   const char *dtile = a.dict + (size_t)(a.tile_first + (g >> 3)) * nsteps * TG_BLOCK + (size_t)(g & 7) * 1024;
   const char *etile = a.exp + (size_t)(cb >> 1) * nsteps * TG_BLOCK + (size_t)(((cb & 1) << 2) + wv) * 1024;
   const unsigned goff = (unsigned)lane * 16u;
-  const int dplane = wv < 3 ? wv : 2;  // (wave 3 repeats the last dictionary piece: four pieces per wave and step, one vmcnt for all)
+  char *wbase = smem + wv * TG_WAVE;  // this wave's 6 KB of every stage: [3 planes of its column group][3 planes of the dictionary rows]
 
-  // piece i of this wave's four 1 KB pieces of step s into stage `st`: experimental planes 0..2 of column group wv (i = 0..2),
-  // dictionary plane dplane (i = 3)
+  // piece i of this wave's six 1 KB pieces of step s into stage `st`: i < 3: experimental plane i, else dictionary plane i - 3
   auto issue = [&](int i, int s, int st) {
-    char *base = smem + st * TG_STAGE;
-    if (i < 3) {
-      __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void *)(etile + (size_t)s * TG_BLOCK), 0, 0x7fffffff, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (__attribute__((address_space(3))) void *)(base + (i * 4 + wv) * 1024), 16,
-                                               (int)goff, i * 8192, 0, 0);
-    } else {
-      __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(dtile + (size_t)s * TG_BLOCK), 0, 0x7fffffff, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (__attribute__((address_space(3))) void *)(base + 12288 + dplane * 1024), 16,
-                                               (int)goff, dplane * 8192, 0, 0);
-    }
+    char *base = wbase + st * TG_STAGE;
+    const char *src = (i < 3 ? etile : dtile) + (size_t)s * TG_BLOCK;
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)(base + i * 1024), 16, (int)goff,
+                                             (i < 3 ? i : i - 3) * 8192, 0, 0);
   };
   // lane l reads row (l & 31) of a 32-row group: the 16-byte half (l >> 5) of the row's 32 bytes of a plane, halves
   // swapped for rows with bit 3 set (match16.hip: fa_lane)
@@ -75,21 +72,19 @@ __global__ __launch_bounds__(256, 1) void tail_gemm_kernel(TailGemmArgs a) {
   f32x4 fa[3], fb[3], na[3], nb[3];
   // fragment read i of a stage: i even = dictionary plane i / 2, odd = experimental plane i / 2
   auto read = [&](int i, int st, f32x4 (&A)[3], f32x4 (&B)[3]) {
-    const char *base = smem + st * TG_STAGE;
+    const char *base = wbase + st * TG_STAGE;
     if (i & 1)
-      B[i >> 1] = *(const f32x4 *)(base + ((i >> 1) * 4 + wv) * 1024 + fl);
+      B[i >> 1] = *(const f32x4 *)(base + (i >> 1) * 1024 + fl);
     else
-      A[i >> 1] = *(const f32x4 *)(base + 12288 + (i >> 1) * 1024 + fl);
+      A[i >> 1] = *(const f32x4 *)(base + (3 + (i >> 1)) * 1024 + fl);
   };
 
   const int last = nsteps - 1;
 #pragma unroll
   for (int s = 0; s < TG_AHEAD; ++s)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue(i, s < last ? s : last, s);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (TG_AHEAD - 1)) : "memory");  // step 0 has landed
-  __builtin_amdgcn_s_barrier();  // (a bare barrier: __syncthreads() would wait for ALL loads in flight)
-  asm volatile("" ::: "memory");
+    for (int i = 0; i < TG_PIECES; ++i) issue(i, s < last ? s : last, s);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TG_PIECES * (TG_AHEAD - 1)) : "memory");  // step 0 has landed (this wave's own pieces: no barrier)
 #pragma unroll
   for (int i = 0; i < 6; ++i) read(i, 0, fa, fb);
 
@@ -104,21 +99,16 @@ __global__ __launch_bounds__(256, 1) void tail_gemm_kernel(TailGemmArgs a) {
     const int sl = s + TG_AHEAD < last ? s + TG_AHEAD : last;  // past the end the last step is loaded again - harmless, and the
                                                                // wait counts stay what they are
     // The step's 12 MFMAs (one accumulator: a dependent chain, 64 cycles each) with everything else in their shadow:
-    //   behind MFMA 0..3: this wave's four pieces of step s + AHEAD into the stage of step s - 1 - every wave read that
-    //     stage's fragments during iteration s - 2 and has passed the barrier of iteration s - 1 since: no barrier needed;
-    //   behind MFMA 4: the step's only synchronisation - this wave's pieces of step s + 1 have landed (all but the newest
-    //     AHEAD - 1 steps' pieces), and after the barrier everybody's have;
-    //   behind MFMA 5..10: the six fragment reads of step s + 1.
+    //   behind MFMA 0..5: this wave's six pieces of step s + AHEAD into the stage of step s - 1, whose fragments it read
+    //     during iteration s - 2 (its own part of LDS: program order is all the synchronisation there is);
+    //   behind MFMA 5: its pieces of step s + 1 have landed (all but the newest AHEAD - 1 steps' pieces);
+    //   behind MFMA 6..11: the six fragment reads of step s + 1.
 #pragma unroll
     for (int slot = 0; slot < 12; ++slot) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot >> 2][slot & 3], fb[slot >> 2][slot & 3], acc, 0, 0, 0);
-      if (slot < 4) issue(slot, sl, st_prev);
-      if (slot == 4) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (TG_AHEAD - 1)) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
-      if (slot >= 5 && slot < 11) read(slot - 5, st_next, na, nb);
+      if (slot < TG_PIECES) issue(slot, sl, st_prev);
+      if (slot == TG_PIECES - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TG_PIECES * (TG_AHEAD - 1)) : "memory");
+      if (slot >= 6) read(slot - 6, st_next, na, nb);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll

@@ -517,7 +517,10 @@ def test_the_two_f32_kernels_agree_and_are_chosen_by_size(monkeypatch):
         c.push_dictionary_chunk_dev(d, np.float32, 100000, 0)   # 391 tiles of 256 over 16 splits: the one-wave kernel
         assert c.counters()["match_form"] == 3
         c.set_experimental(rng.integers(0, 256, (4096, 60, 60), dtype=np.uint8))
-        c.push_dictionary_chunk_dev(d, np.float32, 12500, 0)    # one rank's share at N = 8: match.hip + quarter-tile tail
+        c.push_dictionary_chunk_dev(d, np.float32, 12500, 0)    # one rank's share at N = 8: three whole rounds + tailgemm.hip
+        assert c.counters()["match_form"] == 3
+        c.set_experimental(rng.integers(0, 256, (4096, 60, 60), dtype=np.uint8))
+        c.push_dictionary_chunk_dev(d, np.float32, 6250, 0)     # ... at N = 16: one round and a half - match.hip + quarter-tile tail
         assert c.counters()["match_form"] == 0
         c.dev_free(d)
 

@@ -68,16 +68,18 @@ def test_eight_in_process_shards_equal_the_single_sweep_at_full_size():
 
 def test_members_on_different_kernel_forms_still_merge_to_the_single_sweep():
     """The "bit for bit" claim of include/kpdi.h rests on every f32 kernel form producing the same bits.  Here the members
-    of one group sweep shares whose sizes make the planner pick DIFFERENT forms (match16.hip's 256 x 256 tiles for
-    50 000 patterns, match.hip's 128 x 256 tiles + quarter-tile tail for 12 500, partial units for the odd rest) - the
-    counters say so - and the merged result is the single sweep's, bit for bit."""
+    of one group sweep shares whose sizes make the planner pick DIFFERENT forms (match16.hip's 256 x 256 tiles with
+    partial units for 50 000 patterns, match.hip's 128 x 256 tiles + quarter-tile tail for 6250, match16.hip + tailgemm.hip
+    for 12 500, whatever it likes for the odd rest) - the counters say so - and the merged result is the single sweep's,
+    bit for bit."""
     from kikuchipy_amd import _lib
 
     exp, dic = synth(2024, 4096, 100000)
     s1, i1 = single(exp, dic, _lib.METRIC_NCC, 20, _lib.COMPUTE_F32)
-    sizes = [50000, 12500, 37397, 103]
+    sizes = [50000, 6250, 12500, 31147, 103]
+    assert sum(sizes) == 100000 and _lib.plan_describe(4096, 12500).tail_gemm_rows == 212
     starts = np.concatenate([[0], np.cumsum(sizes)[:-1]])
-    with _lib.Group([0] * 4) as g:
+    with _lib.Group([0] * 5) as g:
         g.set_problem(60, 60, None, _lib.METRIC_NCC, 20, _lib.COMPUTE_F32)
         g.set_experimental(exp, None)
         d = []
@@ -88,7 +90,7 @@ def test_members_on_different_kernel_forms_still_merge_to_the_single_sweep():
         g.push_dictionary_chunk_dev(d, np.float32, sizes, [int(a) for a in starts])
         s, i = g.finalize(20)
         forms = [m["match_form"] for m in g.counters()["members"]]
-    assert forms[0] == 3 and forms[1] == 0, forms  # (wide, classic; the others whatever the planner likes)
+    assert forms[0] == 3 and forms[1] == 0 and forms[2] == 3, forms  # (wide, classic, wide + tail kernel; the others whatever the planner likes)
     assert np.array_equal(s, s1) and np.array_equal(i, i1)
 
 
@@ -118,16 +120,17 @@ def test_the_tutorial_call_on_eight_members_equals_the_single_sweep_at_full_size
     exp, dic = synth(2024, 4096, 100000)
     s1, i1 = single(exp, dic, _lib.METRIC_NCC, 20, _lib.COMPUTE_F32)
     made, stats = [], []
-    real = _lib.make_engine
+    real, real_release = _lib.make_engine, _lib.release_engine
 
     def make(*a, **k):
-        eng = real(*a, **k)
-        close = eng.close
-        eng.close = lambda: (stats.append(eng.counters()), close())  # (the call closes the engine it made: look first)
-        made.append(eng)
-        return eng
+        made.append(real(*a, **k))
+        return made[-1]
 
-    _lib.make_engine = make
+    def release(eng):  # (the call hands the engine it made back when it is done: look at its counters first)
+        stats.append(eng.counters())
+        real_release(eng)
+
+    _lib.make_engine, _lib.release_engine = make, release
     try:
         calls = []
         got = ka.dictionary_indexing(exp, dic, keep_n=20, n_per_iteration=3044, devices=[0] * 8, verbose=False,
@@ -137,8 +140,8 @@ def test_the_tutorial_call_on_eight_members_equals_the_single_sweep_at_full_size
         lazy = Lazy(dic, 3044)
         got_lazy = ka.dictionary_indexing(exp, lazy, keep_n=20, devices=[0] * 8, verbose=False)
     finally:
-        _lib.make_engine = real
-    assert isinstance(grp, _lib.Group) and len(grp) == 8
+        _lib.make_engine, _lib.release_engine = real, real_release
+    assert isinstance(grp, _lib.Group) and len(grp) == 8 and len(made) == 1  # (the second call took the first one's engine)
     assert np.array_equal(got.scores, s1) and np.array_equal(got.simulation_indices, i1)
     assert np.array_equal(got_lazy.scores, s1) and np.array_equal(got_lazy.simulation_indices, i1)
     assert lazy.log == [3044] * 32 + [100000 - 32 * 3044]
