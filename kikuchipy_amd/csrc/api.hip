@@ -230,7 +230,7 @@ int kpdi_destroy(kpdi_ctx *c) {
   if (c->lists_final) (void)hipEventDestroy(c->lists_final);
   if (c->peer_read) (void)hipEventDestroy(c->peer_read);
   for (DevBuf *b : {&c->pix_map, &c->quad_desc, &c->exp_raw, &c->row_map, &c->exp_x, &c->dict_raw, &c->dict_y, &c->part_s,
-                    &c->part_i, &c->tail_s, &c->tail_i, &c->tail_scores, &c->list16, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
+                    &c->part_i, &c->part_cnt, &c->tail_s, &c->tail_i, &c->tail_scores, &c->list16, &c->run_s[0], &c->run_s[1], &c->run_i[0], &c->run_i[1], &c->loc_s, &c->loc_i,
                     &c->bound_s, &c->bound_i, &c->gthr, &c->tile_ctr, &c->gather_s, &c->gather_i, &c->bg, &c->taps, &c->inv_map, &c->pre_scratch,
                     &c->mp_packed, &c->dcos, &c->rot, &c->proj_out,
                     &c->ref_raw, &c->ref_map, &c->ref_rowcol, &c->ref_pat, &c->ref_sqn, &c->ref_in, &c->ref_out,

@@ -230,6 +230,8 @@ struct kpdi_ctx {
 
   // top-k state
   kpdi::DevBuf part_s, part_i;       // partial lists of one match launch
+  kpdi::DevBuf part_cnt;             // match16.hip: entries every partial list holds (only those are written)
+  bool part_counted = false;         // the last run_match's partial lists come with counts
   kpdi::DevBuf tail_s, tail_i;       // partial lists of the quarter-tile tail launch (match.hip: ROWT = 1)
   kpdi::DevBuf epi_stats;            // 4 x u64: what the epilogues of match16.hip did (profiling level 3; kpdi_counters.epi_*)
   kpdi::DevBuf list16;               // float16 form: home of the per-lane lists during a launch (match16.hip)

@@ -61,6 +61,8 @@ struct MatchLaunch {
   int list_len;       // KMAX of the instantiation
   float *part_scores; // [m_pad][2*nsplit][list_len]
   int *part_idx;
+  int *part_cnt = nullptr;  // match16.hip: [m_pad][4*nsplit] entries every list holds - only those are written (the "no entry"
+                            // tails were 9 of 10 of the scattered stores all workgroups issue behind their last tile)
   // optional upper bound per experimental pattern (multi-pass for keep_n > 32):
   // only candidates strictly after (bound_score, bound_idx) in the ranking count
   const float *bound_score; // [m_pad] or nullptr
@@ -178,6 +180,8 @@ struct MergeLaunch {
   int src_len[3];
   int src_row_stride[3];  // elements between consecutive patterns
   int src_list_stride[3]; // elements between consecutive lists of one pattern
+  const int *src_cnt[3] = {nullptr, nullptr, nullptr};  // [m][lists] valid entries per list (what lies behind them was never
+                                                        // written), or nullptr = every entry is valid
   int n_src;
   float *out_scores;    // [m][out_stride] (must not alias a source)
   int *out_idx;

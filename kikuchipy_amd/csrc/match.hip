@@ -503,6 +503,7 @@ hipError_t launch_match(const MatchLaunch &a, hipStream_t s) {
   g.fixed_draws = a.fixed_draws < 3 ? 3 : a.fixed_draws;
   g.tail_first = a.n_tiles;
   g.tail_shift = 0;
+  g.part_cnt = nullptr;
   g.perm_rounds = 0;  // (match.hip hands its tiles out in rising order: list_insert's tie rule relies on it)
   g.perm_stride = 1;
   g.epi_stats = nullptr;

@@ -180,6 +180,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
 #ifdef KPDI16_TIME_PHASES  // developer build: cycles of a launch's phases (tools/probes/one_step.py; profiles/r06_launch_phases.txt)
   const unsigned long long ph_t0 = __builtin_readcyclecounter();
   unsigned long long ph_prologue = 0, ph_first_loop = 0, ph_first_epi = 0, ph_loop_end = 0, ph_epi_t0 = 0;
+  unsigned long long ph_fs_bound = 0, ph_fs_loop = 0;
+  int ph_fs_iters = 0, ph_fs_inserts = 0;
 #endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -809,6 +811,78 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
     const int lists = 4 * a.nsplit;
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg) {
+      const size_t ol = (size_t)(m_lane + 32 * cg) * lists + (size_t)list_id, o = ol * KMAX;
+      // a candidate below the bound has KMAX better ones somewhere among the pattern's lists
+#ifdef KPDI16_TIME_PHASES
+      const unsigned long long fs0 = __builtin_readcyclecounter();
+#endif
+      // (any bound that ever stood is valid; the one this wave refreshed last - during its last tiles - is nearly the
+      // final one and costs nothing: four dependent loads from memory here were 10 us of every launch)
+      float tf = g[cg];
+#ifdef KPDI16_FINAL_BOUND_LOAD  // (developer build: the final stage reads the bound from memory, as before round 6)
+      tf = -INFINITY;
+#endif
+      if (__builtin_amdgcn_ballot_w64(!(tf > -INFINITY)) != 0) tf = shared_bound<KMAX>(line0 + 32 * cg * BOUND_SLOTS, bound_grouped);
+#ifdef KPDI16_TIME_PHASES
+      asm volatile("" : "+v"(tf));
+      const unsigned long long fs1 = __builtin_readcyclecounter();
+      ph_fs_bound += fs1 - fs0;
+#endif
+#ifdef KPDI16_NO_DIRECT  // (developer build: every list through the sorted path)
+      constexpr bool DIRECT = false;
+#else
+      constexpr bool DIRECT = LEX;
+#endif
+      if (DIRECT && !((built >> cg) & 1)) {
+        // ---- the usual case: this list was never built.  The merge kernel takes a partial list as a SET of candidates
+        // (merge.hip ranks by key, whatever the order), so the buffered candidates that reach the final bound - a handful
+        // of a lane's ~10 - go straight to the lane's partial list, in arrival order, unsorted, and "no entry" behind
+        // them: 16 predicated stores per batch instead of one 20-entry sorted insertion per survivor (those insertions, 6
+        // per column group at ~2500 cycles each, were most of what a launch spent behind its last tile:
+        // profiles/r06_launch_phases.txt).  A lane with more than KMAX survivors (adversarial data): the sorted path below.
+#ifdef KPDI16_TIME_PHASES
+        const unsigned long long fs2 = __builtin_readcyclecounter();
+#endif
+        int n = 0;
+#pragma unroll 1
+        for (int base = 0; __builtin_amdgcn_ballot_w64(base < cnt[cg]) != 0; base += 16) {
+          const float *ps = chunk_base(buf_s + (cg * CAND_CAP + base) * 64, 0);
+          const int *pi = chunk_base(buf_i + (cg * CAND_CAP + base) * 64, 0);
+          f32x16 vs;
+          int ids[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const bool in = base + e < cnt[cg];
+            vs[e] = in ? ps[e * 64 + ulane] : -INFINITY;
+            ids[e] = in ? pi[e * 64 + ulane] : INT_MAX;
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            if (vs[e] >= tf && ids[e] != INT_MAX) {
+              if (n < KMAX) {
+                a.part_scores[o + n] = vs[e];
+                a.part_idx[o + n] = ids[e];
+              }
+              ++n;
+            }
+          }
+        }
+#ifdef KPDI16_TIME_PHASES
+        ph_fs_loop += __builtin_readcyclecounter() - fs2;
+        ++ph_fs_iters;
+#endif
+        if (__builtin_amdgcn_ballot_w64(n > KMAX) == 0) {
+          a.part_cnt[ol] = n;  // (the merge takes the first n entries of this list: nothing is stored behind them)
+          if (a.epi_stats) {
+            const unsigned app = wave_sum_u32((unsigned)cnt[cg]);
+            if (lane == 0) {
+              atomicAdd(a.epi_stats, 64ull);
+              atomicAdd(a.epi_stats + 1, (unsigned long long)app);
+            }
+          }
+          continue;
+        }
+      }
       float best[KMAX];
       int bidx[KMAX];
       if (!LEX || ((built >> cg) & 1)) {
@@ -829,8 +903,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
           bidx[j] = INT_MAX;
         }
       }
-      // a candidate below the bound has KMAX better ones somewhere among the pattern's lists
-      const float tf = shared_bound<KMAX>(line0 + 32 * cg * BOUND_SLOTS, bound_grouped);
 #pragma unroll 1
       for (int base = 0; __builtin_amdgcn_ballot_w64(base < cnt[cg]) != 0; base += 16) {
         const float *ps = chunk_base(buf_s + (cg * CAND_CAP + base) * 64, 0);  // 16 entries in flight, not one
@@ -853,8 +925,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
 #pragma unroll
         for (int e = 0; e < 16; ++e)
           pm |= (vs[e] >= tf && (LEX ? ranks_before(vs[e], ids[e], best[KMAX - 1], bidx[KMAX - 1]) : vs[e] > best[KMAX - 1])) ? (1u << e) : 0u;
+#ifdef KPDI16_TIME_PHASES
+        asm volatile("" : "+v"(pm));
+        const unsigned long long fs2 = __builtin_readcyclecounter();
+        ++ph_fs_iters;
+#endif
 #pragma unroll 1
         while (__builtin_amdgcn_ballot_w64(pm != 0) != 0) {
+#ifdef KPDI16_TIME_PHASES
+          ++ph_fs_inserts;
+#endif
           if (pm != 0) {
             const int e = __builtin_ctz(pm);
             pm &= pm - 1;
@@ -872,6 +952,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
             }
           }
         }
+#ifdef KPDI16_TIME_PHASES
+        ph_fs_loop += __builtin_readcyclecounter() - fs2;
+#endif
       }
       if (LEX && a.epi_stats) {
         const unsigned app = wave_sum_u32((unsigned)cnt[cg]);
@@ -880,7 +963,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
           atomicAdd(a.epi_stats + 1, (unsigned long long)app);
         }
       }
-      const size_t o = ((size_t)(m_lane + 32 * cg) * lists + (size_t)list_id) * KMAX;
+      a.part_cnt[ol] = KMAX;  // (the sorted path writes the whole list, "no entry" tail included)
 #pragma unroll
       for (int j = 0; j < KMAX; ++j) {
         a.part_scores[o + j] = best[j];
@@ -893,7 +976,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
     const unsigned long long end = __builtin_readcyclecounter() - ph_t0;
     if ((blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 255) && lane == 0 && wv == 0)
       printf("block %d: prologue %llu, first tile's steps %llu, first epilogue %llu, tile loop ends at %llu, final stage %llu, kernel %llu cycles "
-             "(100 MHz ticks x ?; s_memtime)\n", (int)blockIdx.x, ph_prologue, ph_first_loop, ph_first_epi, ph_loop_end, end - ph_loop_end, end);
+             "(shader cycles); final stage: bound loads %llu, insert loops %llu (%d batches, %d insertions)\n", (int)blockIdx.x, ph_prologue,
+             ph_first_loop, ph_first_epi, ph_loop_end, end - ph_loop_end, end, ph_fs_bound, ph_fs_loop, ph_fs_iters, ph_fs_inserts);
   }
 #endif
 }
@@ -980,6 +1064,8 @@ hipError_t launch_match16(const MatchLaunch &a, int waves, void *list_scratch, h
   g.row_base = 0;
   g.part_scores = a.part_scores;
   g.part_idx = a.part_idx;
+  g.part_cnt = a.part_cnt;
+  if (!g.part_cnt) return hipErrorInvalidValue;
   g.bound_score = a.bound_score;
   g.bound_idx = a.bound_idx;
   g.gthr = a.gthr;

@@ -20,6 +20,7 @@ struct MatchArgs {
   int row_base;  // ROWT = 1 (32-row tail units): dictionary row of unit 0, a multiple of 32
   float *part_scores;
   int *part_idx;
+  int *part_cnt;       // match16.hip: [m_pad][lists] entries written per list (kernels.h: MatchLaunch.part_cnt)
   const float *bound_score;
   const int *bound_idx;
   unsigned *tile_ctr;  // [row blocks] next tile to hand out dynamically; fixed_draws * nsplit at launch

@@ -41,6 +41,7 @@ struct MergeArgs {
   const float *s[3];
   const int *i[3];
   int lists[3];       // lists per pattern in source j
+  const int *cnt[3];  // [m][lists] valid entries of every list of source j, or nullptr (all of them)
   int len[3];         // entries per list
   int stride[3];      // elements between patterns
   int list_stride[3]; // elements between lists
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(256) void merge_kernel(MergeArgs a) {
       const int count = a.lists[j] * len;
       for (int c = lane; c < count; c += 64) {
         const int l = c / len;
+        if (a.cnt[j] && c - l * len >= a.cnt[j][(size_t)m * a.lists[j] + l]) continue;  // (behind what the list holds: never written)
         const size_t e = (size_t)l * a.list_stride[j] + (c - l * len);
         int idx = pi[e];
         if (idx == INT_MAX) continue;
@@ -106,8 +108,26 @@ __global__ __launch_bounds__(256) void merge_kernel(MergeArgs a) {
 // candidate c (sources laid end to end) of pattern m as a key; 0 = none.  Branch-free: a divergent
 // branch around the loads makes the compiler copy the whole key array at every join (312 VGPRs);
 // slots past the last candidate read candidate 0 and are zeroed.
-__device__ __forceinline__ unsigned long long candidate_key(const MergeArgs &a, int m, int c0, int end0, int end1,
-                                                            int end2) {
+// `held[j]`: source j comes with counts and has at most 64 lists - lane l then holds the count of list l of this
+// pattern (one coalesced load per wave; a candidate's count is fetched from its list's lane), INT_MAX in every lane
+// otherwise (counts, if any, are then read from memory per candidate).
+struct ListCounts {
+  int held[3];
+  bool in_lanes[3];
+};
+__device__ __forceinline__ ListCounts load_counts(const MergeArgs &a, int m, int lane) {
+  ListCounts lc;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    lc.in_lanes[j] = a.cnt[j] != nullptr && a.lists[j] <= 64;
+    lc.held[j] = INT_MAX;
+    if (lc.in_lanes[j] && lane < a.lists[j]) lc.held[j] = a.cnt[j][(size_t)m * a.lists[j] + lane];
+  }
+  return lc;
+}
+
+__device__ __forceinline__ unsigned long long candidate_key(const MergeArgs &a, const ListCounts &lc, int m, int c0, int end0,
+                                                            int end1, int end2) {
   const bool live = c0 < end2;
   const int c = live ? c0 : 0;
   // the source of candidate c, picked with constant indices into the argument arrays
@@ -122,13 +142,33 @@ __device__ __forceinline__ unsigned long long candidate_key(const MergeArgs &a, 
   // local + 0.5 is at least 1/64 away from an integer (and float holds it to 2^-9)
   const int l = (int)(((float)local + 0.5f) / (float)len);
   const size_t e = (size_t)m * stride + (size_t)l * list_stride + (local - l * len);
+  // a source with counts: only the first cnt[m][l] entries of a list were written - what lies behind them is stale memory
+  const int *pc = in0 ? a.cnt[0] : (in1 ? a.cnt[1] : a.cnt[2]);
+  const bool lanes = in0 ? lc.in_lanes[0] : (in1 ? lc.in_lanes[1] : lc.in_lanes[2]);
+  // the count of list l of THIS candidate's source sits in lane l's register OF THAT SOURCE: one shuffle per source that
+  // keeps its counts in lanes (uniform over the launch), every lane taking part, each keeping its own source's answer
+  int n_held = INT_MAX;
+  if (lc.in_lanes[0]) {
+    const int t = __shfl(lc.held[0], l & 63, 64);
+    n_held = in0 ? t : n_held;
+  }
+  if (lc.in_lanes[1]) {
+    const int t = __shfl(lc.held[1], l & 63, 64);
+    n_held = (!in0 && in1) ? t : n_held;
+  }
+  if (lc.in_lanes[2]) {
+    const int t = __shfl(lc.held[2], l & 63, 64);
+    n_held = (!in0 && !in1) ? t : n_held;
+  }
+  if (pc != nullptr && !lanes) n_held = pc[(size_t)m * (in0 ? a.lists[0] : (in1 ? a.lists[1] : a.lists[2])) + l];
+  const bool held = pc == nullptr || (local - l * len) < n_held;
   int idx = pi[e];
   if (a.seg_sources != 0) {  // (uniform over the launch)
     const unsigned bit = in0 ? 1u : (in1 ? 2u : 4u);
     idx = (a.seg_sources & bit) ? segment_index(a, idx) : idx;
   }
   const unsigned long long key = topk_key(ps[e], idx);
-  return (live && idx != INT_MAX) ? key : 0ull;
+  return (live && held && idx != INT_MAX) ? key : 0ull;
 }
 
 __device__ __forceinline__ unsigned long long wave_max_key(unsigned long long best) {
@@ -162,9 +202,10 @@ __global__ __launch_bounds__(256) void merge_cached_kernel(MergeArgs a) {
   const int end0 = a.lists[0] * a.len[0];
   const int end1 = end0 + (a.n_src > 1 ? a.lists[1] * a.len[1] : 0);
   const int end2 = end1 + (a.n_src > 2 ? a.lists[2] * a.len[2] : 0);
+  const ListCounts lc = load_counts(a, m, lane);
   unsigned long long keys[NK];
 #pragma unroll
-  for (int i = 0; i < NK; ++i) keys[i] = candidate_key(a, m, lane + 64 * i, end0, end1, end2);
+  for (int i = 0; i < NK; ++i) keys[i] = candidate_key(a, lc, m, lane + 64 * i, end0, end1, end2);
   // Most candidate slots hold nothing (a partial list of the match kernel keeps one or two entries of its 20): the k
   // selection rounds below scan every slot of a lane, 24 x k compare-selects per lane - the kernel was VALU-issue-bound on
   // them (4096 waves x 5000 instructions: 38 us at configs[1]).  The real candidates are first packed into the wave's
@@ -223,9 +264,15 @@ __global__ __launch_bounds__(256) void merge_block_kernel(MergeArgs a) {
   const int end0 = a.lists[0] * a.len[0];
   const int end1 = end0 + (a.n_src > 1 ? a.lists[1] * a.len[1] : 0);
   const int end2 = end1 + (a.n_src > 2 ? a.lists[2] * a.len[2] : 0);
+  ListCounts lc;  // (one workgroup per pattern: up to 1024 lists - counts, if any, are read per candidate)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    lc.held[j] = INT_MAX;
+    lc.in_lanes[j] = false;
+  }
   unsigned long long keys[NK];
 #pragma unroll
-  for (int i = 0; i < NK; ++i) keys[i] = candidate_key(a, m, tid + 256 * i, end0, end1, end2);
+  for (int i = 0; i < NK; ++i) keys[i] = candidate_key(a, lc, m, tid + 256 * i, end0, end1, end2);
   unsigned long long prev = ~0ull;
   for (int r = 0; r < a.k; ++r) {
     unsigned long long best = 0ull;
@@ -256,6 +303,7 @@ hipError_t launch_merge(const MergeLaunch &l, hipStream_t s) {
     a.i[j] = j < l.n_src ? l.src_idx[j] : nullptr;
     a.lists[j] = j < l.n_src ? l.src_lists[j] : 0;
     a.len[j] = j < l.n_src ? l.src_len[j] : 1;
+    a.cnt[j] = j < l.n_src ? l.src_cnt[j] : nullptr;
     a.stride[j] = j < l.n_src ? l.src_row_stride[j] : 0;
     a.list_stride[j] = j < l.n_src ? l.src_list_stride[j] : 0;
   }

@@ -209,6 +209,8 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   const size_t part = (size_t)c->m_pad * lists_per_split * nsplit * list_len;
   HIPCHK(c->part_s.reserve(part * sizeof(float)));
   HIPCHK(c->part_i.reserve(part * sizeof(int)));
+  c->part_counted = f16;
+  if (f16) HIPCHK(c->part_cnt.reserve((size_t)c->m_pad * lists_per_split * nsplit * sizeof(int)));
   kpdi::MatchLaunch ml;
   ml.dict = dict_y;
   ml.exp = c->exp_x.as<float>();
@@ -221,6 +223,7 @@ int run_match(kpdi_ctx *c, const float *dict_y, int n_chunk, int n_tiles, int ns
   ml.list_len = list_len;
   ml.part_scores = c->part_s.as<float>();
   ml.part_idx = c->part_i.as<int>();
+  ml.part_cnt = f16 ? c->part_cnt.as<int>() : nullptr;
   ml.bound_score = bound_s;
   ml.bound_idx = bound_i;
   ml.operand_form = operand_form(c);
@@ -628,6 +631,7 @@ int local_pass(kpdi_ctx *c, const float *y, int n_chunk, int n_tiles, int nsplit
   pm.n_src = 1;
   pm.src_scores[0] = c->part_s.as<float>();
   pm.src_idx[0] = c->part_i.as<int>();
+  pm.src_cnt[0] = c->part_counted ? c->part_cnt.as<int>() : nullptr;
   const int lps = lists_per_split(c);
   pm.src_lists[0] = lps * nsplit;
   pm.src_len[0] = len;
@@ -705,6 +709,7 @@ int sweep_prepared(kpdi_ctx *c, const float *y, int64_t n_chunk, int64_t global_
     if (rc) return rc;
     mg.src_scores[ns] = c->part_s.as<float>();
     mg.src_idx[ns] = c->part_i.as<int>();
+    mg.src_cnt[ns] = c->part_counted ? c->part_cnt.as<int>() : nullptr;
     const int lps = lists_per_split(c);
     mg.src_lists[ns] = lps * nsplit;
     mg.src_len[ns] = len;

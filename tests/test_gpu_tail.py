@@ -42,6 +42,8 @@ FORMS = {"tail kernel": {"KPDI_F32_WIDE": "1", "KPDI_TAIL_GEMM": "1"},
     (257, 600, None, "ncc", False, 1),       # keep_n = 1: list length 1
     (4096, 12500, None, "ncc", False, 20),   # one rank's share of configs[1] at N = 8 (24 x 20 pixels here)
     (40, 5000, None, "ndp", False, 32),      # one row block: 20 tiles over up to 256 splits
+    (4096, 26000, 9000, "ncc", False, 20),   # 16 row blocks x 16 splits = 64 lists per pattern, three chunks: the merge takes
+                                             # the lists' counts from its lanes, beside the running best-k of the chunks before
 ])
 def test_tail_kernel_agrees_with_the_oracle_and_with_the_other_kernels(monkeypatch, m, n, chunk, metric, masked, keep_n):
     rng = np.random.default_rng(m + n)
