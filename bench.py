@@ -243,6 +243,22 @@ def rank_share_leg(_lib, make_context, device, key, n_ranks, d_dic, dic_host, re
                       "ceiling_source": "profiles/r03_mfma_power_probe.txt (bare MFMA loop on random f16: power-bound)"},
             "match_form": int(cnt.get("match_form", 0)),
         }
+        # the kernel's counters (fabric traffic, MFMA busy, clock) cannot be read inside this run: the committed rocprofv3 passes
+        # of the same kernel at the same shape are quoted, labelled as what they are (tools/collect_f16_pmc.sh)
+        prof = os.path.join(ROOT, "profiles", "r06_config5_f16_pmc.json")
+        if os.path.exists(prof):
+            with open(prof) as f:
+                pm = json.load(f)
+            rec["roofline_profiled"] = {
+                "kind": "static: read from the committed profile, NOT measured in this run", "source": os.path.relpath(prof, ROOT),
+                "kernel": pm.get("kernel"), "match_ms": pm.get("match_ms"), "frac_of_2500": pm.get("frac_of_2500"),
+                "traffic": pm.get("fetch_bytes", 0) + pm.get("write_bytes", 0),
+                "algorithmic_operand_bytes": pm.get("algorithmic_operand_bytes"),
+                "fetch_over_algorithmic": pm.get("fetch_over_algorithmic"), "fetch_TBps": pm.get("fetch_TBps"),
+                "l2_hit_rate": pm.get("l2_hit_rate"), "mfma_busy": pm.get("mfma_busy"), "clock_GHz": pm.get("clock_GHz"),
+                "lds_bank_conflicts": pm.get("counters_last_launch", {}).get("SQ_LDS_BANK_CONFLICT"),
+                "note": "fabric traffic 8.1 x the prepared operands: 256 x 256 tiles on a 32-CU XCD share at best (4 row blocks + 8 "
+                        "splits) / 32 = 5.3 x (DESIGN.md 4.1b); 2.4 TB/s, not the limiter - the clock is (power: 1.63 GHz, MFMA busy 0.67)"}
         if n_check:
             from oracle import c_oracle
 
@@ -1248,8 +1264,9 @@ def _main(argv, context_factory=None, group_factory=None):
             import kikuchipy_amd as kpa
 
             leg = {"what": "kikuchipy_amd.dictionary_indexing(4096 patterns, 100 000-pattern dictionary in HOST memory, metric='ncc', "
-                           "keep_n=20, n_per_iteration=...) as a user calls it: one engine per call (created, fed over the host "
-                           "link, closed); wall time of the whole call, best of 3 after a warm-up call"}
+                           "keep_n=20, n_per_iteration=...) as a user calls it: the call makes its engine - or takes the idle one "
+                           "the call before left (kikuchipy_amd._lib: engine pool) - feeds it over the host link and hands it "
+                           "back; wall time of the whole call, best of 3 after a warm-up call"}
             for per in (None, 3044):
                 best_t, res = None, None
                 for rep in range(4):

@@ -84,6 +84,24 @@ def test_bench_under_the_launcher():
     check_line(out, "configs[2]")
 
 
+def test_bench_with_eight_ranks_under_the_launcher():
+    """The driver's 8-GPU command, word for word, on CPU (stand-in engines): rank 0's ONE line carries what the scaling
+    record is judged on - `multi_gpu.rccl_ranks == 8` (or a named fallback), every rank's shard, the identical result on
+    every rank, `roofline.max_over_ranks` - and the shards are the eight contiguous blocks of the dictionary."""
+    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+               "127.0.0.1", "--master-port", str(free_port()), WORKER, "--gpus", "8", "--steps", "2", "--warmup", "1",
+               "--check-rows", "8", "--no-cpu-baseline"], {"OMP_NUM_THREADS": "1"})
+    check_line(out, "configs[1]", n_gpus=8)
+    mg = out["multi_gpu"]
+    assert mg["processes"] == 8 and len(mg["per_rank"]) == 8 and [p["rank"] for p in mg["per_rank"]] == list(range(8))
+    assert mg["rccl_ranks"] == 8 or mg["gather_fallback_reason"]
+    sizes = [p["shard"][1] - p["shard"][0] for p in mg["per_rank"]]
+    assert max(sizes) - min(sizes) <= 1 and sum(sizes) == out["config"]["dictionary_patterns"]
+    mo = out["roofline"]["max_over_ranks"]
+    assert 0 <= mo["rank"] < 8 and mo["avg_launch_ms"] > 0
+    assert "dictionary sharded over 8 GPU(s)" in out["config"]["parallelism"] and out["vs_baseline"] is None
+
+
 def test_bench_imports_no_torch():
     text = open(os.path.join(ROOT, "bench.py")).read()
     assert "import torch" not in text and "from torch" not in text

@@ -67,7 +67,12 @@ def test_default_bench_line_and_its_legs():
         assert seam["without_lookahead"]["ms_upload"] > 0
     sa = out["extra"]["standalone_call"]  # the user's call: same result, chunked or not; the chunked call within 1.5 x the single pass
     assert sa["single_pass"]["identical_to_the_timed_result"] and sa["n_per_iteration_3044"]["identical_to_the_timed_result"]
-    assert sa["n_per_iteration_3044"]["ms_per_call"] < 1.5 * sa["single_pass"]["ms_per_call"]
-    # one rank's share of an 8-rank job takes between an eighth and a quarter of the whole step
+    assert sa["n_per_iteration_3044"]["ms_per_call"] < 1.2 * sa["single_pass"]["ms_per_call"]
+    # one rank's share of an 8- (4-) rank job stays within 10 (6) % of an even share of the whole step (VERDICT r05 item 1;
+    # measured 1.066 - 1.08 and 1.035 - 1.044: profiles/r06_rank_share.json), on the wide kernel + tailgemm.hip
     share = out["extra"]["config2_share_of_8"]
-    assert 1.0 <= share["step_over_even_share"] < 2.0, share
+    assert 1.0 <= share["step_over_even_share"] < 1.10 and share["match_form"] == 3 and share["match_frac"] >= 0.85, share
+    share4 = out["extra"]["config2_share_of_4"]
+    assert 1.0 <= share4["step_over_even_share"] < 1.06, share4
+    f16p = f16.get("roofline_profiled")
+    assert f16p and f16p["traffic"] > 0 and f16p["fetch_over_algorithmic"] > 1 and 0 < f16p["mfma_busy"] < 1
