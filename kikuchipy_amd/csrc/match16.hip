@@ -174,7 +174,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
   static_assert(!F32 || WAVES == 4, "the float32 form runs one wave per SIMD");
   typedef Geo<WAVES> G;
   constexpr int NCG = G::NCG;
+#ifdef KPDI16_NO_LEX  // (developer build: round 5's order and tie handling in every instantiation)
+  constexpr bool LEX = false;
+#else
   constexpr bool LEX = !(KMAX == 32 && WAVES == 8);  // (scan16 above)
+#endif
   constexpr int BLOCK16 = G::DBLOCK, STAGE16 = G::STAGE, NSTAGE16 = G::NSTAGE, KSTEPS16 = G::KS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef KPDI16_TIME_PHASES  // developer build: cycles of a launch's phases (tools/probes/one_step.py; profiles/r06_launch_phases.txt)
@@ -831,7 +835,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
 #ifdef KPDI16_NO_DIRECT  // (developer build: every list through the sorted path)
       constexpr bool DIRECT = false;
 #else
-      constexpr bool DIRECT = LEX;
+      // (the one-wave-per-SIMD forms only.  With this path compiled in, the 8-wave float16 kernel took 8 % LONGER as a whole -
+      // 6.3 -> 6.85 ms at K = 14 400, 2.72 -> 2.97 at K = 3600 - although its tile loop and its final stage count the same
+      // cycles and its hot loop is instruction for instruction the same (A/B of developer builds on one box, alternating:
+      // profiles/r06_f16_ab.txt; why is not established - not the scratch size, which is the same either way).  Its final
+      // stage is 20 k cycles of 5 M: there is nothing to gain there for it anyway.)
+      constexpr bool DIRECT = LEX && WAVES == 4;
 #endif
       if (DIRECT && !((built >> cg) & 1)) {
         // ---- the usual case: this list was never built.  The merge kernel takes a partial list as a SET of candidates
@@ -1006,6 +1015,9 @@ static hipError_t launch16_t(const MatchArgs &args_in, int grid, void *scratch, 
   }
   MatchArgs args = args_in;
   if (KMAX == 32 && WAVES == 8) args.perm_rounds = 0;  // (!LEX instantiations: natural order, match16_kernel)
+#ifdef KPDI16_NO_LEX
+  args.perm_rounds = 0;
+#endif
   // scratch: scores of all lists, then their indices
   float *ls = (float *)scratch;
   int *li = (int *)(ls + scratch16_entries(grid, WAVES, KMAX));
