@@ -277,6 +277,14 @@ int kpdi_project_patterns_varying_pc(kpdi_ctx *ctx, const double *rotations, con
  * sy*sx pixels (kpdi_set_problem). */
 int kpdi_push_rotations_chunk(kpdi_ctx *ctx, const double *rotations, int64_t n,
                               int64_t global_start, int rescale, double out_min, double out_max);
+/* the same with ONE PROJECTION CENTRE PER PATTERN - a lazy `get_patterns(rotations, detector)` whose detector holds a PC
+ * for every rotation (signals/ebsd_master_pattern.py:236-241, :274-283: `nav_shape_det != (1,)`): pattern i of the chunk is
+ * projected with pcs[i] = (PCx, PCy, PCz), Bruker convention, on the problem's sy x sx detector (the direction cosines are
+ * formed on the device, as in kpdi_project_patterns_varying_pc), then the chunk is swept.  Needs kpdi_set_master_pattern;
+ * no kpdi_set_detector. */
+int kpdi_push_rotations_chunk_varying_pc(kpdi_ctx *ctx, const double *rotations, const double *pcs, int64_t n,
+                                         int64_t global_start, const double *om_detector_to_sample, int rescale,
+                                         double out_min, double out_max);
 
 /* ---- resident dictionary: one dictionary, many maps -------------------------------
  * The reference prepares the dictionary again for every `dictionary_indexing()` call

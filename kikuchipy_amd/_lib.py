@@ -135,6 +135,7 @@ SIGNATURES = {
     "kpdi_project_patterns": (_i, [_vp, _vp, _i64, _i, C.c_double, C.c_double, _i, _vp]),
     "kpdi_project_patterns_varying_pc": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, C.c_double, C.c_double, _i, _vp]),
     "kpdi_push_rotations_chunk": (_i, [_vp, _vp, _i64, _i64, _i, C.c_double, C.c_double]),
+    "kpdi_push_rotations_chunk_varying_pc": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _i, C.c_double, C.c_double]),
     "kpdi_hold_dictionary_chunk": (_i, [_vp, _vp, _i, _i64, _i64]),
     "kpdi_hold_dictionary_chunk_dev": (_i, [_vp, _vp, _i, _i64, _i64]),
     "kpdi_hold_rotations_chunk": (_i, [_vp, _vp, _i64, _i64, _i, C.c_double, C.c_double]),
@@ -531,6 +532,19 @@ class Context:
         rot = np.ascontiguousarray(rotations, dtype=np.float64).reshape(-1, 4)
         check(self._f.push_rotations_chunk(self._h, _ptr(rot), rot.shape[0], int(global_start),
                                                int(bool(rescale)), float(out_min), float(out_max)))
+
+    def push_rotations_chunk_varying_pc(self, rotations, pcs, global_start, om_detector_to_sample, rescale=False,
+                                        out_min=-1.0, out_max=1.0):
+        """A dictionary chunk simulated on the device with ONE projection centre per pattern, then swept."""
+        rot = np.ascontiguousarray(rotations, dtype=np.float64).reshape(-1, 4)
+        pc = np.ascontiguousarray(pcs, dtype=np.float64).reshape(-1, 3)
+        if pc.shape[0] != rot.shape[0]:
+            raise KpdiError(f"{rot.shape[0]} rotations but {pc.shape[0]} projection centres")
+        om = np.ascontiguousarray(om_detector_to_sample, dtype=np.float64).ravel()
+        if om.size != 9:
+            raise KpdiError("om_detector_to_sample must have 9 elements")
+        check(load().kpdi_push_rotations_chunk_varying_pc(self._h, _ptr(rot), _ptr(pc), rot.shape[0], int(global_start), _ptr(om),
+                                                          int(bool(rescale)), float(out_min), float(out_max)))
 
     # -- refinement
     def refine_set_patterns(self, patterns, signal_mask=None, rescale=False, om_detector_to_sample=None):
@@ -1087,6 +1101,18 @@ class Group(Context):
 
     def project_patterns(self, *args, **kwargs):
         return self.root.project_patterns(*args, **kwargs)
+
+    def push_rotations_chunk_varying_pc(self, rotations, pcs, global_start, om_detector_to_sample, rescale=False,
+                                        out_min=-1.0, out_max=1.0):
+        """One contiguous block of the chunk per member (the members' queues are joined first: this path drives the member
+        contexts from the caller's thread)."""
+        rot = np.ascontiguousarray(rotations, dtype=np.float64).reshape(-1, 4)
+        pc = np.ascontiguousarray(pcs, dtype=np.float64).reshape(-1, 3)
+        self.synchronize()
+        for i, m in enumerate(self.members):
+            a, b = self.chunk_share(rot.shape[0], i, len(self.members))
+            if b > a:
+                m.push_rotations_chunk_varying_pc(rot[a:b], pc[a:b], global_start + a, om_detector_to_sample, rescale, out_min, out_max)
 
     def project_patterns_varying_pc(self, *args, **kwargs):
         return self.root.project_patterns_varying_pc(*args, **kwargs)

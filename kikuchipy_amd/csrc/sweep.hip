@@ -1047,6 +1047,24 @@ int kpdi_push_rotations_chunk(kpdi_ctx *c, const double *rotations, int64_t n, i
   return push_chunk_dev(c, c->dict_raw.p, KPDI_F32, n, global_start, true);
 }
 
+int kpdi_push_rotations_chunk_varying_pc(kpdi_ctx *c, const double *rotations, const double *pcs, int64_t n,
+                                         int64_t global_start, const double *om, int rescale, double out_min, double out_max) {
+  if (!c) return fail(KPDI_EINVAL, "ctx is NULL");
+  if (!pcs || !om) return fail(KPDI_EINVAL, "NULL argument");
+  if (!c->have_problem) return fail(KPDI_EINVAL, "kpdi_set_problem has not been called");
+  int rc = check_chunk_args(c, KPDI_F32, n, global_start);
+  if (rc) return rc;
+  rc = use_device(c);
+  if (rc) return rc;
+  // (every pattern has its own direction cosines: projected into the raw chunk buffer, then swept like a resident chunk;
+  // the projection centres are read before this returns)
+  HIPCHK(c->dict_raw.reserve((size_t)n * c->npix * sizeof(float)));
+  const VarPc var{pcs, c->sy, c->sx, om};
+  rc = project_to_device(c, rotations, n, rescale, out_min, out_max, KPDI_F32, c->dict_raw.p, &var);
+  if (rc) return rc;
+  return push_chunk_dev(c, c->dict_raw.p, KPDI_F32, n, global_start, true);
+}
+
 int kpdi_hold_rotations_chunk(kpdi_ctx *c, const double *rotations, int64_t n, int64_t global_start, int rescale,
                               double out_min, double out_max) {
   if (!c) return fail(KPDI_EINVAL, "ctx is NULL");

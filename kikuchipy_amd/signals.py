@@ -397,22 +397,12 @@ class EBSDMasterPattern:
             rescale = False
             out_min, out_max = 1, 2
         master_upper, master_lower = self._get_master_pattern_arrays_from_energy(energy)
-        if detector.navigation_size != 1:
-            # one PC per rotation (signals/ebsd_master_pattern.py:236-241, :274-281)
-            if not compute:
-                raise NotImplementedError("one projection centre per pattern needs compute=True")
-            with _lib.Context(self._device) as ctx:
-                ctx.set_master_pattern(np.ascontiguousarray(master_upper), np.ascontiguousarray(master_lower))
-                data = ctx.project_patterns_varying_pc(rot.reshape(-1, 4), detector.pc_flattened, detector.shape,
-                                                       detector.detector_to_sample, rescale, out_min, out_max,
-                                                       dtype_out)
-            out = EBSD(data.reshape(nav_shape + detector.shape), xmap=DictionaryXmap(rot.reshape(-1, 4), self.phase_name),
-                       device=self._device)
-            out.detector = detector
-            return out
+        # one PC per rotation (signals/ebsd_master_pattern.py:236-241, :274-283: `nav_shape_det != (1,)`): the lazy
+        # dictionary carries the PCs and every chunk is projected with them on the device, inside the indexing loop
+        pcs = detector.pc_flattened if detector.navigation_size != 1 else None
         lazy = ProjectedDictionary(np.ascontiguousarray(master_upper), np.ascontiguousarray(master_lower),
                                    rot.reshape(-1, 4), detector, rescale, out_min, out_max, dtype_out,
-                                   device=self._device, chunk=kwargs.get("chunk_shape"))
+                                   device=self._device, chunk=kwargs.get("chunk_shape"), pcs=pcs)
         xmap = DictionaryXmap(rot.reshape(-1, 4), self.phase_name)
         if compute:
             data = lazy.compute().reshape(nav_shape + detector.shape)

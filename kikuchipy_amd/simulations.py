@@ -30,10 +30,15 @@ class ProjectedDictionary:
     (`ndim`, `shape`, `dtype`, `chunksize`, slicing along axis 0, `compute()`)."""
 
     def __init__(self, master_upper, master_lower, rotations, detector, rescale, out_min, out_max,
-                 dtype_out=np.float32, device=0, chunk=None, _root=None):
+                 dtype_out=np.float32, device=0, chunk=None, _root=None, pcs=None):
+        """`pcs`: None - the detector's one projection centre for every pattern; (N, 3) - one PC per pattern (a detector
+        with a PC for every rotation: signals/ebsd_master_pattern.py:236-241, :274-283 of the reference)."""
         self.master_upper = master_upper
         self.master_lower = master_lower
         self.rotations = np.ascontiguousarray(rotations, dtype=np.float64).reshape(-1, 4)
+        self.pcs = None if pcs is None else np.ascontiguousarray(pcs, dtype=np.float64).reshape(-1, 3)
+        if self.pcs is not None and self.pcs.shape[0] != self.rotations.shape[0]:
+            raise ValueError(f"{self.rotations.shape[0]} rotations but {self.pcs.shape[0]} projection centres")
         self.detector = detector
         self.rescale = bool(rescale)
         self.out_min, self.out_max = float(out_min), float(out_max)
@@ -76,7 +81,7 @@ class ProjectedDictionary:
             raise IndexError("a ProjectedDictionary can only be sliced along its first axis")
         return ProjectedDictionary(self.master_upper, self.master_lower, self.rotations[key], self.detector,
                                    self.rescale, self.out_min, self.out_max, self.dtype, self.device,
-                                   self._chunk, _root=self._root)
+                                   self._chunk, _root=self._root, pcs=None if self.pcs is None else self.pcs[key])
 
     # ---- engine
     def configure(self, ctx):
@@ -85,6 +90,13 @@ class ProjectedDictionary:
         # refinement on the same context (which loads ITS master pattern) cannot leave a stale match;
         # the detector enters by value: an in-place change of its PC must reach the engine
         det = self.detector
+        if self.pcs is not None:  # one PC per pattern: the direction cosines are formed on the device, per pattern
+            key = (id(self.master_upper), id(self.master_lower), "one PC per pattern")
+            if getattr(ctx, "_projection_key", None) != key:
+                ctx.set_master_pattern(self.master_upper, self.master_lower)
+                ctx._projection_key = key
+                ctx._projection_refs = (self.master_upper, self.master_lower, det)
+            return
         key = (id(self.master_upper), id(self.master_lower), tuple(np.ravel(det.gnomonic_bounds)), float(det.pcz),
                det.nrows, det.ncols, tuple(np.ravel(det.detector_to_sample)))
         if getattr(ctx, "_projection_key", None) != key:
@@ -102,12 +114,16 @@ class ProjectedDictionary:
             ctx.push_dictionary_chunk(self.compute(ctx), global_start)
             return
         self.configure(ctx)
+        if self.pcs is not None:
+            ctx.push_rotations_chunk_varying_pc(self.rotations, self.pcs, global_start, self.detector.detector_to_sample,
+                                                self.rescale, self.out_min, self.out_max)
+            return
         ctx.push_rotations_chunk(self.rotations, global_start, self.rescale, self.out_min, self.out_max)
 
     def hold_in_engine(self, ctx, global_start):
         """Generate this (slice of the) dictionary in device memory and keep it prepared there
         (`kikuchipy_amd.ResidentDictionary`)."""
-        if self.dtype != np.float32:
+        if self.dtype != np.float32 or self.pcs is not None:
             ctx.hold_dictionary_chunk(self.compute(ctx), global_start)
             return
         self.configure(ctx)
@@ -125,8 +141,13 @@ class ProjectedDictionary:
         n, step = len(self), self.chunksize[0]
         flat = out.reshape(n, -1)
         for a in range(0, n, step):
-            flat[a:a + step] = ctx.project_patterns(self.rotations[a:a + step], self.rescale, self.out_min,
-                                                    self.out_max, self.dtype)
+            if self.pcs is not None:
+                flat[a:a + step] = ctx.project_patterns_varying_pc(self.rotations[a:a + step], self.pcs[a:a + step],
+                                                                   self.detector.shape, self.detector.detector_to_sample,
+                                                                   self.rescale, self.out_min, self.out_max, self.dtype)
+            else:
+                flat[a:a + step] = ctx.project_patterns(self.rotations[a:a + step], self.rescale, self.out_min,
+                                                        self.out_max, self.dtype)
         return out
 
     def __array__(self, dtype=None, copy=None):

@@ -116,6 +116,37 @@ def test_get_patterns_with_one_pc_per_rotation(g):
     assert np.allclose(sim.data.reshape(4, -1), g["varpc_u8mp_f32__patterns"], rtol=3e-7, atol=3e-7)
 
 
+def test_lazy_dictionary_with_one_pc_per_rotation(g):
+    """`get_patterns(rotations, detector)` with a PC for every rotation and `compute=False` - the branch
+    `nav_shape_det != (1,)` of signals/ebsd_master_pattern.py:236-241, :274-283 - is a LAZY dictionary whose chunks are
+    projected with their own PCs on the device inside the indexing loop (`kpdi_push_rotations_chunk_varying_pc`): its
+    patterns are the reference's (golden `varpc_*`), and indexing against it equals indexing against the computed array."""
+    import kikuchipy_amd as ka
+
+    mp = ka.EBSDMasterPattern(np.stack([g["mp_upper"], g["mp_lower"]]))
+    det = ka.EBSDDetector(shape=(60, 60), pc=g["varpc__pcs"])
+    sim = mp.get_patterns(g["rot8"][:4], det)                      # compute=False
+    assert type(sim.data).__name__ == "ProjectedDictionary" and sim.data.pcs.shape == (4, 3)
+    assert np.allclose(sim.data.compute().reshape(4, -1), g["varpc_u8mp_f32__patterns"], rtol=3e-7, atol=3e-7)
+    # a dictionary worth indexing: 700 rotations, PCs scattered around the detector's, chunks of 300
+    rng = np.random.default_rng(21)
+    q = rng.standard_normal((700, 4))
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    pcs = np.array([0.42, 0.78, 0.5]) + 0.02 * rng.standard_normal((700, 3))
+    det = ka.EBSDDetector(shape=(60, 60), pc=pcs)
+    lazy = mp.get_patterns(q, det, chunk_shape=300)
+    dense = mp.get_patterns(q, det, compute=True)
+    assert np.array_equal(lazy.data.compute(), dense.data)
+    exp = np.clip((dense.data[::70] + 1) * 100 + 5 * rng.standard_normal((10, 60, 60)), 0, 255).astype(np.uint8)  # (float32 output is rescaled to [-1, 1])
+    s = ka.EBSD(exp)
+    a = s.dictionary_indexing(lazy, keep_n=5, verbose=False)
+    b = s.dictionary_indexing(dense, keep_n=5, verbose=False)
+    assert np.array_equal(a.scores, b.scores) and np.array_equal(a.simulation_indices, b.simulation_indices)
+    assert list(a.simulation_indices[:, 0]) == list(range(0, 700, 70))
+    c = s.dictionary_indexing(lazy, keep_n=5, devices=[0, 0], verbose=False)   # ... and over a group's members
+    assert np.array_equal(a.scores, c.scores) and np.array_equal(a.simulation_indices, c.simulation_indices)
+
+
 def test_single_hemisphere_and_f64_output(ctx, g):
     up = g["mp_upper"].astype(np.float32)
     ctx.set_master_pattern(up)  # lower = upper

@@ -84,8 +84,12 @@ def test_detector_with_one_pc_per_point():
     mp = ka.EBSDMasterPattern(np.zeros((11, 11)))
     with pytest.raises(ValueError, match="must be equal to `rotations.shape`"):
         mp.get_patterns(np.array([[1.0, 0, 0, 0]]), det)
-    with pytest.raises(NotImplementedError, match="needs compute=True"):
+    with pytest.raises(NotImplementedError, match="pass compute=True"):  # (a LAZY result is one-dimensional)
         mp.get_patterns(np.tile([1.0, 0, 0, 0], (2, 2, 1)), det)
+    flat = ka.EBSDDetector(shape=(60, 60), pc=pcs.reshape(4, 3))
+    lazy = mp.get_patterns(np.tile([1.0, 0, 0, 0], (4, 1)), flat).data  # one PC per rotation, lazily (no GPU touched yet)
+    assert lazy.shape == (4, 60, 60) and lazy.pcs.shape == (4, 3) and lazy[1:3].pcs.shape == (2, 3)
+    assert np.array_equal(lazy[1:3].pcs, pcs.reshape(4, 3)[1:3])
     tsl = ka.EBSDDetector(shape=(60, 80), pc=[[0.35, 1, 0.65], [0.1, 0.2, 0.3]], convention="tsl")
     assert np.allclose(tsl.pc, [[0.35, 0, 0.65], [0.1, 0.8, 0.3]])
 
