@@ -840,7 +840,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
       // cycles and its hot loop is instruction for instruction the same (A/B of developer builds on one box, alternating:
       // profiles/r06_f16_ab.txt; why is not established - not the scratch size, which is the same either way).  Its final
       // stage is 20 k cycles of 5 M: there is nothing to gain there for it anyway.)
+#ifdef KPDI16_DIRECT_ALL  // (developer build: the A/B of profiles/r06_f16_ab.txt)
+      constexpr bool DIRECT = LEX;
+#else
       constexpr bool DIRECT = LEX && WAVES == 4;
+#endif
 #endif
       if (DIRECT && !((built >> cg) & 1)) {
         // ---- the usual case: this list was never built.  The merge kernel takes a partial list as a SET of candidates
