@@ -151,3 +151,46 @@ def test_ebsd_keeps_its_group(monkeypatch):
     assert len(made) == 1 and np.array_equal(a.simulation_indices, b.simulation_indices)
     rs, ri = ko.dictionary_indexing(s.data, d.data, keep_n=4)
     ko.assert_topk_parity(a.scores, a.simulation_indices, rs, ri, atol=1e-5)
+
+
+def test_a_one_shot_call_hands_its_engine_back_or_closes_it(monkeypatch):
+    """The stand-alone driver's own engine (metric given by name): a call that SUCCEEDS hands it to the engine pool for the
+    next call on the same device; a call that FAILS half-way closes it at once (not when the garbage collector
+    finds the metric); the progress callback fires after each chunk has been handed over, in order; `KPDI_ENGINE_CACHE=0`
+    closes every engine with its call."""
+    import kikuchipy_amd as ka
+    from kikuchipy_amd import _lib
+
+    class Engine(StandInContext):
+        closed = 0
+        fail_at = None
+
+        def push_dictionary_chunk(self, patterns, global_start):
+            if Engine.fail_at is not None and global_start >= Engine.fail_at:
+                raise _lib.KpdiError("injected upload failure")
+            events.append(("push", global_start))
+            return super().push_dictionary_chunk(patterns, global_start)
+
+        def close(self):
+            Engine.closed += 1
+            super().close()
+
+    made, events = [], []
+    monkeypatch.setattr(_lib, "make_engine", lambda device=0, devices=None, gather=None: made.append(Engine(device)) or made[-1])
+    rng = np.random.default_rng(9)
+    exp = rng.integers(0, 256, (6, 12, 10), dtype=np.uint8)
+    dic = rng.random((90, 12, 10), dtype=np.float32)
+    a = ka.dictionary_indexing(exp, dic, keep_n=4, n_per_iteration=30, device=0, verbose=False,
+                               progress=lambda done, total: events.append(("progress", done, total)))
+    assert events == [("push", 0), ("progress", 1, 3), ("push", 30), ("progress", 2, 3), ("push", 60), ("progress", 3, 3)]
+    assert len(made) == 1 and Engine.closed == 0 and _lib._ENGINE_POOL[((0,), None)] is made[0]
+    b = ka.dictionary_indexing(exp, dic, keep_n=4, device=0, verbose=False)      # the idle engine serves the next call
+    assert len(made) == 1 and np.array_equal(a.simulation_indices, b.simulation_indices)
+    Engine.fail_at = 30
+    with pytest.raises(_lib.KpdiError, match="injected upload failure"):
+        ka.dictionary_indexing(exp, dic, keep_n=4, n_per_iteration=30, device=0, verbose=False)
+    assert Engine.closed == 1 and not _lib._ENGINE_POOL                           # closed by the failing call, not kept
+    Engine.fail_at = None
+    monkeypatch.setenv("KPDI_ENGINE_CACHE", "0")
+    ka.dictionary_indexing(exp, dic, keep_n=4, device=0, verbose=False)
+    assert len(made) == 2 and Engine.closed == 2 and not _lib._ENGINE_POOL
