@@ -7,8 +7,10 @@ mask).  bench.py's headline uses i.i.d. uniform-random patterns - the friendlies
 fused top-k.  This module builds, from what the repo ships and nothing else:
 
   * the Ni master pattern the reference ships (tests/golden/projection.npz: mp_upper / mp_lower, uint8 401 x 401);
-  * a dictionary of 100 000 orientations on a Bunge-Euler lattice in LEXICOGRAPHIC order (80 x 25 x 50 = phi1 x Phi x phi2,
-    the order a sampler emits: neighbours in index are neighbours in orientation, long runs of similar scores),
+  * a dictionary of 100 000 orientations AS THE REFERENCE'S SAMPLER EMITS THEM: `get_sample_fundamental` (cubochoric
+    sampling of the cubic fundamental zone, kikuchipy_amd/sampling.py - the restatement of orix's, pinned by the
+    reference's own numbers) at 67 steps per semi-edge (~2 degrees: 100 347 orientations, the first 100 000 of them), in
+    its lexicographic order - neighbours in index are neighbours in orientation, long runs of similar scores -
     projected on the device (kpdi::project_kernel);
   * 4096 experimental patterns laid out as a 64 x 64 MAP OF A FEW DOZEN GRAINS (Voronoi cells; neighbouring rows share an
     orientation up to 0.2 degrees of scatter), each a projection of the same master pattern under a smooth detector
@@ -31,17 +33,23 @@ F32_MFMA_PEAK_TFLOPS = 157.3
 # detector of the reference's Ni test data (tests/golden/projection.npz det60: pc (0.421, 0.7794, 0.5049), tilt 0,
 # sample tilt 70)
 PC = (0.421, 0.7794, 0.5049)
-LATTICE = (80, 25, 50)  # phi1 x Phi x phi2 steps -> 100 000 orientations
+SEMI_EDGE_STEPS = 67  # cubochoric grid of the dictionary: 100 347 orientations in the cubic fundamental zone (~2 degrees)
 
 
-def euler_lattice(n1=LATTICE[0], n2=LATTICE[1], n3=LATTICE[2]):
-    """(n1 n2 n3, 3) Bunge angles (radians), lexicographic: phi1 slowest, phi2 fastest.  phi1 in [0, 360), Phi in
-    (0, 90], phi2 in [0, 90): the cubic (m-3m) Euler box a lattice sampler walks."""
-    p1 = (np.arange(n1) + 0.5) * (2 * np.pi / n1)
-    p = (np.arange(n2) + 0.5) * (0.5 * np.pi / n2)
-    p2 = (np.arange(n3) + 0.5) * (0.5 * np.pi / n3)
-    g = np.stack(np.meshgrid(p1, p, p2, indexing="ij"), axis=-1)
-    return g.reshape(-1, 3)
+def quaternion_multiply(a, b):
+    """Hamilton product of (..., 4) quaternions (a, b, c, d)."""
+    a0, a1, a2, a3 = np.moveaxis(a, -1, 0)
+    b0, b1, b2, b3 = np.moveaxis(b, -1, 0)
+    return np.stack([a0 * b0 - a1 * b1 - a2 * b2 - a3 * b3, a0 * b1 + a1 * b0 + a2 * b3 - a3 * b2,
+                     a0 * b2 - a1 * b3 + a2 * b0 + a3 * b1, a0 * b3 + a1 * b2 - a2 * b1 + a3 * b0], axis=-1)
+
+
+def small_rotations(rng, n, degrees):
+    """n rotations by angles ~ N(0, degrees) about random axes, as quaternions."""
+    axis = rng.standard_normal((n, 3))
+    axis /= np.linalg.norm(axis, axis=1)[:, None]
+    half = 0.5 * np.deg2rad(degrees) * rng.standard_normal(n)
+    return np.column_stack([np.cos(half), axis * np.sin(half)[:, None]])
 
 
 def grain_map(ny=64, nx=64, n_grains=40, seed=11):
@@ -67,24 +75,25 @@ def master_pattern():
     return z["mp_upper"].astype(np.float32), z["mp_lower"].astype(np.float32)
 
 
-def build(ctx, m=4096, sy=60, sx=60, seed=11, lattice=LATTICE):
+def build(ctx, m=4096, sy=60, sx=60, seed=11, n=100000):
     """Inputs of the structured workload, made with the engine's own projection kernel on `ctx`:
     (exp uint8 (m, sy, sx), dictionary float32 (n, sy, sx) in sampler order, static background uint8 (sy, sx))."""
-    from kikuchipy_amd.indexing._refinement import rotation_from_euler
+    from kikuchipy_amd.sampling import get_sample_fundamental
 
     rng = np.random.default_rng(seed)
+    rot = get_sample_fundamental(semi_edge_steps=SEMI_EDGE_STEPS, point_group="m-3m")[:n]
     mpu, mpl = master_pattern()
     ctx.set_master_pattern(mpu, mpl)
     bounds, pcz, det_to_sample = detector_geometry(sy, sx)
     ctx.set_detector(bounds, pcz, sy, sx, det_to_sample)
-    dic = ctx.project_patterns(rotation_from_euler(euler_lattice(*lattice))).reshape(-1, sy, sx)
+    dic = ctx.project_patterns(rot).reshape(-1, sy, sx)
     side = int(round(np.sqrt(m)))
     assert side * side == m, "the experimental set is a square map"
     labels = grain_map(side, side, 40, seed)
-    grain_euler = np.column_stack([rng.uniform(0, 2 * np.pi, 40), rng.uniform(0.05, 0.5 * np.pi, 40),
-                                   rng.uniform(0, 0.5 * np.pi, 40)])
-    eu = grain_euler[labels] + np.deg2rad(0.2) * rng.standard_normal((m, 3))
-    sim = ctx.project_patterns(rotation_from_euler(eu)).reshape(m, sy, sx)
+    # a grain = an orientation of the fundamental zone, off the dictionary's grid by ~0.7 degrees; its points scatter by 0.2
+    grains = quaternion_multiply(rot[rng.choice(len(rot), 40, replace=False)], small_rotations(rng, 40, 0.7))
+    points = quaternion_multiply(grains[labels], small_rotations(rng, m, 0.2))
+    sim = ctx.project_patterns(points).reshape(m, sy, sx)
     # raw detector image: a smooth background hump carrying ~10 % Kikuchi contrast, plus noise
     yy, xx = np.mgrid[:sy, :sx]
     hump = 60.0 + 140.0 * np.exp(-((yy - 0.45 * sy) ** 2 + (xx - 0.55 * sx) ** 2) / (2 * (0.47 * sy) ** 2))
@@ -212,8 +221,8 @@ def leg(_lib, device, reps=8, n_check=64, m=4096, sy=60, sx=60, keep_n=20, hosti
         out = {
             "what": f"configs[1]'s size on PHYSICAL structure: {m} patterns = a {int(np.sqrt(m))} x {int(np.sqrt(m))} map of 40 "
                     f"grains (0.2 deg scatter), projections of the Ni master pattern the reference ships under a smooth detector "
-                    f"background + noise, uint8; dictionary = {n} orientations on a Bunge-Euler lattice "
-                    f"{LATTICE[0]} x {LATTICE[1]} x {LATTICE[2]} in the sampler's (lexicographic) order, projected on the device; "
+                    f"background + noise, uint8; dictionary = the first {n} orientations of get_sample_fundamental (cubochoric, cubic "
+                    f"fundamental zone, {SEMI_EDGE_STEPS} steps per semi-edge ~ 2 degrees) in the sampler's order, projected on the device; "
                     "static + dynamic background subtract + circular mask fused pre-kernel, ncc, keep_n=20, raw inputs resident",
             "kept_pixels": int(cnt["k_kept"]),
             "best_score_mean": float(scores[:, 0].mean()),

@@ -26,6 +26,7 @@ from kikuchipy_amd.signals import EBSD, DictionaryXmap, EBSDMasterPattern  # noq
 from kikuchipy_amd.simulations import ProjectedDictionary  # noqa: E402,F401
 from kikuchipy_amd.io import load  # noqa: E402,F401
 from kikuchipy_amd import filters  # noqa: E402,F401
+from kikuchipy_amd.sampling import get_sample_fundamental  # noqa: E402,F401
 
 from kikuchipy_amd._lib import clear_engine_cache  # noqa: E402,F401
 
@@ -44,6 +45,7 @@ __all__ = [
     "clear_engine_cache",
     "dictionary_indexing",
     "filters",
+    "get_sample_fundamental",
     "load",
     "merge_crystal_maps",
     "orientation_similarity_map",

@@ -62,7 +62,7 @@ def rows(d):
             f"{k(c3['patterns_per_s'])} patterns/s, match {c3['match_frac']:.3f} of peak, pre-kernel {c3['prekernel_ms'] * 1e3:.0f} µs", "`extra.config3`")
     st = e.get("structured_config2")
     if st:
-        add("the same size on **structured data**: 64 × 64 grain map × orientation-ordered Ni dictionary (sampler order)",
+        add("the same size on **structured data**: 64 × 64 grain map × Ni dictionary of `get_sample_fundamental` (cubochoric, sampler order)",
             f"{k(st['patterns_per_s'])} patterns/s, match **{st['match_frac']:.3f}** of peak; "
             f"{st.get('candidates_appended_per_lane_list', '?')} candidates appended per lane list, "
             f"{st.get('buffer_overflows_per_launch', '?')} buffer overflows per launch", "`extra.structured_config2`")
