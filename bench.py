@@ -1287,12 +1287,18 @@ def _main(argv, context_factory=None, group_factory=None):
     if solo and not a.no_generation:
         try:
             # informational: the dictionary is SIMULATED on the device inside the step
-            # from n rotations (32 B each over PCIe) and a 401 x 401 x 2 synthetic master pattern, then
-            # swept as above.  Never `value`.
-            rng = np.random.default_rng(7)
-            quat = rng.standard_normal((w["n"], 4))
-            quat /= np.linalg.norm(quat, axis=1)[:, None]
-            ctx.set_master_pattern(rng.random((401, 401), dtype=np.float32), rng.random((401, 401), dtype=np.float32))
+            # from n rotations (32 B each over PCIe) - the orientations `get_sample_fundamental` emits for the cubic
+            # fundamental zone, in its order - and the Ni master pattern the reference ships (2 x 401 x 401,
+            # tests/golden/projection.npz), then swept as above.  Never `value`.
+            import bench_structured
+            from kikuchipy_amd.sampling import get_sample_fundamental
+
+            quat = get_sample_fundamental(semi_edge_steps=bench_structured.SEMI_EDGE_STEPS, point_group="m-3m")
+            if len(quat) < w["n"]:  # (a workload larger than the sampler's 100 347: random orientations fill up)
+                fill = np.random.default_rng(7).standard_normal((w["n"] - len(quat), 4))
+                quat = np.concatenate([quat, fill / np.linalg.norm(fill, axis=1)[:, None]])
+            quat = np.ascontiguousarray(quat[:w["n"]])
+            ctx.set_master_pattern(*bench_structured.master_pattern())
             pc = (0.421, 0.7794, 0.5049)
             aspect = w["sx"] / w["sy"]
             bounds = [-aspect * pc[0] / pc[2], aspect * (1 - pc[0]) / pc[2], -(1 - pc[1]) / pc[2], pc[1] / pc[2]]
@@ -1313,7 +1319,8 @@ def _main(argv, context_factory=None, group_factory=None):
             pj = ctx.counters()["project_ms"] / reps
             ctx.set_profiling(False)
             out["extra"]["dictionary_generation"] = {
-                "what": "100k patterns projected from a 2x401x401 master pattern inside the step (kpdi::project_kernel)",
+                "what": "the dictionary's patterns projected from the Ni master pattern (2 x 401 x 401) at the sampler's orientations "
+                        "(get_sample_fundamental, cubic fundamental zone, sampler order) inside the step (kpdi::project_kernel)",
                 "project_ms_per_step": round(pj, 3),
                 "gpixel_per_s": round(w["n"] * w["sy"] * w["sx"] / (pj * 1e-3) / 1e9, 1),
                 "patterns_per_s_including_generation": round(w["m"] / dt, 1),
@@ -1329,6 +1336,7 @@ def _main(argv, context_factory=None, group_factory=None):
             # on a few of the patterns.  Never `value`.
             from kikuchipy_amd.indexing._refinement import rotation_from_euler
 
+            rng = np.random.default_rng(7)
             eu = np.column_stack([rng.uniform(0.3, 6, w["m"]), rng.uniform(0.3, 2.8, w["m"]), rng.uniform(0.3, 6, w["m"])])
             mpu = np.fft.irfft2(np.fft.rfft2(rng.standard_normal((401, 401))) * np.exp(
                 -(np.add.outer(np.fft.fftfreq(401) ** 2, np.fft.rfftfreq(401) ** 2)) / (2 * 0.03**2)), s=(401, 401))

@@ -29,7 +29,7 @@ constexpr double FORM_WIDE_GAIN_K = 0.02;
 // (KPDI_FORM_WIDE_LAUNCH overrides it for fitting runs of tools/form_probe.py; after the first tile's candidates left the
 // buffers - launch 0.20 -> 0.166 ms - 1.0 and 0.9 leave the grid's worst point and mean regret where they are, 0.8 adds a 7 % miss)
 constexpr double FORM_WIDE_LAUNCH = 1.1;
-// Round 6 (profiles/r06_form_choice.json, 80 shapes, with the last partial round on tailgemm.hip): for sweeps of ONE launch
+// Round 6 (profiles/r06_form_choice_launch0.6.json / _launch0.45.json, 80 shapes, with the last partial round on tailgemm.hip): for sweeps of ONE launch
 // (M <= 4096 here) the wide kernel now wins from 12 500 dictionary patterns up - one rank's share of configs[1] at N = 8
 // 2.92 vs 3.01 ms, at N = 4 5.57 vs 5.67 - which the constant above (fitted when a launch cost 0.2 ms and the tail a quarter
 // round) hid; 0.6 gets every single-launch shape of the grid right (worst 0.6 %).  Sweeps of several launches (M = 10 000:

@@ -816,6 +816,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void match16_kernel(MatchArg
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg) {
       const size_t ol = (size_t)(m_lane + 32 * cg) * lists + (size_t)list_id, o = ol * KMAX;
+#ifdef KPDI16_SKIP_FINAL  // (developer build, TIMING ONLY - results are wrong: what a launch costs without its final stage)
+      if (LEX) {
+        a.part_cnt[ol] = 0;
+        continue;
+      }
+#endif
       // a candidate below the bound has KMAX better ones somewhere among the pattern's lists
 #ifdef KPDI16_TIME_PHASES
       const unsigned long long fs0 = __builtin_readcyclecounter();

@@ -15,13 +15,13 @@
 //     loads what IT needs - 3 x 1 KB of its column group + 3 x 1 KB of the dictionary rows - into its own part of LDS, six
 //     lane-linear LDS-DMA pieces per step.  The dictionary pieces are thereby loaded four times per workgroup (from L2:
 //     9 KB per step) - and NO wave ever waits for another: no barrier in the kernel (one per step cost a quarter of the
-//     matrix pipe's time: 64.8 -> us for 212 rows, profiles/r06_tail_kernel.txt);
+//     matrix pipe's time; without it 212 rows x 4096 patterns take 60-63 us, profiles/r06_share8_kernel_stats.csv);
 //   * a ring of SIX stages of 4 x 6 KB, loads running FIVE steps ahead (5 x 768 cycles of matrix work hide the latency),
 //     one `s_waitcnt vmcnt` per step, the fragments of step s + 1 read while the MFMAs of step s run;
 //   * NO fused top-k: the 32 x 128 scores go to a small matrix S[row][pattern] (212 x 4096 floats = 3.5 MB); by then the
-//     main kernel has finished and the shared rejection bound of every pattern is FINAL, so tail_select_kernel (one
-//     thread per pattern, coalesced over patterns) passes a handful of the rows to a sorted list that joins the merge
-//     as a source of its own (sweep.hip).
+//     main kernel has finished and the shared rejection bound of every pattern is FINAL, so tail_select_kernel (16
+//     patterns x 16 row classes per workgroup, coalesced over patterns, candidates collected in LDS) passes a handful of
+//     the rows to a sorted list that joins the merge as a source of its own (sweep.hip).
 // Arithmetic: the same `v_mfma_f32_32x32x2_f32` sequence per accumulator as match16.hip (plane by plane, element j of the
 // two 16-byte fragments feeds MFMA j), so every score is bit for bit what the main kernel would have produced - results
 // do not depend on which kernel took a row (tests/test_gpu_engine.py: the two f32 kernels agree; chunking invariance).

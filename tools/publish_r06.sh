@@ -39,7 +39,7 @@ if [ -s $O/standalone_call.txt ]; then
     echo "# KPDI_ENGINE_CACHE=0: one engine per call, created and destroyed by it (rounds 1-5)"; cat $O/standalone_call_nocache.txt; } > profiles/r06_standalone_call.txt
 fi
 [ -s $O/ramp_wide.txt ] && { echo "# per-launch cost of the wide f32 kernel = intercept of match ms against whole tiles per workgroup (tools/tile_ramp_probe.py wide; profiling level 1)"; cat $O/ramp_wide.txt; } > profiles/r06_tile_ramp.txt
-[ -s $O/launch_phases.txt ] && { echo "# one rank's share at N = 8 on a developer build of match16.hip (-DKPDI16_TIME_PHASES, tools/probes/share_step.py): shader cycles of a launch's phases, blocks 0 / 100 / 255, wave 0"; grep -a "^block\|^---" $O/launch_phases.txt; } > profiles/r06_launch_phases_final.txt
+grep -aq "^block" $O/launch_phases.txt 2>/dev/null && { echo "# one rank's share at N = 8 on a developer build of match16.hip (-DKPDI16_TIME_PHASES, tools/probes/share_step.py): shader cycles of a launch's phases, blocks 0 / 100 / 255, wave 0"; grep -a "^block\|^---" $O/launch_phases.txt; } > profiles/r06_launch_phases.txt
 grep -a "passed\|failed" $O/pytest_gpu.log | tail -2 > profiles/r06_pytest_gpu.txt
 tail -2 $O/stress.log > profiles/r06_stress.txt
 python tools/make_measurements.py
