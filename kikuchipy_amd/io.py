@@ -13,16 +13,25 @@ from kikuchipy_amd.detectors import EBSDDetector
 from kikuchipy_amd.signals import EBSD, DictionaryXmap
 
 
-def load(filename, scan_group_names=None, device=None, devices=None):
-    """Load one scan of a kikuchipy h5ebsd file.
+def load(filename, lazy=False, *, scan_group_names=None, device=None, devices=None):
+    """Load one scan of a kikuchipy h5ebsd file - `kikuchipy.load(filename, lazy=False, **kwargs)`
+    (io/_io.py:57-150) with the h5ebsd reader's keyword (io/plugins/kikuchipy_h5ebsd/_api.py:64-78).
 
+    lazy
+        Accepted as in the reference.  The patterns are read into host memory at once either way: this
+        package's `EBSD` holds an array, the engine takes it from there in pieces.
     scan_group_names
         Name of the scan group ("Scan 1"); the first scan of the file if not
         given (as in the reference).  A list loads several scans and returns a
         list, like `kikuchipy.load`.
+    device, devices
+        Where the returned signal's engine lives (see `EBSD`).
     """
+    if not isinstance(lazy, (bool, np.bool_)):
+        raise TypeError(f"`lazy` must be a bool, not {type(lazy).__name__} (the scan is named by the keyword "
+                        "`scan_group_names`, as in kikuchipy.load)")
     if isinstance(scan_group_names, (list, tuple)):
-        return [load(filename, name, device, devices) for name in scan_group_names]
+        return [load(filename, lazy, scan_group_names=name, device=device, devices=devices) for name in scan_group_names]
     info, pats, bg, pc = _lib.h5ebsd_read(str(filename), scan_group_names)
     ny, nx, sy, sx = info.ny, info.nx, info.sy, info.sx
     # the reference squeezes singleton navigation axes (io/plugins/_h5ebsd.py:366)

@@ -112,6 +112,9 @@ class EBSD:
         out = EBSD(np.array(self.data, copy=True),
                    None if self.static_background is None else np.array(self.static_background),
                    self.xmap, self.step_sizes, self.scan_unit, self._device, self._devices)
+        for name in ("detector", "original_metadata"):
+            if hasattr(self, name):
+                setattr(out, name, getattr(self, name))
         return out
 
     @property
@@ -151,8 +154,23 @@ class EBSD:
         return ids[0], self._groups[key]
 
     # ------------------------------------------------------------------ pre-processing
-    def remove_static_background(self, operation="subtract", static_bg=None, scale_bg=False,
-                                 inplace=True, *, devices=None):
+    def _like(self, data):
+        """A new signal around `data` with this one's custom attributes (the reference carries `detector`,
+        `static_background` and `xmap` over, signals/ebsd.py:564-573, :686-696)."""
+        out = EBSD(data, self.static_background, self.xmap, self.step_sizes, self.scan_unit, self._device, self._devices)
+        for name in ("detector", "original_metadata"):
+            if hasattr(self, name):
+                setattr(out, name, getattr(self, name))
+        return out
+
+    def remove_static_background(self, operation="subtract", static_bg=None, scale_bg=False, show_progressbar=None,
+                                 inplace=True, lazy_output=None, *, devices=None):
+        """signals/ebsd.py:442-573, with the reference's parameters in the reference's order.  `show_progressbar`
+        is accepted and has nothing to show (the whole signal is one kernel launch per GPU); `lazy_output=True`
+        (only with `inplace=False`, as there) returns an ordinary signal - the result is computed on the device either
+        way, this package has no lazy experimental signal."""
+        if lazy_output and inplace:
+            raise ValueError("'lazy_output=True' requires 'inplace=False'")
         if static_bg is None:
             static_bg = self.static_background
             if not isinstance(static_bg, np.ndarray) and not hasattr(static_bg, "compute"):
@@ -163,17 +181,20 @@ class EBSD:
         if inplace:
             self.data = out
             return None
-        return EBSD(out, self.static_background, self.xmap, self.step_sizes, self.scan_unit, self._device, self._devices)
+        return self._like(out)
 
-    def remove_dynamic_background(self, operation="subtract", filter_domain="frequency", std=None,
-                                  truncate=4.0, inplace=True, *, devices=None):
+    def remove_dynamic_background(self, operation="subtract", filter_domain="frequency", std=None, truncate=4.0,
+                                  show_progressbar=None, inplace=True, lazy_output=None, *, devices=None):
+        """signals/ebsd.py:575-696; `show_progressbar` / `lazy_output` as in `remove_static_background`."""
+        if lazy_output and inplace:
+            raise ValueError("'lazy_output=True' requires 'inplace=False'")
         contexts = self._member_contexts(devices, PREPROCESS_GROUP_MIN_POINTS)
         out = _pattern.remove_dynamic_background(np.asarray(self.data), operation, filter_domain, std,
                                                  truncate, context=None if contexts else self.context, contexts=contexts)
         if inplace:
             self.data = out
             return None
-        return EBSD(out, self.static_background, self.xmap, self.step_sizes, self.scan_unit, self._device, self._devices)
+        return self._like(out)
 
     # ------------------------------------------------------------------ refinement
     def _refine(self, mode, xmap, detector, master_pattern, energy, navigation_mask, signal_mask,

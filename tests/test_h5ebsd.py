@@ -62,7 +62,7 @@ def test_load_compressed_scan_and_several_scans(want):
 def test_short_file_is_zero_padded(want):
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        s = ka.load(PATH, "Scan 3")
+        s = ka.load(PATH, scan_group_names="Scan 3")
     assert any("zero padding incomplete patterns" in str(x.message) for x in w)
     assert s.data.shape == (9, 60, 60) and s.data.dtype == np.float32  # (1, 9) navigation shape squeezed
     assert np.array_equal(s.data, want["scan3"]) and s.static_background is None
@@ -71,7 +71,7 @@ def test_short_file_is_zero_padded(want):
 
 def test_errors(want, tmp_path):
     with pytest.raises(_lib.KpdiError, match="Scan 'Scan 9' is not among the scans"):
-        ka.load(PATH, "Scan 9")
+        ka.load(PATH, scan_group_names="Scan 9")
     with pytest.raises(_lib.KpdiError, match="cannot open"):
         ka.load(str(tmp_path / "nothing.h5"))
     bad = tmp_path / "text.h5"

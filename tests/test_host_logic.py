@@ -165,13 +165,67 @@ def test_filters_window():
     g = load_golden("di_synth.npz")
     w = ka.filters.Window("circular", (60, 60))
     assert np.array_equal(~w.astype(bool), g["circular_mask"]) and int(w.sum()) == 2819
-    assert w.circular and w.name == "rectangular" and w.origin == (30, 30) and tuple(w.n_neighbours) == (29, 29)
+    assert w.circular and w.name == "circular" and w.origin == (30, 30) and tuple(w.n_neighbours) == (29, 29)
     for shape in [(61, 47), (3, 3), (120, 120), (5, 8)]:
         assert np.array_equal(np.asarray(ka.filters.Window("circular", shape)), ko.circular_window(shape))
     gw = ka.filters.Window("gaussian", (30, 30), std=7.5)
     assert np.allclose(gw, np.outer(ko.gaussian_window_1d(30, 7.5), ko.gaussian_window_1d(30, 7.5)))
-    with pytest.raises(NotImplementedError, match="supports 'circular'"):
+    with pytest.raises(NotImplementedError, match="FFT-filter window"):
         ka.filters.Window("modified_hann", (5, 5))
+
+
+def test_filters_window_like_the_reference_tests():
+    """The known answers and error texts of the reference's tests/test_filters/test_window.py:36-222 (restated as data)."""
+    from scipy.signal.windows import gaussian, general_gaussian
+
+    from kikuchipy_amd.filters import Window
+
+    circular33 = np.array([0, 1, 0, 1, 1, 1, 0, 1, 0]).reshape(3, 3)
+    circular54 = np.array([0, 0, 1, 0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 0, 0, 1, 0]).reshape(5, 4)
+    gauss33_circular = np.array([0, 0.60653066, 0, 0.60653066, 1, 0.60653066, 0, 0.60653066, 0]).reshape(3, 3)
+    custom = np.arange(25).reshape(5, 5)
+    w = Window()  # the defaults: "circular", (3, 3)
+    assert w.is_valid and w.name == "circular" and w.circular is True and np.array_equal(w, circular33)
+    assert w.__array_finalize__(None) is None
+    w = Window(window=custom, shape=(10, 20))
+    assert w.name == "custom" and w.shape == (5, 5) and w.circular is False and np.array_equal(w, custom)
+    w = Window(window="gaussian", shape=(5, 5), kwargs=2)  # (how the reference's test passes std: by position in **kwargs)
+    assert w.name == "gaussian" and np.allclose(w, np.outer(gaussian(5, 2), gaussian(5, 2)))
+    w = Window(window="general_gaussian", shape=(5, 5), p=0.5, std=2)
+    assert w.is_valid and w.name == "general_gaussian"
+    assert np.allclose(w, np.outer(general_gaussian(5, 0.5, 2), general_gaussian(5, 0.5, 2)))
+    for nx in (3, 5, 7, 8):
+        assert Window(Nx=nx).shape == (nx,)
+    for window, shape, err, match in [
+        ([[0, 1, 0], [1, 1, 1], [0, 1, 0]], (5, 5), ValueError, "Window <class 'list'> must be of type numpy.ndarray,"),
+        ("boxcar", (5, -5), ValueError, "All window axes .* must be > 0"),
+        ("boxcar", (5, 5.1), TypeError, "Window shape .* must be a sequence of ints."),
+    ]:
+        with pytest.raises(err, match=match):
+            Window(window=window, shape=shape)
+    a = np.arange(5)
+    w = Window(a)
+    assert isinstance(w, Window) and w.name == "custom" and w.circular is False and w.sum() == a.sum()
+    assert isinstance(w[1:], Window) and w[1:].name == "custom" and isinstance(a.view(Window), Window)
+    for window, shape, coeff, circ, name in [
+        ("rectangular", (3, 3), circular33, True, "circular"), ("boxcar", (3, 3), circular33, True, "circular"),
+        ("rectangular", (3,), np.ones(3), False, "rectangular"), ("gaussian", (3, 3), gauss33_circular, True, "gaussian"),
+        ("rectangular", (5, 4), circular54, True, "circular"),
+    ]:
+        k = Window(window=window, shape=shape, **({"std": 1} if window == "gaussian" else {}))
+        k.make_circular()
+        assert np.allclose(k, coeff) and k.name == name and k.circular is circ
+    for shape, ok in [((3,), True), ((3, 3), True), ((3, 4), False), ((4, 3), False), ((4, 4), False)]:
+        assert Window(shape=shape).shape_compatible((3, 3)) == ok  # (the dummy signal's navigation shape)
+    # is_valid: a non-string name, a third axis, a non-bool `circular`
+    w = Window()
+    w._name = 1
+    assert not w.is_valid
+    assert not np.expand_dims(Window(), 1).is_valid
+    w = Window()
+    w._circular = "True"
+    assert not w.is_valid
+    assert repr(Window()).startswith("Window (3, 3) circular\n")
 
 
 # ---------------------------------------------------------------------------------------------
