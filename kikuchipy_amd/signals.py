@@ -59,6 +59,22 @@ class DictionaryXmap:
         return getattr(self, "_shape", (self.rotations.shape[0],))
 
 
+class _Axes:
+    """See `EBSD.axes_manager`."""
+
+    def __init__(self, navigation_shape, signal_shape):
+        self.navigation_shape = tuple(int(v) for v in navigation_shape)
+        self.signal_shape = tuple(int(v) for v in signal_shape)
+
+    navigation_dimension = property(lambda self: len(self.navigation_shape))
+    signal_dimension = property(lambda self: len(self.signal_shape))
+    navigation_size = property(lambda self: int(np.prod(self.navigation_shape)) if self.navigation_shape else 0)
+    signal_size = property(lambda self: int(np.prod(self.signal_shape)))
+
+    def __repr__(self):
+        return f"<axes: navigation {self.navigation_shape} | signal {self.signal_shape}>"
+
+
 class EBSD:
     def __init__(self, data, static_background=None, xmap=None, step_sizes=None, scan_unit="px",
                  device=None, devices=None):
@@ -107,6 +123,14 @@ class EBSD:
     @property
     def navigation_size(self):
         return int(np.prod(self._navigation_shape_rc)) if self._navigation_shape_rc else 0
+
+    @property
+    def axes_manager(self):
+        """The four numbers scripts written for kikuchipy read from HyperSpy's axes manager around this path
+        (`s.axes_manager.signal_shape[::-1]`, `sim.axes_manager.navigation_size // 10` in the reference's
+        doc/tutorials/pattern_matching.ipynb): shapes in HyperSpy's (x, y) order - the REVERSE of the array's - and
+        sizes.  Nothing else of the signal model is here (out of scope)."""
+        return _Axes(self._navigation_shape_rc[::-1], self._signal_shape_rc[::-1])
 
     def deepcopy(self):
         out = EBSD(np.array(self.data, copy=True),

@@ -1,0 +1,72 @@
+"""The reference's pattern-matching tutorial (doc/tutorials/pattern_matching.ipynb), cell by cell, with ITS call forms
+(keyword names, `axes_manager` reads, `kp.signals.EBSD(...)`, `kp.indexing.compute_refine_*`) on this package - what a
+user who switches writes.  Data: the nine Ni patterns and the Ni master pattern the reference ships (committed fixtures),
+orientations from this package's cubochoric sampler.  Results are held to the oracle (indexing) and to what refinement
+must do (scores do not fall; the projection centre stays inside its trust region)."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import kpdi_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tutorial_cells_run_as_written():
+    import kikuchipy_amd as kp
+    from kikuchipy_amd import sampling
+
+    pre, proj = load_golden("preproc.npz"), load_golden("projection.npz")
+    # cell 2-3: the signal, background removal
+    s = kp.signals.EBSD(pre["ni"].copy(), static_background=pre["ni_bg"])
+    s.remove_static_background()
+    s.remove_dynamic_background()
+    # (the parity contract of the dynamic background: at most one grey level on at most 1e-3 of the pixels)
+    diff = np.abs(s.data.astype(int) - pre["ni__static_then_dynamic"].astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() <= 1e-3
+    # cell 5: master pattern with an energy axis
+    energy = 20
+    mp = kp.signals.EBSDMasterPattern(np.stack([proj["mp_upper"], proj["mp_lower"]])[:, None], energies=[energy],
+                                      hemisphere="both", projection="lambert")
+    # cell 8: orientations (coarser than the tutorial's 3 degrees: 3557 instead of 30 443 patterns)
+    R = sampling.get_sample_fundamental(method="cubochoric", resolution=6, point_group="m-3m")
+    # cell 9: detector, from the signal's axes manager as the tutorial does
+    det = kp.detectors.EBSDDetector(shape=s.axes_manager.signal_shape[::-1], pc=[0.4198, 0.2136, 0.5015], sample_tilt=70)
+    assert det.shape == (60, 60)
+    # cell 11: the dictionary
+    sim = mp.get_patterns(rotations=R, detector=det, energy=energy, dtype_out=np.float32, compute=True)
+    assert sim.axes_manager.navigation_size == len(R) and sim.data.shape == (len(R), 60, 60)
+    # cell 13-14: mask and indexing
+    signal_mask = ~kp.filters.Window("circular", det.shape).astype(bool)
+    xmap = s.dictionary_indexing(sim, metric="ncc", keep_n=20, n_per_iteration=sim.axes_manager.navigation_size // 10,
+                                 signal_mask=signal_mask, verbose=False)
+    want_s, want_i = ko.dictionary_indexing(np.asarray(s.data), np.asarray(sim.data), metric="ncc", keep_n=20,
+                                            signal_mask=signal_mask)
+    ko.assert_topk_parity(xmap.scores, xmap.simulation_indices, want_s, want_i, atol=1e-5)
+    assert xmap.scores.shape == (9, 20) and xmap.scores[:, 0].mean() > 0.15
+    # cell 20: orientation similarity map
+    os_map = kp.indexing.orientation_similarity_map(xmap)
+    assert os_map.shape == (3, 3)
+    assert np.array_equal(os_map, ko.orientation_similarity_map(xmap.simulation_indices, (3, 3)))
+    # cell 22: best matching patterns as a signal
+    best_patterns = np.asarray(sim.data)[xmap.simulation_indices[:, 0]].reshape(s.data.shape)
+    s_best = kp.signals.EBSD(best_patterns)
+    assert s_best.axes_manager.navigation_shape == (3, 3)
+    # cell 25: orientation refinement with the defaults written out
+    xmap_ref = s.refine_orientation(xmap=xmap, detector=det, master_pattern=mp, energy=energy, signal_mask=signal_mask,
+                                    method="minimize", method_kwargs=dict(method="Nelder-Mead", tol=1e-4), compute=True,
+                                    verbose=False)
+    assert xmap_ref.scores.shape == (9,) and (xmap_ref.scores >= xmap.scores[:, 0] - 1e-5).all()
+    assert xmap_ref.scores.mean() > xmap.scores[:, 0].mean() and xmap_ref.num_evals.mean() > 10
+    # cell 33-34: projection-centre refinement, deferred, with another SciPy method and a trust region
+    result_arr = s.refine_projection_center(xmap=xmap, detector=det, master_pattern=mp, energy=energy,
+                                            signal_mask=signal_mask, method="minimize",
+                                            method_kwargs=dict(method="Powell", tol=1e-3), trust_region=[0.02, 0.02, 0.02],
+                                            compute=False, verbose=False)
+    ncc_after_pc_ref, det_ref, num_evals_ref = kp.indexing.compute_refine_projection_center_results(
+        results=result_arr, detector=det, xmap=xmap)
+    assert ncc_after_pc_ref.shape == (9,) and (ncc_after_pc_ref >= xmap.scores[:, 0] - 1e-5).all()
+    assert det_ref.navigation_shape == (3, 3) and np.abs(det_ref.pc - det.pc).max() <= 0.02 + 1e-9
+    assert num_evals_ref.mean() > 10
+    assert np.allclose(det_ref.pc_average, det_ref.pc.reshape(-1, 3).mean(axis=0))
