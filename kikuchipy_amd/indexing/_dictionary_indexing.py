@@ -16,7 +16,35 @@ import numpy as np
 from kikuchipy_amd.indexing.similarity_metrics import METRICS, SimilarityMetric, _HipMetric
 
 
-class DictionaryIndexingResult:
+class MapData:
+    """`get_map_data` of orix's `CrystalMap` (third party, not vendored; used by the reference's tutorials on the maps
+    this path returns) for the result holders of this package."""
+
+    def get_map_data(self, item, decimals=None, fill_value=np.nan):
+        """A property (by name: "scores", "simulation_indices", "num_evals", ... or an array with one row per point
+        in the data) laid out on the map: shape `self.shape` (+ the property's trailing axes), points outside the
+        navigation mask filled with `fill_value` (integers: `fill_value` if it is finite, else 0)."""
+        if isinstance(item, str):
+            if item not in self.prop:
+                raise ValueError(f"{item!r} is not among the properties {sorted(self.prop)}")
+            values = np.asarray(self.prop[item])
+        else:
+            values = np.asarray(item)
+        in_data = np.asarray(self.is_in_data, dtype=bool).ravel()
+        if values.shape[0] != int(in_data.sum()):
+            raise ValueError(f"{values.shape[0]} values for {int(in_data.sum())} points in the data")
+        if np.issubdtype(values.dtype, np.integer) or values.dtype == bool:
+            fill = fill_value if np.isfinite(fill_value) else 0
+        else:
+            fill = fill_value
+        out = np.full((in_data.size,) + values.shape[1:], fill, dtype=values.dtype)
+        out[in_data] = values
+        if decimals is not None:
+            out = np.round(out, decimals=decimals)
+        return out.reshape(tuple(self.shape) + values.shape[1:])
+
+
+class DictionaryIndexingResult(MapData):
     """What the reference stores in the returned `CrystalMap`
     (indexing/_dictionary_indexing.py:141-167): `scores` and
     `simulation_indices` of shape (n_points, keep_n) - squeezed to 1-D when

@@ -13,8 +13,10 @@ from math import copysign
 
 import numpy as np
 
+from kikuchipy_amd.indexing._dictionary_indexing import MapData
 
-class MergedIndexingResult:
+
+class MergedIndexingResult(MapData):
     """The merged map: per point the winning phase (`phase_id`, -1 = not indexed
     in any map; `phase_names[id]`), its `rotations`, `scores` and
     `simulation_indices`, and the rankings over all phases `merged_scores`,

@@ -20,6 +20,7 @@ import time
 import numpy as np
 
 from kikuchipy_amd import _lib
+from kikuchipy_amd.indexing._dictionary_indexing import MapData
 
 MODES = {"ori": _lib.REFINE_ORI, "pc": _lib.REFINE_PC, "ori_pc": _lib.REFINE_ORI_PC}
 # indexing/_refinement/__init__.py:33-66
@@ -74,7 +75,7 @@ def quaternion_multiply(p, q):
 
 
 # --------------------------------------------------------------------------- results
-class RefinementResult:
+class RefinementResult(MapData):
     """What the reference puts into the refined `CrystalMap`
     (indexing/_refinement/_refinement.py:58-131): per refined point the
     `scores` (NCC), `num_evals`, `rotations` (quaternions from the refined Euler

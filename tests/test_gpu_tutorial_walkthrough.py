@@ -59,6 +59,9 @@ def test_tutorial_cells_run_as_written():
                                     verbose=False)
     assert xmap_ref.scores.shape == (9,) and (xmap_ref.scores >= xmap.scores[:, 0] - 1e-5).all()
     assert xmap_ref.scores.mean() > xmap.scores[:, 0].mean() and xmap_ref.num_evals.mean() > 10
+    # cell 27: scores laid out on the map
+    ncc_after_ori_ref = xmap_ref.get_map_data("scores")
+    assert ncc_after_ori_ref.shape == (3, 3) and np.array_equal(ncc_after_ori_ref.ravel(), xmap_ref.scores)
     # cell 33-34: projection-centre refinement, deferred, with another SciPy method and a trust region
     result_arr = s.refine_projection_center(xmap=xmap, detector=det, master_pattern=mp, energy=energy,
                                             signal_mask=signal_mask, method="minimize",

@@ -311,3 +311,20 @@ def test_to_crystal_map_needs_rotations(orix_stub):
     res = DictionaryIndexingResult(np.zeros((2, 1)), np.zeros((2, 1), int), (2,), (1,), np.ones(2, bool), 1)
     with pytest.raises(ValueError, match="dictionary_rotations"):
         res.to_crystal_map()
+
+
+def test_get_map_data_of_the_result_holders():
+    """`xmap.get_map_data("scores")` as the reference's tutorial calls it on the maps this path returns (orix's
+    CrystalMap.get_map_data: the property laid out on the map, NaN outside the navigation mask)."""
+    from kikuchipy_amd.indexing._dictionary_indexing import DictionaryIndexingResult
+
+    in_data = np.array([1, 0, 1, 1, 1, 1], dtype=bool)
+    scores = np.arange(10, dtype=np.float32).reshape(5, 2)
+    res = DictionaryIndexingResult(scores, np.arange(10).reshape(5, 2), (2, 3), (1, 1), in_data, 2)
+    m = res.get_map_data("scores")
+    assert m.shape == (2, 3, 2) and np.isnan(m[0, 1]).all() and np.array_equal(m.reshape(6, 2)[in_data], scores)
+    i = res.get_map_data("simulation_indices")
+    assert i.dtype.kind == "i" and (i[0, 1] == 0).all() and i[1, 2, 1] == 9
+    assert np.array_equal(res.get_map_data(np.array([0.26, 1, 2, 3, 4]), decimals=1)[0], [0.3, np.nan, 1.0], equal_nan=True)
+    with pytest.raises(ValueError, match="not among the properties"):
+        res.get_map_data("nothing")
