@@ -341,8 +341,14 @@ def _master_pattern_data(master_pattern, energy):
 def refine(mode, patterns, rotations, detector, master_pattern, energy=None, navigation_mask=None,
            signal_mask=None, pseudo_symmetry_ops=None, method="minimize", method_kwargs=None, trust_region=None,
            initial_step=None, rtol=1e-4, maxeval=None, context=None, device=0, verbose=True, comm=None, compute=True,
-           contexts=None):
+           contexts=None, is_in_data=None, xmap_shape=None):
     """Shared driver of the three refinements.
+
+    is_in_data, xmap_shape
+        Of the crystal map the rotations come from: only points that are in ITS data are refined - the navigation mask
+        is combined with it (signals/util/_crystal_map.py:111-161) - and its shape must be the signal's navigation shape
+        (`_xmap_is_compatible_with_signal`, :28-61).  `rotations` may then hold rows for the points in the data only
+        (what orix's `CrystalMap.rotations` gives) or for every point of the map (what this package's holders store).
 
     contexts
         Several engine contexts (one per GPU - the members of a `kikuchipy_amd._lib.Group`): the points are independent,
@@ -391,9 +397,30 @@ def refine(mode, patterns, rotations, detector, master_pattern, energy=None, nav
         raise ValueError(
             f"Signal mask shape {signal_mask.shape} and signal's signal shape {sig_shape} must be the same shape"
         )
+    if xmap_shape is not None and tuple(xmap_shape) != (nav_shape or (1,)) and tuple(xmap_shape) != nav_shape:
+        raise ValueError(
+            f"Crystal map shape {tuple(xmap_shape)} and signal's navigation shape {nav_shape} must be the same "
+            "(see EBSD.axes_manager)"
+        )
     rot = np.asarray(getattr(rotations, "data", rotations), dtype=np.float64)
     if rot.shape[-1] != 4:
         raise ValueError("`rotations` must be quaternions with a last axis of size 4")
+    in_data = None
+    if is_in_data is not None:
+        in_data = np.asarray(is_in_data, dtype=bool).ravel()
+        if in_data.size != nav_size:
+            raise ValueError(
+                f"Crystal map with {in_data.size} points and signal's navigation shape {nav_shape} must be the same "
+                "(see EBSD.axes_manager)"
+            )
+        n_in = int(in_data.sum())
+        if n_in < nav_size and n_in > 0 and rot.size % (n_in * 4) == 0 and rot.size % (nav_size * 4) != 0:
+            # rows for the points in the data only: laid out on the whole map (identity elsewhere, never refined)
+            rows = rot.reshape(n_in, -1, 4)
+            full = np.zeros((nav_size,) + rows.shape[1:])
+            full[..., 0] = 1
+            full[in_data] = rows
+            rot = full
     if rot.size % (nav_size * 4) != 0 or rot.size == 0:
         raise ValueError(f"need one rotation per pattern ({nav_size}), got an array of shape {rot.shape}")
     # several rotations per point (the k best of dictionary indexing): refine the best
@@ -408,6 +435,10 @@ def refine(mode, patterns, rotations, detector, master_pattern, energy=None, nav
             raise ValueError("The navigation mask must allow refinement of at least one pattern")
     else:
         points = np.ones(nav_size, dtype=bool)
+    if in_data is not None:
+        points = points & in_data
+        if not points.any():
+            raise ValueError("No point is both in the crystal map's data and allowed by the navigation mask")
     n = int(points.sum())
     rot = rot[points]
     pats = patterns.reshape((nav_size,) + sig_shape)[points]
@@ -508,7 +539,7 @@ def _run_refinement(mode, n, starts, x0, fixed, lower, upper, pats, signal_mask,
     if mode != "ori":
         new_pc = x[:, -3:]
         new_detector = detector.deepcopy()
-        if navigation_mask is None and nav_shape:
+        if points.all() and nav_shape:
             new_pc = new_pc.reshape(nav_shape + (3,))
         new_detector.pc = new_pc
     # the reference's result rows (_refinement.py:120-128, :184-190, :284-290): score, number of evaluations, the refined

@@ -231,7 +231,8 @@ class EBSD:
         return refine(mode, np.asarray(self.data), _rotations_of(xmap), detector, master_pattern, energy,
                       navigation_mask, signal_mask, pseudo_symmetry_ops, method, method_kwargs, trust_region,
                       initial_step, rtol, maxeval, context=None if contexts else self.context, verbose=verbose, comm=comm,
-                      compute=compute, contexts=contexts)
+                      compute=compute, contexts=contexts, is_in_data=getattr(xmap, "is_in_data", None),
+                      xmap_shape=getattr(xmap, "shape", None) if hasattr(xmap, "is_in_data") else None)
 
     def refine_orientation(self, xmap, detector, master_pattern, energy=None, navigation_mask=None,
                            signal_mask=None, pseudo_symmetry_ops=None, method="minimize", method_kwargs=None,

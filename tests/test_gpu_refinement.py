@@ -455,3 +455,37 @@ def test_refinement_over_a_group_of_devices(api_inputs):
     rows = later.compute()
     res, new_det = s.refine_orientation_projection_center(rot0, det, mp, verbose=False)
     assert np.array_equal(rows[:, 0], res.scores) and np.array_equal(rows[:, -3:], new_det.pc.reshape(-1, 3))
+
+
+def test_only_points_in_the_crystal_maps_data_are_refined(api_inputs, g115):
+    """signals/util/_crystal_map.py:111-161: the points to refine are `xmap.is_in_data`, further reduced by the navigation
+    mask; `xmap.rotations` of an orix CrystalMap holds rows for the points in the data only, this package's
+    holders store the whole map - either is taken.  Equal to refining those points alone."""
+    from types import SimpleNamespace
+
+    s, det, mp, rot0 = api_inputs
+    in_data = np.array([True, False, True, True])
+    whole = s.refine_orientation(rot0, det, mp, verbose=False,
+                                 navigation_mask=~in_data.reshape(2, 2))           # the same points, by mask
+    full_rows = rot0.reshape(4, 4).copy()
+    full_rows[~in_data] = [1, 0, 0, 0]                                              # (never looked at)
+    for rotations in (full_rows, full_rows[in_data]):                               # holder style, orix style
+        xmap = SimpleNamespace(rotations=rotations, is_in_data=in_data, shape=(2, 2))
+        res = s.refine_orientation(xmap, det, mp, verbose=False)
+        assert res.size == 3 and np.array_equal(res.is_in_data, in_data)
+        assert np.array_equal(res.scores, whole.scores) and np.array_equal(res.euler, whole.euler)
+    # ... combined with a navigation mask
+    nav = np.array([[False, False], [True, False]])
+    res = s.refine_orientation(SimpleNamespace(rotations=full_rows, is_in_data=in_data, shape=(2, 2)), det, mp,
+                               navigation_mask=nav, verbose=False)
+    assert res.size == 2 and np.array_equal(res.is_in_data, [True, False, False, True])
+    assert np.array_equal(res.scores, whole.scores[[0, 2]])
+    # a refined map (rows for its three points) goes straight into the next refinement, as in the reference's tutorial
+    scores, new_det, num_evals = s.refine_projection_center(whole, det, mp, verbose=False,
+                                                            method_kwargs=dict(method="Nelder-Mead", options=dict(maxfev=40)))
+    assert scores.shape == (3,) and new_det.pc.shape == (3, 3) and (scores >= whole.scores - 1e-4).all()
+    with pytest.raises(ValueError, match=r"Crystal map shape \(3, 2\) and signal's navigation shape \(2, 2\) must be the same"):
+        s.refine_orientation(SimpleNamespace(rotations=rot0, is_in_data=np.ones(6, bool), shape=(3, 2)), det, mp)
+    with pytest.raises(ValueError, match="No point is both in the crystal map's data"):
+        s.refine_orientation(SimpleNamespace(rotations=full_rows, is_in_data=in_data, shape=(2, 2)), det, mp,
+                             navigation_mask=in_data.reshape(2, 2))
