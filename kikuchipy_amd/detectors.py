@@ -11,6 +11,9 @@ dictionary generation uses a single PC for the whole dictionary (SURVEY.md
 fitting/extrapolation and file I/O are out of scope.
 """
 
+from collections.abc import Iterable
+from numbers import Number
+
 import numpy as np
 
 # detectors/_ebsd_detector.py:71-91
@@ -50,15 +53,13 @@ class EBSDDetector:
 
     def __init__(self, shape=(1, 1), px_size=1.0, binning=1, tilt=0.0, azimuthal=0.0, twist=0.0,
                  sample_tilt=70.0, pc=(0.5, 0.5, 0.5), convention="bruker"):
-        self.shape = tuple(int(v) for v in shape)
-        if len(self.shape) != 2 or min(self.shape) < 1:
-            raise ValueError("`shape` must be (number of rows, number of columns)")
-        self.px_size = float(px_size)
-        self._binning = float(binning)
-        self.tilt = float(tilt)
-        self.azimuthal = float(azimuthal)
-        self.twist = float(twist)
-        self.sample_tilt = float(sample_tilt)
+        self.shape = shape
+        self.px_size = px_size
+        self.binning = binning
+        self.tilt = tilt
+        self.azimuthal = azimuthal
+        self.twist = twist
+        self.sample_tilt = sample_tilt
         pc = np.atleast_2d(np.asarray(pc, dtype=np.float64))
         if pc.shape[-1] != 3 or pc.ndim > 3:
             raise ValueError(
@@ -111,9 +112,55 @@ class EBSDDetector:
     def aspect_ratio(self):
         return self.ncols / self.nrows
 
+    # ---- validated attributes: the reference's checks and texts (detectors/_ebsd_detector.py:2281-2292 and the setters
+    # :337-340, :365-368, :392-395, :417-420, :582-585, :691-694)
+    @property
+    def shape(self):
+        return self._shape
+
+    @shape.setter
+    def shape(self, value):
+        if (not isinstance(value, Iterable) or isinstance(value, (str, bytes)) or len(value) != 2
+                or not all(isinstance(v, Number) for v in value) or min(value) < 1):
+            raise ValueError(f"Invalid shape {value}. Must be an iterable of two integers.")
+        self._shape = tuple(int(v) for v in value)
+
     @property
     def binning(self):
         return int(self._binning)
+
+    @binning.setter
+    def binning(self, value):
+        if not isinstance(value, Number):
+            raise ValueError(f"Invalid binning {value}. Must be an integer.")
+        self._binning = float(value)
+
+    @property
+    def px_size(self):
+        return self._px_size
+
+    @px_size.setter
+    def px_size(self, value):
+        if not isinstance(value, Number):
+            raise ValueError(f"Invalid pixel size {value}. Must be a number.")
+        self._px_size = float(value)
+
+    def _angle(name, text):  # noqa: N805 - a small property factory
+        def get(self):
+            return getattr(self, "_" + name)
+
+        def set_(self, value):
+            if not isinstance(value, Number):
+                raise ValueError(f"Invalid {text} {value!r}. Must be a number.")
+            setattr(self, "_" + name, float(value))
+
+        return property(get, set_)
+
+    tilt = _angle("tilt", "detector tilt")
+    azimuthal = _angle("azimuthal", "azimuthal")
+    twist = _angle("twist", "twist")
+    sample_tilt = _angle("sample_tilt", "sample tilt")
+    del _angle
 
     @property
     def navigation_shape(self):
@@ -147,17 +194,65 @@ class EBSDDetector:
         v = self._pc[..., i]
         return v[0] if v.shape == (1,) else v
 
+    def _set_component(self, i, value):
+        self._pc[..., i] = np.reshape(np.asarray(value, dtype=np.float64), -1) if np.size(value) > 1 else value
+
     @property
     def pcx(self):
         return self._component(0)
+
+    @pcx.setter
+    def pcx(self, value):
+        self._set_component(0, value)
 
     @property
     def pcy(self):
         return self._component(1)
 
+    @pcy.setter
+    def pcy(self, value):
+        self._set_component(1, value)
+
     @property
     def pcz(self):
         return self._component(2)
+
+    @pcz.setter
+    def pcz(self, value):
+        self._set_component(2, value)
+
+    # ---- derived sizes (detectors/_ebsd_detector.py:605-727)
+    @property
+    def navigation_dimension(self):
+        return len(self.navigation_shape)
+
+    @property
+    def bounds(self):
+        """Detector bounds [x0, x1, y0, y1] in pixel coordinates."""
+        return np.array([0, self.ncols - 1, 0, self.nrows - 1])
+
+    @property
+    def unbinned_shape(self):
+        return tuple(int(v) for v in np.array(self.shape, dtype=int) * self._binning)
+
+    @property
+    def height(self):
+        """Detector height in microns."""
+        return self.nrows * self.px_size * self._binning
+
+    @property
+    def width(self):
+        """Detector width in microns."""
+        return self.ncols * self.px_size * self._binning
+
+    @property
+    def px_size_binned(self):
+        return self.px_size * self._binning
+
+    @property
+    def specimen_scintillator_distance(self):
+        """PCz x detector height, in microns."""
+        return self.pcz * self.height
 
     # ---- gnomonic coordinates (detectors/_ebsd_detector.py:731-818)
     @property
@@ -175,6 +270,34 @@ class EBSDDetector:
     @property
     def y_max(self):
         return self.pcy / self.pcz
+
+    @property
+    def x_range(self):
+        """(x_min, x_max) per projection centre: navigation shape + (2,)  (detectors/_ebsd_detector.py:749-755)."""
+        return np.stack([np.atleast_1d(self.x_min), np.atleast_1d(self.x_max)], axis=-1).reshape(self.navigation_shape + (2,))
+
+    @property
+    def y_range(self):
+        return np.stack([np.atleast_1d(self.y_min), np.atleast_1d(self.y_max)], axis=-1).reshape(self.navigation_shape + (2,))
+
+    @property
+    def x_scale(self):
+        """Width of a pixel in gnomonic coordinates (detectors/_ebsd_detector.py:785-795)."""
+        d = np.diff(self.x_range)
+        return (d if self.ncols == 1 else d / (self.ncols - 1)).reshape(self.navigation_shape)
+
+    @property
+    def y_scale(self):
+        d = np.diff(self.y_range)
+        return (d if self.nrows == 1 else d / (self.nrows - 1)).reshape(self.navigation_shape)
+
+    @property
+    def r_max(self):
+        """Largest distance from the pattern centre to a detector corner in gnomonic coordinates, with the corners the
+        reference takes (detectors/_ebsd_detector.py:821-833: its "lower left" repeats the upper left)."""
+        x0, x1, y0, y1 = (np.atleast_1d(v) for v in (self.x_min, self.x_max, self.y_min, self.y_max))
+        corners = np.stack([x0**2 + y0**2, x1**2 + y0**2, x1**2 + y1**2, x0**2 + y0**2], axis=-1)
+        return np.atleast_2d(np.sqrt(corners.max(axis=-1)).reshape(self.navigation_shape))
 
     @property
     def gnomonic_bounds(self):
@@ -197,7 +320,15 @@ class EBSDDetector:
                             self.sample_tilt, self._pc.copy(), "bruker")
 
     def __repr__(self):
+        """The reference's text (detectors/_ebsd_detector.py:319-331)."""
         pc = tuple(float(v) for v in np.round(self.pc_average, 3))
-        return (f"EBSDDetector(shape={self.shape}, pc={pc}, sample_tilt={self.sample_tilt}, "
-                f"tilt={self.tilt}, azimuthal={self.azimuthal}, twist={self.twist}, "
-                f"binning={self.binning}, px_size={self.px_size} um)")
+        deg = "\N{DEGREE SIGN}"
+        return ("EBSDDetector\n"
+                f"  shape (Ny, Nx):     {self.shape}\n"
+                f"  pc (PCx, PCy, PCz): {pc}\n"
+                f"  sample_tilt:        {self.sample_tilt}{deg}\n"
+                f"  tilt:               {self.tilt}{deg}\n"
+                f"  azimuthal:          {self.azimuthal}{deg}\n"
+                f"  twist:              {self.twist}{deg}\n"
+                f"  binning:            {self.binning}\n"
+                f"  px_size:            {self.px_size} um")

@@ -101,7 +101,7 @@ def test_sample_to_detector_golden(g):
     assert np.allclose(det.sample_to_detector, g["det48x60__s2d"], rtol=0, atol=1e-15)
     assert np.allclose(det.detector_to_sample @ det.sample_to_detector, np.eye(3), atol=1e-14)
     assert det.navigation_shape == (1,) and det.size == 48 * 60 and det.aspect_ratio == 1.25
-    assert "EBSDDetector(shape=(48, 60)" in repr(det)
+    assert "shape (Ny, Nx):     (48, 60)" in repr(det)
 
 
 # ---------------------------------------------------------------- master pattern
@@ -170,3 +170,58 @@ def test_get_patterns_lazy_protocol_and_rescale_rule(g):
     assert mpf.get_patterns(rot, det).data.chunksize == (1200, 60, 60)
     big = ka.ProjectedDictionary(None, None, np.zeros((800000, 4)), det, False, 1, 2)
     assert big.chunksize[0] == (8 << 30) // (4 * 3600)
+
+
+def test_detector_like_the_reference_tests():
+    """Known answers and error texts of the reference's tests/test_detectors/test_ebsd_detector.py:41-176 (restated as
+    data): validated attributes, derived sizes, the text representation, PC components that can be set."""
+    import kikuchipy_amd as ka
+
+    pc1 = [0.4210, 0.7794, 0.5049]
+    det = ka.EBSDDetector(shape=(1, 2), px_size=3, binning=4, tilt=5, pc=pc1)
+    assert det.shape == (1, 2) and det.aspect_ratio == 2 and np.issubdtype(det.pc.dtype, np.floating)
+    assert all(type(v) is float for v in (det.sample_tilt, det.tilt, det.azimuthal, det.px_size))
+    d = ka.EBSDDetector()
+    for attr, value, text in [("shape", 2, "Invalid shape 2. Must be an iterable of"),
+                              ("shape", (2,), r"Invalid shape \(2,\). Must be an "),
+                              ("shape", (2, "a"), r"Invalid shape \(2, 'a'\). Must be an "),
+                              ("binning", (3, 4), r"Invalid binning \(3, 4\). Must be an "),
+                              ("sample_tilt", "a", "Invalid sample tilt "), ("tilt", "a", "Invalid detector tilt "),
+                              ("azimuthal", "a", "Invalid azimuthal "), ("twist", "a", "Invalid twist "),
+                              ("px_size", "a", "Invalid pixel size ")]:
+        with pytest.raises(ValueError, match=text):
+            setattr(d, attr, value)
+    for nav_shape, want_shape, want_dim in [((), (1,), 1), ((1,), (1,), 1), ((10, 1), (10,), 1), ((10, 10, 1), (10, 10), 2)]:
+        det = ka.EBSDDetector(pc=np.tile(pc1, nav_shape))
+        assert det.navigation_shape == want_shape and det.navigation_dimension == want_dim
+    for shape, px_size, binning, pc, ssd, width, height, size, unbinned, px_binned in [
+        ((60, 60), 70, 8, [1, 1, 0.5], 16800, 33600, 33600, 3600, (480, 480), 560),
+        ((60, 60), 70, 8, [1, 1, 0.7], 23520, 33600, 33600, 3600, (480, 480), 560),
+        ((480, 460), 70, 0.5, [1, 1, 0.7], 11760, 16100, 16800, 220800, (240, 230), 35),
+        ((340, 680), 40, 2, [1, 1, 0.7], 19040, 54400, 27200, 231200, (680, 1360), 80),
+    ]:
+        det = ka.EBSDDetector(shape=shape, px_size=px_size, binning=binning, pc=pc)
+        assert np.isclose(det.specimen_scintillator_distance, ssd) and (det.width, det.height, det.size) == (width, height, size)
+        assert det.unbinned_shape == unbinned and det.px_size_binned == px_binned
+    det = ka.EBSDDetector(shape=(1, 2), px_size=3, binning=4, tilt=5, azimuthal=2, twist=1.02, pc=[0.421, 0.779, 0.505])
+    assert repr(det) == (
+        "EBSDDetector\n"
+        "  shape (Ny, Nx):     (1, 2)\n"
+        "  pc (PCx, PCy, PCz): (0.421, 0.779, 0.505)\n"
+        "  sample_tilt:        70.0\N{DEGREE SIGN}\n"
+        "  tilt:               5.0\N{DEGREE SIGN}\n"
+        "  azimuthal:          2.0\N{DEGREE SIGN}\n"
+        "  twist:              1.02\N{DEGREE SIGN}\n"
+        "  binning:            4\n"
+        "  px_size:            3.0 um"
+    )
+    one = ka.EBSDDetector(pc=[0.421, 0.779, 0.505])
+    two = one.deepcopy()
+    one.pcx += 0.1
+    assert np.allclose(one.pcx, 0.521) and np.allclose(two.pcx, 0.421)
+    # ranges and scales are what the gnomonic bounds say
+    det = ka.EBSDDetector(shape=(60, 80), pc=np.tile([0.4, 0.6, 0.5], (2, 3, 1)))
+    assert det.x_range.shape == (2, 3, 2) and det.x_scale.shape == (2, 3) and det.r_max.shape == (2, 3)
+    assert np.allclose(det.x_range[..., 1] - det.x_range[..., 0], det.x_scale * 79)
+    assert np.allclose(det.gnomonic_bounds, np.concatenate([det.x_range, det.y_range], axis=-1))
+    assert np.array_equal(det.bounds, [0, 79, 0, 59])
