@@ -357,12 +357,18 @@ class EBSDMasterPattern:
         self.data = np.asarray(data)
         if self.data.ndim < 2 or self.data.ndim > 4:
             raise ValueError("master pattern data must have 2 signal axes and at most 2 navigation axes")
-        self.projection = projection
+        # (_utils/vector.py:47-60, _utils/exceptions.py:21-36: case-insensitive, the reference's texts)
+        if not isinstance(projection, str) or projection.lower() not in ("stereographic", "lambert"):
+            raise ValueError(f"Unknown projection {projection!r}, options are 'stereographic' and 'lambert'")
+        self.projection = projection.lower()
         self.energies = None if energies is None else np.asarray(energies, dtype=np.float64)
         n_nav = self.data.ndim - 2
         has_energy = self.energies is not None
         if hemisphere is None:
             hemisphere = "both" if n_nav - int(has_energy) == 1 else "upper"
+        if not isinstance(hemisphere, str) or hemisphere.lower() not in ("upper", "lower", "both"):
+            raise ValueError(f"Unknown hemisphere {hemisphere!r}, options are 'upper', 'lower', or 'both'")
+        hemisphere = hemisphere.lower()
         self.hemisphere = hemisphere
         expected_nav = int(hemisphere == "both") + int(has_energy)
         if expected_nav != n_nav or (hemisphere == "both" and self.data.shape[0] != 2):

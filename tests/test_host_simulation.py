@@ -142,6 +142,12 @@ def test_master_pattern_suitability():
     mp = ka.EBSDMasterPattern(np.zeros((11, 11)))
     with pytest.raises(ValueError, match="can only have one or two dimensions"):
         mp.get_patterns(np.zeros((2, 2, 2, 4)), det)
+    # tests/test_signals/test_ebsd_master_pattern.py: the texts of _utils/exceptions.py
+    with pytest.raises(ValueError, match="Unknown projection 'gnomonic'"):
+        ka.EBSDMasterPattern(np.zeros((11, 11)), projection="gnomonic")
+    with pytest.raises(ValueError, match="Unknown hemisphere 'west'"):
+        ka.EBSDMasterPattern(np.zeros((11, 11)), hemisphere="west")
+    assert ka.EBSDMasterPattern(np.zeros((2, 11, 11)), projection="Lambert", hemisphere="BOTH").hemisphere == "both"
 
 
 def test_get_patterns_lazy_protocol_and_rescale_rule(g):
