@@ -45,6 +45,11 @@ class KpdiError(RuntimeError):
     """A libkpdi call failed (message from kpdi_last_error())."""
 
 
+class KpdiIOError(KpdiError, OSError):
+    """A file could not be read (`kikuchipy_amd.load`): an `OSError` like the reference's reader raises
+    (io/plugins/_h5ebsd.py:210, :292-300), and a `KpdiError` like every failed libkpdi call."""
+
+
 class Counters(C.Structure):
     _fields_ = [
         ("match_ms", C.c_double),

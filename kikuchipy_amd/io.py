@@ -31,8 +31,23 @@ def load(filename, lazy=False, *, scan_group_names=None, device=None, devices=No
         raise TypeError(f"`lazy` must be a bool, not {type(lazy).__name__} (the scan is named by the keyword "
                         "`scan_group_names`, as in kikuchipy.load)")
     if isinstance(scan_group_names, (list, tuple)):
-        return [load(filename, lazy, scan_group_names=name, device=device, devices=devices) for name in scan_group_names]
-    info, pats, bg, pc = _lib.h5ebsd_read(str(filename), scan_group_names)
+        # several scans: one that is not in the file is an error only when it is the only one asked for, else a warning
+        # (io/plugins/_h5ebsd.py:285-301)
+        out = []
+        for name in scan_group_names:
+            try:
+                out.append(load(filename, lazy, scan_group_names=name, device=device, devices=devices))
+            except _lib.KpdiIOError as err:
+                if len(scan_group_names) == 1 or "is not among the scans" not in str(err):
+                    raise
+                warnings.warn(str(err))
+        return out
+    try:
+        info, pats, bg, pc = _lib.h5ebsd_read(str(filename), scan_group_names)
+    except _lib.KpdiIOError:
+        raise
+    except _lib.KpdiError as err:  # (cannot open, no such scan, no patterns: the reference raises OSError / IOError)
+        raise _lib.KpdiIOError(str(err)) from None
     ny, nx, sy, sx = info.ny, info.nx, info.sy, info.sx
     # the reference squeezes singleton navigation axes (io/plugins/_h5ebsd.py:366)
     nav_shape = tuple(n for n in (ny, nx) if n > 1)

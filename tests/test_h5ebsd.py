@@ -74,6 +74,15 @@ def test_errors(want, tmp_path):
         ka.load(PATH, scan_group_names="Scan 9")
     with pytest.raises(_lib.KpdiError, match="cannot open"):
         ka.load(str(tmp_path / "nothing.h5"))
+    # like the reference's reader (tests/test_io/test_kikuchipy_h5ebsd.py:201-209): an OSError; with several names one
+    # that is missing is a warning, and an error only when it is the only one
+    with pytest.raises(OSError, match="Scan 'Scan 9' is not among the"):
+        ka.load(PATH, scan_group_names=["Scan 9"])
+    with pytest.warns(UserWarning, match="Scan 'Scan 9' is not among "):
+        s1, s2 = ka.load(PATH, scan_group_names=["Scan 1", "Scan 2", "Scan 9"])
+    assert np.array_equal(s1.data, want["scan1"]) and np.array_equal(s2.data, want["scan2"])
+    with pytest.raises(OSError, match="cannot open"):
+        ka.load(str(tmp_path / "nothing.h5"))
     bad = tmp_path / "text.h5"
     bad.write_text("not hdf5")
     with pytest.raises(_lib.KpdiError, match="cannot open"):
