@@ -195,7 +195,10 @@ class EBSDDetector:
         return v[0] if v.shape == (1,) else v
 
     def _set_component(self, i, value):
-        self._pc[..., i] = np.reshape(np.asarray(value, dtype=np.float64), -1) if np.size(value) > 1 else value
+        v = np.asarray(value, dtype=np.float64)
+        if v.size > 1 and v.size == self.navigation_size:
+            v = v.reshape(self._pc.shape[:-1])  # one value per projection centre, in any layout
+        self._pc[..., i] = v
 
     @property
     def pcx(self):
