@@ -414,8 +414,10 @@ def refine(mode, patterns, rotations, detector, master_pattern, energy=None, nav
                 "(see EBSD.axes_manager)"
             )
         n_in = int(in_data.sum())
-        if n_in < nav_size and n_in > 0 and rot.size % (n_in * 4) == 0 and rot.size % (nav_size * 4) != 0:
-            # rows for the points in the data only: laid out on the whole map (identity elsewhere, never refined)
+        if 0 < n_in < nav_size and rot.ndim >= 2 and rot.shape[0] == n_in:
+            # a crystal map keeps its rotations flat, one row (of k) per point: `size` rows are the points in the data
+            # only (orix) - laid out on the whole map here (identity elsewhere, never refined); `nav_size` rows are the
+            # whole map (this package's holders)
             rows = rot.reshape(n_in, -1, 4)
             full = np.zeros((nav_size,) + rows.shape[1:])
             full[..., 0] = 1

@@ -489,3 +489,18 @@ def test_only_points_in_the_crystal_maps_data_are_refined(api_inputs, g115):
     with pytest.raises(ValueError, match="No point is both in the crystal map's data"):
         s.refine_orientation(SimpleNamespace(rotations=full_rows, is_in_data=in_data, shape=(2, 2)), det, mp,
                              navigation_mask=in_data.reshape(2, 2))
+
+
+def test_in_data_rows_with_several_rotations_per_point(api_inputs):
+    """A masked map with keep_n rotations per point whose row count could be read either way (2 points x 2 rotations =
+    4 rows = the 4 points of the map): the first axis says which - `size` rows are the points in the data."""
+    from types import SimpleNamespace
+
+    s, det, mp, rot0 = api_inputs
+    in_data = np.array([False, True, False, True])
+    flat = rot0.reshape(4, 4)
+    best_then_other = np.stack([flat[in_data], flat[~in_data]], axis=1)           # (2 points, 2 rotations, 4)
+    res = s.refine_orientation(SimpleNamespace(rotations=best_then_other, is_in_data=in_data, shape=(2, 2)), det, mp,
+                               verbose=False)
+    alone = s.refine_orientation(rot0, det, mp, navigation_mask=~in_data.reshape(2, 2), verbose=False)
+    assert res.size == 2 and np.array_equal(res.scores, alone.scores) and np.array_equal(res.euler, alone.euler)
