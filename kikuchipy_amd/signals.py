@@ -77,11 +77,13 @@ class _Axes:
 
 class EBSD:
     def __init__(self, data, static_background=None, xmap=None, step_sizes=None, scan_unit="px",
-                 device=None, devices=None):
+                 device=None, devices=None, *, detector=None):
         """device: the GPU this signal's engine context lives on (None: GPU 0, and `dictionary_indexing`
         is free to shard the dictionary over every visible GPU); devices: "all" / a list of ids for
-        `dictionary_indexing` (see `kikuchipy_amd.dictionary_indexing`)."""
+        `dictionary_indexing` (see `kikuchipy_amd.dictionary_indexing`); `detector`, `static_background`, `xmap`: the
+        reference's custom attributes (signals/ebsd.py:188-199) - without a detector, one of the signal's shape."""
         self.data = data
+        self._detector = None
         ndim = data.ndim if hasattr(data, "ndim") else np.ndim(data)  # lazy data is not touched
         if ndim < 2 or ndim > 4:
             raise ValueError("EBSD data must have 0, 1 or 2 navigation axes and 2 signal axes")
@@ -93,6 +95,30 @@ class EBSD:
         self._devices = devices
         self._ctx = None
         self._groups = {}  # device ids -> _lib.Group, kept from call to call (its communicator is made once)
+        if detector is not None:
+            self.detector = detector
+
+    @property
+    def detector(self):
+        """The detector - sample geometry (signals/ebsd.py:203-223): by default a detector of the signal's shape with
+        the reference's default projection centre; setting one checks it against the signal as the reference does
+        (signals/util/_detector.py:28-59)."""
+        if self._detector is None:
+            from kikuchipy_amd.detectors import EBSDDetector
+
+            self._detector = EBSDDetector(shape=self._signal_shape_rc)
+        return self._detector
+
+    @detector.setter
+    def detector(self, value):
+        if tuple(value.shape) != self._signal_shape_rc:
+            raise ValueError(f"Detector shape {value.shape} must be equal to the signal shape {self._signal_shape_rc}.")
+        if value.navigation_shape != (1,) and value.navigation_shape != self._navigation_shape_rc:
+            raise ValueError(
+                "Detector must have exactly one projection center (PC), or one PC per pattern in an array of shape "
+                "equal to signal's navigation shape + (3,)."
+            )
+        self._detector = value
 
     # ------------------------------------------------------------------ engines
     def close(self):
@@ -136,9 +162,9 @@ class EBSD:
         out = EBSD(np.array(self.data, copy=True),
                    None if self.static_background is None else np.array(self.static_background),
                    self.xmap, self.step_sizes, self.scan_unit, self._device, self._devices)
-        for name in ("detector", "original_metadata"):
-            if hasattr(self, name):
-                setattr(out, name, getattr(self, name))
+        out._detector = None if self._detector is None else self._detector.deepcopy()
+        if hasattr(self, "original_metadata"):
+            out.original_metadata = self.original_metadata
         return out
 
     @property
@@ -182,9 +208,9 @@ class EBSD:
         """A new signal around `data` with this one's custom attributes (the reference carries `detector`,
         `static_background` and `xmap` over, signals/ebsd.py:564-573, :686-696)."""
         out = EBSD(data, self.static_background, self.xmap, self.step_sizes, self.scan_unit, self._device, self._devices)
-        for name in ("detector", "original_metadata"):
-            if hasattr(self, name):
-                setattr(out, name, getattr(self, name))
+        out._detector = None if self._detector is None else self._detector.deepcopy()
+        if hasattr(self, "original_metadata"):
+            out.original_metadata = self.original_metadata
         return out
 
     def remove_static_background(self, operation="subtract", static_bg=None, scale_bg=False, show_progressbar=None,

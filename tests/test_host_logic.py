@@ -328,3 +328,20 @@ def test_get_map_data_of_the_result_holders():
     assert np.array_equal(res.get_map_data(np.array([0.26, 1, 2, 3, 4]), decimals=1)[0], [0.3, np.nan, 1.0], equal_nan=True)
     with pytest.raises(ValueError, match="not among the properties"):
         res.get_map_data("nothing")
+
+
+def test_signal_detector_attribute():
+    """signals/ebsd.py:188-223: a signal always has a detector (by default one of its shape), a detector that is set is
+    checked against the signal with the reference's texts (signals/util/_detector.py:28-59), copies carry it."""
+    s = kpa.EBSD(np.zeros((2, 3, 6, 8), np.uint8))
+    assert s.detector.shape == (6, 8) and s.detector.navigation_shape == (1,)
+    with pytest.raises(ValueError, match=r"Detector shape \(6, 6\) must be equal to the signal shape \(6, 8\)"):
+        s.detector = kpa.EBSDDetector(shape=(6, 6))
+    with pytest.raises(ValueError, match="Detector must have exactly one projection center"):
+        s.detector = kpa.EBSDDetector(shape=(6, 8), pc=np.ones((4, 3)))
+    s.detector = kpa.EBSDDetector(shape=(6, 8), pc=np.full((2, 3, 3), 0.5))
+    t = s.deepcopy()
+    t.detector.pcx = 0.1
+    assert t.detector.navigation_shape == (2, 3) and s.detector.pcx[0, 0] == 0.5
+    u = kpa.EBSD(np.zeros((6, 8)), detector=kpa.EBSDDetector(shape=(6, 8), pc=(0.4, 0.2, 0.6)))
+    assert u.detector.pcz == 0.6
