@@ -20,6 +20,8 @@ that `kpdi_push_dictionary_chunk` then matches), as `bench.py --workload
 config3` does.
 """
 
+import warnings
+
 import numpy as np
 
 from kikuchipy_amd import _lib
@@ -87,8 +89,8 @@ class EBSD:
         ndim = data.ndim if hasattr(data, "ndim") else np.ndim(data)  # lazy data is not touched
         if ndim < 2 or ndim > 4:
             raise ValueError("EBSD data must have 0, 1 or 2 navigation axes and 2 signal axes")
-        self.static_background = static_background
-        self.xmap = xmap
+        self._static_background = static_background  # (the constructor does not check: signals/ebsd.py:198-199)
+        self._xmap = xmap
         self.step_sizes = step_sizes
         self.scan_unit = scan_unit
         self._device = device
@@ -108,6 +110,38 @@ class EBSD:
 
             self._detector = EBSDDetector(shape=self._signal_shape_rc)
         return self._detector
+
+    @property
+    def xmap(self):
+        """Crystal map of the signal (signals/ebsd.py:225-245): anything with a `shape`; setting one whose shape is not
+        the navigation shape raises as the reference does (signals/util/_crystal_map.py:55-59)."""
+        return self._xmap
+
+    @xmap.setter
+    def xmap(self, value):
+        shape = getattr(value, "shape", None)
+        nav = self._navigation_shape_rc
+        if value is not None and shape is not None and tuple(shape) != nav and tuple(shape) != (nav or (1,)):
+            raise ValueError(
+                f"Crystal map shape {tuple(shape)} and signal's navigation shape {nav} must be the same "
+                "(see EBSD.axes_manager)"
+            )
+        self._xmap = value
+
+    @property
+    def static_background(self):
+        """Static background pattern (signals/ebsd.py:247-266); one of another data type or shape is set with the
+        reference's warning (`remove_static_background` then refuses it)."""
+        return self._static_background
+
+    @static_background.setter
+    def static_background(self, value):
+        if value is not None:
+            if getattr(value, "dtype", None) != self.data.dtype:
+                warnings.warn("Background pattern has different data type from patterns")
+            if tuple(getattr(value, "shape", ())) != self._signal_shape_rc:
+                warnings.warn("Background pattern has different shape from patterns")
+        self._static_background = value
 
     @detector.setter
     def detector(self, value):

@@ -345,3 +345,17 @@ def test_signal_detector_attribute():
     assert t.detector.navigation_shape == (2, 3) and s.detector.pcx[0, 0] == 0.5
     u = kpa.EBSD(np.zeros((6, 8)), detector=kpa.EBSDDetector(shape=(6, 8), pc=(0.4, 0.2, 0.6)))
     assert u.detector.pcz == 0.6
+
+
+def test_signal_xmap_and_static_background_setters():
+    """signals/ebsd.py:236-266: a crystal map of another shape is refused (signals/util/_crystal_map.py:55-59), a
+    background of another data type or shape is taken with a warning."""
+    s = kpa.EBSD(np.zeros((2, 3, 6, 8), np.uint8), static_background=np.zeros((6, 8), np.uint8))
+    with pytest.warns(UserWarning, match="Background pattern has different data type from patterns"):
+        s.static_background = np.zeros((6, 8), np.float32)
+    with pytest.warns(UserWarning, match="Background pattern has different shape from patterns"):
+        s.static_background = np.zeros((6, 6), np.uint8)
+    with pytest.raises(ValueError, match=r"Crystal map shape \(5,\) and signal's navigation shape \(2, 3\) must be the same"):
+        s.xmap = kpa.DictionaryXmap(np.zeros((5, 4)))
+    s.xmap = kpa.DictionaryXmap.empty((2, 3))
+    assert s.xmap.shape == (2, 3)
