@@ -70,6 +70,7 @@ class DictionaryIndexingResult(MapData):
         # default) | "statistical" (KPDI_F64_EPS=statistical), "uncertified_patterns": n}; a result is the exact float64
         # best-k for ANY data with mode "worstcase" and 0 uncertified patterns (include/kpdi.h, KPDI_COMPUTE_F64); else None
         self.float64_certificate = float64_certificate
+        self.phase_list = None  # (`EBSD.dictionary_indexing`: the dictionary crystal map's `phases_in_data`, if it has one)
 
     @property
     def size(self):
@@ -86,6 +87,8 @@ class DictionaryIndexingResult(MapData):
         from orix.crystal_map import CrystalMap, create_coordinate_arrays
         from orix.quaternion import Rotation
 
+        if phase_list is None:
+            phase_list = self.phase_list
         kw, _ = create_coordinate_arrays(self.shape, self.step_sizes)
         if self.rotations is None:
             raise ValueError("dictionary_rotations were not given to dictionary_indexing()")
@@ -293,7 +296,8 @@ def dictionary_indexing(
             "shapes must be identical"
         )
     if dictionary_rotations is not None:
-        dictionary_rotations = np.asarray(dictionary_rotations)
+        # (an orix `Rotation` keeps its quaternions in `.data`)
+        dictionary_rotations = np.asarray(getattr(dictionary_rotations, "data", dictionary_rotations))
         if dictionary_rotations.shape != (dict_size, 4):
             raise ValueError(
                 "Dictionary signal must have a non-empty `EBSD.xmap` attribute of equal size as "

@@ -375,13 +375,17 @@ class EBSD:
             device, engine = self._engine(devices, comm, dict_size)
             metric = METRICS[metric](device=device, compute=compute, context=engine)
             metric.rechunk = rechunk
-        return _dictionary_indexing(
+        res = _dictionary_indexing(
             self.data, dict_data, metric, keep_n, n_per_iteration, navigation_mask, signal_mask,
             rechunk, dtype, step_sizes=self.step_sizes, dictionary_rotations=dict_xmap.rotations,
-            phase_name=dict_xmap.phase_name, scan_unit=self.scan_unit, device=self._device, comm=comm,
+            phase_name=getattr(dict_xmap, "phase_name", None), scan_unit=self.scan_unit, device=self._device, comm=comm,
             compute=compute,
             verbose=verbose,
         )
+        # the phase list the reference hands to the returned CrystalMap (indexing/_dictionary_indexing.py:165): kept for
+        # `to_crystal_map()` when the dictionary's crystal map is orix's
+        res.phase_list = getattr(dict_xmap, "phases_in_data", None)
+        return res
 
 
 def _rotations_of(xmap):
