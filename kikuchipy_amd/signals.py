@@ -60,6 +60,10 @@ class DictionaryXmap:
     def shape(self):
         return getattr(self, "_shape", (self.rotations.shape[0],))
 
+    @property
+    def size(self):
+        return int(self.rotations.shape[0])
+
 
 class _Axes:
     """See `EBSD.axes_manager`."""
